@@ -1,0 +1,119 @@
+/*
+ * mars_hip.h -- additive extensions of the MI355X build.  Nothing in here
+ * exists in the reference; nothing in here changes what the reference API
+ * (nna.h, nna_memory.h, nna_tensor.h, mars_runtime.h, mxu_ops.h) does for a
+ * single-frame caller.  Plain C ABI: pointers and sizes only.
+ *
+ * Why they exist:
+ *  - the reference has no batch dimension (every kernel ignores shape[0],
+ *    reference mars_runtime.c:566-589): mars_hip_set_batch() turns the model's
+ *    I/O tensors into `n` independent frames, each computed exactly as one
+ *    reference mars_run would compute it;
+ *  - the detection tail (decode + NMS) lives in a demo program in the reference
+ *    (src/mars/mars_yolo_test.c:80-130), not in its library;
+ *  - HBM-resident I/O and one-shot parameter broadcast for one-process-per-GPU
+ *    frame sharding.
+ */
+#ifndef MARS_HIP_H
+#define MARS_HIP_H
+
+#include "mars_runtime.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ---------------------------------------------------------------- batching */
+/* Re-plans the model for `n` frames.  After the call mars_get_input()->vaddr
+ * is a pinned host buffer of n * frame_bytes (frame-major, frames densely
+ * packed), ->alloc_size says so; same for outputs.  Activations are re-zeroed. */
+mars_error_t mars_hip_set_batch(mars_model_t *model, int n);
+int mars_hip_get_batch(const mars_model_t *model);
+
+/* mars_run() = upload + run_device + download.  The three parts: */
+mars_error_t mars_hip_upload_inputs(mars_model_t *model);    /* pinned host -> HBM, waits */
+mars_error_t mars_hip_run_device(mars_model_t *model);       /* enqueue all layers, waits */
+mars_error_t mars_hip_run_device_async(mars_model_t *model); /* enqueue only */
+mars_error_t mars_hip_download_outputs(mars_model_t *model); /* HBM -> pinned host, waits */
+mars_error_t mars_hip_sync(void);
+
+/* Device address / per-frame stride of any tensor (weights: stride 0). */
+void *mars_hip_tensor_device(mars_model_t *model, int tensor_index, size_t *frame_stride);
+/* Copy `bytes` of frame `frame` of any tensor to host memory (debug/parity). */
+mars_error_t mars_hip_read_tensor(mars_model_t *model, int tensor_index, int frame, void *dst,
+                                  size_t bytes);
+/* Write one frame of an activation tensor from host memory (tests). */
+mars_error_t mars_hip_write_tensor(mars_model_t *model, int tensor_index, int frame,
+                                   const void *src, size_t bytes);
+
+/* Fusion level: 0 = one kernel per reference layer, every tensor materialised
+ * (per-layer parity); 1 (default) = conv epilogue fusion of the
+ * conv->sigmoid->mul chain and ReLU, copies elided where bit-identical.
+ * Must be set before mars_hip_set_batch / first run; re-plans. */
+mars_error_t mars_hip_set_fusion(mars_model_t *model, int level);
+
+/* ------------------------------------------------------- per-layer timing */
+/* When on, every kernel launch is bracketed by HIP events on the library's
+ * stream; read back after a run. */
+void mars_hip_set_profiling(mars_model_t *model, int on);
+int mars_hip_num_ops(const mars_model_t *model);
+/* kind: 0 conv_i8, 1 conv_f32, 2 elementwise, 3 data movement, 4 other */
+int mars_hip_op_info(const mars_model_t *model, int op, int *layer, int *kind, double *macs,
+                     double *bytes, float *last_ms);
+void *mars_hip_stream(void); /* hipStream_t of the library, as void* */
+
+/* ------------------------------------------------------ parameter arena */
+/* One contiguous HBM block holding everything derived from the weight blob
+ * (blob mirror, packed conv weights, biases, LUTs).  Identical layout on every
+ * rank that loaded the same descriptors, so rank 0 can broadcast it. */
+#define MARS_HIP_LOAD_DEFER_WEIGHTS 1u /* parse descriptors, leave the arena unfilled */
+mars_error_t mars_hip_load_memory_ex(const void *data, size_t size, unsigned flags,
+                                     mars_model_t **model);
+void *mars_hip_param_arena(mars_model_t *model, size_t *bytes);
+
+/* ------------------------------------------------------- detection tail */
+/* Same record as det_t of reference mars_yolo_test.c:37 (24 bytes). */
+typedef struct {
+    float x, y, w, h, conf;
+    int cls;
+} mars_det_t;
+
+#define MARS_YOLO_MAX_DET 1000 /* candidate cap of the reference demo (:187-189) */
+
+/* Host-pointer forms with the reference's exact semantics (one frame):
+ * parse_output (:80-104) and nms (:107-130), executed on the GPU. */
+int mars_yolo_parse_output(const int8_t *data, int npred, float scale, mars_det_t *dets, int maxd);
+int mars_yolo_nms(mars_det_t *dets, int n, float thresh);
+
+/* Batched, device-resident: decode + NMS over the model's current batch.
+ * The prediction list of a frame is the concatenation, in the order given, of
+ * the listed output tensors, each viewed as rows of 85 int8 with its own
+ * desc.scale.  dets: host buffer [batch][MARS_YOLO_MAX_DET]; counts: [batch]
+ * (kept detections, sorted as the reference leaves them). */
+mars_error_t mars_hip_detect(mars_model_t *model, const int *output_indices, int n_outputs,
+                             float nms_thresh, mars_det_t *dets, int *counts);
+/* Same, but results stay in HBM (no D2H) -- used by the benchmark loop. */
+mars_error_t mars_hip_detect_device(mars_model_t *model, const int *output_indices, int n_outputs,
+                                    float nms_thresh);
+
+/* --------------------------------------------------- synthetic .mars writer */
+/* Well-formed graphs (NHWC activations, OHWI int8 weights, int32 bias; or
+ * NCHW/OIHW float32) with the YOLOv5 layer sequence and seeded weights, for
+ * the model files the reference repo does not ship (.MISSING_LARGE_BLOBS).
+ * Format restated from reference include/mars.h:103-221. */
+typedef struct {
+    int width_x16;   /* channel multiple: 4 = yolov5n (0.25), 8 = yolov5s (0.50) */
+    int depth_x3;    /* depth multiple in thirds: 1 = n/s (0.33) */
+    int input_hw;    /* square input, multiple of 32 */
+    int float32;     /* 0: int8 NHWC; 1: float32 NCHW */
+    int nchw_int8;   /* int8 only: emit NCHW/OIHW tags instead of NHWC/OHWI */
+    unsigned seed;
+    int tiny;        /* 1: 3-conv "tiny_160" chain instead of YOLOv5 */
+} mars_synth_opts_t;
+/* returns the file size; writes at most cap bytes (call with cap 0 to size) */
+size_t mars_synth_model(const mars_synth_opts_t *opts, void *buf, size_t cap);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MARS_HIP_H */

@@ -1,0 +1,121 @@
+"""Seeded test cases shared by the golden generator, the oracle tests and the GPU parity tests.
+
+All data derive from conftest.lcg_frame (a plain 32-bit LCG), so they are
+identical on every machine and numpy version.
+"""
+import hashlib
+
+import numpy as np
+
+from conftest import lcg_frame
+
+
+def digest(a):
+    return hashlib.sha256(np.ascontiguousarray(a).view(np.uint8).tobytes()).hexdigest()[:24]
+
+
+def i8(seed, n):
+    return lcg_frame(seed, n).view(np.int8)
+
+
+def f32(seed, n, lo=-1.0, hi=1.0):
+    u = lcg_frame(seed, n).astype(np.float32) / np.float32(255.0)
+    return (u * np.float32(hi - lo) + np.float32(lo)).astype(np.float32)
+
+
+# (name, nhwc, in_h, in_w, in_c, out_c, kh, kw, sh, sw, pad_top, pad_left, out_h, out_w, in_s, w_s, out_s, bias)
+CONV_I8_CASES = [
+    ("k3_c16", 1, 12, 14, 16, 32, 3, 3, 1, 1, 1, 1, 12, 14, 0.02, 0.004, 0.05, True),
+    ("k3_c64_s2", 1, 17, 19, 64, 64, 3, 3, 2, 2, 0, 0, 9, 10, 0.03, 0.002, 0.08, True),
+    ("k1_c32_o255", 1, 9, 7, 32, 255, 1, 1, 1, 1, 0, 0, 9, 7, 0.03, 0.01, 0.05, True),   # head conv, N tail
+    ("k1_c128_o16", 1, 6, 6, 128, 16, 1, 1, 1, 1, 0, 0, 6, 6, 0.03, 0.003, 0.05, False),
+    ("stem_k6_c3", 1, 32, 32, 3, 16, 6, 6, 2, 2, 2, 2, 16, 16, 0.0157, 0.003, 0.04, True),  # K=108, row pad
+    ("k3_c3_valid", 1, 20, 20, 3, 16, 3, 3, 1, 1, 0, 0, 18, 18, 1.0, 0.0026, 0.9, True),   # tiny_160 layer 0 shape
+    ("k5_c24_pad", 1, 11, 13, 24, 40, 5, 5, 1, 1, 2, 2, 11, 13, 0.02, 0.003, 0.07, True),  # in_c % 16 != 0
+    ("k3_c48_asym", 1, 10, 10, 48, 48, 3, 1, 1, 2, 1, 0, 10, 5, 0.02, 0.004, 0.06, True),
+    ("ties_half", 1, 8, 8, 16, 32, 1, 1, 1, 1, 0, 0, 8, 8, 1.0, 0.5, 16.0, False),          # acc*cs hits x.5 often
+    ("overflow", 1, 8, 8, 16, 32, 3, 3, 1, 1, 1, 1, 8, 8, 1.0, 13272.3, 1e-6, True),        # +/-overflow -> -128
+    ("nan_scale", 1, 4, 4, 16, 32, 1, 1, 1, 1, 0, 0, 4, 4, 0.0, 1.0, 0.0, True),            # 0/0 -> NaN -> -128
+    ("neg_scale", 1, 6, 6, 32, 32, 3, 3, 1, 1, 1, 1, 6, 6, 0.02, -0.004, 0.05, True),
+    ("big_k", 1, 5, 5, 512, 64, 3, 3, 1, 1, 1, 1, 5, 5, 0.03, 0.0007, 0.05, True),          # K = 4608
+    ("out_gt_in", 1, 5, 5, 16, 32, 3, 3, 1, 1, 0, 0, 7, 7, 0.03, 0.004, 0.05, True),        # output larger than valid
+    ("nchw_k3", 0, 12, 14, 3, 16, 3, 3, 1, 1, 0, 0, 10, 12, 1.0, 0.0026, 0.5, True),
+    ("nchw_k3_c16_s2", 0, 15, 15, 16, 32, 3, 3, 2, 2, 1, 1, 8, 8, 0.03, 0.004, 0.05, True),
+    ("nchw_k1_c40", 0, 7, 9, 40, 24, 1, 1, 1, 1, 0, 0, 7, 9, 0.03, 0.006, 0.05, False),
+]
+
+# (name, in_h, in_w, in_c, out_c, kh, kw, sh, sw, pt, pl, out_h, out_w, bias)
+CONV_F32_CASES = [
+    ("f_k3", 10, 12, 3, 16, 3, 3, 1, 1, 0, 0, 8, 10, True),
+    ("f_k3_pad_s2", 13, 13, 8, 12, 3, 3, 2, 2, 1, 1, 7, 7, True),
+    ("f_k1", 6, 6, 32, 20, 1, 1, 1, 1, 0, 0, 6, 6, False),
+    ("f_k5", 9, 9, 4, 6, 5, 5, 1, 1, 2, 2, 9, 9, True),
+]
+
+
+def conv_i8_inputs(case, seed=1):
+    (name, nhwc, in_h, in_w, in_c, out_c, kh, kw, sh, sw, pt, pl, out_h, out_w, in_s, w_s, out_s, has_b) = case
+    x = i8(seed * 7919 + 1, in_h * in_w * in_c)
+    w = i8(seed * 7919 + 2, out_c * kh * kw * in_c)
+    b = None
+    if has_b:
+        b = (lcg_frame(seed * 7919 + 3, out_c * 4).view(np.int32) >> 18).astype(np.int32)
+    return x, w, b
+
+
+def conv_i8_call(fn, case, seed=1):
+    (name, nhwc, in_h, in_w, in_c, out_c, kh, kw, sh, sw, pt, pl, out_h, out_w, in_s, w_s, out_s, has_b) = case
+    x, w, b = conv_i8_inputs(case, seed)
+    return fn(nhwc, x, in_h, in_w, in_c, w, out_c, kh, kw, b, out_h, out_w, sh, sw, pt, pl,
+              np.float32(in_s), np.float32(w_s), np.float32(out_s))
+
+
+def conv_f32_call(fn, case, seed=1):
+    (name, in_h, in_w, in_c, out_c, kh, kw, sh, sw, pt, pl, out_h, out_w, has_b) = case
+    x = f32(seed * 104729 + 1, in_h * in_w * in_c)
+    w = f32(seed * 104729 + 2, out_c * in_c * kh * kw, -0.5, 0.5)
+    b = f32(seed * 104729 + 3, out_c) if has_b else None
+    return fn(x, in_h, in_w, in_c, w, out_c, kh, kw, b, out_h, out_w, sh, sw, pt, pl)
+
+
+# detection tail: (name, npred, scale, seed, transform)
+YOLO_CASES = [
+    ("rand_0p05", 25200, 0.05, 11, "raw"),          # the survey probe: cap of 1000 reached
+    ("sparse", 6300, 0.04, 12, "sparse"),           # few candidates
+    ("ties", 4000, 0.1, 13, "ties"),                # many equal confidences -> exchange-sort permutation
+    ("clustered", 3000, 0.05, 14, "cluster"),       # overlapping same-class boxes -> suppression
+    ("none", 500, 0.05, 15, "none"),                # no candidate at all
+]
+
+
+def yolo_pred(case):
+    name, npred, scale, seed, kind = case
+    p = i8(seed, npred * 85).reshape(npred, 85).copy()
+    if kind == "sparse":
+        p[:, 4] = np.where(np.arange(npred) % 97 == 0, p[:, 4] | 64, -100).astype(np.int8)
+    elif kind == "ties":
+        p[:, 4] = np.int8(40)
+        p[:, 5:] = (p[:, 5:] // 32 * 32).astype(np.int8)          # few distinct logits -> equal conf
+        p[:, 0:4] = (np.abs(p[:, 0:4].astype(np.int16)) // 2).astype(np.int8)
+    elif kind == "cluster":
+        p[:, 4] = np.int8(60)
+        p[:, 5:] = np.int8(-90)
+        p[np.arange(npred), 5 + (np.arange(npred) % 3)] = (40 + (np.arange(npred) % 50)).astype(np.int8)
+        p[:, 0] = (np.arange(npred) % 7 * 3).astype(np.int8)
+        p[:, 1] = (np.arange(npred) // 7 % 5 * 3).astype(np.int8)
+        p[:, 2] = np.int8(40)
+        p[:, 3] = np.int8(36)
+    elif kind == "none":
+        p[:, 4] = np.int8(-120)
+    return np.ascontiguousarray(p.reshape(-1)), npred, np.float32(scale)
+
+
+SHIPPED = ["test_model", "test_simple", "tiny_160_int8", "tiny_160_f32", "yolov5n_int8"]
+# synthetic graphs small enough for the CPU oracle: (name, synth kwargs)
+SYNTH = [
+    ("v5n_64", dict(width_x16=4, input_hw=64, seed=1)),
+    ("v5s_96", dict(width_x16=8, input_hw=96, seed=2)),
+    ("tiny_40", dict(tiny=True, input_hw=40, seed=3)),
+    ("v5n_64_nchw", dict(width_x16=4, input_hw=64, nchw_int8=True, seed=4)),
+    ("tiny_32_f32", dict(tiny=True, input_hw=32, float32=True, seed=5)),
+]

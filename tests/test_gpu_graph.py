@@ -1,0 +1,213 @@
+"""GPU parity, graph level: mars_load_memory / mars_run through the C-ABI against the CPU
+oracle (O2 memory semantics) and the golden vectors of the reference.  Covers the shipped
+model files, the synthetic YOLOv5 twins (fused and unfused plans), batching and the
+per-layer graphs of test_oracle.py."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+import cases
+import marsfile
+from conftest import lcg_frame
+from test_oracle import LAYER_KINDS, _layer_graph, model_bytes, model_input
+
+pytestmark = pytest.mark.gpu
+HERE = os.path.dirname(os.path.abspath(__file__))
+GOLD = json.load(open(os.path.join(HERE, "golden", "golden.json")))
+
+
+def run_oracle(orc, d, x):
+    g = orc.Graph(d)
+    g.set_input(0, x.tobytes())
+    rc = g.run()
+    return g, rc
+
+
+@pytest.mark.parametrize("name", cases.SHIPPED)
+def test_shipped_models_all_tensors(gpu, orc, name):
+    """as shipped: NCHW-tagged, packed-weight bytes walked as OIHW, f32/fp16 bias bytes read as
+    int32 -- every activation tensor must equal what the reference leaves (golden + oracle)"""
+    d = model_bytes(name)
+    hdr, tensors, _ = marsfile.parse(d)
+    x = model_input(tensors[hdr["inputs"][0]], "pattern")
+    m = gpu.Model(d, fusion=0)
+    m.input_view(0)[0, :len(x)] = x
+    want = GOLD["models"][name]["pattern"]
+    if want["rc"] == 0:
+        m.run()
+    else:
+        with pytest.raises(gpu.MarsError) as e:
+            m.run()
+        assert e.value.code == want["rc"]
+    for ti, dg in want["tensors"].items():
+        got = m.read_tensor(int(ti))
+        assert cases.digest(got) == dg, "tensor %s" % ti
+    out = m.output_view(0)[0]
+    assert cases.digest(out) == want["out"]
+    m.close()
+
+
+@pytest.mark.parametrize("name,kw", cases.SYNTH, ids=lambda v: v if isinstance(v, str) else "")
+@pytest.mark.parametrize("fusion", [0, 1])
+def test_synthetic_models(gpu, orc, name, kw, fusion):
+    d = gpu.synth_model(**kw)
+    hdr, tensors, _ = marsfile.parse(d)
+    tin = tensors[hdr["inputs"][0]]
+    B = 3
+    xs = [model_input(tin, "lcg")] + [lcg_frame(0x5EED0000 + f, marsfile.tensor_nbytes(tin)) for f in range(1, B)]
+    if tin["dtype"] == 0:
+        xs = [xs[0]] + [cases.f32(0x5EED0000 + f, marsfile.tensor_nbytes(tin) // 4, 0, 1).view(np.uint8) for f in range(1, B)]
+    m = gpu.Model(d, batch=B, fusion=fusion)
+    for f in range(B):
+        m.input_view(0)[f] = xs[f]
+    m.run()
+    for f in range(B):
+        g, rc = run_oracle(orc, d, xs[f])
+        assert rc == 0
+        for oi, ti in enumerate(hdr["outputs"]):
+            want = g.tensor(ti)
+            got = m.output_view(oi)[f]
+            assert np.array_equal(got, want), "frame %d output %d: %d bytes differ" % (f, oi, int((got != want).sum()))
+        if fusion == 0 and f == 1:  # unfused plan materialises every tensor: check them all
+            for ti, t in enumerate(tensors):
+                if t["size"] == 0 and marsfile.tensor_nbytes(t):
+                    assert np.array_equal(m.read_tensor(ti, frame=f), g.tensor(ti)), "tensor %d" % ti
+    # a second run over the same inputs is idempotent
+    first = [m.output_view(i).copy() for i in range(len(hdr["outputs"]))]
+    m.run()
+    for i in range(len(hdr["outputs"])):
+        assert np.array_equal(first[i], m.output_view(i))
+    m.close()
+
+
+@pytest.mark.parametrize("kind", LAYER_KINDS)
+def test_single_layer_graphs(gpu, orc, kind):
+    d = _layer_graph(kind)
+    hdr, tensors, _ = marsfile.parse(d)
+    x = model_input(tensors[hdr["inputs"][0]], "lcg")
+    g, rc = run_oracle(orc, d, x)
+    m = gpu.Model(d, batch=2, fusion=0)
+    m.input_view(0)[0] = x
+    m.input_view(0)[1] = x[::-1]
+    if rc == 0:
+        m.run()
+    else:
+        with pytest.raises(gpu.MarsError) as e:
+            m.run()
+        assert e.value.code == rc
+    for ti, t in enumerate(tensors):
+        if t["size"] == 0 and marsfile.tensor_nbytes(t):
+            try:
+                got = m.read_tensor(ti, frame=0)
+            except gpu.MarsError:
+                continue  # tensor no layer touches: not materialised on the device
+            want = g.tensor(ti)
+            if t["dtype"] == 0 and kind == "f32_chain":
+                a, b = got.view(np.float32), want.view(np.float32)
+                assert np.all(np.abs(a - b) <= 1e-4 * np.maximum(1, np.abs(b)))
+            else:
+                assert np.array_equal(got, want), "tensor %d" % ti
+    m.close()
+
+
+def test_mars_test_c_call_pattern(gpu):
+    """the reference's executor smoke (src/mars/mars_test.c:33-148): init -> load_file -> fill
+    alloc_size bytes of the input -> run -> read the output through vaddr -> free"""
+    import ctypes as C
+    L = gpu.lib()
+    p = C.POINTER(gpu.MarsModel)()
+    path = os.path.join(HERE, "golden", "models", "tiny_160_int8.mars").encode()
+    assert L.mars_load_file(path, C.byref(p)) == 0
+    assert L.mars_get_num_inputs(p) == 1 and L.mars_get_num_outputs(p) == 1
+    tin = L.mars_get_input(p, 0).contents
+    assert tin.vaddr and tin.paddr and tin.alloc_size == 3 * 160 * 160
+    assert not L.mars_get_input(p, 1) and not L.mars_get_output(p, -1)
+    buf = np.ctypeslib.as_array(C.cast(tin.vaddr, C.POINTER(C.c_int8)), shape=(tin.alloc_size,))
+    buf[:] = (np.arange(tin.alloc_size) % 127).astype(np.int8)
+    assert L.mars_run(p) == 0 and L.mars_run(p) == 0
+    assert p.contents.inference_count == 2 and p.contents.total_inference_us > 0
+    tout = L.mars_get_output(p, 0).contents
+    out = np.ctypeslib.as_array(C.cast(tout.vaddr, C.POINTER(C.c_uint8)), shape=(tout.alloc_size,))
+    assert cases.digest(out) == GOLD["models"]["tiny_160_int8"]["pattern"]["out"]
+    L.mars_print_summary(p)
+    L.mars_free(p)
+    assert L.mars_load_file(b"/nonexistent.mars", C.byref(p)) == gpu.MARS_ERR_INVALID_FILE
+
+
+def test_test_init_c_call_pattern(gpu):
+    """the reference's L1 acceptance test (examples/test_init.c:33-131)"""
+    import ctypes as C
+    L = gpu.lib()
+    assert L.nna_init() == 0 and L.nna_is_ready() == 1  # idempotent
+    hw = gpu.HwInfo()
+    assert L.nna_get_hw_info(C.byref(hw)) == 0
+    assert hw.oram_size == 160 * 1024 and hw.version == 950
+    p = L.nna_malloc(1 << 20)
+    assert p
+    C.memset(p, 0xAA, 1 << 20)
+    assert C.cast(p, C.POINTER(C.c_ubyte))[0] == 0xAA
+    L.nna_free(p)
+    L.nna_free(p)  # unknown pointer: logs, does not crash
+    q = L.nna_calloc(100, 10)
+    assert q and bytes((C.c_ubyte * 1000).from_address(q)) == b"\0" * 1000
+    L.nna_free(q)
+    assert L.nna_oram_malloc(4096) == 1
+    tot, used, free = C.c_size_t(), C.c_size_t(), C.c_size_t()
+    assert L.nna_oram_get_stats(C.byref(tot), C.byref(used), C.byref(free)) == 0
+    assert tot.value == 160 * 1024 and used.value >= 4096 and free.value == tot.value - used.value
+    assert L.nna_lock() == 0 and L.nna_unlock() == 0
+
+
+def test_full_size_properties(gpu, orc):
+    """BASELINE config sizes, through size-independent properties: (i) every frame of a batch
+    equals the same frame run alone (frames are independent), (ii) fused == unfused plan,
+    (iii) one frame of the full 640x640 yolov5n twin against the CPU oracle."""
+    d = gpu.synth_model(width_x16=4, input_hw=640, seed=7)
+    hdr, tensors, _ = marsfile.parse(d)
+    nb = marsfile.tensor_nbytes(tensors[hdr["inputs"][0]])
+    B = 8
+    m = gpu.Model(d, batch=B, fusion=1)
+    for f in range(B):
+        m.input_view(0)[f] = lcg_frame(0x5EED0000 + f, nb)
+    m.run()
+    outs = [m.output_view(i).copy() for i in range(3)]
+    m.set_batch(1)
+    for f in (0, 5):
+        m.input_view(0)[0] = lcg_frame(0x5EED0000 + f, nb)
+        m.run()
+        for i in range(3):
+            assert np.array_equal(m.output_view(i)[0], outs[i][f])
+    m.set_fusion(0)
+    m.input_view(0)[0] = lcg_frame(0x5EED0000 + 5, nb)
+    m.run()
+    for i in range(3):
+        assert np.array_equal(m.output_view(i)[0], outs[i][5])
+    m.close()
+    g, rc = run_oracle(orc, d, lcg_frame(0x5EED0000, nb))
+    assert rc == 0
+    for i, ti in enumerate(hdr["outputs"]):
+        assert np.array_equal(g.tensor(ti), outs[i][0])
+
+
+def test_detect_on_model_outputs(gpu, orc):
+    """decode + NMS over the three head tensors of a batch == the reference tail on the
+    concatenated [sum(H*W*3), 85] prediction list of each frame"""
+    d = gpu.synth_model(width_x16=4, input_hw=128, seed=11)
+    hdr, tensors, _ = marsfile.parse(d)
+    nb = marsfile.tensor_nbytes(tensors[hdr["inputs"][0]])
+    B = 4
+    m = gpu.Model(d, batch=B)
+    for f in range(B):
+        m.input_view(0)[f] = lcg_frame(0x5EED0000 + f, nb)
+    m.run()
+    dets = m.detect(outputs=(0, 1, 2), thresh=0.45)
+    scale = np.float32(tensors[hdr["outputs"][0]]["scale"])
+    for f in range(B):
+        pred = np.concatenate([m.output_view(i)[f] for i in range(3)]).view(np.int8)
+        raw = orc.parse_output(pred, len(pred) // 85, scale)
+        want = orc.nms(raw, 0.45)
+        assert len(raw) > 10
+        assert dets[f].tobytes() == want.tobytes()
+    m.close()

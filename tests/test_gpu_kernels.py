@@ -1,0 +1,93 @@
+"""GPU parity, kernel level: the HIP kernels called through the C-ABI's host-pointer entry
+points (include/mxu_ops.h, mars_yolo_* of include/mars_hip.h) against the CPU oracle and the
+golden vectors the reference produced.  Bit-exact for every int8 / index result; the f32
+convolution keeps the reference's summation order and is compared bit-exactly too (the task's
+tolerance is 1e-4; asserted as well, with the formula written out)."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+import cases
+
+pytestmark = pytest.mark.gpu
+HERE = os.path.dirname(os.path.abspath(__file__))
+GOLD = json.load(open(os.path.join(HERE, "golden", "golden.json")))
+
+
+@pytest.mark.parametrize("case", cases.CONV_I8_CASES, ids=lambda c: c[0])
+def test_conv_i8_bit_exact(gpu, orc, case):
+    got = cases.conv_i8_call(gpu.conv2d_int8, case)
+    assert cases.digest(got) == GOLD["conv_i8"][case[0]]          # what the reference itself produced
+    for seed in (2, 3):
+        a = cases.conv_i8_call(gpu.conv2d_int8, case, seed)
+        b = cases.conv_i8_call(orc.conv2d_int8, case, seed)
+        assert np.array_equal(a, b), "mismatches: %d" % int((a != b).sum())
+
+
+@pytest.mark.parametrize("case", cases.CONV_F32_CASES, ids=lambda c: c[0])
+def test_conv_f32(gpu, orc, case):
+    got = cases.conv_f32_call(gpu.conv2d_f32, case)
+    want = cases.conv_f32_call(orc.conv2d_f32, case)
+    tol = 1e-4  # north_star: |a-b| <= 1e-4 * max(1, |b|)
+    assert np.all(np.abs(got - want) <= tol * np.maximum(1.0, np.abs(want)))
+    assert np.array_equal(got.view(np.uint32), want.view(np.uint32))  # same order, same roundings
+    assert cases.digest(got) == GOLD["conv_f32"][case[0]]
+
+
+def test_conv_i8_larger_shapes(gpu, orc):
+    """yolov5s-shaped layers at sizes the oracle still finishes quickly: M tails, all N tiles"""
+    shapes = [  # in_h, in_w, in_c, out_c, k, s
+        (40, 40, 64, 128, 3, 2), (20, 20, 256, 256, 1, 1), (23, 17, 128, 64, 3, 1), (16, 16, 512, 255, 1, 1),
+        (64, 64, 32, 32, 1, 1), (48, 48, 3, 32, 6, 2)]
+    for i, (h, w, ic, oc, k, s) in enumerate(shapes):
+        oh, ow = (h + s - 1) // s, (w + s - 1) // s
+        ph = max((oh - 1) * s + k - h, 0) // 2
+        pw = max((ow - 1) * s + k - w, 0) // 2
+        case = ("big%d" % i, 1, h, w, ic, oc, k, k, s, s, ph, pw, oh, ow, 0.03, 0.003 / (k * k * ic) ** 0.5 * 8, 0.05, True)
+        a = cases.conv_i8_call(gpu.conv2d_int8, case, 4)
+        b = cases.conv_i8_call(orc.conv2d_int8, case, 4)
+        assert np.array_equal(a, b), case[0]
+        assert len(np.unique(a)) > 32  # not a saturated / all-zero comparison
+
+
+def test_mxu_f32_elementwise(gpu):
+    L = gpu.lib()
+    n = 100003
+    a, b = cases.f32(1, n, -3, 3), cases.f32(2, n, -3, 3)
+    out = np.zeros(n, np.float32)
+    L.mxu_mul_f32(out.ctypes.data, a.ctypes.data, b.ctypes.data, n)
+    assert np.array_equal(out, a * b)
+    L.mxu_add_f32(out.ctypes.data, a.ctypes.data, b.ctypes.data, n)
+    assert np.array_equal(out, a + b)
+    L.mxu_sub_f32(out.ctypes.data, a.ctypes.data, b.ctypes.data, n)
+    assert np.array_equal(out, a - b)
+    L.mxu_relu_f32(out.ctypes.data, a.ctypes.data, n)
+    assert np.array_equal(out, np.where(a > 0, a, a * np.float32(0)))
+    L.mxu_init(None)
+    assert L.mxu_is_initialized() == 1
+
+
+@pytest.mark.parametrize("case", cases.YOLO_CASES, ids=lambda c: c[0])
+def test_decode_and_nms_bit_exact(gpu, orc, case):
+    pred, npred, scale = cases.yolo_pred(case)
+    raw = gpu.parse_output(pred, npred, scale)
+    want_raw = orc.parse_output(pred, npred, scale)
+    assert raw.tobytes() == want_raw.tobytes()
+    kept = gpu.nms(raw, 0.45)
+    want = orc.nms(want_raw, 0.45)
+    assert len(kept) == len(want)
+    assert kept.tobytes() == want.tobytes()                      # same boxes in the same order (ties included)
+    g = GOLD["yolo"][case[0]]
+    assert (len(raw), len(kept)) == (g["raw"], g["kept"])
+    assert cases.digest(raw) == g["raw_digest"] and cases.digest(kept) == g["kept_digest"]
+    k2 = gpu.nms(raw, 0.1)
+    assert k2.tobytes() == orc.nms(want_raw, 0.1).tobytes()
+
+
+def test_decode_cap_and_maxd(gpu, orc):
+    pred, npred, scale = cases.yolo_pred(cases.YOLO_CASES[0])
+    a = gpu.parse_output(pred, npred, scale, maxd=37)
+    b = orc.parse_output(pred, npred, scale, maxd=37)
+    assert len(a) == 37 and a.tobytes() == b.tobytes()

@@ -1,0 +1,34 @@
+#!/bin/bash
+# Builds libnna_mars.so (host C + hand-written gfx950 HIP kernels) in-tree.
+#   host/*.c   gcc   -O2 -ffp-contract=off   (x86 float semantics of the reference's C)
+#   hip/*.hip  hipcc --offload-arch=gfx950 -ffp-contract=off (no FMA contraction in epilogues)
+set -euo pipefail
+HERE="$(cd "$(dirname "$0")" && pwd)"
+SRC="$HERE/csrc"
+OUT="$HERE/lib"
+OBJ="$HERE/build"
+INC="-I$HERE/../include -I$SRC -I$SRC/host"
+mkdir -p "$OUT" "$OBJ"
+HIPCC=${HIPCC:-/opt/rocm/bin/hipcc}
+CC=${CC:-gcc}
+CXX=${CXX:-g++}
+CFLAGS="-O2 -ffp-contract=off -fPIC -Wall -Wextra -Wno-unused-parameter $INC"
+HIPFLAGS="--offload-arch=gfx950 -O3 -ffp-contract=off -fPIC -std=c++17 -Wno-unused-result $INC"
+pids=()
+for f in "$SRC"/hip/*.hip; do
+  o="$OBJ/$(basename "$f" .hip).hip.o"
+  if [ ! -f "$o" ] || [ "$f" -nt "$o" ] || [ "$SRC/mhip.h" -nt "$o" ]; then
+    $HIPCC $HIPFLAGS -c "$f" -o "$o" & pids+=($!)
+  fi
+done
+for f in "$SRC"/host/*.c; do
+  o="$OBJ/$(basename "$f" .c).o"
+  $CC $CFLAGS -c "$f" -o "$o"
+done
+for f in "$SRC"/host/*.cpp; do
+  o="$OBJ/$(basename "$f" .cpp).o"
+  $CXX -O2 -fPIC -std=c++17 $INC -c "$f" -o "$o"
+done
+for p in "${pids[@]:-}"; do [ -n "$p" ] && wait "$p"; done
+$HIPCC --offload-arch=gfx950 -shared -fPIC -Wl,-Bsymbolic -o "$OUT/libnna_mars.so" "$OBJ"/*.o -lm
+echo "built $OUT/libnna_mars.so"

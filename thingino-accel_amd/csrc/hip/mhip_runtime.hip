@@ -1,0 +1,137 @@
+// mhip_runtime.hip -- device bring-up, memory and stream plumbing behind the
+// C-ABI of mhip.h.  Stands where the reference has ioctl/mmap access to
+// /dev/soc-nna and the NNDMA descriptor engine (reference src/device.c:133-302,
+// src/memory.c:76-196, src/nna_dma.c:130-252): HBM allocations, pinned host
+// buffers and async copies on ONE library stream.
+#include <hip/hip_runtime.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include "../mhip.h"
+
+static hipStream_t g_stream = nullptr;
+static int g_ready = 0;
+static int g_device = -1;
+static char g_err[256] = "";
+
+extern "C" hipStream_t mhip_stream_native(void) { return g_stream; }
+
+extern "C" int mhip_check(hipError_t e, const char *what) {
+    if (e == hipSuccess) return 0;
+    snprintf(g_err, sizeof(g_err), "%s: %s", what, hipGetErrorString(e));
+    if (getenv("MARS_VERBOSE")) fprintf(stderr, "mars-hip: %s\n", g_err);
+    return -(int)e;
+}
+
+extern "C" const char *mhip_last_error(void) { return g_err; }
+
+extern "C" int mhip_init(int device_hint) {
+    if (g_ready) return 0;
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) {
+        snprintf(g_err, sizeof(g_err), "no HIP device visible");
+        return -1;
+    }
+    int dev = device_hint >= 0 ? device_hint % n : 0;
+    hipDeviceProp_t prop;
+    if (mhip_check(hipGetDeviceProperties(&prop, dev), "hipGetDeviceProperties")) return -1;
+    // the kernels are built for gfx950 only; refuse anything else loudly
+    if (strncmp(prop.gcnArchName, "gfx950", 6) != 0) {
+        snprintf(g_err, sizeof(g_err), "device %d is %s, this build targets gfx950 (MI355X)", dev, prop.gcnArchName);
+        return -2;
+    }
+    if (mhip_check(hipSetDevice(dev), "hipSetDevice")) return -1;
+    if (mhip_check(hipStreamCreateWithFlags(&g_stream, hipStreamNonBlocking), "hipStreamCreate")) return -3;
+    g_device = dev;
+    g_ready = 1;
+    return 0;
+}
+
+extern "C" void mhip_shutdown(void) {
+    if (!g_ready) return;
+    (void)hipStreamSynchronize(g_stream);
+    (void)hipStreamDestroy(g_stream);
+    g_stream = nullptr;
+    g_ready = 0;
+}
+
+extern "C" int mhip_ready(void) { return g_ready; }
+
+extern "C" int mhip_device_info(int *cu_count, int *lds_bytes, int *gfx_version, size_t *hbm_bytes) {
+    if (!g_ready) return -1;
+    hipDeviceProp_t prop;
+    if (mhip_check(hipGetDeviceProperties(&prop, g_device), "hipGetDeviceProperties")) return -1;
+    if (cu_count) *cu_count = prop.multiProcessorCount;
+    if (lds_bytes) *lds_bytes = (int)prop.maxSharedMemoryPerMultiProcessor;
+    if (gfx_version) *gfx_version = atoi(prop.gcnArchName + 3);
+    if (hbm_bytes) *hbm_bytes = prop.totalGlobalMem;
+    return 0;
+}
+
+extern "C" void *mhip_stream(void) { return (void *)g_stream; }
+
+extern "C" int mhip_sync(void) { return mhip_check(hipStreamSynchronize(g_stream), "hipStreamSynchronize"); }
+
+extern "C" void *mhip_malloc(size_t bytes) {
+    void *p = nullptr;
+    if (!g_ready) return nullptr;
+    if (mhip_check(hipMalloc(&p, bytes ? bytes : 256), "hipMalloc")) return nullptr;
+    return p;
+}
+
+extern "C" void mhip_free(void *p) {
+    if (p) (void)hipFree(p);
+}
+
+extern "C" void *mhip_host_alloc(size_t bytes) {
+    void *p = nullptr;
+    if (!g_ready) return nullptr;
+    if (mhip_check(hipHostMalloc(&p, bytes ? bytes : 256, hipHostMallocDefault), "hipHostMalloc")) return nullptr;
+    return p;
+}
+
+extern "C" void mhip_host_free(void *p) {
+    if (p) (void)hipHostFree(p);
+}
+
+extern "C" int mhip_memset_async(void *dst, int value, size_t bytes) {
+    return mhip_check(hipMemsetAsync(dst, value, bytes, g_stream), "hipMemsetAsync");
+}
+extern "C" int mhip_h2d_async(void *dst, const void *src, size_t bytes) {
+    return mhip_check(hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, g_stream), "H2D");
+}
+extern "C" int mhip_d2h_async(void *dst, const void *src, size_t bytes) {
+    return mhip_check(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, g_stream), "D2H");
+}
+extern "C" int mhip_d2d_async(void *dst, const void *src, size_t bytes) {
+    return mhip_check(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, g_stream), "D2D");
+}
+extern "C" int mhip_h2d_2d_async(void *dst, size_t dpitch, const void *src, size_t spitch, size_t row_bytes,
+                                 size_t rows) {
+    if (dpitch == row_bytes && spitch == row_bytes) return mhip_h2d_async(dst, src, row_bytes * rows);
+    return mhip_check(hipMemcpy2DAsync(dst, dpitch, src, spitch, row_bytes, rows, hipMemcpyHostToDevice, g_stream), "H2D 2D");
+}
+extern "C" int mhip_d2h_2d_async(void *dst, size_t dpitch, const void *src, size_t spitch, size_t row_bytes,
+                                 size_t rows) {
+    if (dpitch == row_bytes && spitch == row_bytes) return mhip_d2h_async(dst, src, row_bytes * rows);
+    return mhip_check(hipMemcpy2DAsync(dst, dpitch, src, spitch, row_bytes, rows, hipMemcpyDeviceToHost, g_stream), "D2H 2D");
+}
+
+extern "C" void *mhip_event_create(void) {
+    hipEvent_t ev;
+    if (hipEventCreate(&ev) != hipSuccess) return nullptr;
+    return (void *)ev;
+}
+extern "C" void mhip_event_destroy(void *ev) {
+    if (ev) (void)hipEventDestroy((hipEvent_t)ev);
+}
+extern "C" int mhip_event_record(void *ev) {
+    return mhip_check(hipEventRecord((hipEvent_t)ev, g_stream), "hipEventRecord");
+}
+extern "C" float mhip_event_elapsed_ms(void *start, void *stop) {
+    float ms = 0.f;
+    if (hipEventSynchronize((hipEvent_t)stop) != hipSuccess) return -1.f;
+    if (hipEventElapsedTime(&ms, (hipEvent_t)start, (hipEvent_t)stop) != hipSuccess) return -1.f;
+    return ms;
+}

@@ -1,0 +1,187 @@
+// move.hip -- byte-moving layers of the .mars executor on gfx950: max-pool,
+// channel concat, nearest up-sampling, and the NCHW->NHWC relayout that feeds
+// the MFMA conv kernel when a graph is tagged NCHW.
+//
+// Index math is the reference's (src/mars/mars_runtime.c): all three layers
+// read shape[1..3] as H, W, C and move int8 BYTES whatever the tensor's tag or
+// dtype (:919-957 maxpool, :971-999 concat, :1014-1041 upsample); maxpool has
+// no padding, clips its window at the bottom/right edge and starts from -128.
+// All are HBM-bound; consecutive lanes touch consecutive channel bytes.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../mhip.h"
+
+extern "C" hipStream_t mhip_stream_native(void);
+extern "C" int mhip_check(hipError_t e, const char *what);
+
+typedef int v4i __attribute__((ext_vector_type(4)));
+#define MV_THREADS 256
+
+static inline dim3 mv_grid(size_t work, int frames) {
+    size_t bx = (work + MV_THREADS - 1) / MV_THREADS;
+    return dim3((unsigned)(bx ? bx : 1), (unsigned)frames);
+}
+
+// ----------------------------------------------------------------- maxpool
+// VEC = channels handled per thread (4 when ch % 4 == 0 and pointers aligned)
+template <int VEC>
+__global__ __launch_bounds__(MV_THREADS) void maxpool_kernel(const int8_t *in, size_t is, int8_t *out, size_t os,
+                                                             int in_h, int in_w, int ch, int out_h, int out_w, int kh,
+                                                             int kw, int sh, int sw) {
+    const int cv = ch / VEC;
+    size_t idx = (size_t)blockIdx.x * MV_THREADS + threadIdx.x;
+    size_t total = (size_t)out_h * out_w * cv;
+    if (idx >= total) return;
+    int c = (int)(idx % cv) * VEC;
+    size_t pix = idx / cv;
+    int ox = (int)(pix % out_w), oy = (int)(pix / out_w);
+    const int8_t *src = in + (size_t)blockIdx.y * is;
+    int best[VEC];
+#pragma unroll
+    for (int v = 0; v < VEC; v++) best[v] = -128;
+    for (int ky = 0; ky < kh; ky++) {
+        int iy = oy * sh + ky;
+        if (iy >= in_h) break;
+        for (int kx = 0; kx < kw; kx++) {
+            int ix = ox * sw + kx;
+            if (ix >= in_w) break;
+            const int8_t *q = src + ((size_t)iy * in_w + ix) * ch + c;
+            if (VEC == 4) {
+                uint32_t w = *(const uint32_t *)q;
+#pragma unroll
+                for (int v = 0; v < 4; v++) {
+                    int e = (int8_t)(w >> (8 * v));
+                    best[v] = e > best[v] ? e : best[v];
+                }
+            } else {
+                int e = q[0];
+                best[0] = e > best[0] ? e : best[0];
+            }
+        }
+    }
+    int8_t *dst = out + (size_t)blockIdx.y * os + pix * ch + c;
+    if (VEC == 4) {
+        *(uint32_t *)dst = (uint32_t)(best[0] & 255) | ((uint32_t)(best[1] & 255) << 8) |
+                           ((uint32_t)(best[2] & 255) << 16) | ((uint32_t)(best[3] & 255) << 24);
+    } else {
+        dst[0] = (int8_t)best[0];
+    }
+}
+
+extern "C" int mhip_maxpool_i8(const int8_t *in, size_t in_stride, int8_t *out, size_t out_stride, int frames,
+                               int in_h, int in_w, int ch, int out_h, int out_w, int kh, int kw, int sh, int sw) {
+    if (!in || !out || frames <= 0 || in_h < 0 || in_w < 0 || ch < 0 || out_h < 0 || out_w < 0 || kh < 0 || kw < 0 ||
+        sh < 0 || sw < 0)
+        return -1;
+    size_t total = (size_t)out_h * out_w * ch;
+    if (total == 0) return 0;
+    bool v4 = (ch % 4 == 0) && ((((uintptr_t)in | (uintptr_t)out | in_stride | out_stride) & 3) == 0);
+    if (v4)
+        hipLaunchKernelGGL((maxpool_kernel<4>), mv_grid(total / 4, frames), dim3(MV_THREADS), 0, mhip_stream_native(),
+                           in, in_stride, out, out_stride, in_h, in_w, ch, out_h, out_w, kh, kw, sh, sw);
+    else
+        hipLaunchKernelGGL((maxpool_kernel<1>), mv_grid(total, frames), dim3(MV_THREADS), 0, mhip_stream_native(), in,
+                           in_stride, out, out_stride, in_h, in_w, ch, out_h, out_w, kh, kw, sh, sw);
+    return mhip_check(hipGetLastError(), "maxpool");
+}
+
+// ------------------------------------------------------------ concat slice
+// out[(pix)*out_c + ch_off + c] = in[pix*in_c + c], pix over out_h*out_w
+template <int VEC>
+__global__ __launch_bounds__(MV_THREADS) void concat_kernel(const int8_t *in, size_t is, int8_t *out, size_t os,
+                                                            size_t npix, int in_c, int out_c, int ch_off) {
+    const int cv = in_c / VEC;
+    size_t idx = (size_t)blockIdx.x * MV_THREADS + threadIdx.x;
+    if (idx >= npix * cv) return;
+    int c = (int)(idx % cv) * VEC;
+    size_t pix = idx / cv;
+    const int8_t *s = in + (size_t)blockIdx.y * is + pix * in_c + c;
+    int8_t *d = out + (size_t)blockIdx.y * os + pix * out_c + ch_off + c;
+    if (VEC == 16) *(v4i *)d = *(const v4i *)s;
+    else d[0] = s[0];
+}
+
+extern "C" int mhip_concat_slice(const int8_t *in, size_t in_stride, int8_t *out, size_t out_stride, int frames,
+                                 int out_h, int out_w, int in_c, int out_c, int ch_off) {
+    if (!in || !out || frames <= 0 || out_h < 0 || out_w < 0 || in_c < 0 || out_c < 0 || ch_off < 0) return -1;
+    size_t npix = (size_t)out_h * out_w;
+    if (npix == 0 || in_c == 0) return 0;
+    bool v16 = (in_c % 16 == 0) && (out_c % 16 == 0) && (ch_off % 16 == 0) &&
+               ((((uintptr_t)in | (uintptr_t)out | in_stride | out_stride) & 15) == 0);
+    if (v16)
+        hipLaunchKernelGGL((concat_kernel<16>), mv_grid(npix * (in_c / 16), frames), dim3(MV_THREADS), 0,
+                           mhip_stream_native(), in, in_stride, out, out_stride, npix, in_c, out_c, ch_off);
+    else
+        hipLaunchKernelGGL((concat_kernel<1>), mv_grid(npix * in_c, frames), dim3(MV_THREADS), 0,
+                           mhip_stream_native(), in, in_stride, out, out_stride, npix, in_c, out_c, ch_off);
+    return mhip_check(hipGetLastError(), "concat");
+}
+
+// ---------------------------------------------------------------- upsample
+template <int VEC>
+__global__ __launch_bounds__(MV_THREADS) void upsample_kernel(const int8_t *in, size_t is, int8_t *out, size_t os,
+                                                              int in_h, int in_w, int ch, int out_h, int out_w,
+                                                              int scale_h, int scale_w) {
+    const int cv = ch / VEC;
+    size_t idx = (size_t)blockIdx.x * MV_THREADS + threadIdx.x;
+    if (idx >= (size_t)out_h * out_w * cv) return;
+    int c = (int)(idx % cv) * VEC;
+    size_t pix = idx / cv;
+    int ox = (int)(pix % out_w), oy = (int)(pix / out_w);
+    int iy = oy / scale_h, ix = ox / scale_w;
+    if (iy >= in_h) iy = in_h - 1;
+    if (ix >= in_w) ix = in_w - 1;
+    const int8_t *s = in + (size_t)blockIdx.y * is + ((size_t)iy * in_w + ix) * ch + c;
+    int8_t *d = out + (size_t)blockIdx.y * os + pix * ch + c;
+    if (VEC == 16) *(v4i *)d = *(const v4i *)s;
+    else d[0] = s[0];
+}
+
+extern "C" int mhip_upsample_i8(const int8_t *in, size_t in_stride, int8_t *out, size_t out_stride, int frames,
+                                int in_h, int in_w, int ch, int out_h, int out_w, int scale_h, int scale_w) {
+    if (!in || !out || frames <= 0 || in_h <= 0 || in_w <= 0 || ch < 0 || out_h < 0 || out_w < 0 || scale_h <= 0 ||
+        scale_w <= 0)
+        return -1;
+    size_t total = (size_t)out_h * out_w * ch;
+    if (total == 0) return 0;
+    bool v16 = (ch % 16 == 0) && ((((uintptr_t)in | (uintptr_t)out | in_stride | out_stride) & 15) == 0);
+    if (v16)
+        hipLaunchKernelGGL((upsample_kernel<16>), mv_grid(total / 16, frames), dim3(MV_THREADS), 0,
+                           mhip_stream_native(), in, in_stride, out, out_stride, in_h, in_w, ch, out_h, out_w,
+                           scale_h, scale_w);
+    else
+        hipLaunchKernelGGL((upsample_kernel<1>), mv_grid(total, frames), dim3(MV_THREADS), 0, mhip_stream_native(),
+                           in, in_stride, out, out_stride, in_h, in_w, ch, out_h, out_w, scale_h, scale_w);
+    return mhip_check(hipGetLastError(), "upsample");
+}
+
+// ------------------------------------------------- [C][HW] -> [HW][c_pad]
+__global__ __launch_bounds__(MV_THREADS) void nchw_to_nhwc_kernel(const int8_t *in, size_t is, int8_t *out, size_t os,
+                                                                  int c, int hw, int c_pad) {
+    const int groups = c_pad / 16;
+    size_t idx = (size_t)blockIdx.x * MV_THREADS + threadIdx.x;
+    if (idx >= (size_t)hw * groups) return;
+    // consecutive threads -> consecutive pixels: the strided channel reads coalesce
+    int pix = (int)(idx % hw);
+    int g = (int)(idx / hw);
+    const int8_t *s = in + (size_t)blockIdx.y * is + pix;
+    uint32_t w[4] = {0, 0, 0, 0};
+#pragma unroll
+    for (int e = 0; e < 16; e++) {
+        int ci = g * 16 + e;
+        uint32_t b = ci < c ? (uint8_t)s[(size_t)ci * hw] : 0u;
+        w[e >> 2] |= b << (8 * (e & 3));
+    }
+    v4i v = {(int)w[0], (int)w[1], (int)w[2], (int)w[3]};
+    *(v4i *)(out + (size_t)blockIdx.y * os + (size_t)pix * c_pad + g * 16) = v;
+}
+
+extern "C" int mhip_nchw_to_nhwc_pad(const int8_t *in, size_t in_stride, int8_t *out, size_t out_stride, int frames,
+                                     int c, int hw, int c_pad) {
+    if (!in || !out || frames <= 0 || c <= 0 || hw <= 0 || c_pad < c || (c_pad & 15)) return -1;
+    if ((((uintptr_t)out | out_stride) & 15) != 0) return -1;
+    hipLaunchKernelGGL(nchw_to_nhwc_kernel, mv_grid((size_t)hw * (c_pad / 16), frames), dim3(MV_THREADS), 0,
+                       mhip_stream_native(), in, in_stride, out, out_stride, c, hw, c_pad);
+    return mhip_check(hipGetLastError(), "nchw_to_nhwc");
+}

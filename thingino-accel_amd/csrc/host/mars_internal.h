@@ -1,0 +1,92 @@
+/*
+ * mars_internal.h -- private state of the MI355X .mars executor (host side).
+ * The public prefix of mars_model_ext_t is the reference's mars_model_t
+ * (include/mars_runtime.h), so a mars_model_t* handed to callers is also a
+ * pointer to the private record.
+ */
+#ifndef MARS_INTERNAL_H
+#define MARS_INTERNAL_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#include "../mhip.h"
+#include "mars_hip.h"
+#include "mars_runtime.h"
+
+enum {
+    OP_CONV_I8 = 0,
+    OP_CONV_F32,
+    OP_RELU_BYTES,
+    OP_LUT_I8,
+    OP_BINARY_I8,
+    OP_SIGMOID_F32,
+    OP_BINARY_F32,
+    OP_RELU_F32,
+    OP_BN,
+    OP_MAXPOOL,
+    OP_CONCAT_SLICE,
+    OP_UPSAMPLE,
+    OP_FAIL, /* mars_run stops here with op->err, as the reference would at this layer */
+};
+
+#define NO_OFF ((size_t)-1)
+
+typedef struct {
+    size_t bytes;    /* numel * elemsize by shape */
+    size_t extent;   /* largest byte offset + 1 any op touches (>= bytes) */
+    size_t stride;   /* device bytes per frame (0 for weights) */
+    uint8_t *dev;    /* device base */
+    int is_weight;
+    int needed;      /* touched by an op, or graph input/output */
+    int io_in, io_out; /* 1-based graph input / output slot, 0 if none */
+    uint8_t *host;   /* pinned staging for graph I/O: batch * bytes */
+} mtensor_t;
+
+typedef struct {
+    int kind, layer, err;
+    int t_in[4], n_in, t_out; /* tensor indices, -1 if none */
+    /* geometry (conv / pool / concat / upsample share these) */
+    int in_h, in_w, in_c, out_h, out_w, out_c, kh, kw, sh, sw, pt, pl;
+    int nchw, relu, is_mul, is_f32, leaky;
+    int row_pad, oc_pad, c_pad;
+    int ch_off, scale_h, scale_w, bn_n;
+    float cs, f0, f1, f2;
+    size_t n;                 /* elements per frame for element-wise ops */
+    size_t w_off, b_off, lut_off, s_off; /* offsets into the parameter arena */
+    size_t w_blob_off[2];     /* operands that live in the blob mirror */
+    double macs, bytes;       /* algorithmic work per frame */
+    int prof_kind;
+    float last_ms;
+    void *ev0, *ev1;
+} mars_op_t;
+
+typedef struct {
+    mars_model_t pub; /* MUST stay first */
+    int batch, fusion, profiling, deferred;
+    mtensor_t *mt;
+    mars_op_t *ops;
+    int n_ops, cap_ops;
+    /* parameter arena: host image + device copy */
+    uint8_t *arena_host;
+    size_t arena_size, arena_cap;
+    uint8_t *arena_dev;
+    size_t blob_mirror_bytes;
+    /* activations */
+    uint8_t *act_dev;
+    size_t act_bytes;
+    uint8_t *scratch_dev;
+    size_t scratch_per_frame;
+    /* detection tail */
+    void *det_dev;
+    int *det_counts_dev;
+    float *det_lut_dev;
+    int det_cap;
+} mars_model_ext_t;
+
+/* shared host helpers (mars_model.c) */
+int32_t mars_trunc_x86(float x);
+void mars_pack_conv_i8(const int8_t *w, size_t avail, int nchw, int out_c, int in_c, int kh, int kw,
+                       int c_pad, int row_pad, int oc_pad, int8_t *dst);
+
+#endif

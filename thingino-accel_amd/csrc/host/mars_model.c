@@ -1,0 +1,1040 @@
+/*
+ * mars_model.c -- .mars loader, launch planner and executor for MI355X.
+ *
+ * Public behaviour: reference include/mars_runtime.h:79-138, implemented in
+ * the reference by src/mars/mars_runtime.c.  What changes underneath:
+ *   - the 8 MiB round-robin "DDR" arena (mars_runtime.c:205-334) becomes one
+ *     HBM buffer per activation tensor and frame, zero-initialised, sized from
+ *     the byte extents the layers actually touch (no aliasing between live
+ *     tensors; the reference's in-place hazards cannot occur);
+ *   - the per-call dispatch switch (mars_runtime.c:1161-1224) becomes a launch
+ *     plan built once at load: tensor ids resolved, weights re-packed for the
+ *     MFMA kernel, float scales folded on the host exactly as the C code folds
+ *     them, 256-entry LUTs for every int8 transcendental;
+ *   - a frame batch dimension (the reference has none).
+ * Layer semantics, including the quirks, follow the reference line by line;
+ * each planner below cites the lines it mirrors.
+ */
+#include <math.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <time.h>
+
+#include "mars_internal.h"
+#include "nna.h"
+
+#define ALIGN_UP(x, a) (((x) + (size_t)(a) - 1) & ~((size_t)(a) - 1))
+#define NO_TENSOR 0xFFFFFFFFu
+#define MAX_DIM_PRODUCT ((size_t)1 << 40)
+
+static int verbose(void) {
+    static int v = -1;
+    if (v < 0) v = getenv("MARS_VERBOSE") ? 1 : 0;
+    return v;
+}
+#define VLOG(...) do { if (verbose()) fprintf(stderr, "Mars: " __VA_ARGS__); } while (0)
+
+/* ------------------------------------------------------------------ errors */
+static const char *const k_err[] = {
+    "OK", "Invalid magic number", "Version mismatch", "Memory allocation failed",
+    "Invalid file format", "NNA initialization failed", "Layer execution failed",
+    "Invalid tensor", "Invalid layer",
+};
+
+const char *mars_get_error_string(mars_error_t err) {
+    int i = -(int)err;
+    if (i >= 0 && i < (int)(sizeof(k_err) / sizeof(k_err[0]))) return k_err[i];
+    return "Unknown error";
+}
+
+/* ------------------------------------------------------- host arithmetic */
+int32_t mars_trunc_x86(float x) {
+    /* x86 cvttss2si: out of range or NaN -> INT32_MIN */
+    if (x >= -2147483648.0f && x < 2147483648.0f) return (int32_t)x;
+    return INT32_MIN;
+}
+static int sat8(int32_t v) { return v > 127 ? 127 : (v < -128 ? -128 : v); }
+static int q_half_up(float v) { return sat8(mars_trunc_x86(v + 0.5f)); }
+
+static size_t elem_size(uint32_t dtype) {
+    switch (dtype) {
+        case MARS_DTYPE_FLOAT32: case MARS_DTYPE_INT32: return 4;
+        case MARS_DTYPE_INT16: return 2;
+        default: return 1;
+    }
+}
+
+static size_t shape_numel(const mars_tensor_t *d) {
+    size_t n = 1;
+    for (uint32_t i = 0; i < d->ndims && i < MARS_MAX_DIMS; i++) {
+        if (d->shape[i] <= 0) return 0;
+        n *= (size_t)d->shape[i];
+        if (n > MAX_DIM_PRODUCT) return 0;
+    }
+    return n;
+}
+
+/* --------------------------------------------------------- parameter arena */
+static size_t arena_reserve(mars_model_ext_t *m, size_t bytes) {
+    size_t off = ALIGN_UP(m->arena_size, 256);
+    size_t end = off + ALIGN_UP(bytes ? bytes : 1, 256);
+    if (end > m->arena_cap) {
+        size_t cap = m->arena_cap ? m->arena_cap : (1u << 20);
+        while (cap < end) cap *= 2;
+        uint8_t *p = (uint8_t *)realloc(m->arena_host, cap);
+        if (!p) return NO_OFF;
+        memset(p + m->arena_cap, 0, cap - m->arena_cap);
+        m->arena_host = p;
+        m->arena_cap = cap;
+    }
+    m->arena_size = end;
+    return off;
+}
+
+/* bytes [off, off+n) of the weight blob; beyond its end the blob reads as zeros */
+static void blob_read(const mars_model_ext_t *m, size_t off, size_t n, void *dst) {
+    const uint8_t *blob = (const uint8_t *)m->pub.weights;
+    size_t have = m->pub.weights_size;
+    memset(dst, 0, n);
+    if (!blob || off >= have) return;
+    size_t c = have - off < n ? have - off : n;
+    memcpy(dst, blob + off, c);
+}
+
+/* weights -> [oc_pad][k64] rows, each kernel row padded to row_pad bytes.
+ * nchw: source is OIHW and the (transposed) input has c_pad channels. */
+void mars_pack_conv_i8(const int8_t *w, size_t avail, int nchw, int out_c, int in_c, int kh, int kw,
+                       int c_pad, int row_pad, int oc_pad, int8_t *dst) {
+    const int k64 = (int)ALIGN_UP((size_t)kh * row_pad, 64);
+    memset(dst, 0, (size_t)oc_pad * k64);
+    for (int oc = 0; oc < out_c; oc++)
+        for (int ky = 0; ky < kh; ky++)
+            for (int kx = 0; kx < kw; kx++)
+                for (int ic = 0; ic < in_c; ic++) {
+                    size_t src = nchw ? (((size_t)oc * in_c + ic) * kh + ky) * kw + kx
+                                      : (((size_t)oc * kh + ky) * kw + kx) * in_c + ic;
+                    int8_t v = src < avail ? w[src] : 0;
+                    dst[(size_t)oc * k64 + (size_t)ky * row_pad + (size_t)kx * c_pad + ic] = v;
+                }
+}
+
+/* ------------------------------------------------------------------- ops */
+static mars_op_t *new_op(mars_model_ext_t *m, int kind, int layer) {
+    if (m->n_ops == m->cap_ops) {
+        int cap = m->cap_ops ? m->cap_ops * 2 : 64;
+        mars_op_t *p = (mars_op_t *)realloc(m->ops, (size_t)cap * sizeof(mars_op_t));
+        if (!p) return NULL;
+        m->ops = p;
+        m->cap_ops = cap;
+    }
+    mars_op_t *op = &m->ops[m->n_ops++];
+    memset(op, 0, sizeof(*op));
+    op->kind = kind;
+    op->layer = layer;
+    op->t_in[0] = op->t_in[1] = op->t_in[2] = op->t_in[3] = op->t_out = -1;
+    op->w_off = op->b_off = op->lut_off = op->s_off = NO_OFF;
+    op->w_blob_off[0] = op->w_blob_off[1] = NO_OFF;
+    op->prof_kind = 4;
+    return op;
+}
+
+static void fail_op(mars_model_ext_t *m, int layer, int err) {
+    mars_op_t *op = new_op(m, OP_FAIL, layer);
+    if (op) op->err = err;
+}
+
+/* the executor searches tensors by desc.id, first match (mars_runtime.c:516-558, 713-721) */
+static int find_tensor(const mars_model_ext_t *m, uint32_t id) {
+    if (id == NO_TENSOR) return -1;
+    for (uint32_t i = 0; i < m->pub.header.num_tensors; i++)
+        if (m->pub.tensors[i].desc.id == id) return (int)i;
+    return -1;
+}
+
+static void touch(mars_model_ext_t *m, int ti, size_t extent) {
+    if (ti < 0) return;
+    mtensor_t *t = &m->mt[ti];
+    t->needed = 1;
+    if (t->is_weight) {
+        size_t end = (size_t)m->pub.tensors[ti].desc.data_offset + extent;
+        if (end > m->blob_mirror_bytes) m->blob_mirror_bytes = end;
+    } else if (extent > t->extent) {
+        t->extent = extent;
+    }
+}
+
+static size_t lut_i8(mars_model_ext_t *m, const int8_t table[256]) {
+    size_t off = arena_reserve(m, 256);
+    if (off != NO_OFF) memcpy(m->arena_host + off, table, 256);
+    return off;
+}
+
+/* int8 sigmoid of one value, reference mars_runtime.c:758-768 */
+static int sigmoid_q(int q, float in_scale, float out_scale) {
+    float os = out_scale > 0 ? out_scale : 1.0f;
+    float x = (float)q * in_scale;
+    float y = 1.0f / (1.0f + expf(-x));
+    return q_half_up(y / os);
+}
+/* int8 mul/add of one pair, reference mars_runtime.c:822-835 / :889-902 */
+static int binary_q(int is_mul, int a, int b, float sa, float sb, float so) {
+    float inv = 1.0f / (so > 0 ? so : 1.0f);
+    float va = (float)a * sa, vb = (float)b * sb;
+    float y = is_mul ? va * vb : va + vb;
+    return q_half_up(y * inv);
+}
+
+/* ---- CONV2D: reference mars_runtime.c:511-710 */
+static void plan_conv(mars_model_ext_t *m, int li) {
+    const mars_layer_t *L = &m->pub.layers[li].desc;
+    const mars_conv_params_t *cp = &L->params.conv;
+    int ti = find_tensor(m, L->input_tensor_ids[0]);
+    int to = find_tensor(m, L->output_tensor_ids[0]);
+    int tw = find_tensor(m, cp->weight_tensor_id);
+    int tb = find_tensor(m, cp->bias_tensor_id);
+    if (ti < 0 || to < 0 || tw < 0) { fail_op(m, li, MARS_ERR_INVALID_TENSOR); return; }
+    const mars_tensor_t *in = &m->pub.tensors[ti].desc, *out = &m->pub.tensors[to].desc;
+    const mars_tensor_t *w = &m->pub.tensors[tw].desc;
+    /* weights / bias must come from the blob, the result must be an activation, and a
+     * parallel kernel cannot run a layer in place */
+    if (!m->mt[tw].is_weight || (tb >= 0 && !m->mt[tb].is_weight) || m->mt[to].is_weight || ti == to) {
+        fail_op(m, li, MARS_ERR_LAYER_FAILED);
+        return;
+    }
+    const int in_nhwc = in->format == MARS_FORMAT_NHWC, out_nhwc = out->format == MARS_FORMAT_NHWC;
+    int in_h, in_w, in_c, out_h, out_w, out_c;
+    if (in_nhwc) { in_h = in->shape[1]; in_w = in->shape[2]; in_c = in->shape[3]; }
+    else         { in_c = in->shape[1]; in_h = in->shape[2]; in_w = in->shape[3]; }
+    if (out_nhwc) { out_h = out->shape[1]; out_w = out->shape[2]; out_c = out->shape[3]; }
+    else          { out_c = out->shape[1]; out_h = out->shape[2]; out_w = out->shape[3]; }
+    const int kh = (int)cp->kernel_h, kw = (int)cp->kernel_w, sh = (int)cp->stride_h, sw = (int)cp->stride_w;
+    int pt = 0, pl = 0;
+    if (cp->padding == MARS_PAD_SAME) { /* EXPLICIT / VALID run unpadded (:592-598) */
+        int32_t ph = (int32_t)((uint32_t)(out_h - 1) * cp->stride_h + cp->kernel_h - (uint32_t)in_h);
+        int32_t pw = (int32_t)((uint32_t)(out_w - 1) * cp->stride_w + cp->kernel_w - (uint32_t)in_w);
+        pt = ph / 2;
+        pl = pw / 2;
+    }
+    if (out_h <= 0 || out_w <= 0 || out_c <= 0) return; /* empty loops in the reference: nothing is written */
+    if (in_h <= 0 || in_w <= 0 || in_c <= 0 || kh <= 0 || kw <= 0 || sh < 0 || sw < 0 || kh > 64 || kw > 64 ||
+        (size_t)in_h * in_w * in_c > MAX_DIM_PRODUCT || (size_t)out_h * out_w * out_c > MAX_DIM_PRODUCT) {
+        fail_op(m, li, MARS_ERR_LAYER_FAILED); /* degenerate geometry this build does not launch */
+        return;
+    }
+    const int is_f32 = in->dtype == MARS_DTYPE_FLOAT32;
+    mars_op_t *op = new_op(m, is_f32 ? OP_CONV_F32 : OP_CONV_I8, li);
+    if (!op) return;
+    op->t_in[0] = ti; op->n_in = 1; op->t_out = to;
+    op->in_h = in_h; op->in_w = in_w; op->in_c = in_c;
+    op->out_h = out_h; op->out_w = out_w; op->out_c = out_c;
+    op->kh = kh; op->kw = kw; op->sh = sh; op->sw = sw; op->pt = pt; op->pl = pl;
+    op->is_f32 = is_f32;
+    op->macs = (double)out_h * out_w * out_c * in_c * kh * kw;
+    const size_t es = is_f32 ? 4 : 1;
+    touch(m, ti, (size_t)in_h * in_w * in_c * es);
+    touch(m, to, (size_t)out_h * out_w * out_c * es);
+    m->mt[tw].needed = 1;
+    op->bytes = (double)((size_t)in_h * in_w * in_c + (size_t)out_h * out_w * out_c) * es;
+    const size_t wcount = (size_t)out_c * in_c * kh * kw;
+
+    if (is_f32) {
+        op->prof_kind = 1;
+        op->w_off = arena_reserve(m, wcount * 4);
+        if (op->w_off == NO_OFF) return;
+        if (!m->deferred) blob_read(m, (size_t)w->data_offset, wcount * 4, m->arena_host + op->w_off);
+        if (tb >= 0) {
+            op->b_off = arena_reserve(m, (size_t)out_c * 4);
+            if (!m->deferred)
+                blob_read(m, (size_t)m->pub.tensors[tb].desc.data_offset, (size_t)out_c * 4, m->arena_host + op->b_off);
+        }
+        if (cp->activation == MARS_ACT_RELU) { /* byte-wise clamp over H*W*C BYTES of the f32 result (:700-707) */
+            mars_op_t *r = new_op(m, OP_RELU_BYTES, li);
+            if (r) { r->t_out = to; r->n = (size_t)out_h * out_w * out_c; r->prof_kind = 2; r->bytes = 2.0 * r->n; }
+        }
+        return;
+    }
+
+    op->prof_kind = 0;
+    op->nchw = !in_nhwc; /* the kernel is chosen by the INPUT tag (:640-662) */
+    op->c_pad = op->nchw ? (int)ALIGN_UP((size_t)in_c, 16) : in_c;
+    mhip_conv_i8_pack_geom(op->c_pad, kw, out_c, &op->row_pad, &op->oc_pad);
+    const size_t k64 = ALIGN_UP((size_t)kh * op->row_pad, 64);
+    op->w_off = arena_reserve(m, (size_t)op->oc_pad * k64);
+    if (op->w_off == NO_OFF) return;
+    if (!m->deferred) {
+        int8_t *tmp = (int8_t *)malloc(wcount ? wcount : 1);
+        if (!tmp) return;
+        blob_read(m, (size_t)w->data_offset, wcount, tmp);
+        mars_pack_conv_i8(tmp, wcount, op->nchw, out_c, in_c, kh, kw, op->c_pad, op->row_pad, op->oc_pad,
+                          (int8_t *)m->arena_host + op->w_off);
+        free(tmp);
+    }
+    if (tb >= 0) { /* raw bytes reinterpreted as int32, whatever the tensor says it is (:645,656) */
+        op->b_off = arena_reserve(m, (size_t)op->oc_pad * 4);
+        if (op->b_off != NO_OFF && !m->deferred)
+            blob_read(m, (size_t)m->pub.tensors[tb].desc.data_offset, (size_t)out_c * 4, m->arena_host + op->b_off);
+    }
+    op->cs = (in->scale * w->scale) / out->scale; /* float32, this order (mxu_conv.c:639,722) */
+    op->relu = cp->activation == MARS_ACT_RELU;
+    if (op->nchw) {
+        size_t need = (size_t)in_h * in_w * op->c_pad;
+        if (need > m->scratch_per_frame) m->scratch_per_frame = need;
+        op->bytes += 2.0 * need;
+    }
+}
+
+static size_t numel_of(const mars_model_ext_t *m, int ti) { return shape_numel(&m->pub.tensors[ti].desc); }
+
+/* ---- SIGMOID / RELU family: unary maps (mars_runtime.c:724-771, 1047-1089) */
+static void plan_unary(mars_model_ext_t *m, int li) {
+    const mars_layer_t *L = &m->pub.layers[li].desc;
+    int ti = find_tensor(m, L->input_tensor_ids[0]), to = find_tensor(m, L->output_tensor_ids[0]);
+    if (ti < 0 || to < 0) { fail_op(m, li, MARS_ERR_INVALID_TENSOR); return; }
+    if (m->mt[to].is_weight) { fail_op(m, li, MARS_ERR_LAYER_FAILED); return; }
+    const mars_tensor_t *in = &m->pub.tensors[ti].desc, *out = &m->pub.tensors[to].desc;
+    const size_t n = numel_of(m, ti);
+    if (n == 0) return;
+    const int is_sig = L->type == MARS_LAYER_SIGMOID;
+    const int leaky = L->type == MARS_LAYER_LEAKY_RELU;
+    if (in->dtype == MARS_DTYPE_FLOAT32) {
+        mars_op_t *op = new_op(m, is_sig ? OP_SIGMOID_F32 : OP_RELU_F32, li);
+        if (!op) return;
+        op->t_in[0] = ti; op->n_in = 1; op->t_out = to; op->n = n;
+        op->f0 = leaky ? 0.01f : 0.0f; /* slope is a constant in the reference (:1064) */
+        op->prof_kind = 2; op->bytes = 8.0 * n;
+        touch(m, ti, n * 4); touch(m, to, n * 4);
+        return;
+    }
+    int8_t tab[256];
+    for (int q = -128; q < 128; q++) {
+        int r;
+        if (is_sig) r = sigmoid_q(q, in->scale, out->scale);
+        else if (q > 0) r = q;
+        else if (leaky) { int32_t v = mars_trunc_x86((float)q * 0.01f); r = (int8_t)(v < -128 ? -128 : v); }
+        else r = 0; /* RELU and RELU6 alike: no upper clamp (:1179-1182) */
+        tab[q + 128] = (int8_t)r;
+    }
+    mars_op_t *op = new_op(m, OP_LUT_I8, li);
+    if (!op) return;
+    op->t_in[0] = ti; op->n_in = 1; op->t_out = to; op->n = n;
+    op->lut_off = lut_i8(m, tab);
+    op->prof_kind = 2; op->bytes = 2.0 * n;
+    touch(m, ti, n); touch(m, to, n);
+}
+
+/* ---- MUL / ADD (mars_runtime.c:774-905): extent from operand A only */
+static void plan_binary(mars_model_ext_t *m, int li) {
+    const mars_layer_t *L = &m->pub.layers[li].desc;
+    int ta = find_tensor(m, L->input_tensor_ids[0]), tb = find_tensor(m, L->input_tensor_ids[1]);
+    int to = find_tensor(m, L->output_tensor_ids[0]);
+    if (ta < 0 || tb < 0 || to < 0) { fail_op(m, li, MARS_ERR_INVALID_TENSOR); return; }
+    if (m->mt[to].is_weight) { fail_op(m, li, MARS_ERR_LAYER_FAILED); return; }
+    const mars_tensor_t *a = &m->pub.tensors[ta].desc, *b = &m->pub.tensors[tb].desc, *o = &m->pub.tensors[to].desc;
+    const size_t n = numel_of(m, ta);
+    if (n == 0) return;
+    const int f32 = a->dtype == MARS_DTYPE_FLOAT32;
+    mars_op_t *op = new_op(m, f32 ? OP_BINARY_F32 : OP_BINARY_I8, li);
+    if (!op) return;
+    op->t_in[0] = ta; op->t_in[1] = tb; op->n_in = 2; op->t_out = to; op->n = n;
+    op->is_mul = L->type == MARS_LAYER_MUL;
+    op->f0 = a->scale; op->f1 = b->scale;
+    op->f2 = 1.0f / (o->scale > 0 ? o->scale : 1.0f);
+    op->prof_kind = 2; op->bytes = 3.0 * n * (f32 ? 4 : 1);
+    const size_t es = f32 ? 4 : 1;
+    touch(m, ta, n * es); touch(m, tb, n * es); touch(m, to, n * es);
+}
+
+/* ---- MAXPOOL (mars_runtime.c:908-960) */
+static void plan_maxpool(mars_model_ext_t *m, int li) {
+    const mars_layer_t *L = &m->pub.layers[li].desc;
+    const mars_pool_params_t *pp = &L->params.pool;
+    int ti = find_tensor(m, L->input_tensor_ids[0]), to = find_tensor(m, L->output_tensor_ids[0]);
+    if (ti < 0 || to < 0) { fail_op(m, li, MARS_ERR_INVALID_TENSOR); return; }
+    if (m->mt[to].is_weight || ti == to) { fail_op(m, li, MARS_ERR_LAYER_FAILED); return; }
+    const mars_tensor_t *in = &m->pub.tensors[ti].desc, *out = &m->pub.tensors[to].desc;
+    int in_h = in->shape[1], in_w = in->shape[2], ch = in->shape[3], out_h = out->shape[1], out_w = out->shape[2];
+    if (out_h <= 0 || out_w <= 0 || ch <= 0) return;
+    if (in_h < 0 || in_w < 0 || (int)pp->kernel_h < 0 || (int)pp->kernel_w < 0 || (int)pp->stride_h < 0 ||
+        (int)pp->stride_w < 0 || pp->kernel_h > 4096 || pp->kernel_w > 4096) {
+        fail_op(m, li, MARS_ERR_LAYER_FAILED);
+        return;
+    }
+    mars_op_t *op = new_op(m, OP_MAXPOOL, li);
+    if (!op) return;
+    op->t_in[0] = ti; op->n_in = 1; op->t_out = to;
+    op->in_h = in_h; op->in_w = in_w; op->in_c = ch; op->out_h = out_h; op->out_w = out_w;
+    op->kh = (int)pp->kernel_h; op->kw = (int)pp->kernel_w; op->sh = (int)pp->stride_h; op->sw = (int)pp->stride_w;
+    op->prof_kind = 3;
+    op->bytes = (double)in_h * in_w * ch + (double)out_h * out_w * ch;
+    /* reads stay inside in_h*in_w*ch by the window clip; writes cover out_h*out_w*ch */
+    if (op->kh > 0 && op->kw > 0) touch(m, ti, (size_t)in_h * in_w * ch);
+    else m->mt[ti].needed = 1;
+    touch(m, to, (size_t)out_h * out_w * ch);
+}
+
+/* ---- CONCAT (mars_runtime.c:963-1000): one copy kernel per input, in order */
+static void plan_concat(mars_model_ext_t *m, int li) {
+    const mars_layer_t *L = &m->pub.layers[li].desc;
+    int to = find_tensor(m, L->output_tensor_ids[0]);
+    if (to < 0) { fail_op(m, li, MARS_ERR_INVALID_TENSOR); return; }
+    if (m->mt[to].is_weight) { fail_op(m, li, MARS_ERR_LAYER_FAILED); return; }
+    const mars_tensor_t *out = &m->pub.tensors[to].desc;
+    const int out_h = out->shape[1], out_w = out->shape[2], out_c = out->shape[3];
+    if (L->num_inputs > 4) { fail_op(m, li, MARS_ERR_INVALID_LAYER); return; }
+    int off = 0;
+    for (uint32_t k = 0; k < L->num_inputs; k++) {
+        int ti = find_tensor(m, L->input_tensor_ids[k]);
+        if (ti < 0) continue; /* skipped without advancing the channel offset (:980) */
+        const int in_c = m->pub.tensors[ti].desc.shape[3];
+        if (out_h > 0 && out_w > 0 && in_c > 0) {
+            /* pixel slots of one input may not overlap each other in a parallel copy */
+            if (in_c > out_c || out_c <= 0 || ti == to) { fail_op(m, li, MARS_ERR_LAYER_FAILED); return; }
+            mars_op_t *op = new_op(m, OP_CONCAT_SLICE, li);
+            if (!op) return;
+            op->t_in[0] = ti; op->n_in = 1; op->t_out = to;
+            op->out_h = out_h; op->out_w = out_w; op->in_c = in_c; op->out_c = out_c; op->ch_off = off;
+            op->prof_kind = 3;
+            const size_t npix = (size_t)out_h * out_w;
+            op->bytes = 2.0 * npix * in_c;
+            touch(m, ti, npix * in_c);
+            touch(m, to, (npix - 1) * out_c + off + in_c);
+        }
+        off += in_c;
+    }
+}
+
+/* ---- UPSAMPLE (mars_runtime.c:1003-1044) */
+static void plan_upsample(mars_model_ext_t *m, int li) {
+    const mars_layer_t *L = &m->pub.layers[li].desc;
+    const mars_upsample_params_t *up = &L->params.upsample;
+    int ti = find_tensor(m, L->input_tensor_ids[0]), to = find_tensor(m, L->output_tensor_ids[0]);
+    if (ti < 0 || to < 0) { fail_op(m, li, MARS_ERR_INVALID_TENSOR); return; }
+    if (m->mt[to].is_weight || ti == to) { fail_op(m, li, MARS_ERR_LAYER_FAILED); return; }
+    const mars_tensor_t *in = &m->pub.tensors[ti].desc, *out = &m->pub.tensors[to].desc;
+    int in_h = in->shape[1], in_w = in->shape[2], ch = in->shape[3], out_h = out->shape[1], out_w = out->shape[2];
+    if ((up->scale_h == 0 && in_h == 0) || (up->scale_w == 0 && in_w == 0)) { fail_op(m, li, MARS_ERR_LAYER_FAILED); return; }
+    int sh = up->scale_h > 0 ? (int)up->scale_h : out_h / in_h;
+    int sw = up->scale_w > 0 ? (int)up->scale_w : out_w / in_w;
+    if (out_h <= 0 || out_w <= 0 || ch <= 0) return;
+    if (sh <= 0 || sw <= 0 || in_h <= 0 || in_w <= 0) { fail_op(m, li, MARS_ERR_LAYER_FAILED); return; }
+    mars_op_t *op = new_op(m, OP_UPSAMPLE, li);
+    if (!op) return;
+    op->t_in[0] = ti; op->n_in = 1; op->t_out = to;
+    op->in_h = in_h; op->in_w = in_w; op->in_c = ch; op->out_h = out_h; op->out_w = out_w;
+    op->scale_h = sh; op->scale_w = sw;
+    op->prof_kind = 3;
+    op->bytes = (double)in_h * in_w * ch + (double)out_h * out_w * ch;
+    touch(m, ti, (size_t)in_h * in_w * ch);
+    touch(m, to, (size_t)out_h * out_w * ch);
+}
+
+/* ---- BATCHNORM (mars_runtime.c:1092-1158) */
+static void plan_batchnorm(mars_model_ext_t *m, int li) {
+    const mars_layer_t *L = &m->pub.layers[li].desc;
+    int ti = find_tensor(m, L->input_tensor_ids[0]), to = find_tensor(m, L->output_tensor_ids[0]);
+    int ts = find_tensor(m, L->input_tensor_ids[1]), tb = find_tensor(m, L->input_tensor_ids[2]);
+    if (ti < 0 || to < 0) { fail_op(m, li, MARS_ERR_INVALID_TENSOR); return; }
+    if (m->mt[to].is_weight || (ts >= 0 && !m->mt[ts].is_weight) || (tb >= 0 && !m->mt[tb].is_weight)) {
+        fail_op(m, li, MARS_ERR_LAYER_FAILED);
+        return;
+    }
+    const mars_tensor_t *in = &m->pub.tensors[ti].desc, *out = &m->pub.tensors[to].desc;
+    int n = in->shape[0] > 0 ? in->shape[0] : 1, c = in->shape[1] > 0 ? in->shape[1] : 1;
+    int h = in->shape[2] > 0 ? in->shape[2] : 1, w = in->shape[3] > 0 ? in->shape[3] : 1;
+    if ((size_t)n * c * h * w > MAX_DIM_PRODUCT) { fail_op(m, li, MARS_ERR_LAYER_FAILED); return; }
+    const int f32 = in->dtype == MARS_DTYPE_FLOAT32;
+    mars_op_t *op = new_op(m, OP_BN, li);
+    if (!op) return;
+    op->t_in[0] = ti; op->n_in = 1; op->t_out = to;
+    op->bn_n = n; op->in_c = c; op->in_h = h; op->in_w = w; op->is_f32 = f32;
+    op->f0 = in->scale > 0 ? in->scale : 1.0f;
+    op->f1 = out->scale > 0 ? out->scale : 1.0f;
+    if (ts >= 0) {
+        op->s_off = arena_reserve(m, (size_t)c * 4);
+        if (op->s_off != NO_OFF && !m->deferred)
+            blob_read(m, (size_t)m->pub.tensors[ts].desc.data_offset, (size_t)c * 4, m->arena_host + op->s_off);
+    }
+    if (tb >= 0) {
+        op->b_off = arena_reserve(m, (size_t)c * 4);
+        if (op->b_off != NO_OFF && !m->deferred)
+            blob_read(m, (size_t)m->pub.tensors[tb].desc.data_offset, (size_t)c * 4, m->arena_host + op->b_off);
+    }
+    const size_t total = (size_t)n * c * h * w * (f32 ? 4 : 1);
+    op->prof_kind = 2; op->bytes = 2.0 * total;
+    touch(m, ti, total); touch(m, to, total);
+}
+
+/* dispatcher, reference mars_runtime.c:1161-1224 */
+static void plan_layer(mars_model_ext_t *m, int li) {
+    switch (m->pub.layers[li].desc.type) {
+        case MARS_LAYER_CONV2D: plan_conv(m, li); break;
+        case MARS_LAYER_SIGMOID:
+        case MARS_LAYER_RELU:
+        case MARS_LAYER_RELU6:
+        case MARS_LAYER_LEAKY_RELU: plan_unary(m, li); break;
+        case MARS_LAYER_MUL:
+        case MARS_LAYER_ADD: plan_binary(m, li); break;
+        case MARS_LAYER_MAXPOOL: plan_maxpool(m, li); break;
+        case MARS_LAYER_CONCAT: plan_concat(m, li); break;
+        case MARS_LAYER_UPSAMPLE: plan_upsample(m, li); break;
+        case MARS_LAYER_BATCHNORM: plan_batchnorm(m, li); break;
+        case MARS_LAYER_DEPTHWISE_CONV2D: /* accepted, not executed (:1168-1213) */
+        case MARS_LAYER_AVGPOOL:
+        case MARS_LAYER_SILU:
+        case MARS_LAYER_RESHAPE:
+        case MARS_LAYER_TRANSPOSE:
+        case MARS_LAYER_SOFTMAX: break;
+        default: fail_op(m, li, MARS_ERR_INVALID_LAYER); break; /* GLOBAL_AVGPOOL, FC, unknown (:1218-1220) */
+    }
+}
+
+/* ------------------------------------------------------------------ fusion
+ * conv -> sigmoid -> mul (SiLU as exported to ONNX) collapses into the conv
+ * epilogue: every value of the chain is a function of the conv's int8 result
+ * q1 alone, so lut[q1] = mul(q1, sigmoid(q1)) computed on the host with the
+ * reference's own float steps is bit-identical.
+ * Only done when q1 and sigmoid(q1) have no other reader and are not outputs. */
+static void fuse_silu(mars_model_ext_t *m) {
+    const int nt = (int)m->pub.header.num_tensors;
+    int *readers = (int *)calloc((size_t)nt + 1, sizeof(int));
+    int *writers = (int *)calloc((size_t)nt + 1, sizeof(int));
+    if (!readers || !writers) { free(readers); free(writers); return; }
+    for (int i = 0; i < m->n_ops; i++) {
+        for (int k = 0; k < m->ops[i].n_in; k++)
+            if (m->ops[i].t_in[k] >= 0) readers[m->ops[i].t_in[k]]++;
+        if (m->ops[i].t_out >= 0) writers[m->ops[i].t_out]++;
+    }
+    for (int i = 0; i + 2 < m->n_ops; i++) {
+        mars_op_t *c = &m->ops[i], *s = &m->ops[i + 1], *mu = &m->ops[i + 2];
+        if (c->kind != OP_CONV_I8 || s->kind != OP_LUT_I8 || mu->kind != OP_BINARY_I8 || !mu->is_mul) continue;
+        if (m->pub.layers[s->layer].desc.type != MARS_LAYER_SIGMOID) continue;
+        const int q1 = c->t_out, q2 = s->t_out, q3 = mu->t_out;
+        if (s->t_in[0] != q1) continue;
+        const int fwd = mu->t_in[0] == q1 && mu->t_in[1] == q2, rev = mu->t_in[0] == q2 && mu->t_in[1] == q1;
+        if (!fwd && !rev) continue;
+        if (q1 == q2 || q2 == q3 || q1 == q3) continue;
+        if (readers[q1] != 2 || readers[q2] != 1 || writers[q1] != 1 || writers[q2] != 1 || writers[q3] != 1) continue;
+        if (m->mt[q1].io_out || m->mt[q2].io_out || m->mt[q1].io_in || m->mt[q2].io_in) continue;
+        const size_t n1 = (size_t)c->out_h * c->out_w * c->out_c;
+        if (s->n != n1 || mu->n != n1) continue; /* the chain must cover exactly the conv's result */
+        const mars_tensor_t *d1 = &m->pub.tensors[q1].desc, *d2 = &m->pub.tensors[q2].desc, *d3 = &m->pub.tensors[q3].desc;
+        int8_t tab[256];
+        for (int q = -128; q < 128; q++) {
+            int sg = sigmoid_q(q, d1->scale, d2->scale);
+            tab[q + 128] = (int8_t)(fwd ? binary_q(1, q, sg, d1->scale, d2->scale, d3->scale)
+                                        : binary_q(1, sg, q, d2->scale, d1->scale, d3->scale));
+        }
+        c->lut_off = lut_i8(m, tab);
+        c->t_out = q3;
+        c->bytes += 0; /* same bytes written, to q3 instead of q1 */
+        touch(m, q3, n1);
+        m->mt[q1].needed = 0;
+        m->mt[q2].needed = 0;
+        /* drop the two element-wise ops */
+        memmove(&m->ops[i + 1], &m->ops[i + 3], (size_t)(m->n_ops - i - 3) * sizeof(mars_op_t));
+        m->n_ops -= 2;
+    }
+    free(readers);
+    free(writers);
+}
+
+/* ------------------------------------------------------------------- load */
+static void free_device_state(mars_model_ext_t *m) {
+    if (m->act_dev) mhip_free(m->act_dev);
+    if (m->scratch_dev) mhip_free(m->scratch_dev);
+    m->act_dev = m->scratch_dev = NULL;
+    for (uint32_t i = 0; m->mt && i < m->pub.header.num_tensors; i++) {
+        if (m->mt[i].host) mhip_host_free(m->mt[i].host);
+        m->mt[i].host = NULL;
+        if (!m->mt[i].is_weight) m->mt[i].dev = NULL;
+    }
+    if (m->det_dev) mhip_free(m->det_dev);
+    if (m->det_counts_dev) mhip_free(m->det_counts_dev);
+    m->det_dev = NULL;
+    m->det_counts_dev = NULL;
+    m->det_cap = 0;
+}
+
+static void free_ops(mars_model_ext_t *m) {
+    for (int i = 0; i < m->n_ops; i++) {
+        if (m->ops[i].ev0) mhip_event_destroy(m->ops[i].ev0);
+        if (m->ops[i].ev1) mhip_event_destroy(m->ops[i].ev1);
+    }
+    free(m->ops);
+    m->ops = NULL;
+    m->n_ops = m->cap_ops = 0;
+}
+
+void mars_free(mars_model_t *model) {
+    if (!model) return;
+    mars_model_ext_t *m = (mars_model_ext_t *)model;
+    if (mhip_ready()) mhip_sync();
+    free_device_state(m);
+    free_ops(m);
+    if (m->arena_dev) mhip_free(m->arena_dev);
+    if (m->det_lut_dev) mhip_free(m->det_lut_dev);
+    free(m->arena_host);
+    free(m->mt);
+    free(m->pub.weights);
+    free(m->pub.layers);
+    free(m->pub.tensors);
+    free(m);
+}
+
+static mars_error_t build_plan(mars_model_ext_t *m) {
+    const uint32_t nt = m->pub.header.num_tensors, nl = m->pub.header.num_layers;
+    free_ops(m);
+    m->arena_size = 0;
+    if (m->arena_host) memset(m->arena_host, 0, m->arena_cap); /* re-plans must not see stale bytes */
+    m->scratch_per_frame = 0;
+    m->blob_mirror_bytes = m->pub.weights_size;
+    for (uint32_t i = 0; i < nt; i++) {
+        m->mt[i].extent = m->mt[i].bytes;
+        m->mt[i].needed = (m->mt[i].io_in || m->mt[i].io_out) ? 1 : 0;
+    }
+    /* slot 0 of the arena: mirror of the raw blob (element-wise layers may read weight
+     * tensors directly); sized after planning, so reserve generously now */
+    for (uint32_t i = 0; i < nl; i++) plan_layer(m, (int)i);
+    if (m->fusion >= 1) fuse_silu(m);
+    return MARS_OK;
+}
+
+static mars_error_t upload_params(mars_model_ext_t *m) {
+    /* final arena = [planned entries][blob mirror]; mirror appended last so its size is known */
+    size_t mirror_off = arena_reserve(m, m->blob_mirror_bytes + 64);
+    if (mirror_off == NO_OFF) return MARS_ERR_ALLOC_FAILED;
+    if (!m->deferred) blob_read(m, 0, m->blob_mirror_bytes, m->arena_host + mirror_off);
+    if (m->arena_dev) mhip_free(m->arena_dev);
+    m->arena_dev = (uint8_t *)mhip_malloc(m->arena_size);
+    if (!m->arena_dev) return MARS_ERR_ALLOC_FAILED;
+    if (mhip_h2d_async(m->arena_dev, m->arena_host, m->arena_size) || mhip_sync()) return MARS_ERR_NNA_INIT_FAILED;
+    for (uint32_t i = 0; i < m->pub.header.num_tensors; i++) {
+        if (!m->mt[i].is_weight) continue;
+        m->mt[i].dev = m->arena_dev + mirror_off + (size_t)m->pub.tensors[i].desc.data_offset;
+        m->mt[i].stride = 0;
+        m->pub.tensors[i].paddr = m->mt[i].dev;
+    }
+    m->pub.ddr_paddr = m->arena_dev;
+    m->pub.ddr_size = m->arena_size;
+    return MARS_OK;
+}
+
+static mars_error_t alloc_batch(mars_model_ext_t *m, int n) {
+    const uint32_t nt = m->pub.header.num_tensors;
+    if (mhip_sync()) return MARS_ERR_LAYER_FAILED;
+    free_device_state(m);
+    size_t per_frame = 0;
+    for (uint32_t i = 0; i < nt; i++) {
+        mtensor_t *t = &m->mt[i];
+        if (t->is_weight || !t->needed) continue;
+        t->stride = ALIGN_UP(t->extent > t->bytes ? t->extent : t->bytes, 256);
+        if (t->stride == 0) t->stride = 256;
+        per_frame += t->stride;
+    }
+    m->act_bytes = per_frame * (size_t)n;
+    m->act_dev = (uint8_t *)mhip_malloc(m->act_bytes);
+    if (!m->act_dev) return MARS_ERR_ALLOC_FAILED;
+    if (mhip_memset_async(m->act_dev, 0, m->act_bytes)) return MARS_ERR_ALLOC_FAILED;
+    size_t off = 0;
+    for (uint32_t i = 0; i < nt; i++) {
+        mtensor_t *t = &m->mt[i];
+        mars_runtime_tensor_t *rt = &m->pub.tensors[i];
+        if (t->is_weight) continue;
+        rt->vaddr = NULL; rt->paddr = NULL; rt->alloc_size = 0;
+        if (!t->needed) continue;
+        t->dev = m->act_dev + off;
+        off += t->stride * (size_t)n;
+        rt->paddr = t->dev;
+        rt->alloc_size = t->stride * (size_t)n;
+        if (t->io_in || t->io_out) {
+            size_t hb = t->bytes * (size_t)n;
+            t->host = (uint8_t *)mhip_host_alloc(hb ? hb : 64);
+            if (!t->host) return MARS_ERR_ALLOC_FAILED;
+            memset(t->host, 0, hb);
+            rt->vaddr = t->host;
+            rt->alloc_size = hb; /* what a caller may fill / read through vaddr (mars_test.c:73-84) */
+        }
+    }
+    if (m->scratch_per_frame) {
+        m->scratch_dev = (uint8_t *)mhip_malloc(ALIGN_UP(m->scratch_per_frame, 256) * (size_t)n);
+        if (!m->scratch_dev) return MARS_ERR_ALLOC_FAILED;
+    }
+    m->batch = n;
+    return mhip_sync() ? MARS_ERR_ALLOC_FAILED : MARS_OK;
+}
+
+mars_error_t mars_hip_load_memory_ex(const void *data, size_t size, unsigned flags, mars_model_t **out_model) {
+    if (!data || !out_model || size < sizeof(mars_header_t)) return MARS_ERR_INVALID_FILE;
+    const uint8_t *p = (const uint8_t *)data;
+    mars_header_t h;
+    memcpy(&h, p, sizeof(h));
+    if (h.magic != MARS_MAGIC) {
+        VLOG("Invalid magic 0x%08x (expected 0x%08x)\n", h.magic, MARS_MAGIC);
+        return MARS_ERR_INVALID_MAGIC;
+    }
+    if (h.version_major != MARS_VERSION_MAJOR) return MARS_ERR_VERSION_MISMATCH;
+    /* superset of the reference: it trusts every count and offset (mars_runtime.c:172-200, 220) */
+    if (h.num_tensors > 65536 || h.num_layers > 65536 || h.num_inputs > 4 || h.num_outputs > 4) return MARS_ERR_INVALID_FILE;
+    const size_t tables = sizeof(h) + (size_t)h.num_tensors * sizeof(mars_tensor_t) + (size_t)h.num_layers * sizeof(mars_layer_t);
+    if (tables > size) return MARS_ERR_INVALID_FILE;
+    const int deferred = (flags & MARS_HIP_LOAD_DEFER_WEIGHTS) != 0;
+    if (!deferred && h.weights_size > 0 && (h.weights_offset > size || h.weights_size > size - h.weights_offset))
+        return MARS_ERR_INVALID_FILE;
+    if (h.weights_size > ((uint64_t)1 << 36)) return MARS_ERR_INVALID_FILE;
+
+    mars_model_ext_t *m = (mars_model_ext_t *)calloc(1, sizeof(*m));
+    if (!m) return MARS_ERR_ALLOC_FAILED;
+    m->pub.header = h;
+    m->fusion = getenv("MARS_HIP_FUSION") ? atoi(getenv("MARS_HIP_FUSION")) : 1;
+    m->deferred = deferred;
+    m->pub.tensors = (mars_runtime_tensor_t *)calloc(h.num_tensors ? h.num_tensors : 1, sizeof(mars_runtime_tensor_t));
+    m->pub.layers = (mars_runtime_layer_t *)calloc(h.num_layers ? h.num_layers : 1, sizeof(mars_runtime_layer_t));
+    m->mt = (mtensor_t *)calloc(h.num_tensors ? h.num_tensors : 1, sizeof(mtensor_t));
+    if (!m->pub.tensors || !m->pub.layers || !m->mt) { mars_free(&m->pub); return MARS_ERR_ALLOC_FAILED; }
+    const uint8_t *q = p + sizeof(h);
+    for (uint32_t i = 0; i < h.num_tensors; i++, q += sizeof(mars_tensor_t)) memcpy(&m->pub.tensors[i].desc, q, sizeof(mars_tensor_t));
+    for (uint32_t i = 0; i < h.num_layers; i++, q += sizeof(mars_layer_t)) memcpy(&m->pub.layers[i].desc, q, sizeof(mars_layer_t));
+
+    m->pub.weights_size = (size_t)h.weights_size;
+    if (h.weights_size) {
+        m->pub.weights = calloc(1, (size_t)h.weights_size);
+        if (!m->pub.weights) { mars_free(&m->pub); return MARS_ERR_ALLOC_FAILED; }
+        if (!deferred) memcpy(m->pub.weights, p + h.weights_offset, (size_t)h.weights_size);
+    }
+    m->pub.ddr_base = m->pub.weights;
+    for (uint32_t i = 0; i < h.num_tensors; i++) {
+        mars_runtime_tensor_t *rt = &m->pub.tensors[i];
+        if (rt->desc.ndims > MARS_MAX_DIMS) { mars_free(&m->pub); return MARS_ERR_INVALID_FILE; }
+        m->mt[i].bytes = shape_numel(&rt->desc) * elem_size(rt->desc.dtype);
+        if (rt->desc.data_size > 0) {
+            if (rt->desc.data_offset > h.weights_size) { mars_free(&m->pub); return MARS_ERR_INVALID_FILE; }
+            m->mt[i].is_weight = 1;
+            rt->vaddr = (uint8_t *)m->pub.weights + rt->desc.data_offset;
+            rt->alloc_size = (size_t)rt->desc.data_size;
+        }
+    }
+    for (uint32_t i = 0; i < h.num_inputs; i++) {
+        uint32_t id = h.input_tensor_ids[i];
+        if (id < h.num_tensors && !m->mt[id].is_weight) m->mt[id].io_in = (int)i + 1;
+    }
+    for (uint32_t i = 0; i < h.num_outputs; i++) {
+        uint32_t id = h.output_tensor_ids[i];
+        if (id < h.num_tensors && !m->mt[id].is_weight) m->mt[id].io_out = (int)i + 1;
+    }
+
+    mars_error_t err = build_plan(m);
+    if (err != MARS_OK) { mars_free(&m->pub); return err; }
+    VLOG("%u layers -> %d launches, parameter arena %zu bytes\n", h.num_layers, m->n_ops, m->arena_size);
+
+    /* everything above is host-only; from here on a GPU is required.  No CPU fallback. */
+    if (!nna_is_ready() || !mhip_ready()) {
+        fprintf(stderr, "Mars: no initialised MI355X device (call nna_init first); refusing to load\n");
+        mars_free(&m->pub);
+        return MARS_ERR_NNA_INIT_FAILED;
+    }
+    err = upload_params(m);
+    if (err == MARS_OK) err = alloc_batch(m, 1);
+    if (err != MARS_OK) { mars_free(&m->pub); return err; }
+    *out_model = &m->pub;
+    return MARS_OK;
+}
+
+mars_error_t mars_load_memory(const void *data, size_t size, mars_model_t **model) {
+    return mars_hip_load_memory_ex(data, size, 0, model);
+}
+
+mars_error_t mars_load_file(const char *path, mars_model_t **model) {
+    if (!path || !model) return MARS_ERR_INVALID_FILE;
+    FILE *fp = fopen(path, "rb");
+    if (!fp) {
+        fprintf(stderr, "Mars: Cannot open %s\n", path);
+        return MARS_ERR_INVALID_FILE;
+    }
+    fseek(fp, 0, SEEK_END);
+    long size = ftell(fp);
+    fseek(fp, 0, SEEK_SET);
+    if (size <= 0) { fclose(fp); return MARS_ERR_INVALID_FILE; }
+    void *buf = malloc((size_t)size);
+    if (!buf) { fclose(fp); return MARS_ERR_ALLOC_FAILED; }
+    if (fread(buf, 1, (size_t)size, fp) != (size_t)size) { free(buf); fclose(fp); return MARS_ERR_INVALID_FILE; }
+    fclose(fp);
+    mars_error_t err = mars_load_memory(buf, (size_t)size, model);
+    free(buf); /* the model keeps its own copy (reference :384) */
+    return err;
+}
+
+/* ---------------------------------------------------------------- accessors */
+mars_runtime_tensor_t *mars_get_input(mars_model_t *model, int index) {
+    if (!model || index < 0 || (uint32_t)index >= model->header.num_inputs) return NULL;
+    uint32_t tid = model->header.input_tensor_ids[index];
+    if (tid >= model->header.num_tensors) return NULL;
+    return &model->tensors[tid];
+}
+
+mars_runtime_tensor_t *mars_get_output(mars_model_t *model, int index) {
+    if (!model || index < 0 || (uint32_t)index >= model->header.num_outputs) return NULL;
+    uint32_t tid = model->header.output_tensor_ids[index];
+    if (tid >= model->header.num_tensors) return NULL;
+    return &model->tensors[tid];
+}
+
+int mars_get_num_inputs(mars_model_t *model) { return model ? (int)model->header.num_inputs : 0; }
+int mars_get_num_outputs(mars_model_t *model) { return model ? (int)model->header.num_outputs : 0; }
+
+void mars_print_summary(mars_model_t *model) {
+    if (!model) return;
+    mars_model_ext_t *m = (mars_model_ext_t *)model;
+    printf("\nMars model summary (MI355X)\n");
+    printf("Layers: %u\n", model->header.num_layers);
+    printf("Tensors: %u\n", model->header.num_tensors);
+    printf("Inputs: %u\n", model->header.num_inputs);
+    printf("Outputs: %u\n", model->header.num_outputs);
+    printf("Weights: %zu bytes\n", model->weights_size);
+    printf("Launches per run: %d, batch %d, activations %zu bytes, parameters %zu bytes\n\n", m->n_ops, m->batch,
+           m->act_bytes, m->arena_size);
+}
+
+/* ------------------------------------------------------------------ running */
+static uint8_t *tdev(const mars_model_ext_t *m, int ti) { return ti >= 0 ? m->mt[ti].dev : NULL; }
+static size_t tstride(const mars_model_ext_t *m, int ti) { return ti >= 0 ? m->mt[ti].stride : 0; }
+
+static int launch_op(mars_model_ext_t *m, mars_op_t *op) {
+    const int B = m->batch;
+    uint8_t *A = m->arena_dev;
+    switch (op->kind) {
+        case OP_CONV_I8: {
+            mhip_conv_i8_t p;
+            memset(&p, 0, sizeof(p));
+            p.in = (const int8_t *)tdev(m, op->t_in[0]); p.in_stride = tstride(m, op->t_in[0]);
+            p.in_c = op->in_c;
+            if (op->nchw) {
+                const size_t ss = ALIGN_UP(m->scratch_per_frame, 256);
+                int rc = mhip_nchw_to_nhwc_pad(p.in, p.in_stride, (int8_t *)m->scratch_dev, ss, B, op->in_c,
+                                               op->in_h * op->in_w, op->c_pad);
+                if (rc) return rc;
+                p.in = (const int8_t *)m->scratch_dev; p.in_stride = ss; p.in_c = op->c_pad;
+            }
+            p.out = (int8_t *)tdev(m, op->t_out); p.out_stride = tstride(m, op->t_out);
+            p.w = (const int8_t *)(A + op->w_off);
+            p.bias = op->b_off != NO_OFF ? (const int32_t *)(A + op->b_off) : NULL;
+            p.lut = op->lut_off != NO_OFF ? A + op->lut_off : NULL;
+            p.frames = B;
+            p.in_h = op->in_h; p.in_w = op->in_w;
+            p.out_h = op->out_h; p.out_w = op->out_w; p.out_c = op->out_c;
+            p.kh = op->kh; p.kw = op->kw; p.stride_h = op->sh; p.stride_w = op->sw; p.pad_top = op->pt; p.pad_left = op->pl;
+            p.row_pad = op->row_pad; p.oc_pad = op->oc_pad; p.cs = op->cs; p.relu = op->relu; p.out_nchw = op->nchw;
+            return mhip_conv_i8(&p);
+        }
+        case OP_CONV_F32: {
+            mhip_conv_f32_t p;
+            memset(&p, 0, sizeof(p));
+            p.in = (const float *)tdev(m, op->t_in[0]); p.in_stride = tstride(m, op->t_in[0]);
+            p.out = (float *)tdev(m, op->t_out); p.out_stride = tstride(m, op->t_out);
+            p.w = (const float *)(A + op->w_off);
+            p.bias = op->b_off != NO_OFF ? (const float *)(A + op->b_off) : NULL;
+            p.frames = B;
+            p.in_h = op->in_h; p.in_w = op->in_w; p.in_c = op->in_c;
+            p.out_h = op->out_h; p.out_w = op->out_w; p.out_c = op->out_c;
+            p.kh = op->kh; p.kw = op->kw; p.stride_h = op->sh; p.stride_w = op->sw; p.pad_top = op->pt; p.pad_left = op->pl;
+            return mhip_conv_f32(&p);
+        }
+        case OP_RELU_BYTES:
+            return mhip_relu_bytes((int8_t *)tdev(m, op->t_out), tstride(m, op->t_out), B, op->n);
+        case OP_LUT_I8:
+            return mhip_lut_i8((const int8_t *)tdev(m, op->t_in[0]), tstride(m, op->t_in[0]), (int8_t *)tdev(m, op->t_out),
+                               tstride(m, op->t_out), B, op->n, A + op->lut_off);
+        case OP_BINARY_I8:
+            return mhip_binary_i8(op->is_mul, (const int8_t *)tdev(m, op->t_in[0]), tstride(m, op->t_in[0]),
+                                  (const int8_t *)tdev(m, op->t_in[1]), tstride(m, op->t_in[1]),
+                                  (int8_t *)tdev(m, op->t_out), tstride(m, op->t_out), B, op->n, op->f0, op->f1, op->f2);
+        case OP_SIGMOID_F32:
+            return mhip_sigmoid_f32((const float *)tdev(m, op->t_in[0]), tstride(m, op->t_in[0]),
+                                    (float *)tdev(m, op->t_out), tstride(m, op->t_out), B, op->n);
+        case OP_RELU_F32:
+            return mhip_relu_f32((const float *)tdev(m, op->t_in[0]), tstride(m, op->t_in[0]), (float *)tdev(m, op->t_out),
+                                 tstride(m, op->t_out), B, op->n, op->f0);
+        case OP_BINARY_F32:
+            return mhip_binary_f32(op->is_mul ? 1 : 0, (const float *)tdev(m, op->t_in[0]), tstride(m, op->t_in[0]),
+                                   (const float *)tdev(m, op->t_in[1]), tstride(m, op->t_in[1]),
+                                   (float *)tdev(m, op->t_out), tstride(m, op->t_out), B, op->n);
+        case OP_BN: {
+            const float *s = op->s_off != NO_OFF ? (const float *)(A + op->s_off) : NULL;
+            const float *b = op->b_off != NO_OFF ? (const float *)(A + op->b_off) : NULL;
+            if (op->is_f32)
+                return mhip_batchnorm_f32((const float *)tdev(m, op->t_in[0]), tstride(m, op->t_in[0]),
+                                          (float *)tdev(m, op->t_out), tstride(m, op->t_out), B, op->bn_n, op->in_c,
+                                          op->in_h * op->in_w, s, b);
+            return mhip_batchnorm_i8((const int8_t *)tdev(m, op->t_in[0]), tstride(m, op->t_in[0]),
+                                     (int8_t *)tdev(m, op->t_out), tstride(m, op->t_out), B, op->bn_n, op->in_c,
+                                     op->in_h * op->in_w, s, b, op->f0, op->f1);
+        }
+        case OP_MAXPOOL:
+            return mhip_maxpool_i8((const int8_t *)tdev(m, op->t_in[0]), tstride(m, op->t_in[0]), (int8_t *)tdev(m, op->t_out),
+                                   tstride(m, op->t_out), B, op->in_h, op->in_w, op->in_c, op->out_h, op->out_w, op->kh,
+                                   op->kw, op->sh, op->sw);
+        case OP_CONCAT_SLICE:
+            return mhip_concat_slice((const int8_t *)tdev(m, op->t_in[0]), tstride(m, op->t_in[0]),
+                                     (int8_t *)tdev(m, op->t_out), tstride(m, op->t_out), B, op->out_h, op->out_w,
+                                     op->in_c, op->out_c, op->ch_off);
+        case OP_UPSAMPLE:
+            return mhip_upsample_i8((const int8_t *)tdev(m, op->t_in[0]), tstride(m, op->t_in[0]),
+                                    (int8_t *)tdev(m, op->t_out), tstride(m, op->t_out), B, op->in_h, op->in_w, op->in_c,
+                                    op->out_h, op->out_w, op->scale_h, op->scale_w);
+        default: return -1;
+    }
+}
+
+mars_error_t mars_hip_run_device_async(mars_model_t *model) {
+    if (!model) return MARS_ERR_INVALID_FILE;
+    mars_model_ext_t *m = (mars_model_ext_t *)model;
+    if (!m->act_dev || !m->arena_dev) return MARS_ERR_NNA_INIT_FAILED;
+    for (uint32_t i = 0; i < model->header.num_layers; i++) model->layers[i].is_executed = false;
+    for (int i = 0; i < m->n_ops; i++) {
+        mars_op_t *op = &m->ops[i];
+        if (op->kind == OP_FAIL) {
+            fprintf(stderr, "Mars: Layer %d execution failed\n", op->layer);
+            return (mars_error_t)op->err;
+        }
+        if (m->profiling) {
+            if (!op->ev0) op->ev0 = mhip_event_create();
+            if (!op->ev1) op->ev1 = mhip_event_create();
+            mhip_event_record(op->ev0);
+        }
+        int rc = launch_op(m, op);
+        if (m->profiling) mhip_event_record(op->ev1);
+        if (rc != 0) {
+            fprintf(stderr, "Mars: Layer %d launch failed: %s\n", op->layer, mhip_last_error());
+            return MARS_ERR_LAYER_FAILED;
+        }
+    }
+    for (uint32_t i = 0; i < model->header.num_layers; i++) model->layers[i].is_executed = true;
+    return MARS_OK;
+}
+
+static double now_us(void) {
+    struct timespec ts;
+    clock_gettime(CLOCK_MONOTONIC, &ts);
+    return ts.tv_sec * 1e6 + ts.tv_nsec * 1e-3;
+}
+
+mars_error_t mars_hip_run_device(mars_model_t *model) {
+    double t0 = now_us();
+    mars_error_t e = mars_hip_run_device_async(model);
+    if (e != MARS_OK) { mhip_sync(); return e; }
+    if (mhip_sync()) return MARS_ERR_LAYER_FAILED;
+    mars_model_ext_t *m = (mars_model_ext_t *)model;
+    if (m->profiling)
+        for (int i = 0; i < m->n_ops; i++)
+            if (m->ops[i].ev0 && m->ops[i].ev1) m->ops[i].last_ms = mhip_event_elapsed_ms(m->ops[i].ev0, m->ops[i].ev1);
+    model->total_inference_us += (uint64_t)(now_us() - t0);
+    model->inference_count++;
+    return MARS_OK;
+}
+
+mars_error_t mars_hip_upload_inputs(mars_model_t *model) {
+    if (!model) return MARS_ERR_INVALID_FILE;
+    mars_model_ext_t *m = (mars_model_ext_t *)model;
+    for (uint32_t i = 0; i < model->header.num_tensors; i++) {
+        mtensor_t *t = &m->mt[i];
+        if (!t->io_in || !t->host || !t->dev || t->bytes == 0) continue;
+        if (mhip_h2d_2d_async(t->dev, t->stride, t->host, t->bytes, t->bytes, (size_t)m->batch)) return MARS_ERR_LAYER_FAILED;
+    }
+    return mhip_sync() ? MARS_ERR_LAYER_FAILED : MARS_OK;
+}
+
+mars_error_t mars_hip_download_outputs(mars_model_t *model) {
+    if (!model) return MARS_ERR_INVALID_FILE;
+    mars_model_ext_t *m = (mars_model_ext_t *)model;
+    for (uint32_t i = 0; i < model->header.num_tensors; i++) {
+        mtensor_t *t = &m->mt[i];
+        if (!t->io_out || !t->host || !t->dev || t->bytes == 0) continue;
+        if (mhip_d2h_2d_async(t->host, t->bytes, t->dev, t->stride, t->bytes, (size_t)m->batch)) return MARS_ERR_LAYER_FAILED;
+    }
+    return mhip_sync() ? MARS_ERR_LAYER_FAILED : MARS_OK;
+}
+
+mars_error_t mars_run(mars_model_t *model) {
+    if (!model) return MARS_ERR_INVALID_FILE; /* reference :440 */
+    mars_error_t e = mars_hip_upload_inputs(model);
+    if (e != MARS_OK) return e;
+    e = mars_hip_run_device(model);
+    if (e != MARS_OK) return e;
+    return mars_hip_download_outputs(model);
+}
+
+mars_error_t mars_hip_sync(void) { return mhip_sync() ? MARS_ERR_LAYER_FAILED : MARS_OK; }
+
+/* --------------------------------------------------------------- extensions */
+mars_error_t mars_hip_set_batch(mars_model_t *model, int n) {
+    if (!model || n <= 0 || n > 65535) return MARS_ERR_INVALID_FILE;
+    return alloc_batch((mars_model_ext_t *)model, n);
+}
+
+int mars_hip_get_batch(const mars_model_t *model) { return model ? ((const mars_model_ext_t *)model)->batch : 0; }
+
+mars_error_t mars_hip_set_fusion(mars_model_t *model, int level) {
+    if (!model) return MARS_ERR_INVALID_FILE;
+    mars_model_ext_t *m = (mars_model_ext_t *)model;
+    if (m->deferred) return MARS_ERR_INVALID_FILE;
+    mhip_sync();
+    m->fusion = level;
+    mars_error_t e = build_plan(m);
+    if (e == MARS_OK) e = upload_params(m);
+    if (e == MARS_OK) e = alloc_batch(m, m->batch > 0 ? m->batch : 1);
+    return e;
+}
+
+void *mars_hip_tensor_device(mars_model_t *model, int ti, size_t *frame_stride) {
+    if (!model || ti < 0 || (uint32_t)ti >= model->header.num_tensors) return NULL;
+    mars_model_ext_t *m = (mars_model_ext_t *)model;
+    if (frame_stride) *frame_stride = m->mt[ti].stride;
+    return m->mt[ti].dev;
+}
+
+mars_error_t mars_hip_read_tensor(mars_model_t *model, int ti, int frame, void *dst, size_t bytes) {
+    if (!model || !dst || ti < 0 || (uint32_t)ti >= model->header.num_tensors) return MARS_ERR_INVALID_TENSOR;
+    mars_model_ext_t *m = (mars_model_ext_t *)model;
+    mtensor_t *t = &m->mt[ti];
+    if (!t->dev || frame < 0 || (!t->is_weight && frame >= m->batch)) return MARS_ERR_INVALID_TENSOR;
+    if (!t->is_weight && bytes > t->stride) return MARS_ERR_INVALID_TENSOR;
+    if (mhip_sync()) return MARS_ERR_LAYER_FAILED;
+    if (mhip_d2h_async(dst, t->dev + (size_t)frame * t->stride, bytes) || mhip_sync()) return MARS_ERR_LAYER_FAILED;
+    return MARS_OK;
+}
+
+mars_error_t mars_hip_write_tensor(mars_model_t *model, int ti, int frame, const void *src, size_t bytes) {
+    if (!model || !src || ti < 0 || (uint32_t)ti >= model->header.num_tensors) return MARS_ERR_INVALID_TENSOR;
+    mars_model_ext_t *m = (mars_model_ext_t *)model;
+    mtensor_t *t = &m->mt[ti];
+    if (!t->dev || t->is_weight || frame < 0 || frame >= m->batch || bytes > t->stride) return MARS_ERR_INVALID_TENSOR;
+    if (mhip_h2d_async(t->dev + (size_t)frame * t->stride, src, bytes) || mhip_sync()) return MARS_ERR_LAYER_FAILED;
+    return MARS_OK;
+}
+
+void mars_hip_set_profiling(mars_model_t *model, int on) {
+    if (model) ((mars_model_ext_t *)model)->profiling = on;
+}
+
+int mars_hip_num_ops(const mars_model_t *model) { return model ? ((const mars_model_ext_t *)model)->n_ops : 0; }
+
+int mars_hip_op_info(const mars_model_t *model, int i, int *layer, int *kind, double *macs, double *bytes, float *last_ms) {
+    if (!model) return -1;
+    const mars_model_ext_t *m = (const mars_model_ext_t *)model;
+    if (i < 0 || i >= m->n_ops) return -1;
+    if (layer) *layer = m->ops[i].layer;
+    if (kind) *kind = m->ops[i].prof_kind;
+    if (macs) *macs = m->ops[i].macs;
+    if (bytes) *bytes = m->ops[i].bytes;
+    if (last_ms) *last_ms = m->ops[i].last_ms;
+    return 0;
+}
+
+void *mars_hip_stream(void) { return mhip_stream(); }
+
+void *mars_hip_param_arena(mars_model_t *model, size_t *bytes) {
+    if (!model) return NULL;
+    mars_model_ext_t *m = (mars_model_ext_t *)model;
+    if (bytes) *bytes = m->arena_size;
+    return m->arena_dev;
+}

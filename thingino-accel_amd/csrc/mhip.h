@@ -1,0 +1,123 @@
+/*
+ * mhip.h -- the thin C-ABI layer between the C host code (csrc/host) and the
+ * HIP translation units (csrc/hip).  Plain pointers, sizes and small POD
+ * structs only; no HIP types cross this boundary.  Every launcher enqueues on
+ * the library's single stream and returns 0 or a negative hipError_t.
+ *
+ * Replaces, conceptually: ioctl/mmap device access (reference src/device.c),
+ * NNDMA staging (reference src/nna_dma.c) and the MXUv3 kernels (reference
+ * src/mars/mxu_conv.c, mxu_ops.c).
+ */
+#ifndef MHIP_H
+#define MHIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ---- runtime */
+int mhip_init(int device_hint);          /* 0 ok; <0: no device / wrong arch */
+void mhip_shutdown(void);
+int mhip_ready(void);
+int mhip_device_info(int *cu_count, int *lds_bytes, int *gfx_version, size_t *hbm_bytes);
+void *mhip_stream(void);
+int mhip_sync(void);
+void *mhip_malloc(size_t bytes);         /* HBM */
+void mhip_free(void *p);
+void *mhip_host_alloc(size_t bytes);     /* pinned + device mapped */
+void mhip_host_free(void *p);
+int mhip_memset_async(void *dst, int value, size_t bytes);
+int mhip_h2d_async(void *dst, const void *src, size_t bytes);
+int mhip_d2h_async(void *dst, const void *src, size_t bytes);
+int mhip_d2d_async(void *dst, const void *src, size_t bytes);
+/* strided copies: `rows` rows of `row_bytes`, source/destination pitches */
+int mhip_h2d_2d_async(void *dst, size_t dpitch, const void *src, size_t spitch, size_t row_bytes, size_t rows);
+int mhip_d2h_2d_async(void *dst, size_t dpitch, const void *src, size_t spitch, size_t row_bytes, size_t rows);
+/* event pairs for per-op timing */
+void *mhip_event_create(void);
+void mhip_event_destroy(void *ev);
+int mhip_event_record(void *ev);
+float mhip_event_elapsed_ms(void *start, void *stop); /* waits for stop */
+const char *mhip_last_error(void);
+
+/* ---- int8 convolution (conv_i8.hip) */
+typedef struct {
+    const int8_t *in;  size_t in_stride;   /* per-frame stride, bytes */
+    int8_t *out;       size_t out_stride;
+    const int8_t *w;   /* packed: [oc_pad][kh][row_pad], see mhip_conv_i8_pack_geom */
+    const int32_t *bias; /* [oc_pad] or NULL */
+    const uint8_t *lut;  /* 256-entry post-requant map (index q+128) or NULL */
+    int frames;
+    int in_h, in_w, in_c;       /* input as NHWC */
+    int out_h, out_w, out_c;
+    int kh, kw, stride_h, stride_w, pad_top, pad_left;
+    int row_pad;                /* bytes per kernel row in the packed weights (multiple of 16) */
+    int oc_pad;                 /* packed output channels (multiple of 16) */
+    float cs;                   /* (in_scale*w_scale)/out_scale, evaluated on the host in f32 */
+    int relu;                   /* clamp negative results to 0 (fused ReLU, byte semantics) */
+    int out_nchw;               /* store [O][H][W] instead of [H][W][O] */
+} mhip_conv_i8_t;
+/* packing geometry shared by host packer and kernel */
+void mhip_conv_i8_pack_geom(int in_c, int kw, int out_c, int *row_pad, int *oc_pad);
+int mhip_conv_i8(const mhip_conv_i8_t *p);
+
+/* ---- float32 convolution (conv_f32.hip): NCHW / OIHW, reference summation order */
+typedef struct {
+    const float *in;  size_t in_stride;
+    float *out;       size_t out_stride;
+    const float *w;   const float *bias;
+    int frames;
+    int in_h, in_w, in_c, out_h, out_w, out_c;
+    int kh, kw, stride_h, stride_w, pad_top, pad_left;
+} mhip_conv_f32_t;
+int mhip_conv_f32(const mhip_conv_f32_t *p);
+
+/* ---- element-wise (eltwise.hip).  n = elements per frame. */
+int mhip_lut_i8(const int8_t *in, size_t in_stride, int8_t *out, size_t out_stride, int frames,
+                size_t n, const uint8_t *lut_dev);
+int mhip_relu_bytes(int8_t *buf, size_t stride, int frames, size_t n);
+int mhip_binary_i8(int is_mul, const int8_t *a, size_t a_stride, const int8_t *b, size_t b_stride,
+                   int8_t *out, size_t out_stride, int frames, size_t n, float sa, float sb, float inv_so);
+int mhip_sigmoid_f32(const float *in, size_t in_stride, float *out, size_t out_stride, int frames, size_t n);
+int mhip_binary_f32(int op /*0 add,1 mul,2 sub*/, const float *a, size_t a_stride, const float *b,
+                    size_t b_stride, float *out, size_t out_stride, int frames, size_t n);
+int mhip_relu_f32(const float *in, size_t in_stride, float *out, size_t out_stride, int frames,
+                  size_t n, float alpha);
+int mhip_batchnorm_i8(const int8_t *in, size_t in_stride, int8_t *out, size_t out_stride, int frames,
+                      int n, int c, int hw, const float *s, const float *b, float in_scale, float out_scale);
+int mhip_batchnorm_f32(const float *in, size_t in_stride, float *out, size_t out_stride, int frames,
+                       int n, int c, int hw, const float *s, const float *b);
+
+/* ---- data movement (move.hip); all int8-byte semantics, NHWC index math */
+int mhip_maxpool_i8(const int8_t *in, size_t in_stride, int8_t *out, size_t out_stride, int frames,
+                    int in_h, int in_w, int ch, int out_h, int out_w, int kh, int kw, int sh, int sw);
+int mhip_concat_slice(const int8_t *in, size_t in_stride, int8_t *out, size_t out_stride, int frames,
+                      int out_h, int out_w, int in_c, int out_c, int ch_off);
+int mhip_upsample_i8(const int8_t *in, size_t in_stride, int8_t *out, size_t out_stride, int frames,
+                     int in_h, int in_w, int ch, int out_h, int out_w, int scale_h, int scale_w);
+/* [C][HW] -> [HW][c_pad] with zero channel padding (feeds the NHWC conv kernel) */
+int mhip_nchw_to_nhwc_pad(const int8_t *in, size_t in_stride, int8_t *out, size_t out_stride,
+                          int frames, int c, int hw, int c_pad);
+
+/* ---- detection tail (yolo_tail.hip) */
+typedef struct {
+    const int8_t *pred[4]; size_t stride[4]; int npred[4];
+    const float *lut[4];   /* per segment, device: 3 x 256 floats: value[q], obj[q], den[q] */
+    int nseg;
+    int frames;
+    float nms_thresh;
+    void *dets;            /* device [frames][1000] records of 24 bytes */
+    int *counts;           /* device [frames] kept */
+    int *raw_counts;       /* device [frames] candidates before NMS (or NULL) */
+    int do_nms;
+} mhip_detect_t;
+int mhip_detect(const mhip_detect_t *p);
+int mhip_nms_only(void *dets_dev, int *count_dev, int n, float thresh);
+
+#ifdef __cplusplus
+}
+#endif
+#endif
