@@ -1,0 +1,222 @@
+#!/usr/bin/env python3
+"""Benchmark of the mars_runtime hot path on MI355X.
+
+A "step" = one pass of the whole hot path over one batch of synthetic frames that are
+already resident in HBM: every layer of the .mars graph (int8 MFMA conv + fused requant /
+SiLU-LUT epilogue, pooling, concat, upsample, add) and the decode + NMS detection tail.
+
+Workload at N=1 = the configuration BASELINE.json's metric is quoted on: yolov5s_int8,
+640x640, batch 256.  The reference repo does not ship that file (.MISSING_LARGE_BLOBS), so it
+is the seeded synthetic twin written by mars_synth_model() (same format, same YOLOv5s layer
+sequence, NHWC/OHWI int8).  N>1: one process per GPU (torch.distributed.run), frames sharded
+(256 per GPU, weak scaling), parameters broadcast once over RCCL, no collective in the
+forward pass.
+
+Prints ONE JSON line (rank 0).  `roofline` is for the dominant kernel (conv_i8_kernel, the
+implicit-GEMM MFMA convolution): algorithmic int8 ops of all its launches / their summed
+duration, measured with HIP events on the library's stream inside the timed region.
+`cpu_baseline` is the reference's own C code (oracle/_ref, -O3 -funroll-loops as in its
+Makefile:21) on one host core over a bounded sample (1 frame of the same workload); the GPU
+result for that frame is compared with it bit for bit.
+"""
+import argparse
+import importlib.util
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+
+def load_marsrt():
+    spec = importlib.util.spec_from_file_location("marsrt", os.path.join(ROOT, "thingino-accel_amd", "marsrt.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod
+
+
+class _DevBuf:
+    """zero-copy view of a raw HBM pointer for torch (RCCL broadcast of the parameter arena)"""
+
+    def __init__(self, ptr, nbytes):
+        self.__cuda_array_interface__ = {"shape": (nbytes,), "typestr": "|u1", "data": (ptr, False), "version": 2}
+
+
+def frames_for_rank(rank, per_gpu, nbytes):
+    from conftest import lcg_frame
+    return [lcg_frame(0x5EED0000 + rank * per_gpu + f, nbytes) for f in range(per_gpu)]
+
+
+def cpu_baseline(model_bytes, frame0, out_ids, tensors):
+    """rank 0, N=1 only: the reference (or, failing that, this repo's port) on host cores"""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    res = {}
+    try:
+        import refbind
+        if refbind.available():
+            m = refbind.O2Model(model_bytes, slack_mult=1, slack_add=4096, fast=True)
+            m.set_input(0, frame0.tobytes())
+            t0 = time.time()
+            rc = m.run()
+            dt = time.time() - t0
+            outs = [m.tensor(ti) for ti in out_ids]
+            m.close()
+            if rc == 0:
+                return dict(value=1.0 / dt, unit="images/s", cores=1, kind="reference",
+                            sample="1 frame of the same workload through the reference's own layer functions "
+                                   "(oracle/_ref, gcc -O3 -funroll-loops), %.1f s" % dt), outs
+    except Exception as e:  # noqa: BLE001
+        res["ref_error"] = str(e)
+    import orcbind
+    g = orcbind.Graph(model_bytes, slack_mult=1, slack_add=4096)
+    g.set_input(0, frame0.tobytes())
+    t0 = time.time()
+    rc = g.run()
+    dt = time.time() - t0
+    outs = [g.tensor(ti) for ti in out_ids]
+    return dict(value=1.0 / dt, unit="images/s", cores=1, kind="port",
+                sample="1 frame of the same workload through oracle/restate (gcc -O2), %.1f s" % dt), outs
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=256, help="frames per GPU")
+    ap.add_argument("--hw", type=int, default=640)
+    ap.add_argument("--width", type=int, default=8, help="channel multiple x16: 8 = yolov5s, 4 = yolov5n")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-tail", action="store_true", help="graph only, skip decode+NMS")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    dist = None
+    if world > 1:
+        import torch
+        import torch.distributed as dist
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    os.environ.setdefault("MARS_HIP_DEVICE", str(local_rank))
+
+    M = load_marsrt()
+    import marsfile
+    M.nna_init()
+    model_bytes = M.synth_model(width_x16=args.width, input_hw=args.hw, seed=1)
+    hdr, tensors, _ = marsfile.parse(model_bytes)
+    in_bytes = marsfile.tensor_nbytes(tensors[hdr["inputs"][0]])
+    out_ids = list(hdr["outputs"])
+
+    if world > 1 and rank != 0:
+        # descriptors only; the packed parameters arrive by RCCL broadcast from rank 0
+        blank = bytearray(model_bytes)
+        blank[hdr["woff"]:hdr["woff"] + hdr["wsz"]] = bytes(hdr["wsz"])
+        model = M.Model(bytes(blank), batch=args.batch, flags=1)
+    else:
+        model = M.Model(model_bytes, batch=args.batch)
+    if world > 1:
+        import torch
+        ptr, nbytes = model.param_arena()
+        t = torch.as_tensor(_DevBuf(ptr, nbytes), device="cuda")
+        dist.broadcast(t, src=0)  # the one collective of the path: weights over xGMI
+        torch.cuda.synchronize()
+
+    frames = frames_for_rank(rank, args.batch, in_bytes)
+    iv = model.input_view(0)
+    for f in range(args.batch):
+        iv[f] = frames[f]
+    model.upload()  # inputs resident in HBM before the timed region
+    outputs = tuple(range(len(out_ids)))
+
+    def step():
+        model.run_device(sync=False)
+        if not args.no_tail:
+            model.detect_device(outputs=outputs, thresh=0.45)
+        M.lib().mars_hip_sync()
+
+    def barrier():
+        M.lib().mars_hip_sync()
+        if dist is not None:
+            import torch
+            torch.cuda.synchronize()
+            dist.barrier()
+
+    for _ in range(args.warmup):
+        step()
+    # ---- timed region: exactly K steps, per-kernel HIP events on the library's stream
+    model.set_profiling(True)
+    conv_ms = conv_ops = all_ms = 0.0
+    per_kind = {}
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+        for op in model.ops():
+            per_kind[op["kind"]] = per_kind.get(op["kind"], 0.0) + op["ms"]
+            all_ms += op["ms"]
+            if op["kind"] == 0:
+                conv_ms += op["ms"]
+                conv_ops += 2.0 * op["macs"] * args.batch
+    barrier()
+    dt = time.perf_counter() - t0
+    model.set_profiling(False)
+    if dist is not None:
+        import torch
+        tt = torch.tensor([dt], device="cuda", dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
+
+    result = None
+    if rank == 0:
+        n_conv = sum(1 for op in model.ops() if op["kind"] == 0)
+        macs_per_img = sum(op["macs"] for op in model.ops() if op["kind"] == 0)
+        bytes_per_img = sum(op["bytes"] for op in model.ops())
+        achieved = conv_ops / (conv_ms * 1e-3) / 1e12 if conv_ms > 0 else 0.0
+        peak = 5000.0  # dense int8 MFMA, TOP/s: 2x the ~2.5 PF bf16 dense peak (MI355X_MICROARCH.md, Matrix cores)
+        result = {
+            "metric": "images/sec yolov5s_int8 640x640 batch256",
+            "value": world * args.batch * args.steps / dt,
+            "unit": "images/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": dt / args.steps * 1e3,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "int8",
+            "data": "synthetic",
+            "config": {"workload": "synthetic yolov5s_int8.mars twin (mars_synth_model width_x16=%d, seed 1), %dx%d int8 "
+                                   "NHWC frames, batch %d per GPU, decode+NMS tail %s" %
+                                   (args.width, args.hw, args.hw, args.batch, "off" if args.no_tail else "on"),
+                       "frames_per_gpu": args.batch, "sharding": "frames", "collectives_in_forward": 0,
+                       "conv_gmac_per_image": macs_per_img / 1e9, "algorithmic_mb_per_image": bytes_per_img / 1e6},
+            "roofline": {"bound": "mfma", "kernel": "conv_i8_kernel (%d launches per step)" % n_conv,
+                         "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak,
+                         "traffic": None,
+                         "conv_ms_per_step": conv_ms / args.steps,
+                         "all_kernels_ms_per_step": all_ms / args.steps,
+                         "ms_per_step_by_kind": {str(k): v / args.steps for k, v in sorted(per_kind.items())}},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            base, ref_outs = cpu_baseline(model_bytes, frames[0], out_ids, tensors)
+            model.download()
+            same = all(np.array_equal(ref_outs[i], model.output_view(i)[0]) for i in range(len(out_ids)))
+            base["gpu_matches_bit_exact"] = bool(same)
+            result["cpu_baseline"] = base
+    model.close()
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+    if rank == 0:
+        print(json.dumps(result))
+
+
+if __name__ == "__main__":
+    main()

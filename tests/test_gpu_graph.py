@@ -73,7 +73,12 @@ def test_synthetic_models(gpu, orc, name, kw, fusion):
         if fusion == 0 and f == 1:  # unfused plan materialises every tensor: check them all
             for ti, t in enumerate(tensors):
                 if t["size"] == 0 and marsfile.tensor_nbytes(t):
-                    assert np.array_equal(m.read_tensor(ti, frame=f), g.tensor(ti)), "tensor %d" % ti
+                    try:
+                        got = m.read_tensor(ti, frame=f)
+                    except gpu.MarsError:  # written by no layer (no-op kinds): not materialised in HBM
+                        assert not g.tensor(ti).any()
+                        continue
+                    assert np.array_equal(got, g.tensor(ti)), "tensor %d" % ti
     # a second run over the same inputs is idempotent
     first = [m.output_view(i).copy() for i in range(len(hdr["outputs"]))]
     m.run()
@@ -102,7 +107,8 @@ def test_single_layer_graphs(gpu, orc, kind):
             try:
                 got = m.read_tensor(ti, frame=0)
             except gpu.MarsError:
-                continue  # tensor no layer touches: not materialised on the device
+                assert not g.tensor(ti).any()  # tensor no layer writes: not materialised on the device
+                continue
             want = g.tensor(ti)
             if t["dtype"] == 0 and kind == "f32_chain":
                 a, b = got.view(np.float32), want.view(np.float32)

@@ -1026,7 +1026,11 @@ int mars_hip_op_info(const mars_model_t *model, int i, int *layer, int *kind, do
     if (kind) *kind = m->ops[i].prof_kind;
     if (macs) *macs = m->ops[i].macs;
     if (bytes) *bytes = m->ops[i].bytes;
-    if (last_ms) *last_ms = m->ops[i].last_ms;
+    if (last_ms) { /* events of the most recent (completed) run; waits for the stop event */
+        mars_op_t *op = (mars_op_t *)&m->ops[i];
+        if (m->profiling && op->ev0 && op->ev1) op->last_ms = mhip_event_elapsed_ms(op->ev0, op->ev1);
+        *last_ms = op->last_ms;
+    }
     return 0;
 }
 
