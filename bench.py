@@ -92,6 +92,7 @@ def main():
     ap.add_argument("--width", type=int, default=8, help="channel multiple x16: 8 = yolov5s, 4 = yolov5n")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-tail", action="store_true", help="graph only, skip decode+NMS")
+    ap.add_argument("--ops", type=str, default="", help="write a per-launch table (last timed step) to this file")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -173,6 +174,16 @@ def main():
         dt = float(tt.item())
 
     result = None
+    if rank == 0 and args.ops:
+        import ctypes as C
+        L = M.lib()
+        with open(args.ops, "w") as fh:
+            fh.write("op layer kind ms gmac_per_img mb_per_img TOPs GBs\n")
+            for i, op in enumerate(model.ops()):
+                tops = 2 * op["macs"] * args.batch / (op["ms"] * 1e-3) / 1e12 if op["ms"] > 0 else 0
+                gbs = op["bytes"] * args.batch / (op["ms"] * 1e-3) / 1e9 if op["ms"] > 0 else 0
+                fh.write("%d %d %d %.4f %.4f %.3f %.1f %.0f\n" % (i, op["layer"], op["kind"], op["ms"], op["macs"] / 1e9,
+                                                                 op["bytes"] / 1e6, tops, gbs))
     if rank == 0:
         n_conv = sum(1 for op in model.ops() if op["kind"] == 0)
         macs_per_img = sum(op["macs"] for op in model.ops() if op["kind"] == 0)
