@@ -1,6 +1,5 @@
 // conv_i8.hip -- int8 convolution for gfx950 (MI355X): im2col-free implicit
-// GEMM on v_mfma_i32_16x16x64_i8 with LDS-staged input and weight tiles and
-// an in-register requantise / ReLU / LUT epilogue.
+// GEMM on v_mfma_i32_16x16x64_i8.
 //
 // Replaces reference src/mars/mxu_conv.c:713-757 (conv2d_int8_nhwc_mxu) and,
 // through the NCHW store mode, :630-670 (conv2d_int8_mxu).  Arithmetic
@@ -14,12 +13,23 @@
 //
 // GEMM view:  D[oc][pixel] = sum_k W[oc][k] * X[pixel][k]
 //   MFMA A operand = weights  (M = 16 output channels)
-//   MFMA B operand = pixels   (N = 16 output pixels, all frames of the batch flattened)
-//   K = kernel rows x (kw*in_c bytes, padded to 16): for NHWC the kw*in_c bytes
-//       of one kernel row are CONTIGUOUS in the input, so a 16-byte K chunk is
-//       one 16-byte global load -- no im2col buffer anywhere.
-// Each lane ends up with 4 consecutive output channels of one pixel per
-// accumulator, i.e. one packed dword store for NHWC output.
+//   MFMA B operand = pixels   (N = 16 output pixels; all frames of the batch flattened)
+//   K = kernel rows x (kw*in_c bytes padded to 16).  In NHWC the kw*in_c bytes
+//   of one kernel row are CONTIGUOUS in the input, so a 16-byte K chunk of a
+//   pixel is one 16-byte global access -- there is no im2col buffer anywhere.
+//
+// Main kernel (in_c % 16 == 0): both tiles go HBM/L2 -> LDS by LDS-DMA
+// (global_load_lds_dwordx4, no VGPR round trip) in a 3/4-stage ring with
+// counted vmcnt and one raw s_barrier per K step; taps that fall outside the
+// image source a 16-byte zero page.  LDS rows are 64 bytes, XOR-swizzled on the
+// SOURCE side (LDS-DMA writes lane-linearly) so that the ds_read_b128 fragment
+// reads are bank-conflict free (verified: SQ_LDS_BANK_CONFLICT = 0).
+// Epilogue: bias from registers, float requantisation in-register, optional
+// ReLU and 256-entry LUT (fused conv->sigmoid->mul) from LDS, results staged
+// through LDS and written with coalesced 16-byte stores.
+//
+// Generic kernel (any in_c, used for the 3-channel stem): register-staged,
+// byte-granular gather, same arithmetic.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
@@ -27,12 +37,14 @@
 
 extern "C" hipStream_t mhip_stream_native(void);
 extern "C" int mhip_check(hipError_t e, const char *what);
+extern "C" const void *mhip_zero_page(void);
 
 typedef int v4i __attribute__((ext_vector_type(4)));
 
 #define BP 128      // pixels per workgroup
 #define BK 64       // K bytes per step = one MFMA
 #define NTHREADS 256
+#define OPAD 4      // padding of an epilogue LDS row (bytes): spreads pixel rows over banks
 
 // LDS tile row = 64 bytes (4 chunks of 16).  XOR the chunk index with
 // ((row>>2)&1)<<1: conflict-free for the ds_read_b128 lane groups of gfx950
@@ -44,27 +56,228 @@ __device__ __forceinline__ int lds_off(int row, int chunk) {
 __device__ __forceinline__ int requant(int acc, float cs) {
     float scaled = (float)acc * cs;
     float biased = scaled + (scaled >= 0.0f ? 0.5f : -0.5f);
-    int r = (int)biased;                       // v_cvt_i32_f32: saturates, NaN -> 0
+    int r = (int)biased;                        // v_cvt_i32_f32: saturates, NaN -> 0
     if (!(biased < 2147483648.0f)) r = INT_MIN; // x86 cvttss2si: +overflow and NaN -> INT_MIN
     r = r > 127 ? 127 : r;
     r = r < -128 ? -128 : r;
     return r;
 }
 
-template <int BN, bool FAST>
-__global__ __launch_bounds__(NTHREADS) void conv_i8_kernel(const mhip_conv_i8_t p, const long total_pix,
-                                                           const int k64) {
-    __shared__ __attribute__((aligned(16))) int8_t lds[2 * (BP + BN) * BK];
-    constexpr int STAGE = (BP + BN) * BK; // one pipeline stage: X tile then W tile
+template <int N>
+__device__ __forceinline__ void wait_vmcnt() {
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
 
-    const int tid = threadIdx.x;
-    const int lane = tid & 63;
-    const int wv = tid >> 6;
+__device__ __forceinline__ void glds16(const void *gsrc, void *lds_wave_base) {
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)gsrc,
+                                     (__attribute__((address_space(3))) void *)lds_wave_base, 16, 0, 0);
+}
+
+// XCD-aware block order: the 8 XCDs take consecutive dispatch ids round-robin; give each
+// XCD one contiguous range of logical tiles so tiles that share input rows / weight
+// panels share an L2 (bijective for any grid size).
+__device__ __forceinline__ unsigned xcd_remap(unsigned bid, unsigned nblk) {
+    const unsigned q = nblk >> 3, r = nblk & 7, x = bid & 7;
+    return (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + (bid >> 3);
+}
+
+// ---------------------------------------------------------------------------------
+// shared epilogue: accumulators -> requant -> LDS tile -> coalesced global stores
+template <int BN, int WPX, int WOC>
+__device__ __forceinline__ void epilogue(const mhip_conv_i8_t &p, v4i (&acc)[WOC][WPX], int8_t *tile, const uint8_t *slut,
+                                         long pix0, long total_pix, int oc0, int pxw, int ocw, int hw) {
+    const int tid = threadIdx.x, lane = tid & 63;
+    constexpr int ROW = BN + OPAD;
+    // bias for this lane's 4 consecutive channels of each oc subtile
+    v4i bias[WOC];
+#pragma unroll
+    for (int s = 0; s < WOC; s++)
+        bias[s] = p.bias ? *(const v4i *)(p.bias + oc0 + ocw + s * 16 + (lane >> 4) * 4) : (v4i){0, 0, 0, 0};
+#pragma unroll
+    for (int t = 0; t < WPX; t++) {
+        const int prow = pxw + t * 16 + (lane & 15);
+#pragma unroll
+        for (int s = 0; s < WOC; s++) {
+            uint32_t pk = 0;
+#pragma unroll
+            for (int r = 0; r < 4; r++) {
+                int v = requant(acc[s][t][r] + bias[s][r], p.cs);
+                if (p.relu) v = v < 0 ? 0 : v;
+                if (p.lut) v = slut[(v + 128) & 255];
+                pk |= (uint32_t)(v & 255) << (8 * r);
+            }
+            *(uint32_t *)(tile + prow * ROW + ocw + s * 16 + (lane >> 4) * 4) = pk;
+        }
+    }
+    __syncthreads();
+    const int ncols = p.out_c - oc0 < BN ? p.out_c - oc0 : BN; // valid channels of this tile
+    if (!p.out_nchw && (p.out_c & 15) == 0) {
+        constexpr int CPR = BN / 16; // 16-byte chunks per pixel row
+        for (int id = tid; id < BP * CPR; id += NTHREADS) {
+            const int row = id / CPR, c = id - row * CPR;
+            const long pix = pix0 + row;
+            if (pix >= total_pix || c * 16 >= ncols) continue;
+            const long f = pix / hw;
+            const int rem = (int)(pix - f * hw);
+            const int8_t *s = tile + row * ROW + c * 16;
+            v4i v = {*(const int *)s, *(const int *)(s + 4), *(const int *)(s + 8), *(const int *)(s + 12)};
+            *(v4i *)(p.out + (size_t)f * p.out_stride + (size_t)rem * p.out_c + oc0 + c * 16) = v;
+        }
+    } else if (!p.out_nchw) {
+        for (int id = tid; id < BP * BN; id += NTHREADS) {
+            const int row = id / BN, c = id - row * BN;
+            const long pix = pix0 + row;
+            if (pix >= total_pix || c >= ncols) continue;
+            const long f = pix / hw;
+            const int rem = (int)(pix - f * hw);
+            p.out[(size_t)f * p.out_stride + (size_t)rem * p.out_c + oc0 + c] = tile[row * ROW + c];
+        }
+    } else { // [O][H][W]: consecutive lanes -> consecutive pixels of one channel
+        for (int id = tid; id < BP * BN; id += NTHREADS) {
+            const int c = id / BP, row = id - c * BP;
+            const long pix = pix0 + row;
+            if (pix >= total_pix || c >= ncols) continue;
+            const long f = pix / hw;
+            const int rem = (int)(pix - f * hw);
+            p.out[(size_t)f * p.out_stride + (size_t)(oc0 + c) * hw + rem] = tile[row * ROW + c];
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------
+// main kernel: in_c % 16 == 0
+template <int BN, int STAGES>
+__global__ __launch_bounds__(NTHREADS) void conv_i8_mfma(const mhip_conv_i8_t p, const long total_pix, const int k64,
+                                                         const int8_t *__restrict__ zeros, const unsigned noc,
+                                                         const unsigned nblk) {
+    constexpr int STAGE = (BP + BN) * BK;
+    constexpr int NWN = BN == 128 ? 2 : 1;       // waves along oc
+    constexpr int NWM = 4 / NWN;                 // waves along pixels
+    constexpr int WPX = BP / NWM / 16;           // pixel subtiles per wave
+    constexpr int WOC = BN / NWN / 16;           // oc subtiles per wave
+    constexpr int LW = BN >= 128 ? 2 : 1;        // W-tile DMA instructions per wave
+    constexpr int L = 2 + LW;                    // DMA instructions per wave per stage
+    constexpr int TILE_BYTES = BP * (BN + OPAD);
+    constexpr int RING = STAGES * STAGE;
+    constexpr int LDS_BYTES = (RING > TILE_BYTES ? RING : TILE_BYTES) + 256;
+    __shared__ __attribute__((aligned(16))) int8_t lds[LDS_BYTES];
+    uint8_t *slut = (uint8_t *)lds + LDS_BYTES - 256;
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const unsigned id = xcd_remap(blockIdx.x, nblk);
+    const long pix0 = (long)(id / noc) * BP;
+    const int oc0 = (int)(id % noc) * BN;
+    const int hw = p.out_h * p.out_w;
+
+    if (p.lut && tid < 64) ((uint32_t *)slut)[tid] = ((const uint32_t *)p.lut)[tid];
+
+    // ---- DMA assignment.  One wave-instruction fills 16 consecutive 64-byte rows; lane i
+    // lands in row i/4, slot i%4, so it must FETCH chunk (slot ^ swizzle(row)).
+    const int schunk = (lane & 3) ^ (((lane >> 4) & 1) << 1);
+    const int8_t *xbase[2];
+    int iy0[2], ix0[2];
+    bool rvalid[2];
+#pragma unroll
+    for (int j = 0; j < 2; j++) {
+        long pix = pix0 + wv * 32 + j * 16 + (lane >> 2);
+        rvalid[j] = pix < total_pix;
+        long f = rvalid[j] ? pix / hw : 0;
+        int rem = rvalid[j] ? (int)(pix - f * hw) : 0;
+        int oy = rem / p.out_w, ox = rem - oy * p.out_w;
+        iy0[j] = oy * p.stride_h - p.pad_top;
+        ix0[j] = ox * p.stride_w - p.pad_left;
+        xbase[j] = p.in + (size_t)f * p.in_stride;
+    }
+    const int8_t *wsrc[LW];
+    int wq[LW];
+#pragma unroll
+    for (int j = 0; j < LW; j++) {
+        wq[j] = BN >= 64 ? wv * LW + j : (wv & 1); // BN=32: waves 2,3 repeat 0,1 (same bytes, same place)
+        wsrc[j] = p.w + (size_t)(oc0 + wq[j] * 16 + (lane >> 2)) * k64 + schunk * 16;
+    }
+    // K position of this lane's chunk: kernel row ky, tap kx, byte rc inside the tap
+    int ky = 0, kx = 0, rc = schunk * 16;
+    while (rc >= p.in_c) { rc -= p.in_c; kx++; }
+    while (kx >= p.kw) { kx -= p.kw; ky++; }
+
+    const int nks = k64 / BK;
+    auto issue = [&](int ks, int stage) {
+        int8_t *sb = lds + stage * STAGE;
+#pragma unroll
+        for (int j = 0; j < 2; j++) {
+            const int8_t *src = zeros;
+            if (rvalid[j] && ky < p.kh) {
+                const int iy = iy0[j] + ky, ix = ix0[j] + kx;
+                if (iy >= 0 && iy < p.in_h && ix >= 0 && ix < p.in_w)
+                    src = xbase[j] + ((size_t)iy * p.in_w + ix) * p.in_c + rc;
+            }
+            glds16(src, sb + (wv * 32 + j * 16) * BK);
+        }
+#pragma unroll
+        for (int j = 0; j < LW; j++) glds16(wsrc[j] + ks * BK, sb + BP * BK + wq[j] * 16 * BK);
+        rc += BK;
+        while (rc >= p.in_c) { rc -= p.in_c; kx++; }
+        while (kx >= p.kw) { kx -= p.kw; ky++; }
+    };
+
+    v4i acc[WOC][WPX];
+#pragma unroll
+    for (int s = 0; s < WOC; s++)
+#pragma unroll
+        for (int t = 0; t < WPX; t++) acc[s][t] = (v4i){0, 0, 0, 0};
+
+#pragma unroll
+    for (int s = 0; s < STAGES - 1; s++)
+        if (s < nks) issue(s, s);
+
+    const int wm = wv % NWM, wn = wv / NWM;
+    const int pxw = wm * (WPX * 16), ocw = wn * (WOC * 16);
+    const int frow = lane & 15, fchunk = lane >> 4;
+    int stage = 0, nstage = STAGES - 1;
+    for (int ks = 0; ks < nks; ks++) {
+        // tiles still allowed in flight once tile ks must have landed
+        const int ahead = nks - 1 - ks;
+        if (STAGES == 4 && ahead >= 2) wait_vmcnt<2 * L>();
+        else if (ahead >= 1) wait_vmcnt<L>();
+        else wait_vmcnt<0>();
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        if (ks + STAGES - 1 < nks) issue(ks + STAGES - 1, nstage);
+        const int8_t *xs = lds + stage * STAGE, *ws = xs + BP * BK;
+        v4i xb[WPX];
+#pragma unroll
+        for (int t = 0; t < WPX; t++) xb[t] = *(const v4i *)(xs + lds_off(pxw + t * 16 + frow, fchunk));
+#pragma unroll
+        for (int s = 0; s < WOC; s++) {
+            v4i wa = *(const v4i *)(ws + lds_off(ocw + s * 16 + frow, fchunk));
+#pragma unroll
+            for (int t = 0; t < WPX; t++) acc[s][t] = __builtin_amdgcn_mfma_i32_16x16x64_i8(wa, xb[t], acc[s][t], 0, 0, 0);
+        }
+        stage = stage + 1 == STAGES ? 0 : stage + 1;
+        nstage = nstage + 1 == STAGES ? 0 : nstage + 1;
+    }
+    __syncthreads(); // every wave is done reading the ring: reuse it for the output tile
+    epilogue<BN, WPX, WOC>(p, acc, lds, slut, pix0, total_pix, oc0, pxw, ocw, hw);
+}
+
+// ---------------------------------------------------------------------------------
+// generic kernel: any in_c (the 3-channel stem); register-staged byte gather
+template <int BN>
+__global__ __launch_bounds__(NTHREADS) void conv_i8_generic(const mhip_conv_i8_t p, const long total_pix, const int k64) {
+    constexpr int STAGE = (BP + BN) * BK;
+    constexpr int WPX = 2, WOC = BN / 16;
+    constexpr int TILE_BYTES = BP * (BN + OPAD);
+    constexpr int LDS_BYTES = (2 * STAGE > TILE_BYTES ? 2 * STAGE : TILE_BYTES) + 256;
+    __shared__ __attribute__((aligned(16))) int8_t lds[LDS_BYTES];
+    uint8_t *slut = (uint8_t *)lds + LDS_BYTES - 256;
+
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const long pix0 = (long)blockIdx.x * BP;
     const int oc0 = blockIdx.y * BN;
     const int hw = p.out_h * p.out_w;
+    if (p.lut && tid < 64) ((uint32_t *)slut)[tid] = ((const uint32_t *)p.lut)[tid];
 
-    // ---- per-thread staging assignment: 2 pixel rows x one 16-byte chunk
     const int cc = tid & 3;
     const int8_t *xbase[2];
     int iy0[2], ix0[2];
@@ -80,150 +293,80 @@ __global__ __launch_bounds__(NTHREADS) void conv_i8_kernel(const mhip_conv_i8_t 
         ix0[j] = ox * p.stride_w - p.pad_left;
         xbase[j] = p.in + (size_t)f * p.in_stride;
     }
-    // position of this thread's chunk inside K: kernel row ky, tap kx, byte rc in tap (FAST)
-    // or kernel row ky, byte r in the padded row (generic)
-    int ky = 0, kx = 0, rc = cc * 16;
-    if (FAST) {
-        while (rc >= p.in_c) { rc -= p.in_c; kx++; }
-        while (kx >= p.kw) { kx -= p.kw; ky++; }
-    } else {
-        while (rc >= p.row_pad) { rc -= p.row_pad; ky++; }
-    }
+    int ky = 0, rc = cc * 16; // kernel row, byte inside the padded kernel row
+    while (rc >= p.row_pad) { rc -= p.row_pad; ky++; }
     const int row_bytes = p.kw * p.in_c;
-
     const int nks = k64 / BK;
-    v4i xreg[2];
-    v4i wreg[(BN * 4 + NTHREADS - 1) / NTHREADS];
     constexpr int WLOADS = (BN * 4 + NTHREADS - 1) / NTHREADS;
+    v4i xreg[2], wreg[WLOADS];
 
     auto load_global = [&](int ks) {
 #pragma unroll
         for (int j = 0; j < 2; j++) {
             v4i v = {0, 0, 0, 0};
-            if (rvalid[j] && ky < p.kh) {
-                int iy = iy0[j] + ky;
-                if (iy >= 0 && iy < p.in_h) {
-                    if (FAST) {
-                        int ix = ix0[j] + kx;
-                        if (ix >= 0 && ix < p.in_w)
-                            v = *(const v4i *)(xbase[j] + ((size_t)iy * p.in_w + ix) * p.in_c + rc);
-                    } else {
-                        const int8_t *rowp = xbase[j] + ((long)iy * p.in_w + ix0[j]) * p.in_c;
-                        int8_t b[16];
+            const int iy = iy0[j] + ky;
+            if (rvalid[j] && ky < p.kh && iy >= 0 && iy < p.in_h) {
+                const int8_t *rowp = xbase[j] + ((long)iy * p.in_w + ix0[j]) * p.in_c;
+                int8_t b[16];
 #pragma unroll
-                        for (int e = 0; e < 16; e++) {
-                            int rr = rc + e;
-                            int8_t val = 0;
-                            if (rr < row_bytes) {
-                                int t = rr / p.in_c;
-                                int ix = ix0[j] + t;
-                                if (ix >= 0 && ix < p.in_w) val = rowp[rr];
-                            }
-                            b[e] = val;
-                        }
-                        v = *(v4i *)b;
+                for (int e = 0; e < 16; e++) {
+                    const int rr = rc + e;
+                    int8_t val = 0;
+                    if (rr < row_bytes) {
+                        const int ix = ix0[j] + rr / p.in_c;
+                        if (ix >= 0 && ix < p.in_w) val = rowp[rr];
                     }
+                    b[e] = val;
                 }
+                v = *(v4i *)b;
             }
             xreg[j] = v;
         }
 #pragma unroll
         for (int j = 0; j < WLOADS; j++) {
-            int idx = tid + j * NTHREADS; // chunk index in the BN x 4 tile
-            if (idx < BN * 4) {
-                int row = idx >> 2;
-                wreg[j] = *(const v4i *)(p.w + (size_t)(oc0 + row) * k64 + ks * BK + (idx & 3) * 16);
-            }
+            const int idx = tid + j * NTHREADS;
+            if (idx < BN * 4) wreg[j] = *(const v4i *)(p.w + (size_t)(oc0 + (idx >> 2)) * k64 + ks * BK + (idx & 3) * 16);
         }
-        // advance this thread's K position by one step (64 bytes)
         rc += BK;
-        if (FAST) {
-            while (rc >= p.in_c) { rc -= p.in_c; kx++; }
-            while (kx >= p.kw) { kx -= p.kw; ky++; }
-        } else {
-            while (rc >= p.row_pad) { rc -= p.row_pad; ky++; }
-        }
+        while (rc >= p.row_pad) { rc -= p.row_pad; ky++; }
     };
     auto store_lds = [&](int buf) {
 #pragma unroll
-        for (int j = 0; j < 2; j++) {
-            int row = (tid >> 2) + j * 64;
-            *(v4i *)(lds + buf * STAGE + lds_off(row, cc)) = xreg[j];
-        }
+        for (int j = 0; j < 2; j++) *(v4i *)(lds + buf * STAGE + lds_off((tid >> 2) + j * 64, cc)) = xreg[j];
 #pragma unroll
         for (int j = 0; j < WLOADS; j++) {
-            int idx = tid + j * NTHREADS;
+            const int idx = tid + j * NTHREADS;
             if (idx < BN * 4) *(v4i *)(lds + buf * STAGE + BP * BK + lds_off(idx >> 2, idx & 3)) = wreg[j];
         }
     };
 
-    constexpr int NS = BN / 16; // oc subtiles per wave
-    v4i acc[NS][2];
+    v4i acc[WOC][WPX];
 #pragma unroll
-    for (int s = 0; s < NS; s++) {
-        acc[s][0] = (v4i){0, 0, 0, 0};
-        acc[s][1] = (v4i){0, 0, 0, 0};
-    }
+    for (int s = 0; s < WOC; s++)
+#pragma unroll
+        for (int t = 0; t < WPX; t++) acc[s][t] = (v4i){0, 0, 0, 0};
 
     load_global(0);
     store_lds(0);
     __syncthreads();
-
     const int frow = lane & 15, fchunk = lane >> 4;
+    const int pxw = wv * 32;
     for (int ks = 0; ks < nks; ks++) {
         const int buf = ks & 1;
         if (ks + 1 < nks) load_global(ks + 1);
-        v4i xb[2];
+        v4i xb[WPX];
 #pragma unroll
-        for (int ps = 0; ps < 2; ps++) xb[ps] = *(const v4i *)(lds + buf * STAGE + lds_off(wv * 32 + ps * 16 + frow, fchunk));
+        for (int t = 0; t < WPX; t++) xb[t] = *(const v4i *)(lds + buf * STAGE + lds_off(pxw + t * 16 + frow, fchunk));
 #pragma unroll
-        for (int s = 0; s < NS; s++) {
+        for (int s = 0; s < WOC; s++) {
             v4i wa = *(const v4i *)(lds + buf * STAGE + BP * BK + lds_off(s * 16 + frow, fchunk));
-            acc[s][0] = __builtin_amdgcn_mfma_i32_16x16x64_i8(wa, xb[0], acc[s][0], 0, 0, 0);
-            acc[s][1] = __builtin_amdgcn_mfma_i32_16x16x64_i8(wa, xb[1], acc[s][1], 0, 0, 0);
+#pragma unroll
+            for (int t = 0; t < WPX; t++) acc[s][t] = __builtin_amdgcn_mfma_i32_16x16x64_i8(wa, xb[t], acc[s][t], 0, 0, 0);
         }
         if (ks + 1 < nks) store_lds(buf ^ 1);
         __syncthreads();
     }
-
-    // ---- epilogue: lane holds D[oc = s*16 + (lane>>4)*4 + r][pixel = lane&15]
-    const bool vec4 = (p.out_c & 3) == 0 && !p.out_nchw;
-#pragma unroll
-    for (int ps = 0; ps < 2; ps++) {
-        long pix = pix0 + wv * 32 + ps * 16 + (lane & 15);
-        if (pix >= total_pix) continue;
-        long f = pix / hw;
-        int rem = (int)(pix - f * hw);
-        int8_t *obase = p.out + (size_t)f * p.out_stride;
-#pragma unroll
-        for (int s = 0; s < NS; s++) {
-            int oc = oc0 + s * 16 + (lane >> 4) * 4;
-            if (oc >= p.out_c) continue;
-            int q[4];
-#pragma unroll
-            for (int r = 0; r < 4; r++) {
-                int a = acc[s][ps][r];
-                if (p.bias) a += p.bias[oc + r]; // bias is padded to oc_pad
-                int v = requant(a, p.cs);
-                if (p.relu) v = v < 0 ? 0 : v;
-                if (p.lut) v = (int8_t)p.lut[v + 128];
-                q[r] = v;
-            }
-            if (vec4) {
-                uint32_t pk = (uint32_t)(q[0] & 255) | ((uint32_t)(q[1] & 255) << 8) |
-                              ((uint32_t)(q[2] & 255) << 16) | ((uint32_t)(q[3] & 255) << 24);
-                *(uint32_t *)(obase + (size_t)rem * p.out_c + oc) = pk;
-            } else if (!p.out_nchw) {
-#pragma unroll
-                for (int r = 0; r < 4; r++)
-                    if (oc + r < p.out_c) obase[(size_t)rem * p.out_c + oc + r] = (int8_t)q[r];
-            } else {
-#pragma unroll
-                for (int r = 0; r < 4; r++)
-                    if (oc + r < p.out_c) obase[(size_t)(oc + r) * hw + rem] = (int8_t)q[r];
-            }
-        }
-    }
+    epilogue<BN, WPX, WOC>(p, acc, lds, slut, pix0, total_pix, oc0, pxw, 0, hw);
 }
 
 extern "C" void mhip_conv_i8_pack_geom(int in_c, int kw, int out_c, int *row_pad, int *oc_pad) {
@@ -231,27 +374,40 @@ extern "C" void mhip_conv_i8_pack_geom(int in_c, int kw, int out_c, int *row_pad
     if (oc_pad) *oc_pad = (out_c + 31) & ~31;
 }
 
-template <int BN, bool FAST>
-static int launch(const mhip_conv_i8_t *p, long total_pix, int k64) {
+template <int BN, int STAGES>
+static int launch_mfma(const mhip_conv_i8_t *p, long total_pix, int k64) {
+    const unsigned npt = (unsigned)((total_pix + BP - 1) / BP), noc = (unsigned)(p->oc_pad / BN);
+    const unsigned nblk = npt * noc;
+    hipLaunchKernelGGL((conv_i8_mfma<BN, STAGES>), dim3(nblk), dim3(NTHREADS), 0, mhip_stream_native(), *p, total_pix,
+                       k64, (const int8_t *)mhip_zero_page(), noc, nblk);
+    return mhip_check(hipGetLastError(), "conv_i8_mfma launch");
+}
+
+template <int BN>
+static int launch_generic(const mhip_conv_i8_t *p, long total_pix, int k64) {
     dim3 grid((unsigned)((total_pix + BP - 1) / BP), (unsigned)(p->oc_pad / BN));
-    hipLaunchKernelGGL((conv_i8_kernel<BN, FAST>), grid, dim3(NTHREADS), 0, mhip_stream_native(), *p, total_pix, k64);
-    return mhip_check(hipGetLastError(), "conv_i8 launch");
+    hipLaunchKernelGGL((conv_i8_generic<BN>), grid, dim3(NTHREADS), 0, mhip_stream_native(), *p, total_pix, k64);
+    return mhip_check(hipGetLastError(), "conv_i8_generic launch");
 }
 
 extern "C" int mhip_conv_i8(const mhip_conv_i8_t *p) {
-    // host-side shape checks: the kernel trusts these (a faulting kernel can reset the node)
+    // host-side shape checks: the kernels trust these (a faulting kernel can reset the node)
     if (!p || !p->in || !p->out || !p->w) return -1;
     if (p->frames <= 0 || p->in_h <= 0 || p->in_w <= 0 || p->in_c <= 0 || p->out_h <= 0 || p->out_w <= 0 ||
-        p->out_c <= 0 || p->kh <= 0 || p->kw <= 0 || p->stride_h <= 0 || p->stride_w <= 0)
+        p->out_c <= 0 || p->kh <= 0 || p->kw <= 0 || p->stride_h < 0 || p->stride_w < 0)
         return -1;
     int row_pad, oc_pad;
     mhip_conv_i8_pack_geom(p->in_c, p->kw, p->out_c, &row_pad, &oc_pad);
     if (row_pad != p->row_pad || oc_pad != p->oc_pad) return -1;
     const long total_pix = (long)p->frames * p->out_h * p->out_w;
     const int k64 = (p->kh * p->row_pad + BK - 1) / BK * BK;
-    const bool fast = (p->in_c % 16) == 0;
-    if (total_pix <= 0 || (total_pix + BP - 1) / BP > 0x7fffffffL) return -1;
-    if (oc_pad % 128 == 0) return fast ? launch<128, true>(p, total_pix, k64) : launch<128, false>(p, total_pix, k64);
-    if (oc_pad % 64 == 0) return fast ? launch<64, true>(p, total_pix, k64) : launch<64, false>(p, total_pix, k64);
-    return fast ? launch<32, true>(p, total_pix, k64) : launch<32, false>(p, total_pix, k64);
+    if (total_pix <= 0 || (total_pix + BP - 1) / BP * (oc_pad / 32) > 0x7fffffffL) return -1;
+    if ((p->in_c % 16) == 0) {
+        if (!mhip_zero_page()) return -1;
+        if (oc_pad % 128 == 0) return launch_mfma<128, 3>(p, total_pix, k64);
+        if (oc_pad % 64 == 0) return launch_mfma<64, 4>(p, total_pix, k64);
+        return launch_mfma<32, 4>(p, total_pix, k64);
+    }
+    if (oc_pad % 64 == 0) return launch_generic<64>(p, total_pix, k64);
+    return launch_generic<32>(p, total_pix, k64);
 }

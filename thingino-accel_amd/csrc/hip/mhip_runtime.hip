@@ -14,6 +14,7 @@ static hipStream_t g_stream = nullptr;
 static int g_ready = 0;
 static int g_device = -1;
 static char g_err[256] = "";
+static void *g_zero_page = nullptr; // 256 zero bytes in HBM: DMA source for out-of-image conv taps
 
 extern "C" hipStream_t mhip_stream_native(void) { return g_stream; }
 
@@ -43,6 +44,9 @@ extern "C" int mhip_init(int device_hint) {
     }
     if (mhip_check(hipSetDevice(dev), "hipSetDevice")) return -1;
     if (mhip_check(hipStreamCreateWithFlags(&g_stream, hipStreamNonBlocking), "hipStreamCreate")) return -3;
+    if (mhip_check(hipMalloc(&g_zero_page, 256), "hipMalloc zero page") ||
+        mhip_check(hipMemset(g_zero_page, 0, 256), "hipMemset zero page"))
+        return -3;
     g_device = dev;
     g_ready = 1;
     return 0;
@@ -52,11 +56,14 @@ extern "C" void mhip_shutdown(void) {
     if (!g_ready) return;
     (void)hipStreamSynchronize(g_stream);
     (void)hipStreamDestroy(g_stream);
+    if (g_zero_page) (void)hipFree(g_zero_page);
+    g_zero_page = nullptr;
     g_stream = nullptr;
     g_ready = 0;
 }
 
 extern "C" int mhip_ready(void) { return g_ready; }
+extern "C" const void *mhip_zero_page(void) { return g_zero_page; }
 
 extern "C" int mhip_device_info(int *cu_count, int *lds_bytes, int *gfx_version, size_t *hbm_bytes) {
     if (!g_ready) return -1;
