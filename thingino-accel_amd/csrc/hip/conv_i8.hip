@@ -28,8 +28,9 @@
 // ReLU and 256-entry LUT (fused conv->sigmoid->mul) from LDS, results staged
 // through LDS and written with coalesced 16-byte stores.
 //
-// Generic kernel (any in_c, used for the 3-channel stem): register-staged,
-// byte-granular gather, same arithmetic.
+// Small-channel kernel (in_c <= 4: the RGB stem): input patch of an 8x16 output tile
+// staged once in LDS, pixels widened to 4 bytes, weights resident in LDS.
+// Generic kernel (any other in_c): register-staged, byte-granular gather.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
@@ -83,9 +84,10 @@ __device__ __forceinline__ unsigned xcd_remap(unsigned bid, unsigned nblk) {
 
 // ---------------------------------------------------------------------------------
 // shared epilogue: accumulators -> requant -> LDS tile -> coalesced global stores
-template <int BN, int WPX, int WOC>
+// `pixel_of(row)` maps a row of the BP-pixel tile to its global pixel index (frame*H*W + y*W + x), or -1
+template <int BN, int WPX, int WOC, class PixelOf>
 __device__ __forceinline__ void epilogue(const mhip_conv_i8_t &p, v4i (&acc)[WOC][WPX], int8_t *tile, const uint8_t *slut,
-                                         long pix0, long total_pix, int oc0, int pxw, int ocw, int hw) {
+                                         PixelOf pixel_of, int oc0, int pxw, int ocw, int hw) {
     const int tid = threadIdx.x, lane = tid & 63;
     constexpr int ROW = BN + OPAD;
     // bias for this lane's 4 consecutive channels of each oc subtile
@@ -115,8 +117,8 @@ __device__ __forceinline__ void epilogue(const mhip_conv_i8_t &p, v4i (&acc)[WOC
         constexpr int CPR = BN / 16; // 16-byte chunks per pixel row
         for (int id = tid; id < BP * CPR; id += NTHREADS) {
             const int row = id / CPR, c = id - row * CPR;
-            const long pix = pix0 + row;
-            if (pix >= total_pix || c * 16 >= ncols) continue;
+            const long pix = pixel_of(row);
+            if (pix < 0 || c * 16 >= ncols) continue;
             const long f = pix / hw;
             const int rem = (int)(pix - f * hw);
             const int8_t *s = tile + row * ROW + c * 16;
@@ -126,8 +128,8 @@ __device__ __forceinline__ void epilogue(const mhip_conv_i8_t &p, v4i (&acc)[WOC
     } else if (!p.out_nchw) {
         for (int id = tid; id < BP * BN; id += NTHREADS) {
             const int row = id / BN, c = id - row * BN;
-            const long pix = pix0 + row;
-            if (pix >= total_pix || c >= ncols) continue;
+            const long pix = pixel_of(row);
+            if (pix < 0 || c >= ncols) continue;
             const long f = pix / hw;
             const int rem = (int)(pix - f * hw);
             p.out[(size_t)f * p.out_stride + (size_t)rem * p.out_c + oc0 + c] = tile[row * ROW + c];
@@ -135,8 +137,8 @@ __device__ __forceinline__ void epilogue(const mhip_conv_i8_t &p, v4i (&acc)[WOC
     } else { // [O][H][W]: consecutive lanes -> consecutive pixels of one channel
         for (int id = tid; id < BP * BN; id += NTHREADS) {
             const int c = id / BP, row = id - c * BP;
-            const long pix = pix0 + row;
-            if (pix >= total_pix || c >= ncols) continue;
+            const long pix = pixel_of(row);
+            if (pix < 0 || c >= ncols) continue;
             const long f = pix / hw;
             const int rem = (int)(pix - f * hw);
             p.out[(size_t)f * p.out_stride + (size_t)(oc0 + c) * hw + rem] = tile[row * ROW + c];
@@ -258,7 +260,8 @@ __global__ __launch_bounds__(NTHREADS) void conv_i8_mfma(const mhip_conv_i8_t p,
         nstage = nstage + 1 == STAGES ? 0 : nstage + 1;
     }
     __syncthreads(); // every wave is done reading the ring: reuse it for the output tile
-    epilogue<BN, WPX, WOC>(p, acc, lds, slut, pix0, total_pix, oc0, pxw, ocw, hw);
+    epilogue<BN, WPX, WOC>(p, acc, lds, slut, [=](int row) { long q = pix0 + row; return q < total_pix ? q : -1L; }, oc0, pxw,
+                           ocw, hw);
 }
 
 // ---------------------------------------------------------------------------------
@@ -366,12 +369,140 @@ __global__ __launch_bounds__(NTHREADS) void conv_i8_generic(const mhip_conv_i8_t
         if (ks + 1 < nks) store_lds(buf ^ 1);
         __syncthreads();
     }
-    epilogue<BN, WPX, WOC>(p, acc, lds, slut, pix0, total_pix, oc0, pxw, 0, hw);
+    epilogue<BN, WPX, WOC>(p, acc, lds, slut, [=](int row) { long q = pix0 + row; return q < total_pix ? q : -1L; }, oc0, pxw,
+                           0, hw);
 }
 
-extern "C" void mhip_conv_i8_pack_geom(int in_c, int kw, int out_c, int *row_pad, int *oc_pad) {
-    if (row_pad) *row_pad = (kw * in_c + 15) & ~15;
+
+// ---------------------------------------------------------------------------------
+// small-channel kernel (in_c <= 4, kw <= 8: the RGB stem).  The input patch of an
+// 8x16 output tile is staged ONCE in LDS with every pixel widened to 4 bytes, so a
+// kernel row of a pixel is 32 contiguous LDS bytes (kw*4 used, the rest meets zero
+// weights) and one MFMA K step covers two kernel rows.  Weights ([oc][kh][32]) stay in
+// LDS for the lifetime of the (persistent) workgroup.  Input bytes are read once.
+#define SC_TH 8
+#define SC_TW 16
+template <int WOC>
+__global__ __launch_bounds__(NTHREADS) void conv_i8_smallc(const mhip_conv_i8_t p, const int k64, const int tiles_x,
+                                                           const int tiles_y, const long ntiles, const int PH, const int PW,
+                                                           const int PWp) {
+    constexpr int BN = WOC * 16;
+    extern __shared__ __attribute__((aligned(16))) int8_t dyn[];
+    const int wrow = k64 + 16;                       // padded weight row: conflict-free fragment reads
+    int8_t *wl = dyn;                                // [BN][wrow]
+    int8_t *patch = wl + ((BN * wrow + 15) & ~15);   // [(PH+1)][PWp] dwords
+    const int patch_bytes = ((PH + 1) * PWp * 4 + 15) & ~15;
+    int8_t *tile = patch + patch_bytes;              // [128][BN+OPAD]
+    uint8_t *slut = (uint8_t *)tile + BP * (BN + OPAD);
+
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int hw = p.out_h * p.out_w;
+    if (p.lut && tid < 64) ((uint32_t *)slut)[tid] = ((const uint32_t *)p.lut)[tid];
+    for (int i = tid; i < BN * (k64 / 16); i += NTHREADS) {
+        const int row = i / (k64 / 16), c = i - row * (k64 / 16);
+        *(v4i *)(wl + row * wrow + c * 16) = *(const v4i *)(p.w + (size_t)row * k64 + c * 16);
+    }
+    for (int i = tid; i < patch_bytes / 4; i += NTHREADS) ((uint32_t *)patch)[i] = 0;
+
+    const int npp = PH * PW; // input pixels of one patch; host guarantees npp <= 4 * NTHREADS
+    uint32_t pre[4];
+    auto fetch = [&](long t) {
+        const int tx = (int)(t % tiles_x), ty = (int)((t / tiles_x) % tiles_y);
+        const long f = t / ((long)tiles_x * tiles_y);
+        const int8_t *src = p.in + (size_t)f * p.in_stride;
+        const int y0 = ty * SC_TH * p.stride_h - p.pad_top, x0 = tx * SC_TW * p.stride_w - p.pad_left;
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            const int i = tid + j * NTHREADS;
+            uint32_t v = 0;
+            if (i < npp) {
+                const int r = i / PW, x = i - r * PW;
+                const int iy = y0 + r, ix = x0 + x;
+                if (iy >= 0 && iy < p.in_h && ix >= 0 && ix < p.in_w) {
+                    const int8_t *q = src + ((size_t)iy * p.in_w + ix) * p.in_c;
+                    for (int c = 0; c < p.in_c; c++) v |= (uint32_t)(uint8_t)q[c] << (8 * c);
+                }
+            }
+            pre[j] = v;
+        }
+    };
+    auto commit = [&]() {
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            const int i = tid + j * NTHREADS;
+            if (i < npp) {
+                const int r = i / PW, x = i - r * PW;
+                ((uint32_t *)patch)[r * PWp + x] = pre[j];
+            }
+        }
+    };
+
+    const int nks = k64 / BK;
+    long t = blockIdx.x;
+    if (t < ntiles) fetch(t);
+    for (; t < ntiles; t += gridDim.x) {
+        __syncthreads(); // previous tile fully consumed (patch reads and output tile copy-out)
+        commit();
+        __syncthreads();
+        const long tn = t + gridDim.x;
+        if (tn < ntiles) fetch(tn); // next tile's bytes travel while this one is computed
+
+        v4i acc[WOC][2];
+#pragma unroll
+        for (int s = 0; s < WOC; s++) acc[s][0] = acc[s][1] = (v4i){0, 0, 0, 0};
+        const int px = lane & 15, c = lane >> 4;
+        for (int ks = 0; ks < nks; ks++) {
+            const int ky = 2 * ks + (c >> 1);
+            v4i xb[2];
+#pragma unroll
+            for (int u = 0; u < 2; u++) {
+                const int py = wv * 2 + u;
+                const uint32_t *q = (const uint32_t *)patch + (py * p.stride_h + ky) * PWp + px * p.stride_w + (c & 1) * 4;
+                xb[u] = (v4i){(int)q[0], (int)q[1], (int)q[2], (int)q[3]}; // row PH (odd-kh tail) exists and is zero
+            }
+#pragma unroll
+            for (int s = 0; s < WOC; s++) {
+                const v4i wa = *(const v4i *)(wl + (s * 16 + px) * wrow + ks * BK + c * 16);
+                acc[s][0] = __builtin_amdgcn_mfma_i32_16x16x64_i8(wa, xb[0], acc[s][0], 0, 0, 0);
+                acc[s][1] = __builtin_amdgcn_mfma_i32_16x16x64_i8(wa, xb[1], acc[s][1], 0, 0, 0);
+            }
+        }
+        const int tx = (int)(t % tiles_x), ty = (int)((t / tiles_x) % tiles_y);
+        const long f = t / ((long)tiles_x * tiles_y);
+        const int oy0 = ty * SC_TH, ox0 = tx * SC_TW, ow = p.out_w, oh = p.out_h;
+        epilogue<BN, 2, WOC>(p, acc, tile, slut,
+                             [=](int row) {
+                                 const int oy = oy0 + (row >> 4), ox = ox0 + (row & 15);
+                                 return (oy < oh && ox < ow) ? f * hw + (long)oy * ow + ox : -1L;
+                             },
+                             0, wv * 32, 0, hw);
+    }
+}
+
+extern "C" int mhip_conv_i8_small_c(int in_c, int kw, int out_c) { return in_c <= 4 && kw <= 8 && out_c <= 64; }
+
+extern "C" void mhip_conv_i8_pack_geom(int in_c, int kw, int out_c, int *row_pad, int *oc_pad, int *c_eff) {
+    const int small = mhip_conv_i8_small_c(in_c, kw, out_c);
+    if (row_pad) *row_pad = small ? 32 : (kw * in_c + 15) & ~15; // small: every pixel widened to 4 bytes
     if (oc_pad) *oc_pad = (out_c + 31) & ~31;
+    if (c_eff) *c_eff = small ? 4 : in_c;
+}
+
+template <int WOC>
+static int launch_smallc(const mhip_conv_i8_t *p, int k64) {
+    const int tiles_x = (p->out_w + SC_TW - 1) / SC_TW, tiles_y = (p->out_h + SC_TH - 1) / SC_TH;
+    const long ntiles = (long)tiles_x * tiles_y * p->frames;
+    const int PH = (SC_TH - 1) * p->stride_h + p->kh, PW = (SC_TW - 1) * p->stride_w + p->kw;
+    const int PWp = (PW + 8 + 3) & ~3;
+    if ((long)PH * PW > 4 * NTHREADS) return -1;
+    constexpr int BN = WOC * 16;
+    const size_t lds = (((size_t)BN * (k64 + 16) + 15) & ~(size_t)15) + ((((size_t)PH + 1) * PWp * 4 + 15) & ~(size_t)15) +
+                       (size_t)BP * (BN + OPAD) + 256;
+    if (lds > 64 * 1024) return -1;
+    long grid = ntiles < 256L * 8 ? ntiles : 256L * 8;
+    hipLaunchKernelGGL((conv_i8_smallc<WOC>), dim3((unsigned)grid), dim3(NTHREADS), lds, mhip_stream_native(), *p, k64,
+                       tiles_x, tiles_y, ntiles, PH, PW, PWp);
+    return mhip_check(hipGetLastError(), "conv_i8_smallc launch");
 }
 
 template <int BN, int STAGES>
@@ -397,11 +528,17 @@ extern "C" int mhip_conv_i8(const mhip_conv_i8_t *p) {
         p->out_c <= 0 || p->kh <= 0 || p->kw <= 0 || p->stride_h < 0 || p->stride_w < 0)
         return -1;
     int row_pad, oc_pad;
-    mhip_conv_i8_pack_geom(p->in_c, p->kw, p->out_c, &row_pad, &oc_pad);
+    mhip_conv_i8_pack_geom(p->in_c, p->kw, p->out_c, &row_pad, &oc_pad, nullptr);
     if (row_pad != p->row_pad || oc_pad != p->oc_pad) return -1;
     const long total_pix = (long)p->frames * p->out_h * p->out_w;
     const int k64 = (p->kh * p->row_pad + BK - 1) / BK * BK;
     if (total_pix <= 0 || (total_pix + BP - 1) / BP * (oc_pad / 32) > 0x7fffffffL) return -1;
+    if (mhip_conv_i8_small_c(p->in_c, p->kw, p->out_c)) {
+        const int PH = (SC_TH - 1) * p->stride_h + p->kh, PW = (SC_TW - 1) * p->stride_w + p->kw;
+        if (p->stride_h >= 1 && p->stride_w >= 1 && (long)PH * PW <= 4 * NTHREADS)
+            return oc_pad == 32 ? launch_smallc<2>(p, k64) : launch_smallc<4>(p, k64);
+        return -1;
+    }
     if ((p->in_c % 16) == 0) {
         if (!mhip_zero_page()) return -1;
         if (oc_pad % 128 == 0) return launch_mfma<128, 3>(p, total_pix, k64);

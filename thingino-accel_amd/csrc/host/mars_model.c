@@ -258,7 +258,8 @@ static void plan_conv(mars_model_ext_t *m, int li) {
     op->prof_kind = 0;
     op->nchw = !in_nhwc; /* the kernel is chosen by the INPUT tag (:640-662) */
     op->c_pad = op->nchw ? (int)ALIGN_UP((size_t)in_c, 16) : in_c;
-    mhip_conv_i8_pack_geom(op->c_pad, kw, out_c, &op->row_pad, &op->oc_pad);
+    int c_eff = op->c_pad; /* bytes per pixel in the packed K layout (4 in small-channel mode) */
+    mhip_conv_i8_pack_geom(op->c_pad, kw, out_c, &op->row_pad, &op->oc_pad, &c_eff);
     const size_t k64 = ALIGN_UP((size_t)kh * op->row_pad, 64);
     op->w_off = arena_reserve(m, (size_t)op->oc_pad * k64);
     if (op->w_off == NO_OFF) return;
@@ -266,7 +267,7 @@ static void plan_conv(mars_model_ext_t *m, int li) {
         int8_t *tmp = (int8_t *)malloc(wcount ? wcount : 1);
         if (!tmp) return;
         blob_read(m, (size_t)w->data_offset, wcount, tmp);
-        mars_pack_conv_i8(tmp, wcount, op->nchw, out_c, in_c, kh, kw, op->c_pad, op->row_pad, op->oc_pad,
+        mars_pack_conv_i8(tmp, wcount, op->nchw, out_c, in_c, kh, kw, c_eff, op->row_pad, op->oc_pad,
                           (int8_t *)m->arena_host + op->w_off);
         free(tmp);
     }

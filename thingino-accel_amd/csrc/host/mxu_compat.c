@@ -63,8 +63,8 @@ static void conv_i8_host(int nchw, const signed char *input, int in_h, int in_w,
     }
     if (need_device(who)) return;
     const int c_pad = nchw ? (in_c + 15) & ~15 : in_c;
-    int row_pad, oc_pad;
-    mhip_conv_i8_pack_geom(c_pad, kw, out_c, &row_pad, &oc_pad);
+    int row_pad, oc_pad, c_eff;
+    mhip_conv_i8_pack_geom(c_pad, kw, out_c, &row_pad, &oc_pad, &c_eff);
     const size_t k64 = ((size_t)kh * row_pad + 63) & ~(size_t)63;
     const size_t in_b = (size_t)in_h * in_w * in_c, out_b = (size_t)out_h * out_w * out_c;
     const size_t w_b = (size_t)oc_pad * k64, scr_b = nchw ? (size_t)in_h * in_w * c_pad : 0;
@@ -72,7 +72,7 @@ static void conv_i8_host(int nchw, const signed char *input, int in_h, int in_w,
     int32_t *hb = (int32_t *)calloc((size_t)oc_pad, 4);
     uint8_t *d = (uint8_t *)mhip_malloc(A256(in_b) + A256(out_b) + A256(w_b) + A256((size_t)oc_pad * 4) + A256(scr_b) + 256);
     if (!hw || !hb || !d) { fprintf(stderr, "%s: allocation failed\n", who); goto done; }
-    mars_pack_conv_i8((const int8_t *)weight, (size_t)out_c * in_c * kh * kw, nchw, out_c, in_c, kh, kw, c_pad, row_pad,
+    mars_pack_conv_i8((const int8_t *)weight, (size_t)out_c * in_c * kh * kw, nchw, out_c, in_c, kh, kw, c_eff, row_pad,
                       oc_pad, hw);
     if (bias) memcpy(hb, bias, (size_t)out_c * 4);
     {

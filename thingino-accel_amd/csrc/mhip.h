@@ -61,7 +61,8 @@ typedef struct {
     int out_nchw;               /* store [O][H][W] instead of [H][W][O] */
 } mhip_conv_i8_t;
 /* packing geometry shared by host packer and kernel */
-void mhip_conv_i8_pack_geom(int in_c, int kw, int out_c, int *row_pad, int *oc_pad);
+/* c_eff: bytes per input pixel in the packed K layout (4 in small-channel mode, else in_c) */
+void mhip_conv_i8_pack_geom(int in_c, int kw, int out_c, int *row_pad, int *oc_pad, int *c_eff);
 int mhip_conv_i8(const mhip_conv_i8_t *p);
 
 /* ---- float32 convolution (conv_f32.hip): NCHW / OIHW, reference summation order */
