@@ -13,8 +13,10 @@
 //  * the exchange sort `for i: for j>i: if d[j].conf > d[i].conf swap` is NOT
 //    stable; pass i moves the suffix maximum to slot i and shifts the chain of
 //    strict left-to-right records one record-slot down.  Each pass is done here
-//    as one wave-wide (max, first-position) scan, reproducing the permutation
-//    exactly, ties included.
+//    as one wave-wide (max, first-holder) scan over register-resident slots,
+//    reproducing the permutation exactly, ties included;
+//  * suppression: the pair relation is evaluated in parallel into an LDS bit
+//    matrix with the reference's float expression order, then applied greedily.
 #include <hip/hip_runtime.h>
 #include <math.h>
 #include <stdint.h>
@@ -97,130 +99,192 @@ __global__ __launch_bounds__(256) void decode_kernel(const mhip_detect_t p) {
     }
 }
 
-// ---------------------------------------------------------- sort + suppress
-// one wave per frame; everything in LDS
-__global__ __launch_bounds__(64) void sort_nms_kernel(det_rec *all, int *counts, float thresh) {
-    __shared__ float cf[2][1024];
-    __shared__ short id[2][1024];
-    __shared__ float bx[1024], by[1024], bw[1024], bh[1024];
-    __shared__ int bc[1024];
-    __shared__ float sconf[1024];
-    __shared__ short sid[1024];
-    __shared__ unsigned char dead[1024];
+// ------------------------------------------------------------------- sort
+// One wave per frame, the whole candidate list in REGISTERS: lane L owns slots
+// 16L..16L+15.  Pass i of the reference's exchange sort = one (max, holder) scan
+// over slots >= i done with DPP row shifts/broadcasts (no LDS, no barrier):
+//   every strict left-to-right record receives the previous record's element,
+//   slot i receives the suffix maximum (first occurrence).
+// After pass i slot i is final, so when the loop ends the registers hold the
+// permutation the reference produces, ties included.
+#define DPP_ROW_SHR(n) (0x110 + (n))
+#define DPP_ROW_BCAST15 0x142
+#define DPP_ROW_BCAST31 0x143
+#define DPP_WAVE_SHR1 0x138
 
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ void scan_step(float &v, int &id) {
+    const int ninf = __float_as_int(-INFINITY);
+    float ov = __int_as_float(__builtin_amdgcn_update_dpp(ninf, __float_as_int(v), CTRL, ROW_MASK, 0xf, false));
+    int oid = __builtin_amdgcn_update_dpp(-1, id, CTRL, ROW_MASK, 0xf, false);
+    if (!(v > ov)) { v = ov; id = oid; } // the earlier holder stays unless strictly beaten
+}
+
+__global__ __launch_bounds__(64) void sort_kernel(det_rec *all, const int *counts) {
     const int f = blockIdx.x, lane = threadIdx.x;
     det_rec *dets = all + (size_t)f * MAXD;
     int n = counts[f];
     if (n > MAXD) n = MAXD;
-    if (n <= 0) return;
-    for (int j = lane; j < n; j += 64) {
-        cf[0][j] = dets[j].conf;
-        id[0][j] = (short)j;
-    }
-    __syncthreads();
-
-    // ---- exchange sort, pass by pass
-    int cur = 0;
-    for (int i = 0; i + 1 < n; i++) {
-        const int len = n - i;
-        const int per = (len + 63) >> 6;
-        const int b = i + lane * per;
-        const int e = b + per < n ? b + per : n;
-        // (1) chunk maximum and the first position that attains it
-        float mv = -INFINITY;
-        int mp = -1;
-        for (int j = b; j < e; j++) {
-            float v = cf[cur][j];
-            if (v > mv) { mv = v; mp = j; }
-        }
-        // (2) exclusive scan over lanes: running (max, holder) before this chunk
-        float sv = mv;
-        int sp = mp;
+    if (n <= 1) return;
+    float c[16];
+    int d[16];
 #pragma unroll
-        for (int d = 1; d < 64; d <<= 1) {
-            float ov = __shfl_up(sv, d);
-            int op = __shfl_up(sp, d);
-            if (lane >= d && !(sv > ov)) { sv = ov; sp = op; } // keep the earlier holder unless strictly greater
+    for (int k = 0; k < 16; k++) {
+        const int pos = lane * 16 + k;
+        c[k] = pos < n ? dets[pos].conf : -INFINITY;
+        d[k] = pos;
+    }
+    for (int i = 0; i + 1 < n; i++) {
+        // (1) this lane's (max, first holder) over its slots >= i
+        float v = -INFINITY;
+        int id = -1;
+#pragma unroll
+        for (int k = 0; k < 16; k++) {
+            const bool in = lane * 16 + k >= i;
+            if (in && c[k] > v) { v = c[k]; id = d[k]; }
         }
-        float rv = __shfl_up(sv, 1);
-        int rp = __shfl_up(sp, 1);
-        if (lane == 0) { rv = -INFINITY; rp = -1; }
-        const int fin = __shfl(sp, 63); // holder of the suffix maximum after the whole pass
-        // (3) rewrite the suffix: a strict record receives the previous holder's element
-        const int nxt = cur ^ 1;
-        for (int j = b; j < e; j++) {
-            float v = cf[cur][j];
-            int src = j;
-            if (v > rv) {
-                src = rp; // previous record (or -1 for the chain head at slot i)
-                rv = v;
-                rp = j;
+        // (2) inclusive scan across the wave
+        scan_step<DPP_ROW_SHR(1), 0xf>(v, id);
+        scan_step<DPP_ROW_SHR(2), 0xf>(v, id);
+        scan_step<DPP_ROW_SHR(4), 0xf>(v, id);
+        scan_step<DPP_ROW_SHR(8), 0xf>(v, id);
+        scan_step<DPP_ROW_BCAST15, 0xa>(v, id);
+        scan_step<DPP_ROW_BCAST31, 0xc>(v, id);
+        const float fv = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
+        const int fid = __builtin_amdgcn_readlane(id, 63);
+        // running (max, holder) BEFORE this lane's first slot
+        float rv = __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(-INFINITY), __float_as_int(v), DPP_WAVE_SHR1, 0xf, 0xf, false));
+        int rid = __builtin_amdgcn_update_dpp(-1, id, DPP_WAVE_SHR1, 0xf, 0xf, false);
+        // (3) shift the record chain, then drop the maximum into slot i
+#pragma unroll
+        for (int k = 0; k < 16; k++) {
+            const int pos = lane * 16 + k;
+            if (pos >= i && c[k] > rv) {
+                const float tv = c[k];
+                const int tid_ = d[k];
+                c[k] = rv;
+                d[k] = rid;
+                rv = tv;
+                rid = tid_;
             }
-            if (j == i) src = fin; // slot i ends the pass holding the maximum
-            cf[nxt][j] = cf[cur][src < 0 ? j : src];
-            id[nxt][j] = id[cur][src < 0 ? j : src];
+            if (pos == i) { c[k] = fv; d[k] = fid; }
         }
-        __syncthreads();
-        if (lane == 0) {
-            sconf[i] = cf[nxt][i];
-            sid[i] = id[nxt][i];
-        }
-        cur = nxt;
     }
-    if (lane == 0) {
-        sconf[n - 1] = cf[cur][n - 1];
-        sid[n - 1] = id[cur][n - 1];
-    }
+    // gather the records in sorted order (read everything before anything is overwritten)
+    det_rec out[16];
+#pragma unroll
+    for (int k = 0; k < 16; k++)
+        if (lane * 16 + k < n) out[k] = dets[d[k]];
     __syncthreads();
+#pragma unroll
+    for (int k = 0; k < 16; k++)
+        if (lane * 16 + k < n) dets[lane * 16 + k] = out[k];
+}
 
-    // ---- gather boxes in sorted order
-    for (int j = lane; j < n; j += 64) {
-        det_rec d = dets[sid[j]];
+// --------------------------------------------------------------- suppress
+// One 1024-thread workgroup per frame.  The pairwise "same class and IoU > t"
+// relation is evaluated for all j > i in parallel into a bit matrix in LDS
+// (128 KB for 1000 boxes), then one wave walks i = 0..n-1 greedily OR-ing rows,
+// which is exactly the reference's double loop (suppressed boxes suppress nothing).
+#define NMS_THREADS 1024
+__global__ __launch_bounds__(NMS_THREADS) void nms_kernel(det_rec *all, int *counts, float thresh) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    unsigned long long *mask = (unsigned long long *)smem;            // [n][16]
+    float *bx = (float *)(smem + (size_t)MAXD * 16 * 8), *by = bx + 1024, *bw = by + 1024, *bh = bw + 1024;
+    int *bc = (int *)(bh + 1024);
+    __shared__ unsigned long long removed_s[16];
+
+    const int f = blockIdx.x, tid = threadIdx.x;
+    det_rec *dets = all + (size_t)f * MAXD;
+    int n = counts[f];
+    if (n > MAXD) n = MAXD;
+    if (n <= 0) return;
+    for (int j = tid; j < n; j += NMS_THREADS) {
+        det_rec d = dets[j];
         bx[j] = d.x; by[j] = d.y; bw[j] = d.w; bh[j] = d.h; bc[j] = d.cls;
-        dead[j] = 0;
     }
     __syncthreads();
-
-    // ---- greedy suppression, i sequential, j across the wave
-    for (int i = 0; i < n; i++) {
-        if (dead[i]) continue; // uniform: every lane reads the same byte
-        const float xi = bx[i], yi = by[i], wi = bw[i], hi = bh[i];
-        const int ci = bc[i];
-        const float ax1 = xi - wi / 2, ay1 = yi - hi / 2, ax2 = xi + wi / 2, ay2 = yi + hi / 2;
-        const float aarea = wi * hi;
-        for (int j = i + 1 + lane; j < n; j += 64) {
-            if (dead[j] || bc[j] != ci) continue;
-            const float xj = bx[j], yj = by[j], wj = bw[j], hj = bh[j];
-            float x1 = fmaxf(ax1, xj - wj / 2);
-            float y1 = fmaxf(ay1, yj - hj / 2);
-            float x2 = fminf(ax2, xj + wj / 2);
-            float y2 = fminf(ay2, yj + hj / 2);
-            float iw = fmaxf(0.0f, x2 - x1), ih = fmaxf(0.0f, y2 - y1);
-            float inter = iw * ih;
-            float barea = wj * hj;
-            float uni = aarea + barea;
-            uni = uni - inter;
-            uni = uni + 1e-6f;
-            if (inter / uni > thresh) dead[j] = 1;
+    const int nw = (n + 63) >> 6;
+    for (int pair = tid; pair < n * nw; pair += NMS_THREADS) {
+        const int i = pair / nw, w = pair - i * nw;
+        unsigned long long bits = 0;
+        if (w * 64 + 63 > i) {
+            const float xi = bx[i], yi = by[i], wi = bw[i], hi = bh[i];
+            const int ci = bc[i];
+            const float ax1 = xi - wi / 2, ay1 = yi - hi / 2, ax2 = xi + wi / 2, ay2 = yi + hi / 2;
+            const float aarea = wi * hi;
+            const int j0 = w * 64 > i + 1 ? w * 64 : i + 1;
+            const int j1 = w * 64 + 64 < n ? w * 64 + 64 : n;
+            for (int j = j0; j < j1; j++) {
+                if (bc[j] != ci) continue;
+                const float xj = bx[j], yj = by[j], wj = bw[j], hj = bh[j];
+                float x1 = fmaxf(ax1, xj - wj / 2);
+                float y1 = fmaxf(ay1, yj - hj / 2);
+                float x2 = fminf(ax2, xj + wj / 2);
+                float y2 = fminf(ay2, yj + hj / 2);
+                float iw = fmaxf(0.0f, x2 - x1), ih = fmaxf(0.0f, y2 - y1);
+                float inter = iw * ih;
+                float barea = wj * hj;
+                float uni = aarea + barea;
+                uni = uni - inter;
+                uni = uni + 1e-6f;
+                if (inter / uni > thresh) bits |= 1ull << (j & 63);
+            }
         }
-        __syncthreads();
+        mask[(size_t)i * 16 + w] = bits;
     }
-
-    // ---- compact survivors, in order, back to global
-    int kept = 0;
-    for (int base = 0; base < n; base += 64) {
-        int j = base + lane;
-        bool keep = j < n && !dead[j];
-        unsigned long long m = __ballot(keep);
-        int slot = kept + __popcll(m & ((1ull << lane) - 1ull));
-        if (keep) {
-            det_rec d;
-            d.x = bx[j]; d.y = by[j]; d.w = bw[j]; d.h = bh[j]; d.conf = sconf[j]; d.cls = bc[j];
-            dets[slot] = d;
+    __syncthreads();
+    if (tid < 64) {
+        unsigned long long removed = 0; // lane w (< 16) holds word w
+        for (int i = 0; i < n; i++) {
+            const unsigned lo = __builtin_amdgcn_readlane((unsigned)removed, i >> 6);
+            const unsigned hi = __builtin_amdgcn_readlane((unsigned)(removed >> 32), i >> 6);
+            const unsigned long long word = ((unsigned long long)hi << 32) | lo;
+            if ((word >> (i & 63)) & 1ull) continue; // suppressed boxes suppress nothing
+            if (tid < nw) removed |= mask[(size_t)i * 16 + tid];
         }
-        kept += __popcll(m);
+        if (tid < 16) removed_s[tid] = tid < nw ? removed : ~0ull;
     }
-    if (lane == 0) counts[f] = kept;
+    __syncthreads();
+    // compact the survivors in order
+    __shared__ int wave_cnt[16];
+    __shared__ int base_s;
+    if (tid == 0) base_s = 0;
+    __syncthreads();
+    const int lane = tid & 63, wv = tid >> 6;
+    det_rec keep_rec;
+    const bool in = tid < n;
+    const bool keep = in && !((removed_s[tid >> 6] >> (tid & 63)) & 1ull);
+    if (keep) { keep_rec.x = bx[tid]; keep_rec.y = by[tid]; keep_rec.w = bw[tid]; keep_rec.h = bh[tid]; keep_rec.cls = bc[tid]; keep_rec.conf = dets[tid].conf; }
+    const unsigned long long m = __ballot(keep);
+    if (lane == 0) wave_cnt[wv] = __popcll(m);
+    __syncthreads();
+    int off = 0;
+    for (int w = 0; w < wv; w++) off += wave_cnt[w];
+    const int slot = off + __popcll(m & ((1ull << lane) - 1ull));
+    __syncthreads(); // every conf has been read before any record is overwritten
+    if (keep) dets[slot] = keep_rec;
+    if (tid == 0) {
+        int total = 0;
+        for (int w = 0; w < 16; w++) total += wave_cnt[w];
+        counts[f] = total;
+    }
+}
+
+static int launch_sort_nms(det_rec *dets, int *counts, int frames, float thresh) {
+    hipLaunchKernelGGL(sort_kernel, dim3(frames), dim3(64), 0, mhip_stream_native(), dets, counts);
+    int rc = mhip_check(hipGetLastError(), "sort");
+    if (rc) return rc;
+    const size_t lds = (size_t)MAXD * 16 * 8 + 5 * 1024 * 4;
+    static bool attr_set = false;
+    if (!attr_set) {
+        rc = mhip_check(hipFuncSetAttribute((const void *)nms_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds),
+                        "nms LDS attribute");
+        if (rc) return rc;
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(nms_kernel, dim3(frames), dim3(NMS_THREADS), lds, mhip_stream_native(), dets, counts, thresh);
+    return mhip_check(hipGetLastError(), "nms");
 }
 
 extern "C" int mhip_detect(const mhip_detect_t *p) {
@@ -230,14 +294,10 @@ extern "C" int mhip_detect(const mhip_detect_t *p) {
     hipLaunchKernelGGL(decode_kernel, dim3(p->frames), dim3(256), 0, mhip_stream_native(), *p);
     int rc = mhip_check(hipGetLastError(), "decode");
     if (rc || !p->do_nms) return rc;
-    hipLaunchKernelGGL(sort_nms_kernel, dim3(p->frames), dim3(64), 0, mhip_stream_native(), (det_rec *)p->dets,
-                       p->counts, p->nms_thresh);
-    return mhip_check(hipGetLastError(), "sort_nms");
+    return launch_sort_nms((det_rec *)p->dets, p->counts, p->frames, p->nms_thresh);
 }
 
 extern "C" int mhip_nms_only(void *dets_dev, int *count_dev, int n, float thresh) {
     if (!dets_dev || !count_dev || n < 0 || n > MAXD) return -1;
-    hipLaunchKernelGGL(sort_nms_kernel, dim3(1), dim3(64), 0, mhip_stream_native(), (det_rec *)dets_dev, count_dev,
-                       thresh);
-    return mhip_check(hipGetLastError(), "sort_nms");
+    return launch_sort_nms((det_rec *)dets_dev, count_dev, 1, thresh);
 }
