@@ -84,10 +84,24 @@ __device__ __forceinline__ unsigned xcd_remap(unsigned bid, unsigned nblk) {
 
 // ---------------------------------------------------------------------------------
 // shared epilogue: accumulators -> requant -> LDS tile -> coalesced global stores
-// `pixel_of(row)` maps a row of the BP-pixel tile to its global pixel index (frame*H*W + y*W + x), or -1
-template <int BN, int WPX, int WOC, class PixelOf>
+// `rowoff[row]` = byte offset of tile row `row`'s pixel in the output (frame*out_stride + rem*out_c for NHWC,
+// frame*out_stride + rem for NCHW), or -1 when the row is outside the image/batch; filled by fill_rowoff().
+template <class PixelOf>
+__device__ __forceinline__ void fill_rowoff(const mhip_conv_i8_t &p, long *rowoff, PixelOf pixel_of, unsigned hw) {
+    if (threadIdx.x < BP) {
+        const long pix = pixel_of((int)threadIdx.x); // global pixel index (frame*H*W + y*W + x) or -1
+        long off = -1;
+        if (pix >= 0) {
+            const unsigned f = (unsigned)((unsigned long)pix / hw), rem = (unsigned)((unsigned long)pix - (unsigned long)f * hw);
+            off = (long)f * (long)p.out_stride + (p.out_nchw ? (long)rem : (long)rem * p.out_c);
+        }
+        rowoff[threadIdx.x] = off;
+    }
+}
+
+template <int BN, int WPX, int WOC>
 __device__ __forceinline__ void epilogue(const mhip_conv_i8_t &p, v4i (&acc)[WOC][WPX], int8_t *tile, const uint8_t *slut,
-                                         PixelOf pixel_of, int oc0, int pxw, int ocw, int hw) {
+                                         const long *rowoff, int oc0, int pxw, int ocw, int hw) {
     const int tid = threadIdx.x, lane = tid & 63;
     constexpr int ROW = BN + OPAD;
     // bias for this lane's 4 consecutive channels of each oc subtile
@@ -117,31 +131,25 @@ __device__ __forceinline__ void epilogue(const mhip_conv_i8_t &p, v4i (&acc)[WOC
         constexpr int CPR = BN / 16; // 16-byte chunks per pixel row
         for (int id = tid; id < BP * CPR; id += NTHREADS) {
             const int row = id / CPR, c = id - row * CPR;
-            const long pix = pixel_of(row);
-            if (pix < 0 || c * 16 >= ncols) continue;
-            const long f = pix / hw;
-            const int rem = (int)(pix - f * hw);
+            const long off = rowoff[row];
+            if (off < 0 || c * 16 >= ncols) continue;
             const int8_t *s = tile + row * ROW + c * 16;
             v4i v = {*(const int *)s, *(const int *)(s + 4), *(const int *)(s + 8), *(const int *)(s + 12)};
-            *(v4i *)(p.out + (size_t)f * p.out_stride + (size_t)rem * p.out_c + oc0 + c * 16) = v;
+            *(v4i *)(p.out + off + oc0 + c * 16) = v;
         }
     } else if (!p.out_nchw) {
         for (int id = tid; id < BP * BN; id += NTHREADS) {
             const int row = id / BN, c = id - row * BN;
-            const long pix = pixel_of(row);
-            if (pix < 0 || c >= ncols) continue;
-            const long f = pix / hw;
-            const int rem = (int)(pix - f * hw);
-            p.out[(size_t)f * p.out_stride + (size_t)rem * p.out_c + oc0 + c] = tile[row * ROW + c];
+            const long off = rowoff[row];
+            if (off < 0 || c >= ncols) continue;
+            p.out[off + oc0 + c] = tile[row * ROW + c];
         }
     } else { // [O][H][W]: consecutive lanes -> consecutive pixels of one channel
         for (int id = tid; id < BP * BN; id += NTHREADS) {
             const int c = id / BP, row = id - c * BP;
-            const long pix = pixel_of(row);
-            if (pix < 0 || c >= ncols) continue;
-            const long f = pix / hw;
-            const int rem = (int)(pix - f * hw);
-            p.out[(size_t)f * p.out_stride + (size_t)(oc0 + c) * hw + rem] = tile[row * ROW + c];
+            const long off = rowoff[row];
+            if (off < 0 || c >= ncols) continue;
+            p.out[off + (size_t)(oc0 + c) * hw] = tile[row * ROW + c];
         }
     }
 }
@@ -159,11 +167,11 @@ __global__ __launch_bounds__(NTHREADS) void conv_i8_mfma(const mhip_conv_i8_t p,
     constexpr int WOC = BN / NWN / 16;           // oc subtiles per wave
     constexpr int LW = BN >= 128 ? 2 : 1;        // W-tile DMA instructions per wave
     constexpr int L = 2 + LW;                    // DMA instructions per wave per stage
-    constexpr int TILE_BYTES = BP * (BN + OPAD);
-    constexpr int RING = STAGES * STAGE;
-    constexpr int LDS_BYTES = (RING > TILE_BYTES ? RING : TILE_BYTES) + 256;
-    __shared__ __attribute__((aligned(16))) int8_t lds[LDS_BYTES];
-    uint8_t *slut = (uint8_t *)lds + LDS_BYTES - 256;
+    // dynamic LDS: [rowoff 1 KB][lut 256 B][ring: min(nks, STAGES) stages, reused as the output tile]
+    extern __shared__ __attribute__((aligned(16))) int8_t dynlds[];
+    long *rowoff = (long *)dynlds;
+    uint8_t *slut = (uint8_t *)dynlds + BP * 8;
+    int8_t *lds = dynlds + BP * 8 + 256;
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -173,6 +181,7 @@ __global__ __launch_bounds__(NTHREADS) void conv_i8_mfma(const mhip_conv_i8_t p,
     const int hw = p.out_h * p.out_w;
 
     if (p.lut && tid < 64) ((uint32_t *)slut)[tid] = ((const uint32_t *)p.lut)[tid];
+    fill_rowoff(p, rowoff, [=](int row) { long q = pix0 + row; return q < total_pix ? q : -1L; }, (unsigned)hw);
 
     // ---- DMA assignment.  One wave-instruction fills 16 consecutive 64-byte rows; lane i
     // lands in row i/4, slot i%4, so it must FETCH chunk (slot ^ swizzle(row)).
@@ -184,9 +193,9 @@ __global__ __launch_bounds__(NTHREADS) void conv_i8_mfma(const mhip_conv_i8_t p,
     for (int j = 0; j < 2; j++) {
         long pix = pix0 + wv * 32 + j * 16 + (lane >> 2);
         rvalid[j] = pix < total_pix;
-        long f = rvalid[j] ? pix / hw : 0;
-        int rem = rvalid[j] ? (int)(pix - f * hw) : 0;
-        int oy = rem / p.out_w, ox = rem - oy * p.out_w;
+        const unsigned f = rvalid[j] ? (unsigned)((unsigned long)pix / (unsigned)hw) : 0u;
+        const unsigned rem = rvalid[j] ? (unsigned)((unsigned long)pix - (unsigned long)f * (unsigned)hw) : 0u;
+        const int oy = (int)(rem / (unsigned)p.out_w), ox = (int)(rem - (unsigned)oy * (unsigned)p.out_w);
         iy0[j] = oy * p.stride_h - p.pad_top;
         ix0[j] = ox * p.stride_w - p.pad_left;
         xbase[j] = p.in + (size_t)f * p.in_stride;
@@ -240,8 +249,8 @@ __global__ __launch_bounds__(NTHREADS) void conv_i8_mfma(const mhip_conv_i8_t p,
     for (int ks = 0; ks < nks; ks++) {
         // tiles still allowed in flight once tile ks must have landed
         const int ahead = nks - 1 - ks;
-        if (STAGES == 4 && ahead >= 2) wait_vmcnt<2 * L>();
-        else if (ahead >= 1) wait_vmcnt<L>();
+        if (STAGES >= 4 && ahead >= 2) wait_vmcnt<2 * L>();
+        else if (STAGES >= 3 && ahead >= 1) wait_vmcnt<L>();
         else wait_vmcnt<0>();
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
@@ -260,8 +269,7 @@ __global__ __launch_bounds__(NTHREADS) void conv_i8_mfma(const mhip_conv_i8_t p,
         nstage = nstage + 1 == STAGES ? 0 : nstage + 1;
     }
     __syncthreads(); // every wave is done reading the ring: reuse it for the output tile
-    epilogue<BN, WPX, WOC>(p, acc, lds, slut, [=](int row) { long q = pix0 + row; return q < total_pix ? q : -1L; }, oc0, pxw,
-                           ocw, hw);
+    epilogue<BN, WPX, WOC>(p, acc, lds, slut, rowoff, oc0, pxw, ocw, hw);
 }
 
 // ---------------------------------------------------------------------------------
@@ -273,6 +281,7 @@ __global__ __launch_bounds__(NTHREADS) void conv_i8_generic(const mhip_conv_i8_t
     constexpr int TILE_BYTES = BP * (BN + OPAD);
     constexpr int LDS_BYTES = (2 * STAGE > TILE_BYTES ? 2 * STAGE : TILE_BYTES) + 256;
     __shared__ __attribute__((aligned(16))) int8_t lds[LDS_BYTES];
+    __shared__ long rowoff[BP];
     uint8_t *slut = (uint8_t *)lds + LDS_BYTES - 256;
 
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
@@ -280,6 +289,7 @@ __global__ __launch_bounds__(NTHREADS) void conv_i8_generic(const mhip_conv_i8_t
     const int oc0 = blockIdx.y * BN;
     const int hw = p.out_h * p.out_w;
     if (p.lut && tid < 64) ((uint32_t *)slut)[tid] = ((const uint32_t *)p.lut)[tid];
+    fill_rowoff(p, rowoff, [=](int row) { long q = pix0 + row; return q < total_pix ? q : -1L; }, (unsigned)hw);
 
     const int cc = tid & 3;
     const int8_t *xbase[2];
@@ -369,8 +379,7 @@ __global__ __launch_bounds__(NTHREADS) void conv_i8_generic(const mhip_conv_i8_t
         if (ks + 1 < nks) store_lds(buf ^ 1);
         __syncthreads();
     }
-    epilogue<BN, WPX, WOC>(p, acc, lds, slut, [=](int row) { long q = pix0 + row; return q < total_pix ? q : -1L; }, oc0, pxw,
-                           0, hw);
+    epilogue<BN, WPX, WOC>(p, acc, lds, slut, rowoff, oc0, pxw, 0, hw);
 }
 
 
@@ -394,6 +403,7 @@ __global__ __launch_bounds__(NTHREADS) void conv_i8_smallc(const mhip_conv_i8_t 
     const int patch_bytes = ((PH + 1) * PWp * 4 + 15) & ~15;
     int8_t *tile = patch + patch_bytes;              // [128][BN+OPAD]
     uint8_t *slut = (uint8_t *)tile + BP * (BN + OPAD);
+    __shared__ long rowoff[BP];
 
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int hw = p.out_h * p.out_w;
@@ -470,12 +480,13 @@ __global__ __launch_bounds__(NTHREADS) void conv_i8_smallc(const mhip_conv_i8_t 
         const int tx = (int)(t % tiles_x), ty = (int)((t / tiles_x) % tiles_y);
         const long f = t / ((long)tiles_x * tiles_y);
         const int oy0 = ty * SC_TH, ox0 = tx * SC_TW, ow = p.out_w, oh = p.out_h;
-        epilogue<BN, 2, WOC>(p, acc, tile, slut,
-                             [=](int row) {
-                                 const int oy = oy0 + (row >> 4), ox = ox0 + (row & 15);
-                                 return (oy < oh && ox < ow) ? f * hw + (long)oy * ow + ox : -1L;
-                             },
-                             0, wv * 32, 0, hw);
+        fill_rowoff(p, rowoff,
+                    [=](int row) {
+                        const int oy = oy0 + (row >> 4), ox = ox0 + (row & 15);
+                        return (oy < oh && ox < ow) ? f * hw + (long)oy * ow + ox : -1L;
+                    },
+                    (unsigned)hw); // consumed after the barrier inside epilogue(); rewritten after the loop-top barrier
+        epilogue<BN, 2, WOC>(p, acc, tile, slut, rowoff, 0, wv * 32, 0, hw);
     }
 }
 
@@ -509,9 +520,21 @@ template <int BN, int STAGES>
 static int launch_mfma(const mhip_conv_i8_t *p, long total_pix, int k64) {
     const unsigned npt = (unsigned)((total_pix + BP - 1) / BP), noc = (unsigned)(p->oc_pad / BN);
     const unsigned nblk = npt * noc;
-    hipLaunchKernelGGL((conv_i8_mfma<BN, STAGES>), dim3(nblk), dim3(NTHREADS), 0, mhip_stream_native(), *p, total_pix,
+    const int nks = k64 / BK, used = nks < STAGES ? nks : STAGES;
+    size_t ring = (size_t)used * (BP + BN) * BK, tile = (size_t)BP * (BN + OPAD);
+    const size_t lds = BP * 8 + 256 + (ring > tile ? ring : tile);
+    hipLaunchKernelGGL((conv_i8_mfma<BN, STAGES>), dim3(nblk), dim3(NTHREADS), lds, mhip_stream_native(), *p, total_pix,
                        k64, (const int8_t *)mhip_zero_page(), noc, nblk);
     return mhip_check(hipGetLastError(), "conv_i8_mfma launch");
+}
+
+// ring depth: as deep as the K loop can use, bounded by what keeps >= 2-3 workgroups per CU
+template <int BN>
+static int launch_mfma_auto(const mhip_conv_i8_t *p, long total_pix, int k64) {
+    const int nks = k64 / BK;
+    if (nks <= 2) return launch_mfma<BN, 2>(p, total_pix, k64);
+    if (nks == 3 || BN == 128) return launch_mfma<BN, 3>(p, total_pix, k64);
+    return launch_mfma<BN, 4>(p, total_pix, k64);
 }
 
 template <int BN>
@@ -532,7 +555,7 @@ extern "C" int mhip_conv_i8(const mhip_conv_i8_t *p) {
     if (row_pad != p->row_pad || oc_pad != p->oc_pad) return -1;
     const long total_pix = (long)p->frames * p->out_h * p->out_w;
     const int k64 = (p->kh * p->row_pad + BK - 1) / BK * BK;
-    if (total_pix <= 0 || (total_pix + BP - 1) / BP * (oc_pad / 32) > 0x7fffffffL) return -1;
+    if (total_pix <= 0 || total_pix > 0x7fffffffL || (total_pix + BP - 1) / BP * (oc_pad / 32) > 0x7fffffffL) return -1;
     if (mhip_conv_i8_small_c(p->in_c, p->kw, p->out_c)) {
         const int PH = (SC_TH - 1) * p->stride_h + p->kh, PW = (SC_TW - 1) * p->stride_w + p->kw;
         if (p->stride_h >= 1 && p->stride_w >= 1 && (long)PH * PW <= 4 * NTHREADS)
@@ -541,9 +564,9 @@ extern "C" int mhip_conv_i8(const mhip_conv_i8_t *p) {
     }
     if ((p->in_c % 16) == 0) {
         if (!mhip_zero_page()) return -1;
-        if (oc_pad % 128 == 0) return launch_mfma<128, 3>(p, total_pix, k64);
-        if (oc_pad % 64 == 0) return launch_mfma<64, 4>(p, total_pix, k64);
-        return launch_mfma<32, 4>(p, total_pix, k64);
+        if (oc_pad % 128 == 0) return launch_mfma_auto<128>(p, total_pix, k64);
+        if (oc_pad % 64 == 0) return launch_mfma_auto<64>(p, total_pix, k64);
+        return launch_mfma_auto<32>(p, total_pix, k64);
     }
     if (oc_pad % 64 == 0) return launch_generic<64>(p, total_pix, k64);
     return launch_generic<32>(p, total_pix, k64);

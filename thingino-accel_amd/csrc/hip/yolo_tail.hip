@@ -115,9 +115,11 @@ __global__ __launch_bounds__(256) void decode_kernel(const mhip_detect_t p) {
 template <int CTRL, int ROW_MASK>
 __device__ __forceinline__ void scan_step(float &v, int &id) {
     const int ninf = __float_as_int(-INFINITY);
-    float ov = __int_as_float(__builtin_amdgcn_update_dpp(ninf, __float_as_int(v), CTRL, ROW_MASK, 0xf, false));
-    int oid = __builtin_amdgcn_update_dpp(-1, id, CTRL, ROW_MASK, 0xf, false);
-    if (!(v > ov)) { v = ov; id = oid; } // the earlier holder stays unless strictly beaten
+    const float ov = __int_as_float(__builtin_amdgcn_update_dpp(ninf, __float_as_int(v), CTRL, ROW_MASK, 0xf, false));
+    const int oid = __builtin_amdgcn_update_dpp(-1, id, CTRL, ROW_MASK, 0xf, false);
+    const bool keep = v > ov; // the earlier holder stays unless strictly beaten
+    v = keep ? v : ov;
+    id = keep ? id : oid;
 }
 
 __global__ __launch_bounds__(64) void sort_kernel(det_rec *all, const int *counts) {
@@ -135,13 +137,15 @@ __global__ __launch_bounds__(64) void sort_kernel(det_rec *all, const int *count
         d[k] = pos;
     }
     for (int i = 0; i + 1 < n; i++) {
-        // (1) this lane's (max, first holder) over its slots >= i
+        const int rel = i - lane * 16; // slot k of this lane takes part iff k >= rel
+        // (1) this lane's (max, first holder) over its slots >= i  (selects, no branches)
         float v = -INFINITY;
         int id = -1;
 #pragma unroll
         for (int k = 0; k < 16; k++) {
-            const bool in = lane * 16 + k >= i;
-            if (in && c[k] > v) { v = c[k]; id = d[k]; }
+            const bool take = (k >= rel) & (c[k] > v);
+            v = take ? c[k] : v;
+            id = take ? d[k] : id;
         }
         // (2) inclusive scan across the wave
         scan_step<DPP_ROW_SHR(1), 0xf>(v, id);
@@ -158,16 +162,14 @@ __global__ __launch_bounds__(64) void sort_kernel(det_rec *all, const int *count
         // (3) shift the record chain, then drop the maximum into slot i
 #pragma unroll
         for (int k = 0; k < 16; k++) {
-            const int pos = lane * 16 + k;
-            if (pos >= i && c[k] > rv) {
-                const float tv = c[k];
-                const int tid_ = d[k];
-                c[k] = rv;
-                d[k] = rid;
-                rv = tv;
-                rid = tid_;
-            }
-            if (pos == i) { c[k] = fv; d[k] = fid; }
+            const bool rec = (k >= rel) & (c[k] > rv);
+            const bool head = k == rel;
+            const float tv = c[k];
+            const int td = d[k];
+            c[k] = head ? fv : (rec ? rv : tv);
+            d[k] = head ? fid : (rec ? rid : td);
+            rv = rec ? tv : rv;
+            rid = rec ? td : rid;
         }
     }
     // gather the records in sorted order (read everything before anything is overwritten)
