@@ -137,12 +137,20 @@ __device__ __forceinline__ void epilogue(const mhip_conv_i8_t &p, v4i (&acc)[WOC
             v4i v = {*(const int *)s, *(const int *)(s + 4), *(const int *)(s + 8), *(const int *)(s + 12)};
             *(v4i *)(p.out + off + oc0 + c * 16) = v;
         }
-    } else if (!p.out_nchw) {
-        for (int id = tid; id < BP * BN; id += NTHREADS) {
-            const int row = id / BN, c = id - row * BN;
+    } else if (!p.out_nchw) { // e.g. the 255-channel heads: rows are not 16-byte aligned in HBM
+        constexpr int CPR = BN / 16;
+        for (int id = tid; id < BP * CPR; id += NTHREADS) {
+            const int row = id / CPR, c = id - row * CPR;
             const long off = rowoff[row];
-            if (off < 0 || c >= ncols) continue;
-            p.out[off + oc0 + c] = tile[row * ROW + c];
+            if (off < 0 || c * 16 >= ncols) continue;
+            const int8_t *s = tile + row * ROW + c * 16;
+            int8_t *d = p.out + off + oc0 + c * 16;
+            if (c * 16 + 16 <= ncols) { // unaligned dwordx4 store (gfx950 accepts any byte alignment)
+                v4i v = {*(const int *)s, *(const int *)(s + 4), *(const int *)(s + 8), *(const int *)(s + 12)};
+                __builtin_memcpy(d, &v, 16);
+            } else {
+                for (int e = 0; e < ncols - c * 16; e++) d[e] = s[e];
+            }
         }
     } else { // [O][H][W]: consecutive lanes -> consecutive pixels of one channel
         for (int id = tid; id < BP * BN; id += NTHREADS) {
@@ -414,23 +422,43 @@ __global__ __launch_bounds__(NTHREADS) void conv_i8_smallc(const mhip_conv_i8_t 
     }
     for (int i = tid; i < patch_bytes / 4; i += NTHREADS) ((uint32_t *)patch)[i] = 0;
 
-    const int npp = PH * PW; // input pixels of one patch; host guarantees npp <= 4 * NTHREADS
-    uint32_t pre[4];
+    // one staging unit = 4 consecutive patch pixels of one row -> one 16-byte LDS store.
+    // in_c == 3: the 12 source bytes come from ONE unaligned 16-byte global load (gfx950 serves
+    // global accesses at any byte alignment) when all 4 pixels are inside the image.
+    const int gpr = (PW + 3) >> 2;           // units per patch row
+    const int nunits = PH * gpr;             // host guarantees nunits <= 2 * NTHREADS
+    v4i pre[2];
     auto fetch = [&](long t) {
         const int tx = (int)(t % tiles_x), ty = (int)((t / tiles_x) % tiles_y);
         const long f = t / ((long)tiles_x * tiles_y);
         const int8_t *src = p.in + (size_t)f * p.in_stride;
         const int y0 = ty * SC_TH * p.stride_h - p.pad_top, x0 = tx * SC_TW * p.stride_w - p.pad_left;
 #pragma unroll
-        for (int j = 0; j < 4; j++) {
-            const int i = tid + j * NTHREADS;
-            uint32_t v = 0;
-            if (i < npp) {
-                const int r = i / PW, x = i - r * PW;
-                const int iy = y0 + r, ix = x0 + x;
-                if (iy >= 0 && iy < p.in_h && ix >= 0 && ix < p.in_w) {
+        for (int j = 0; j < 2; j++) {
+            const int u = tid + j * NTHREADS;
+            v4i v = {0, 0, 0, 0};
+            if (u < nunits) {
+                const int r = u / gpr, g = u - r * gpr;
+                const int iy = y0 + r, ix = x0 + g * 4;
+                if (iy >= 0 && iy < p.in_h) {
                     const int8_t *q = src + ((size_t)iy * p.in_w + ix) * p.in_c;
-                    for (int c = 0; c < p.in_c; c++) v |= (uint32_t)(uint8_t)q[c] << (8 * c);
+                    if (p.in_c == 3 && ix >= 0 && ix + 4 <= p.in_w) {
+                        v4i raw;
+                        __builtin_memcpy(&raw, q, 16); // unaligned dwordx4; the 4 bytes past the 12 used are discarded
+                        const uint32_t d0 = (uint32_t)raw[0], d1 = (uint32_t)raw[1], d2 = (uint32_t)raw[2];
+                        v[0] = (int)(d0 & 0xFFFFFFu);
+                        v[1] = (int)(((d0 >> 24) | (d1 << 8)) & 0xFFFFFFu);
+                        v[2] = (int)(((d1 >> 16) | (d2 << 16)) & 0xFFFFFFu);
+                        v[3] = (int)(d2 >> 8);
+                    } else {
+#pragma unroll
+                        for (int e = 0; e < 4; e++) {
+                            uint32_t w = 0;
+                            if (ix + e >= 0 && ix + e < p.in_w)
+                                for (int c = 0; c < p.in_c; c++) w |= (uint32_t)(uint8_t)q[e * p.in_c + c] << (8 * c);
+                            v[e] = (int)w;
+                        }
+                    }
                 }
             }
             pre[j] = v;
@@ -438,11 +466,11 @@ __global__ __launch_bounds__(NTHREADS) void conv_i8_smallc(const mhip_conv_i8_t 
     };
     auto commit = [&]() {
 #pragma unroll
-        for (int j = 0; j < 4; j++) {
-            const int i = tid + j * NTHREADS;
-            if (i < npp) {
-                const int r = i / PW, x = i - r * PW;
-                ((uint32_t *)patch)[r * PWp + x] = pre[j];
+        for (int j = 0; j < 2; j++) {
+            const int u = tid + j * NTHREADS;
+            if (u < nunits) {
+                const int r = u / gpr, g = u - r * gpr;
+                *(v4i *)(patch + ((size_t)r * PWp + g * 4) * 4) = pre[j];
             }
         }
     };
@@ -505,7 +533,7 @@ static int launch_smallc(const mhip_conv_i8_t *p, int k64) {
     const long ntiles = (long)tiles_x * tiles_y * p->frames;
     const int PH = (SC_TH - 1) * p->stride_h + p->kh, PW = (SC_TW - 1) * p->stride_w + p->kw;
     const int PWp = (PW + 8 + 3) & ~3;
-    if ((long)PH * PW > 4 * NTHREADS) return -1;
+    if ((long)PH * ((PW + 3) / 4) > 2 * NTHREADS) return -1;
     constexpr int BN = WOC * 16;
     const size_t lds = (((size_t)BN * (k64 + 16) + 15) & ~(size_t)15) + ((((size_t)PH + 1) * PWp * 4 + 15) & ~(size_t)15) +
                        (size_t)BP * (BN + OPAD) + 256;
@@ -558,7 +586,7 @@ extern "C" int mhip_conv_i8(const mhip_conv_i8_t *p) {
     if (total_pix <= 0 || total_pix > 0x7fffffffL || (total_pix + BP - 1) / BP * (oc_pad / 32) > 0x7fffffffL) return -1;
     if (mhip_conv_i8_small_c(p->in_c, p->kw, p->out_c)) {
         const int PH = (SC_TH - 1) * p->stride_h + p->kh, PW = (SC_TW - 1) * p->stride_w + p->kw;
-        if (p->stride_h >= 1 && p->stride_w >= 1 && (long)PH * PW <= 4 * NTHREADS)
+        if (p->stride_h >= 1 && p->stride_w >= 1 && (long)PH * ((PW + 3) / 4) <= 2 * NTHREADS)
             return oc_pad == 32 ? launch_smallc<2>(p, k64) : launch_smallc<4>(p, k64);
         return -1;
     }
