@@ -136,10 +136,11 @@ def main():
     outputs = tuple(range(len(out_ids)))
 
     def step():
+        # graph on the main stream; decode+NMS tail on the auxiliary stream, where it overlaps the
+        # NEXT step's convolutions (the next step's output-writing layers wait for it by event)
         model.run_device(sync=False)
         if not args.no_tail:
             model.detect_device(outputs=outputs, thresh=0.45)
-        M.lib().mars_hip_sync()
 
     def barrier():
         M.lib().mars_hip_sync()

@@ -216,4 +216,14 @@ def test_detect_on_model_outputs(gpu, orc):
         want = orc.nms(raw, 0.45)
         assert len(raw) > 10
         assert dets[f].tobytes() == want.tobytes()
+    # pipelined form used by bench.py: graph on the main stream, tail on the auxiliary stream, no
+    # host sync in between; the next graph's output layers wait for the previous tail by event
+    import ctypes as C
+    for _ in range(3):
+        m.run_device(sync=False)
+        m.detect_device(outputs=(0, 1, 2), thresh=0.45)
+    assert gpu.lib().mars_hip_sync() == 0
+    again = m.detect(outputs=(0, 1, 2), thresh=0.45)
+    for f in range(B):
+        assert again[f].tobytes() == dets[f].tobytes()
     m.close()

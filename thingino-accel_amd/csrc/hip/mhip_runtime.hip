@@ -11,12 +11,14 @@
 #include "../mhip.h"
 
 static hipStream_t g_stream = nullptr;
+static hipStream_t g_aux = nullptr;   // detection tail runs here, beside the next batch's graph
+static int g_use_aux = 0;
 static int g_ready = 0;
 static int g_device = -1;
 static char g_err[256] = "";
 static void *g_zero_page = nullptr; // 256 zero bytes in HBM: DMA source for out-of-image conv taps
 
-extern "C" hipStream_t mhip_stream_native(void) { return g_stream; }
+extern "C" hipStream_t mhip_stream_native(void) { return g_use_aux ? g_aux : g_stream; }
 
 extern "C" int mhip_check(hipError_t e, const char *what) {
     if (e == hipSuccess) return 0;
@@ -44,6 +46,7 @@ extern "C" int mhip_init(int device_hint) {
     }
     if (mhip_check(hipSetDevice(dev), "hipSetDevice")) return -1;
     if (mhip_check(hipStreamCreateWithFlags(&g_stream, hipStreamNonBlocking), "hipStreamCreate")) return -3;
+    if (mhip_check(hipStreamCreateWithFlags(&g_aux, hipStreamNonBlocking), "hipStreamCreate aux")) return -3;
     if (mhip_check(hipMalloc(&g_zero_page, 256), "hipMalloc zero page") ||
         mhip_check(hipMemset(g_zero_page, 0, 256), "hipMemset zero page"))
         return -3;
@@ -55,7 +58,11 @@ extern "C" int mhip_init(int device_hint) {
 extern "C" void mhip_shutdown(void) {
     if (!g_ready) return;
     (void)hipStreamSynchronize(g_stream);
+    (void)hipStreamSynchronize(g_aux);
     (void)hipStreamDestroy(g_stream);
+    (void)hipStreamDestroy(g_aux);
+    g_aux = nullptr;
+    g_use_aux = 0;
     if (g_zero_page) (void)hipFree(g_zero_page);
     g_zero_page = nullptr;
     g_stream = nullptr;
@@ -78,7 +85,17 @@ extern "C" int mhip_device_info(int *cu_count, int *lds_bytes, int *gfx_version,
 
 extern "C" void *mhip_stream(void) { return (void *)g_stream; }
 
-extern "C" int mhip_sync(void) { return mhip_check(hipStreamSynchronize(g_stream), "hipStreamSynchronize"); }
+extern "C" int mhip_sync(void) {
+    int rc = mhip_check(hipStreamSynchronize(g_stream), "hipStreamSynchronize");
+    int rc2 = mhip_check(hipStreamSynchronize(g_aux), "hipStreamSynchronize aux");
+    return rc ? rc : rc2;
+}
+// every launcher enqueues on "the current stream": main by default, aux while selected
+extern "C" void mhip_select_aux(int on) { g_use_aux = on ? 1 : 0; }
+// make stream `aux ? aux : main` wait for an event recorded elsewhere
+extern "C" int mhip_stream_wait(int aux, void *ev) {
+    return mhip_check(hipStreamWaitEvent(aux ? g_aux : g_stream, (hipEvent_t)ev, 0), "hipStreamWaitEvent");
+}
 
 extern "C" void *mhip_malloc(size_t bytes) {
     void *p = nullptr;
@@ -103,26 +120,26 @@ extern "C" void mhip_host_free(void *p) {
 }
 
 extern "C" int mhip_memset_async(void *dst, int value, size_t bytes) {
-    return mhip_check(hipMemsetAsync(dst, value, bytes, g_stream), "hipMemsetAsync");
+    return mhip_check(hipMemsetAsync(dst, value, bytes, mhip_stream_native()), "hipMemsetAsync");
 }
 extern "C" int mhip_h2d_async(void *dst, const void *src, size_t bytes) {
-    return mhip_check(hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, g_stream), "H2D");
+    return mhip_check(hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, mhip_stream_native()), "H2D");
 }
 extern "C" int mhip_d2h_async(void *dst, const void *src, size_t bytes) {
-    return mhip_check(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, g_stream), "D2H");
+    return mhip_check(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, mhip_stream_native()), "D2H");
 }
 extern "C" int mhip_d2d_async(void *dst, const void *src, size_t bytes) {
-    return mhip_check(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, g_stream), "D2D");
+    return mhip_check(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, mhip_stream_native()), "D2D");
 }
 extern "C" int mhip_h2d_2d_async(void *dst, size_t dpitch, const void *src, size_t spitch, size_t row_bytes,
                                  size_t rows) {
     if (dpitch == row_bytes && spitch == row_bytes) return mhip_h2d_async(dst, src, row_bytes * rows);
-    return mhip_check(hipMemcpy2DAsync(dst, dpitch, src, spitch, row_bytes, rows, hipMemcpyHostToDevice, g_stream), "H2D 2D");
+    return mhip_check(hipMemcpy2DAsync(dst, dpitch, src, spitch, row_bytes, rows, hipMemcpyHostToDevice, mhip_stream_native()), "H2D 2D");
 }
 extern "C" int mhip_d2h_2d_async(void *dst, size_t dpitch, const void *src, size_t spitch, size_t row_bytes,
                                  size_t rows) {
     if (dpitch == row_bytes && spitch == row_bytes) return mhip_d2h_async(dst, src, row_bytes * rows);
-    return mhip_check(hipMemcpy2DAsync(dst, dpitch, src, spitch, row_bytes, rows, hipMemcpyDeviceToHost, g_stream), "D2H 2D");
+    return mhip_check(hipMemcpy2DAsync(dst, dpitch, src, spitch, row_bytes, rows, hipMemcpyDeviceToHost, mhip_stream_native()), "D2H 2D");
 }
 
 extern "C" void *mhip_event_create(void) {
@@ -134,7 +151,7 @@ extern "C" void mhip_event_destroy(void *ev) {
     if (ev) (void)hipEventDestroy((hipEvent_t)ev);
 }
 extern "C" int mhip_event_record(void *ev) {
-    return mhip_check(hipEventRecord((hipEvent_t)ev, g_stream), "hipEventRecord");
+    return mhip_check(hipEventRecord((hipEvent_t)ev, mhip_stream_native()), "hipEventRecord");
 }
 extern "C" float mhip_event_elapsed_ms(void *start, void *stop) {
     float ms = 0.f;

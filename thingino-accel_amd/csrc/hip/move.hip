@@ -69,6 +69,51 @@ __global__ __launch_bounds__(MV_THREADS) void maxpool_kernel(const int8_t *in, s
     }
 }
 
+
+// 16 channels per thread: 16-byte loads, bytes widened to packed int16 pairs so the running
+// maximum is two v_pk_max_i16 per dword and tap.
+typedef short s2v __attribute__((ext_vector_type(2)));
+__global__ __launch_bounds__(MV_THREADS) void maxpool16_kernel(const int8_t *in, size_t is, int8_t *out, size_t os,
+                                                               int in_h, int in_w, int ch, int out_h, int out_w, int kh,
+                                                               int kw, int sh, int sw) {
+    const int cv = ch >> 4;
+    size_t idx = (size_t)blockIdx.x * MV_THREADS + threadIdx.x;
+    if (idx >= (size_t)out_h * out_w * cv) return;
+    const int c = (int)(idx % cv) * 16;
+    const size_t pix = idx / cv;
+    const int ox = (int)(pix % out_w), oy = (int)(pix / out_w);
+    const int8_t *src = in + (size_t)blockIdx.y * is;
+    s2v ev[4], od[4];
+    const s2v lowest = {-128, -128};
+#pragma unroll
+    for (int d = 0; d < 4; d++) ev[d] = od[d] = lowest;
+    for (int ky = 0; ky < kh; ky++) {
+        const int iy = oy * sh + ky;
+        if (iy >= in_h) break;
+        for (int kx = 0; kx < kw; kx++) {
+            const int ix = ox * sw + kx;
+            if (ix >= in_w) break;
+            const v4i v = *(const v4i *)(src + ((size_t)iy * in_w + ix) * ch + c);
+#pragma unroll
+            for (int d = 0; d < 4; d++) {
+                const int w = v[d];
+                const s2v x = *(const s2v *)&w;
+                const s2v e = (s2v)(x << (short)8) >> (short)8; // sign-extended even bytes
+                const s2v o = x >> (short)8;                    // sign-extended odd bytes
+                ev[d] = __builtin_elementwise_max(ev[d], e);
+                od[d] = __builtin_elementwise_max(od[d], o);
+            }
+        }
+    }
+    v4i r;
+#pragma unroll
+    for (int d = 0; d < 4; d++) {
+        const s2v m = (ev[d] & (short)0xFF) | (s2v)(od[d] << (short)8);
+        r[d] = *(const int *)&m;
+    }
+    *(v4i *)(out + (size_t)blockIdx.y * os + pix * ch + c) = r;
+}
+
 extern "C" int mhip_maxpool_i8(const int8_t *in, size_t in_stride, int8_t *out, size_t out_stride, int frames,
                                int in_h, int in_w, int ch, int out_h, int out_w, int kh, int kw, int sh, int sw) {
     if (!in || !out || frames <= 0 || in_h < 0 || in_w < 0 || ch < 0 || out_h < 0 || out_w < 0 || kh < 0 || kw < 0 ||
@@ -76,8 +121,12 @@ extern "C" int mhip_maxpool_i8(const int8_t *in, size_t in_stride, int8_t *out, 
         return -1;
     size_t total = (size_t)out_h * out_w * ch;
     if (total == 0) return 0;
+    bool v16 = (ch % 16 == 0) && ((((uintptr_t)in | (uintptr_t)out | in_stride | out_stride) & 15) == 0);
     bool v4 = (ch % 4 == 0) && ((((uintptr_t)in | (uintptr_t)out | in_stride | out_stride) & 3) == 0);
-    if (v4)
+    if (v16)
+        hipLaunchKernelGGL(maxpool16_kernel, mv_grid(total / 16, frames), dim3(MV_THREADS), 0, mhip_stream_native(), in,
+                           in_stride, out, out_stride, in_h, in_w, ch, out_h, out_w, kh, kw, sh, sw);
+    else if (v4)
         hipLaunchKernelGGL((maxpool_kernel<4>), mv_grid(total / 4, frames), dim3(MV_THREADS), 0, mhip_stream_native(),
                            in, in_stride, out, out_stride, in_h, in_w, ch, out_h, out_w, kh, kw, sh, sw);
     else

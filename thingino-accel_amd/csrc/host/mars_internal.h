@@ -82,6 +82,10 @@ typedef struct {
     int *det_counts_dev;
     float *det_lut_dev;
     int det_cap;
+    float det_lut_scale[4]; /* scales the uploaded decode LUTs were built for */
+    int det_lut_n;
+    void *ev_graph_done, *ev_tail_done; /* main->aux and aux->main hand-offs */
+    int tail_pending;
 } mars_model_ext_t;
 
 /* shared host helpers (mars_model.c) */

@@ -555,6 +555,7 @@ static void free_device_state(mars_model_ext_t *m) {
     m->det_dev = NULL;
     m->det_counts_dev = NULL;
     m->det_cap = 0;
+    m->tail_pending = 0;
 }
 
 static void free_ops(mars_model_ext_t *m) {
@@ -575,6 +576,8 @@ void mars_free(mars_model_t *model) {
     free_ops(m);
     if (m->arena_dev) mhip_free(m->arena_dev);
     if (m->det_lut_dev) mhip_free(m->det_lut_dev);
+    if (m->ev_graph_done) mhip_event_destroy(m->ev_graph_done);
+    if (m->ev_tail_done) mhip_event_destroy(m->ev_tail_done);
     free(m->arena_host);
     free(m->mt);
     free(m->pub.weights);
@@ -896,6 +899,12 @@ mars_error_t mars_hip_run_device_async(mars_model_t *model) {
         if (op->kind == OP_FAIL) {
             fprintf(stderr, "Mars: Layer %d execution failed\n", op->layer);
             return (mars_error_t)op->err;
+        }
+        if (m->tail_pending && op->t_out >= 0 && m->mt[op->t_out].io_out) {
+            /* the previous batch's detection tail (auxiliary stream) still reads the graph
+             * outputs: order this launch behind it */
+            mhip_stream_wait(0, m->ev_tail_done);
+            m->tail_pending = 0;
         }
         if (m->profiling) {
             if (!op->ev0) op->ev0 = mhip_event_create();

@@ -39,10 +39,14 @@ static int ensure_det_buffers(mars_model_ext_t *m, int frames) {
 mars_error_t mars_hip_detect_device(mars_model_t *model, const int *output_indices, int n_outputs, float nms_thresh) {
     if (!model || !output_indices || n_outputs <= 0 || n_outputs > 4) return MARS_ERR_INVALID_TENSOR;
     mars_model_ext_t *m = (mars_model_ext_t *)model;
-    if (ensure_det_buffers(m, m->batch)) return MARS_ERR_ALLOC_FAILED;
+    if (m->det_cap < m->batch || !m->det_dev) {
+        if (mhip_sync()) return MARS_ERR_LAYER_FAILED; /* re-allocation: nothing may be in flight */
+        if (ensure_det_buffers(m, m->batch)) return MARS_ERR_ALLOC_FAILED;
+        m->det_lut_n = 0;
+    }
     mhip_detect_t p;
     memset(&p, 0, sizeof(p));
-    float lut[4 * 768];
+    int lut_stale = m->det_lut_n != n_outputs;
     for (int s = 0; s < n_outputs; s++) {
         mars_runtime_tensor_t *t = mars_get_output(model, output_indices[s]);
         if (!t) return MARS_ERR_INVALID_TENSOR;
@@ -51,11 +55,21 @@ mars_error_t mars_hip_detect_device(mars_model_t *model, const int *output_indic
         p.pred[s] = (const int8_t *)m->mt[ti].dev;
         p.stride[s] = m->mt[ti].stride;
         p.npred[s] = (int)(m->mt[ti].bytes / 85); /* rows of 85 int8: x,y,w,h,obj,80 classes */
-        build_decode_lut(t->desc.scale, lut + s * 768);
         p.lut[s] = m->det_lut_dev + s * 768;
+        if (memcmp(&m->det_lut_scale[s], &t->desc.scale, sizeof(float)) != 0) lut_stale = 1;
     }
-    if (mhip_h2d_async(m->det_lut_dev, lut, (size_t)n_outputs * 768 * sizeof(float))) return MARS_ERR_LAYER_FAILED;
-    if (mhip_sync()) return MARS_ERR_LAYER_FAILED; /* `lut` is on this stack frame */
+    if (lut_stale) { /* tables depend only on the output scales: built and uploaded once */
+        float lut[4 * 768];
+        for (int s = 0; s < n_outputs; s++) {
+            float sc = mars_get_output(model, output_indices[s])->desc.scale;
+            build_decode_lut(sc, lut + s * 768);
+            m->det_lut_scale[s] = sc;
+        }
+        if (mhip_sync()) return MARS_ERR_LAYER_FAILED;
+        if (mhip_h2d_async(m->det_lut_dev, lut, (size_t)n_outputs * 768 * sizeof(float)) || mhip_sync())
+            return MARS_ERR_LAYER_FAILED; /* `lut` is on this stack frame */
+        m->det_lut_n = n_outputs;
+    }
     p.nseg = n_outputs;
     p.frames = m->batch;
     p.nms_thresh = nms_thresh;
@@ -63,7 +77,21 @@ mars_error_t mars_hip_detect_device(mars_model_t *model, const int *output_indic
     p.counts = m->det_counts_dev;
     p.raw_counts = m->det_counts_dev + m->batch;
     p.do_nms = 1;
-    return mhip_detect(&p) ? MARS_ERR_LAYER_FAILED : MARS_OK;
+    /* The tail runs on the auxiliary stream: it starts when the graph launches enqueued so far
+     * have finished, and the NEXT run's output-writing layers wait for it (mars_hip_run_device_async),
+     * so decode/sort/NMS of batch k overlap the convolutions of batch k+1. */
+    if (!m->ev_graph_done) m->ev_graph_done = mhip_event_create();
+    if (!m->ev_tail_done) m->ev_tail_done = mhip_event_create();
+    if (!m->ev_graph_done || !m->ev_tail_done) return MARS_ERR_ALLOC_FAILED;
+    if (mhip_event_record(m->ev_graph_done)) return MARS_ERR_LAYER_FAILED;
+    mhip_select_aux(1);
+    int rc = mhip_stream_wait(1, m->ev_graph_done);
+    if (!rc) rc = mhip_detect(&p);
+    if (!rc) rc = mhip_event_record(m->ev_tail_done);
+    mhip_select_aux(0);
+    if (rc) return MARS_ERR_LAYER_FAILED;
+    m->tail_pending = 1;
+    return MARS_OK;
 }
 
 mars_error_t mars_hip_detect(mars_model_t *model, const int *output_indices, int n_outputs, float nms_thresh,
@@ -72,6 +100,7 @@ mars_error_t mars_hip_detect(mars_model_t *model, const int *output_indices, int
     mars_error_t e = mars_hip_detect_device(model, output_indices, n_outputs, nms_thresh);
     if (e != MARS_OK) return e;
     mars_model_ext_t *m = (mars_model_ext_t *)model;
+    if (mhip_sync()) return MARS_ERR_LAYER_FAILED; /* both streams: the tail ran on the auxiliary one */
     if (mhip_d2h_async(dets, m->det_dev, (size_t)m->batch * MARS_YOLO_MAX_DET * sizeof(mars_det_t)) ||
         mhip_d2h_async(counts, m->det_counts_dev, (size_t)m->batch * sizeof(int)) || mhip_sync())
         return MARS_ERR_LAYER_FAILED;

@@ -24,7 +24,9 @@ void mhip_shutdown(void);
 int mhip_ready(void);
 int mhip_device_info(int *cu_count, int *lds_bytes, int *gfx_version, size_t *hbm_bytes);
 void *mhip_stream(void);
-int mhip_sync(void);
+int mhip_sync(void);                    /* both streams */
+void mhip_select_aux(int on);          /* launchers enqueue on the auxiliary stream while on */
+int mhip_stream_wait(int aux, void *ev); /* stream (aux or main) waits for an event */
 void *mhip_malloc(size_t bytes);         /* HBM */
 void mhip_free(void *p);
 void *mhip_host_alloc(size_t bytes);     /* pinned + device mapped */
