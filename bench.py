@@ -39,16 +39,16 @@ def load_marsrt():
     return mod
 
 
-class _DevBuf:
-    """zero-copy view of a raw HBM pointer for torch (RCCL broadcast of the parameter arena)"""
+def load_dist_helpers():
+    spec = importlib.util.spec_from_file_location("mdist", os.path.join(ROOT, "thingino-accel_amd", "dist.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod
 
-    def __init__(self, ptr, nbytes):
-        self.__cuda_array_interface__ = {"shape": (nbytes,), "typestr": "|u1", "data": (ptr, False), "version": 2}
 
-
-def frames_for_rank(rank, per_gpu, nbytes):
+def frames_for_rank(D, rank, world, per_gpu, nbytes):
     from conftest import lcg_frame
-    return [lcg_frame(0x5EED0000 + rank * per_gpu + f, nbytes) for f in range(per_gpu)]
+    return [lcg_frame(0x5EED0000 + f, nbytes) for f in D.shard_frames(per_gpu, rank, world)]
 
 
 def cpu_baseline(model_bytes, frame0, out_ids, tensors):
@@ -107,6 +107,7 @@ def main():
     os.environ.setdefault("MARS_HIP_DEVICE", str(local_rank))
 
     M = load_marsrt()
+    D = load_dist_helpers()
     import marsfile
     M.nna_init()
     model_bytes = M.synth_model(width_x16=args.width, input_hw=args.hw, seed=1)
@@ -116,19 +117,17 @@ def main():
 
     if world > 1 and rank != 0:
         # descriptors only; the packed parameters arrive by RCCL broadcast from rank 0
-        blank = bytearray(model_bytes)
-        blank[hdr["woff"]:hdr["woff"] + hdr["wsz"]] = bytes(hdr["wsz"])
-        model = M.Model(bytes(blank), batch=args.batch, flags=1)
+        model = M.Model(D.strip_weights(model_bytes), batch=args.batch, flags=1)
     else:
         model = M.Model(model_bytes, batch=args.batch)
     if world > 1:
         import torch
         ptr, nbytes = model.param_arena()
-        t = torch.as_tensor(_DevBuf(ptr, nbytes), device="cuda")
+        t = torch.as_tensor(D.DeviceBuffer(ptr, nbytes), device="cuda")
         dist.broadcast(t, src=0)  # the one collective of the path: weights over xGMI
         torch.cuda.synchronize()
 
-    frames = frames_for_rank(rank, args.batch, in_bytes)
+    frames = frames_for_rank(D, rank, world, args.batch, in_bytes)
     iv = model.input_view(0)
     for f in range(args.batch):
         iv[f] = frames[f]
@@ -169,10 +168,7 @@ def main():
     dt = time.perf_counter() - t0
     model.set_profiling(False)
     if dist is not None:
-        import torch
-        tt = torch.tensor([dt], device="cuda", dtype=torch.float64)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        dt = float(tt.item())
+        dt = D.max_over_ranks(dist, dt, device="cuda")
 
     result = None
     if rank == 0 and args.ops:
@@ -216,6 +212,14 @@ def main():
                          "all_kernels_ms_per_step": all_ms / args.steps,
                          "ms_per_step_by_kind": {str(k): v / args.steps for k, v in sorted(per_kind.items())}},
         }
+        if world == 1:
+            # not the headline value: the same batch INCLUDING host->HBM input copies and HBM->host
+            # output copies through the reference API's mars_run() (pinned staging, one stream)
+            M.lib().mars_hip_sync()
+            t1 = time.perf_counter()
+            for _ in range(2):
+                model.run()
+            result["pcie_inclusive_images_per_s"] = 2 * args.batch / (time.perf_counter() - t1)
         if world == 1 and not args.no_cpu_baseline:
             base, ref_outs = cpu_baseline(model_bytes, frames[0], out_ids, tensors)
             model.download()
