@@ -86,9 +86,9 @@ __device__ __forceinline__ unsigned xcd_remap(unsigned bid, unsigned nblk) {
 // shared epilogue: accumulators -> requant -> LDS tile -> coalesced global stores
 // `rowoff[row]` = byte offset of tile row `row`'s pixel in the output (frame*out_stride + rem*out_c for NHWC,
 // frame*out_stride + rem for NCHW), or -1 when the row is outside the image/batch; filled by fill_rowoff().
-template <class PixelOf>
+template <int BPX, class PixelOf>
 __device__ __forceinline__ void fill_rowoff(const mhip_conv_i8_t &p, long *rowoff, PixelOf pixel_of, unsigned hw) {
-    if (threadIdx.x < BP) {
+    if (threadIdx.x < BPX) {
         const long pix = pixel_of((int)threadIdx.x); // global pixel index (frame*H*W + y*W + x) or -1
         long off = -1;
         if (pix >= 0) {
@@ -99,7 +99,7 @@ __device__ __forceinline__ void fill_rowoff(const mhip_conv_i8_t &p, long *rowof
     }
 }
 
-template <int BN, int WPX, int WOC>
+template <int BPX, int BN, int WPX, int WOC>
 __device__ __forceinline__ void epilogue(const mhip_conv_i8_t &p, v4i (&acc)[WOC][WPX], int8_t *tile, const uint8_t *slut,
                                          const long *rowoff, int oc0, int pxw, int ocw, int hw) {
     const int tid = threadIdx.x, lane = tid & 63;
@@ -129,7 +129,7 @@ __device__ __forceinline__ void epilogue(const mhip_conv_i8_t &p, v4i (&acc)[WOC
     const int ncols = p.out_c - oc0 < BN ? p.out_c - oc0 : BN; // valid channels of this tile
     if (!p.out_nchw && (p.out_c & 15) == 0) {
         constexpr int CPR = BN / 16; // 16-byte chunks per pixel row
-        for (int id = tid; id < BP * CPR; id += NTHREADS) {
+        for (int id = tid; id < BPX * CPR; id += NTHREADS) {
             const int row = id / CPR, c = id - row * CPR;
             const long off = rowoff[row];
             if (off < 0 || c * 16 >= ncols) continue;
@@ -139,7 +139,7 @@ __device__ __forceinline__ void epilogue(const mhip_conv_i8_t &p, v4i (&acc)[WOC
         }
     } else if (!p.out_nchw) { // e.g. the 255-channel heads: rows are not 16-byte aligned in HBM
         constexpr int CPR = BN / 16;
-        for (int id = tid; id < BP * CPR; id += NTHREADS) {
+        for (int id = tid; id < BPX * CPR; id += NTHREADS) {
             const int row = id / CPR, c = id - row * CPR;
             const long off = rowoff[row];
             if (off < 0 || c * 16 >= ncols) continue;
@@ -153,8 +153,8 @@ __device__ __forceinline__ void epilogue(const mhip_conv_i8_t &p, v4i (&acc)[WOC
             }
         }
     } else { // [O][H][W]: consecutive lanes -> consecutive pixels of one channel
-        for (int id = tid; id < BP * BN; id += NTHREADS) {
-            const int c = id / BP, row = id - c * BP;
+        for (int id = tid; id < BPX * BN; id += NTHREADS) {
+            const int c = id / BPX, row = id - c * BPX;
             const long off = rowoff[row];
             if (off < 0 || c >= ncols) continue;
             p.out[off + (size_t)(oc0 + c) * hw] = tile[row * ROW + c];
@@ -163,48 +163,51 @@ __device__ __forceinline__ void epilogue(const mhip_conv_i8_t &p, v4i (&acc)[WOC
 }
 
 // ---------------------------------------------------------------------------------
-// main kernel: in_c % 16 == 0
-template <int BN, int STAGES>
+// main kernel: in_c % 16 == 0.  BPX pixels x BN channels per workgroup; every wave owns a
+// 64-pixel x (32|64)-channel accumulator tile (BPX=256 for BN<=64, BPX=128 for BN=128).
+// POW2: in_c is a power of two (every yolov5 layer) -> the K position of a chunk is shifts and
+// one small multiply instead of carried counters.
+template <int BPX, int BN, int STAGES, bool POW2>
 __global__ __launch_bounds__(NTHREADS) void conv_i8_mfma(const mhip_conv_i8_t p, const long total_pix, const int k64,
                                                          const int8_t *__restrict__ zeros, const unsigned noc,
-                                                         const unsigned nblk) {
-    constexpr int STAGE = (BP + BN) * BK;
+                                                         const unsigned nblk, const int lg_inc, const unsigned kw_magic) {
+    constexpr int STAGE = (BPX + BN) * BK;
     constexpr int NWN = BN == 128 ? 2 : 1;       // waves along oc
     constexpr int NWM = 4 / NWN;                 // waves along pixels
-    constexpr int WPX = BP / NWM / 16;           // pixel subtiles per wave
+    constexpr int WPX = BPX / NWM / 16;          // pixel subtiles per wave
     constexpr int WOC = BN / NWN / 16;           // oc subtiles per wave
+    constexpr int XI = BPX / 64;                 // X-tile DMA instructions per wave (16 rows each)
     constexpr int LW = BN >= 128 ? 2 : 1;        // W-tile DMA instructions per wave
-    constexpr int L = 2 + LW;                    // DMA instructions per wave per stage
-    // dynamic LDS: [rowoff 1 KB][lut 256 B][ring: min(nks, STAGES) stages, reused as the output tile]
+    constexpr int L = XI + LW;                   // DMA instructions per wave per stage
+    // dynamic LDS: [rowoff][lut 256 B][ring: min(nks, STAGES) stages, reused as the output tile]
     extern __shared__ __attribute__((aligned(16))) int8_t dynlds[];
     long *rowoff = (long *)dynlds;
-    uint8_t *slut = (uint8_t *)dynlds + BP * 8;
-    int8_t *lds = dynlds + BP * 8 + 256;
+    uint8_t *slut = (uint8_t *)dynlds + BPX * 8;
+    int8_t *lds = dynlds + BPX * 8 + 256;
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
     const unsigned id = xcd_remap(blockIdx.x, nblk);
-    const long pix0 = (long)(id / noc) * BP;
+    const long pix0 = (long)(id / noc) * BPX;
     const int oc0 = (int)(id % noc) * BN;
     const int hw = p.out_h * p.out_w;
 
     if (p.lut && tid < 64) ((uint32_t *)slut)[tid] = ((const uint32_t *)p.lut)[tid];
-    fill_rowoff(p, rowoff, [=](int row) { long q = pix0 + row; return q < total_pix ? q : -1L; }, (unsigned)hw);
+    fill_rowoff<BPX>(p, rowoff, [=](int row) { long q = pix0 + row; return q < total_pix ? q : -1L; }, (unsigned)hw);
 
     // ---- DMA assignment.  One wave-instruction fills 16 consecutive 64-byte rows; lane i
     // lands in row i/4, slot i%4, so it must FETCH chunk (slot ^ swizzle(row)).
     const int schunk = (lane & 3) ^ (((lane >> 4) & 1) << 1);
-    const int8_t *xbase[2];
-    int iy0[2], ix0[2];
-    bool rvalid[2];
+    const int8_t *xbase[XI];
+    int iy0[XI], ix0[XI];
 #pragma unroll
-    for (int j = 0; j < 2; j++) {
-        long pix = pix0 + wv * 32 + j * 16 + (lane >> 2);
-        rvalid[j] = pix < total_pix;
-        const unsigned f = rvalid[j] ? (unsigned)((unsigned long)pix / (unsigned)hw) : 0u;
-        const unsigned rem = rvalid[j] ? (unsigned)((unsigned long)pix - (unsigned long)f * (unsigned)hw) : 0u;
+    for (int j = 0; j < XI; j++) {
+        const long pix = pix0 + wv * (BPX / 4) + j * 16 + (lane >> 2);
+        const bool valid = pix < total_pix;
+        const unsigned f = valid ? (unsigned)((unsigned long)pix / (unsigned)hw) : 0u;
+        const unsigned rem = valid ? (unsigned)((unsigned long)pix - (unsigned long)f * (unsigned)hw) : 0u;
         const int oy = (int)(rem / (unsigned)p.out_w), ox = (int)(rem - (unsigned)oy * (unsigned)p.out_w);
-        iy0[j] = oy * p.stride_h - p.pad_top;
+        iy0[j] = valid ? oy * p.stride_h - p.pad_top : -(1 << 28); // invalid rows fail every bounds test
         ix0[j] = ox * p.stride_w - p.pad_left;
         xbase[j] = p.in + (size_t)f * p.in_stride;
     }
@@ -217,27 +220,40 @@ __global__ __launch_bounds__(NTHREADS) void conv_i8_mfma(const mhip_conv_i8_t p,
     }
     // K position of this lane's chunk: kernel row ky, tap kx, byte rc inside the tap
     int ky = 0, kx = 0, rc = schunk * 16;
-    while (rc >= p.in_c) { rc -= p.in_c; kx++; }
-    while (kx >= p.kw) { kx -= p.kw; ky++; }
+    if (!POW2) {
+        while (rc >= p.in_c) { rc -= p.in_c; kx++; }
+        while (kx >= p.kw) { kx -= p.kw; ky++; }
+    }
+    const int taps = p.kh * p.kw;
 
     const int nks = k64 / BK;
     auto issue = [&](int ks, int stage) {
         int8_t *sb = lds + stage * STAGE;
-#pragma unroll
-        for (int j = 0; j < 2; j++) {
-            const int8_t *src = zeros;
-            if (rvalid[j] && ky < p.kh) {
-                const int iy = iy0[j] + ky, ix = ix0[j] + kx;
-                if (iy >= 0 && iy < p.in_h && ix >= 0 && ix < p.in_w)
-                    src = xbase[j] + ((size_t)iy * p.in_w + ix) * p.in_c + rc;
-            }
-            glds16(src, sb + (wv * 32 + j * 16) * BK);
+        bool kvalid;
+        if (POW2) {
+            const unsigned pos = (unsigned)(ks * BK + schunk * 16);
+            const unsigned tap = pos >> lg_inc;
+            rc = (int)(pos & ((1u << lg_inc) - 1u));
+            ky = (int)((tap * kw_magic) >> 16); // exact tap / kw for tap*(kw-1) < 65536 (host-checked)
+            kx = (int)tap - ky * p.kw;
+            kvalid = (int)tap < taps;
+        } else {
+            kvalid = ky < p.kh;
         }
 #pragma unroll
-        for (int j = 0; j < LW; j++) glds16(wsrc[j] + ks * BK, sb + BP * BK + wq[j] * 16 * BK);
-        rc += BK;
-        while (rc >= p.in_c) { rc -= p.in_c; kx++; }
-        while (kx >= p.kw) { kx -= p.kw; ky++; }
+        for (int j = 0; j < XI; j++) {
+            const int iy = iy0[j] + ky, ix = ix0[j] + kx;
+            const bool ok = kvalid & (iy >= 0) & (iy < p.in_h) & (ix >= 0) & (ix < p.in_w);
+            const int8_t *src = ok ? xbase[j] + ((size_t)iy * p.in_w + ix) * p.in_c + rc : zeros;
+            glds16(src, sb + (wv * (BPX / 4) + j * 16) * BK);
+        }
+#pragma unroll
+        for (int j = 0; j < LW; j++) glds16(wsrc[j] + ks * BK, sb + BPX * BK + wq[j] * 16 * BK);
+        if (!POW2) {
+            rc += BK;
+            while (rc >= p.in_c) { rc -= p.in_c; kx++; }
+            while (kx >= p.kw) { kx -= p.kw; ky++; }
+        }
     };
 
     v4i acc[WOC][WPX];
@@ -263,7 +279,7 @@ __global__ __launch_bounds__(NTHREADS) void conv_i8_mfma(const mhip_conv_i8_t p,
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
         if (ks + STAGES - 1 < nks) issue(ks + STAGES - 1, nstage);
-        const int8_t *xs = lds + stage * STAGE, *ws = xs + BP * BK;
+        const int8_t *xs = lds + stage * STAGE, *ws = xs + BPX * BK;
         v4i xb[WPX];
 #pragma unroll
         for (int t = 0; t < WPX; t++) xb[t] = *(const v4i *)(xs + lds_off(pxw + t * 16 + frow, fchunk));
@@ -277,7 +293,7 @@ __global__ __launch_bounds__(NTHREADS) void conv_i8_mfma(const mhip_conv_i8_t p,
         nstage = nstage + 1 == STAGES ? 0 : nstage + 1;
     }
     __syncthreads(); // every wave is done reading the ring: reuse it for the output tile
-    epilogue<BN, WPX, WOC>(p, acc, lds, slut, rowoff, oc0, pxw, ocw, hw);
+    epilogue<BPX, BN, WPX, WOC>(p, acc, lds, slut, rowoff, oc0, pxw, ocw, hw);
 }
 
 // ---------------------------------------------------------------------------------
@@ -297,7 +313,7 @@ __global__ __launch_bounds__(NTHREADS) void conv_i8_generic(const mhip_conv_i8_t
     const int oc0 = blockIdx.y * BN;
     const int hw = p.out_h * p.out_w;
     if (p.lut && tid < 64) ((uint32_t *)slut)[tid] = ((const uint32_t *)p.lut)[tid];
-    fill_rowoff(p, rowoff, [=](int row) { long q = pix0 + row; return q < total_pix ? q : -1L; }, (unsigned)hw);
+    fill_rowoff<BP>(p, rowoff, [=](int row) { long q = pix0 + row; return q < total_pix ? q : -1L; }, (unsigned)hw);
 
     const int cc = tid & 3;
     const int8_t *xbase[2];
@@ -387,7 +403,7 @@ __global__ __launch_bounds__(NTHREADS) void conv_i8_generic(const mhip_conv_i8_t
         if (ks + 1 < nks) store_lds(buf ^ 1);
         __syncthreads();
     }
-    epilogue<BN, WPX, WOC>(p, acc, lds, slut, rowoff, oc0, pxw, 0, hw);
+    epilogue<BP, BN, WPX, WOC>(p, acc, lds, slut, rowoff, oc0, pxw, 0, hw);
 }
 
 
@@ -508,13 +524,13 @@ __global__ __launch_bounds__(NTHREADS) void conv_i8_smallc(const mhip_conv_i8_t 
         const int tx = (int)(t % tiles_x), ty = (int)((t / tiles_x) % tiles_y);
         const long f = t / ((long)tiles_x * tiles_y);
         const int oy0 = ty * SC_TH, ox0 = tx * SC_TW, ow = p.out_w, oh = p.out_h;
-        fill_rowoff(p, rowoff,
+        fill_rowoff<BP>(p, rowoff,
                     [=](int row) {
                         const int oy = oy0 + (row >> 4), ox = ox0 + (row & 15);
                         return (oy < oh && ox < ow) ? f * hw + (long)oy * ow + ox : -1L;
                     },
                     (unsigned)hw); // consumed after the barrier inside epilogue(); rewritten after the loop-top barrier
-        epilogue<BN, 2, WOC>(p, acc, tile, slut, rowoff, 0, wv * 32, 0, hw);
+        epilogue<BP, BN, 2, WOC>(p, acc, tile, slut, rowoff, 0, wv * 32, 0, hw);
     }
 }
 
@@ -544,25 +560,33 @@ static int launch_smallc(const mhip_conv_i8_t *p, int k64) {
     return mhip_check(hipGetLastError(), "conv_i8_smallc launch");
 }
 
-template <int BN, int STAGES>
+template <int BPX, int BN, int STAGES, bool POW2>
 static int launch_mfma(const mhip_conv_i8_t *p, long total_pix, int k64) {
-    const unsigned npt = (unsigned)((total_pix + BP - 1) / BP), noc = (unsigned)(p->oc_pad / BN);
+    const unsigned npt = (unsigned)((total_pix + BPX - 1) / BPX), noc = (unsigned)(p->oc_pad / BN);
     const unsigned nblk = npt * noc;
     const int nks = k64 / BK, used = nks < STAGES ? nks : STAGES;
-    size_t ring = (size_t)used * (BP + BN) * BK, tile = (size_t)BP * (BN + OPAD);
-    const size_t lds = BP * 8 + 256 + (ring > tile ? ring : tile);
-    hipLaunchKernelGGL((conv_i8_mfma<BN, STAGES>), dim3(nblk), dim3(NTHREADS), lds, mhip_stream_native(), *p, total_pix,
-                       k64, (const int8_t *)mhip_zero_page(), noc, nblk);
+    size_t ring = (size_t)used * (BPX + BN) * BK, tile = (size_t)BPX * (BN + OPAD);
+    const size_t lds = BPX * 8 + 256 + (ring > tile ? ring : tile);
+    int lg = 0;
+    while ((1 << lg) < p->in_c) lg++;
+    const unsigned magic = (65536u + (unsigned)p->kw - 1u) / (unsigned)p->kw;
+    hipLaunchKernelGGL((conv_i8_mfma<BPX, BN, STAGES, POW2>), dim3(nblk), dim3(NTHREADS), lds, mhip_stream_native(), *p,
+                       total_pix, k64, (const int8_t *)mhip_zero_page(), noc, nblk, lg, magic);
     return mhip_check(hipGetLastError(), "conv_i8_mfma launch");
 }
 
 // ring depth: as deep as the K loop can use, bounded by what keeps >= 2-3 workgroups per CU
-template <int BN>
-static int launch_mfma_auto(const mhip_conv_i8_t *p, long total_pix, int k64) {
+template <int BPX, int BN, bool POW2>
+static int launch_mfma_depth(const mhip_conv_i8_t *p, long total_pix, int k64) {
     const int nks = k64 / BK;
-    if (nks <= 2) return launch_mfma<BN, 2>(p, total_pix, k64);
-    if (nks == 3 || BN == 128) return launch_mfma<BN, 3>(p, total_pix, k64);
-    return launch_mfma<BN, 4>(p, total_pix, k64);
+    if (nks <= 2) return launch_mfma<BPX, BN, 2, POW2>(p, total_pix, k64);
+    return launch_mfma<BPX, BN, 3, POW2>(p, total_pix, k64);
+}
+
+template <int BPX, int BN>
+static int launch_mfma_auto(const mhip_conv_i8_t *p, long total_pix, int k64) {
+    const bool pow2 = (p->in_c & (p->in_c - 1)) == 0 && (long)p->kh * p->kw * (p->kw - 1) < 65536 && p->kw >= 1;
+    return pow2 ? launch_mfma_depth<BPX, BN, true>(p, total_pix, k64) : launch_mfma_depth<BPX, BN, false>(p, total_pix, k64);
 }
 
 template <int BN>
@@ -592,9 +616,9 @@ extern "C" int mhip_conv_i8(const mhip_conv_i8_t *p) {
     }
     if ((p->in_c % 16) == 0) {
         if (!mhip_zero_page()) return -1;
-        if (oc_pad % 128 == 0) return launch_mfma_auto<128>(p, total_pix, k64);
-        if (oc_pad % 64 == 0) return launch_mfma_auto<64>(p, total_pix, k64);
-        return launch_mfma_auto<32>(p, total_pix, k64);
+        if (oc_pad % 128 == 0) return launch_mfma_auto<128, 128>(p, total_pix, k64);
+        if (oc_pad % 64 == 0) return launch_mfma_auto<256, 64>(p, total_pix, k64);
+        return launch_mfma_auto<256, 32>(p, total_pix, k64);
     }
     if (oc_pad % 64 == 0) return launch_generic<64>(p, total_pix, k64);
     return launch_generic<32>(p, total_pix, k64);
