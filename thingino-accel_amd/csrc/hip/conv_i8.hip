@@ -54,13 +54,39 @@ __device__ __forceinline__ int lds_off(int row, int chunk) {
     return row * BK + (((chunk ^ ((row >> 1) & 2))) << 4);
 }
 
-__device__ __forceinline__ int requant(int acc, float cs) {
-    float scaled = (float)acc * cs;
-    float biased = scaled + (scaled >= 0.0f ? 0.5f : -0.5f);
-    int r = (int)biased;                        // v_cvt_i32_f32: saturates, NaN -> 0
-    if (!(biased < 2147483648.0f)) r = INT_MIN; // x86 cvttss2si: +overflow and NaN -> INT_MIN
+// One output value: 6 VALU when SAFE.  `lo` is the lower clamp (-128, or 0 for the fused ReLU).
+// The +/-0.5 is copysign(0.5, scaled): same result as the reference's `scaled >= 0 ? 0.5f : -0.5f`
+// for every input (for -0.0 both roundings truncate to 0; NaN stays NaN).
+// SAFE (decided on the host): |acc*cs| can never reach 2^31 and cs is finite, so the x86
+// "integer indefinite" fix-up (out of range / NaN -> INT_MIN -> -128) is provably dead.
+template <bool SAFE>
+__device__ __forceinline__ int requant(int acc, float cs, int lo) {
+    const float scaled = (float)acc * cs;
+    const float half = __int_as_float((__float_as_int(scaled) & (int)0x80000000) | 0x3f000000);
+    const float biased = scaled + half;
+    int r = (int)biased;                                    // v_cvt_i32_f32: saturates, NaN -> 0
+    if (!SAFE) r = biased < 2147483648.0f ? r : INT_MIN;    // x86 cvttss2si: +overflow and NaN -> INT_MIN
+    r = r < lo ? lo : r;
     r = r > 127 ? 127 : r;
-    r = r < -128 ? -128 : r;
+    return r;
+}
+
+// exact unsigned division by a launch-time constant (Granlund & Montgomery, N = 32):
+// q = mulhi(m, n); q = (q + ((n - q) >> s1)) >> s2
+struct fastdiv_t {
+    unsigned m, s1, s2;
+};
+__device__ __forceinline__ unsigned fdiv(unsigned n, const fastdiv_t d) {
+    const unsigned q = __umulhi(d.m, n);
+    return (q + ((n - q) >> d.s1)) >> d.s2;
+}
+static fastdiv_t make_fastdiv(unsigned d) {
+    fastdiv_t r;
+    unsigned l = 0;
+    while ((1ull << l) < d) l++;
+    r.m = (unsigned)(((1ull << 32) * ((1ull << l) - d)) / d + 1);
+    r.s1 = l < 1 ? l : 1;
+    r.s2 = l > 0 ? l - 1 : 0;
     return r;
 }
 
@@ -87,41 +113,39 @@ __device__ __forceinline__ unsigned xcd_remap(unsigned bid, unsigned nblk) {
 // `rowoff[row]` = byte offset of tile row `row`'s pixel in the output (frame*out_stride + rem*out_c for NHWC,
 // frame*out_stride + rem for NCHW), or -1 when the row is outside the image/batch; filled by fill_rowoff().
 template <int BPX, class PixelOf>
-__device__ __forceinline__ void fill_rowoff(const mhip_conv_i8_t &p, long *rowoff, PixelOf pixel_of, unsigned hw) {
+__device__ __forceinline__ void fill_rowoff(const mhip_conv_i8_t &p, long *rowoff, PixelOf pixel_of, unsigned hw,
+                                            const fastdiv_t dhw) {
     if (threadIdx.x < BPX) {
         const long pix = pixel_of((int)threadIdx.x); // global pixel index (frame*H*W + y*W + x) or -1
         long off = -1;
         if (pix >= 0) {
-            const unsigned f = (unsigned)((unsigned long)pix / hw), rem = (unsigned)((unsigned long)pix - (unsigned long)f * hw);
+            const unsigned f = fdiv((unsigned)pix, dhw), rem = (unsigned)pix - f * hw;
             off = (long)f * (long)p.out_stride + (p.out_nchw ? (long)rem : (long)rem * p.out_c);
         }
         rowoff[threadIdx.x] = off;
     }
 }
 
-template <int BPX, int BN, int WPX, int WOC>
-__device__ __forceinline__ void epilogue(const mhip_conv_i8_t &p, v4i (&acc)[WOC][WPX], int8_t *tile, const uint8_t *slut,
-                                         const long *rowoff, int oc0, int pxw, int ocw, int hw) {
+template <int BPX, int BN, int WPX, int WOC, bool HAS_LUT, bool SAFE>
+__device__ __forceinline__ void epilogue_t(const mhip_conv_i8_t &p, v4i (&acc)[WOC][WPX], int8_t *tile, const uint8_t *slut,
+                                           const long *rowoff, int oc0, int pxw, int ocw, int hw) {
     const int tid = threadIdx.x, lane = tid & 63;
     constexpr int ROW = BN + OPAD;
-    // bias for this lane's 4 consecutive channels of each oc subtile
-    v4i bias[WOC];
-#pragma unroll
-    for (int s = 0; s < WOC; s++)
-        bias[s] = p.bias ? *(const v4i *)(p.bias + oc0 + ocw + s * 16 + (lane >> 4) * 4) : (v4i){0, 0, 0, 0};
+    const int lo = p.relu ? 0 : -128; // fused ReLU == raising the lower clamp
+    const uint8_t *lut128 = slut + 128;
 #pragma unroll
     for (int t = 0; t < WPX; t++) {
         const int prow = pxw + t * 16 + (lane & 15);
 #pragma unroll
         for (int s = 0; s < WOC; s++) {
-            uint32_t pk = 0;
+            int q[4];
 #pragma unroll
             for (int r = 0; r < 4; r++) {
-                int v = requant(acc[s][t][r] + bias[s][r], p.cs);
-                if (p.relu) v = v < 0 ? 0 : v;
-                if (p.lut) v = slut[(v + 128) & 255];
-                pk |= (uint32_t)(v & 255) << (8 * r);
+                q[r] = requant<SAFE>(acc[s][t][r], p.cs, lo); // the bias is already inside the accumulator
+                if (HAS_LUT) q[r] = lut128[q[r]];
             }
+            const uint32_t pk = (uint32_t)(q[0] & 255) | ((uint32_t)(q[1] & 255) << 8) | ((uint32_t)(q[2] & 255) << 16) |
+                                ((uint32_t)q[3] << 24);
             *(uint32_t *)(tile + prow * ROW + ocw + s * 16 + (lane >> 4) * 4) = pk;
         }
     }
@@ -162,15 +186,41 @@ __device__ __forceinline__ void epilogue(const mhip_conv_i8_t &p, v4i (&acc)[WOC
     }
 }
 
+template <int BPX, int BN, int WPX, int WOC>
+__device__ __forceinline__ void epilogue(const mhip_conv_i8_t &p, v4i (&acc)[WOC][WPX], int8_t *tile, const uint8_t *slut,
+                                         const long *rowoff, int oc0, int pxw, int ocw, int hw) {
+    if (p.lut) {
+        if (p.safe) epilogue_t<BPX, BN, WPX, WOC, true, true>(p, acc, tile, slut, rowoff, oc0, pxw, ocw, hw);
+        else epilogue_t<BPX, BN, WPX, WOC, true, false>(p, acc, tile, slut, rowoff, oc0, pxw, ocw, hw);
+    } else {
+        if (p.safe) epilogue_t<BPX, BN, WPX, WOC, false, true>(p, acc, tile, slut, rowoff, oc0, pxw, ocw, hw);
+        else epilogue_t<BPX, BN, WPX, WOC, false, false>(p, acc, tile, slut, rowoff, oc0, pxw, ocw, hw);
+    }
+}
+
+// accumulators start at the bias: lane holds channels ocbase + s*16 + (lane>>4)*4 .. +3 of every pixel subtile
+template <int WPX, int WOC>
+__device__ __forceinline__ void init_acc(const mhip_conv_i8_t &p, v4i (&acc)[WOC][WPX], int ocbase) {
+    const int lane = threadIdx.x & 63;
+#pragma unroll
+    for (int s = 0; s < WOC; s++) {
+        const v4i b = p.bias ? *(const v4i *)(p.bias + ocbase + s * 16 + (lane >> 4) * 4) : (v4i){0, 0, 0, 0};
+#pragma unroll
+        for (int t = 0; t < WPX; t++) acc[s][t] = b;
+    }
+}
+
 // ---------------------------------------------------------------------------------
 // main kernel: in_c % 16 == 0.  BPX pixels x BN channels per workgroup; every wave owns a
 // 64-pixel x (32|64)-channel accumulator tile (BPX=256 for BN<=64, BPX=128 for BN=128).
 // POW2: in_c is a power of two (every yolov5 layer) -> the K position of a chunk is shifts and
 // one small multiply instead of carried counters.
-template <int BPX, int BN, int STAGES, bool POW2>
+template <int BPX, int BN, int STAGES>
 __global__ __launch_bounds__(NTHREADS) void conv_i8_mfma(const mhip_conv_i8_t p, const long total_pix, const int k64,
                                                          const int8_t *__restrict__ zeros, const unsigned noc,
-                                                         const unsigned nblk, const int lg_inc, const unsigned kw_magic) {
+                                                         const unsigned nblk, const int lg_inc, const unsigned kw_magic,
+                                                         const fastdiv_t dhw, const fastdiv_t dow) {
+    const bool POW2 = lg_inc >= 0; // in_c is a power of two: K position by shifts, else carried counters
     constexpr int STAGE = (BPX + BN) * BK;
     constexpr int NWN = BN == 128 ? 2 : 1;       // waves along oc
     constexpr int NWM = 4 / NWN;                 // waves along pixels
@@ -193,7 +243,7 @@ __global__ __launch_bounds__(NTHREADS) void conv_i8_mfma(const mhip_conv_i8_t p,
     const int hw = p.out_h * p.out_w;
 
     if (p.lut && tid < 64) ((uint32_t *)slut)[tid] = ((const uint32_t *)p.lut)[tid];
-    fill_rowoff<BPX>(p, rowoff, [=](int row) { long q = pix0 + row; return q < total_pix ? q : -1L; }, (unsigned)hw);
+    fill_rowoff<BPX>(p, rowoff, [=](int row) { long q = pix0 + row; return q < total_pix ? q : -1L; }, (unsigned)hw, dhw);
 
     // ---- DMA assignment.  One wave-instruction fills 16 consecutive 64-byte rows; lane i
     // lands in row i/4, slot i%4, so it must FETCH chunk (slot ^ swizzle(row)).
@@ -204,9 +254,9 @@ __global__ __launch_bounds__(NTHREADS) void conv_i8_mfma(const mhip_conv_i8_t p,
     for (int j = 0; j < XI; j++) {
         const long pix = pix0 + wv * (BPX / 4) + j * 16 + (lane >> 2);
         const bool valid = pix < total_pix;
-        const unsigned f = valid ? (unsigned)((unsigned long)pix / (unsigned)hw) : 0u;
-        const unsigned rem = valid ? (unsigned)((unsigned long)pix - (unsigned long)f * (unsigned)hw) : 0u;
-        const int oy = (int)(rem / (unsigned)p.out_w), ox = (int)(rem - (unsigned)oy * (unsigned)p.out_w);
+        const unsigned f = valid ? fdiv((unsigned)pix, dhw) : 0u;
+        const unsigned rem = valid ? (unsigned)pix - f * (unsigned)hw : 0u;
+        const int oy = (int)fdiv(rem, dow), ox = (int)(rem - (unsigned)oy * (unsigned)p.out_w);
         iy0[j] = valid ? oy * p.stride_h - p.pad_top : -(1 << 28); // invalid rows fail every bounds test
         ix0[j] = ox * p.stride_w - p.pad_left;
         xbase[j] = p.in + (size_t)f * p.in_stride;
@@ -256,18 +306,14 @@ __global__ __launch_bounds__(NTHREADS) void conv_i8_mfma(const mhip_conv_i8_t p,
         }
     };
 
-    v4i acc[WOC][WPX];
-#pragma unroll
-    for (int s = 0; s < WOC; s++)
-#pragma unroll
-        for (int t = 0; t < WPX; t++) acc[s][t] = (v4i){0, 0, 0, 0};
-
 #pragma unroll
     for (int s = 0; s < STAGES - 1; s++)
         if (s < nks) issue(s, s);
 
     const int wm = wv % NWM, wn = wv / NWM;
     const int pxw = wm * (WPX * 16), ocw = wn * (WOC * 16);
+    v4i acc[WOC][WPX];
+    init_acc<WPX, WOC>(p, acc, oc0 + ocw);
     const int frow = lane & 15, fchunk = lane >> 4;
     int stage = 0, nstage = STAGES - 1;
     for (int ks = 0; ks < nks; ks++) {
@@ -299,7 +345,8 @@ __global__ __launch_bounds__(NTHREADS) void conv_i8_mfma(const mhip_conv_i8_t p,
 // ---------------------------------------------------------------------------------
 // generic kernel: any in_c (the 3-channel stem); register-staged byte gather
 template <int BN>
-__global__ __launch_bounds__(NTHREADS) void conv_i8_generic(const mhip_conv_i8_t p, const long total_pix, const int k64) {
+__global__ __launch_bounds__(NTHREADS) void conv_i8_generic(const mhip_conv_i8_t p, const long total_pix, const int k64,
+                                                            const fastdiv_t dhw) {
     constexpr int STAGE = (BP + BN) * BK;
     constexpr int WPX = 2, WOC = BN / 16;
     constexpr int TILE_BYTES = BP * (BN + OPAD);
@@ -313,7 +360,7 @@ __global__ __launch_bounds__(NTHREADS) void conv_i8_generic(const mhip_conv_i8_t
     const int oc0 = blockIdx.y * BN;
     const int hw = p.out_h * p.out_w;
     if (p.lut && tid < 64) ((uint32_t *)slut)[tid] = ((const uint32_t *)p.lut)[tid];
-    fill_rowoff<BP>(p, rowoff, [=](int row) { long q = pix0 + row; return q < total_pix ? q : -1L; }, (unsigned)hw);
+    fill_rowoff<BP>(p, rowoff, [=](int row) { long q = pix0 + row; return q < total_pix ? q : -1L; }, (unsigned)hw, dhw);
 
     const int cc = tid & 3;
     const int8_t *xbase[2];
@@ -378,10 +425,7 @@ __global__ __launch_bounds__(NTHREADS) void conv_i8_generic(const mhip_conv_i8_t
     };
 
     v4i acc[WOC][WPX];
-#pragma unroll
-    for (int s = 0; s < WOC; s++)
-#pragma unroll
-        for (int t = 0; t < WPX; t++) acc[s][t] = (v4i){0, 0, 0, 0};
+    init_acc<WPX, WOC>(p, acc, oc0);
 
     load_global(0);
     store_lds(0);
@@ -418,7 +462,7 @@ __global__ __launch_bounds__(NTHREADS) void conv_i8_generic(const mhip_conv_i8_t
 template <int WOC>
 __global__ __launch_bounds__(NTHREADS) void conv_i8_smallc(const mhip_conv_i8_t p, const int k64, const int tiles_x,
                                                            const int tiles_y, const long ntiles, const int PH, const int PW,
-                                                           const int PWp) {
+                                                           const int PWp, const fastdiv_t dhw) {
     constexpr int BN = WOC * 16;
     extern __shared__ __attribute__((aligned(16))) int8_t dyn[];
     const int wrow = k64 + 16;                       // padded weight row: conflict-free fragment reads
@@ -502,8 +546,7 @@ __global__ __launch_bounds__(NTHREADS) void conv_i8_smallc(const mhip_conv_i8_t 
         if (tn < ntiles) fetch(tn); // next tile's bytes travel while this one is computed
 
         v4i acc[WOC][2];
-#pragma unroll
-        for (int s = 0; s < WOC; s++) acc[s][0] = acc[s][1] = (v4i){0, 0, 0, 0};
+        init_acc<2, WOC>(p, acc, 0);
         const int px = lane & 15, c = lane >> 4;
         for (int ks = 0; ks < nks; ks++) {
             const int ky = 2 * ks + (c >> 1);
@@ -529,9 +572,15 @@ __global__ __launch_bounds__(NTHREADS) void conv_i8_smallc(const mhip_conv_i8_t 
                         const int oy = oy0 + (row >> 4), ox = ox0 + (row & 15);
                         return (oy < oh && ox < ow) ? f * hw + (long)oy * ow + ox : -1L;
                     },
-                    (unsigned)hw); // consumed after the barrier inside epilogue(); rewritten after the loop-top barrier
+                    (unsigned)hw, dhw); // consumed after the barrier inside epilogue(); rewritten after the loop-top barrier
         epilogue<BP, BN, 2, WOC>(p, acc, tile, slut, rowoff, 0, wv * 32, 0, hw);
     }
+}
+
+extern "C" int mhip_conv_i8_is_safe(float cs) {
+    // the accumulator is an int32, so |(float)acc| <= 2^31; with |cs| < 0.99 the product (and the
+    // +-0.5) stays below 2^31 and is never NaN: the out-of-range branch of the reference is unreachable
+    return cs == cs && cs < 0.99f && cs > -0.99f;
 }
 
 extern "C" int mhip_conv_i8_small_c(int in_c, int kw, int out_c) { return in_c <= 4 && kw <= 8 && out_c <= 64; }
@@ -556,43 +605,43 @@ static int launch_smallc(const mhip_conv_i8_t *p, int k64) {
     if (lds > 64 * 1024) return -1;
     long grid = ntiles < 256L * 8 ? ntiles : 256L * 8;
     hipLaunchKernelGGL((conv_i8_smallc<WOC>), dim3((unsigned)grid), dim3(NTHREADS), lds, mhip_stream_native(), *p, k64,
-                       tiles_x, tiles_y, ntiles, PH, PW, PWp);
+                       tiles_x, tiles_y, ntiles, PH, PW, PWp, make_fastdiv((unsigned)(p->out_h * p->out_w)));
     return mhip_check(hipGetLastError(), "conv_i8_smallc launch");
 }
 
-template <int BPX, int BN, int STAGES, bool POW2>
+template <int BPX, int BN, int STAGES>
 static int launch_mfma(const mhip_conv_i8_t *p, long total_pix, int k64) {
     const unsigned npt = (unsigned)((total_pix + BPX - 1) / BPX), noc = (unsigned)(p->oc_pad / BN);
     const unsigned nblk = npt * noc;
     const int nks = k64 / BK, used = nks < STAGES ? nks : STAGES;
     size_t ring = (size_t)used * (BPX + BN) * BK, tile = (size_t)BPX * (BN + OPAD);
     const size_t lds = BPX * 8 + 256 + (ring > tile ? ring : tile);
-    int lg = 0;
-    while ((1 << lg) < p->in_c) lg++;
+    // in_c a power of two and tap/kw small enough for the 16-bit reciprocal: shift-based K position
+    int lg = -1;
+    if ((p->in_c & (p->in_c - 1)) == 0 && (long)p->kh * p->kw * (p->kw - 1) < 65536) {
+        lg = 0;
+        while ((1 << lg) < p->in_c) lg++;
+    }
     const unsigned magic = (65536u + (unsigned)p->kw - 1u) / (unsigned)p->kw;
-    hipLaunchKernelGGL((conv_i8_mfma<BPX, BN, STAGES, POW2>), dim3(nblk), dim3(NTHREADS), lds, mhip_stream_native(), *p,
-                       total_pix, k64, (const int8_t *)mhip_zero_page(), noc, nblk, lg, magic);
+    hipLaunchKernelGGL((conv_i8_mfma<BPX, BN, STAGES>), dim3(nblk), dim3(NTHREADS), lds, mhip_stream_native(), *p, total_pix,
+                       k64, (const int8_t *)mhip_zero_page(), noc, nblk, lg, magic,
+                       make_fastdiv((unsigned)(p->out_h * p->out_w)), make_fastdiv((unsigned)p->out_w));
     return mhip_check(hipGetLastError(), "conv_i8_mfma launch");
 }
 
-// ring depth: as deep as the K loop can use, bounded by what keeps >= 2-3 workgroups per CU
-template <int BPX, int BN, bool POW2>
-static int launch_mfma_depth(const mhip_conv_i8_t *p, long total_pix, int k64) {
-    const int nks = k64 / BK;
-    if (nks <= 2) return launch_mfma<BPX, BN, 2, POW2>(p, total_pix, k64);
-    return launch_mfma<BPX, BN, 3, POW2>(p, total_pix, k64);
-}
-
+// ring depth: as deep as the K loop can use
 template <int BPX, int BN>
 static int launch_mfma_auto(const mhip_conv_i8_t *p, long total_pix, int k64) {
-    const bool pow2 = (p->in_c & (p->in_c - 1)) == 0 && (long)p->kh * p->kw * (p->kw - 1) < 65536 && p->kw >= 1;
-    return pow2 ? launch_mfma_depth<BPX, BN, true>(p, total_pix, k64) : launch_mfma_depth<BPX, BN, false>(p, total_pix, k64);
+    const int nks = k64 / BK;
+    if (nks <= 2) return launch_mfma<BPX, BN, 2>(p, total_pix, k64);
+    return launch_mfma<BPX, BN, 3>(p, total_pix, k64);
 }
 
 template <int BN>
 static int launch_generic(const mhip_conv_i8_t *p, long total_pix, int k64) {
     dim3 grid((unsigned)((total_pix + BP - 1) / BP), (unsigned)(p->oc_pad / BN));
-    hipLaunchKernelGGL((conv_i8_generic<BN>), grid, dim3(NTHREADS), 0, mhip_stream_native(), *p, total_pix, k64);
+    hipLaunchKernelGGL((conv_i8_generic<BN>), grid, dim3(NTHREADS), 0, mhip_stream_native(), *p, total_pix, k64,
+                       make_fastdiv((unsigned)(p->out_h * p->out_w)));
     return mhip_check(hipGetLastError(), "conv_i8_generic launch");
 }
 

@@ -48,7 +48,7 @@ typedef struct {
     int t_in[4], n_in, t_out; /* tensor indices, -1 if none */
     /* geometry (conv / pool / concat / upsample share these) */
     int in_h, in_w, in_c, out_h, out_w, out_c, kh, kw, sh, sw, pt, pl;
-    int nchw, relu, is_mul, is_f32, leaky;
+    int nchw, relu, is_mul, is_f32, leaky, safe;
     int row_pad, oc_pad, c_pad;
     int ch_off, scale_h, scale_w, bn_n;
     float cs, f0, f1, f2;

@@ -277,6 +277,7 @@ static void plan_conv(mars_model_ext_t *m, int li) {
             blob_read(m, (size_t)m->pub.tensors[tb].desc.data_offset, (size_t)out_c * 4, m->arena_host + op->b_off);
     }
     op->cs = (in->scale * w->scale) / out->scale; /* float32, this order (mxu_conv.c:639,722) */
+    op->safe = mhip_conv_i8_is_safe(op->cs);
     op->relu = cp->activation == MARS_ACT_RELU;
     if (op->nchw) {
         size_t need = (size_t)in_h * in_w * op->c_pad;
@@ -828,6 +829,7 @@ static int launch_op(mars_model_ext_t *m, mars_op_t *op) {
             p.out_h = op->out_h; p.out_w = op->out_w; p.out_c = op->out_c;
             p.kh = op->kh; p.kw = op->kw; p.stride_h = op->sh; p.stride_w = op->sw; p.pad_top = op->pt; p.pad_left = op->pl;
             p.row_pad = op->row_pad; p.oc_pad = op->oc_pad; p.cs = op->cs; p.relu = op->relu; p.out_nchw = op->nchw;
+            p.safe = op->safe;
             return mhip_conv_i8(&p);
         }
         case OP_CONV_F32: {

@@ -95,6 +95,7 @@ static void conv_i8_host(int nchw, const signed char *input, int in_h, int in_w,
         p.row_pad = row_pad; p.oc_pad = oc_pad;
         p.cs = (in_scale * w_scale) / out_scale; /* mxu_conv.c:639 / :722 */
         p.out_nchw = nchw;
+        p.safe = mhip_conv_i8_is_safe(p.cs);
         if (!rc) rc = mhip_conv_i8(&p);
         if (!rc) rc = mhip_d2h_async(output, dout, out_b);
         if (mhip_sync() || rc) fprintf(stderr, "%s: GPU execution failed: %s\n", who, mhip_last_error());

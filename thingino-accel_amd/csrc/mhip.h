@@ -61,7 +61,10 @@ typedef struct {
     float cs;                   /* (in_scale*w_scale)/out_scale, evaluated on the host in f32 */
     int relu;                   /* clamp negative results to 0 (fused ReLU, byte semantics) */
     int out_nchw;               /* store [O][H][W] instead of [H][W][O] */
+    int safe;                   /* host proved |acc*cs| < 2^31 and cs finite: skip the x86 overflow fix-up */
 } mhip_conv_i8_t;
+/* is the float->int conversion of acc*cs provably in range for every int32 accumulator? */
+int mhip_conv_i8_is_safe(float cs);
 /* packing geometry shared by host packer and kernel */
 /* c_eff: bytes per input pixel in the packed K layout (4 in small-channel mode, else in_c) */
 void mhip_conv_i8_pack_geom(int in_c, int kw, int out_c, int *row_pad, int *oc_pad, int *c_eff);
