@@ -33,6 +33,7 @@
 // Generic kernel (any other in_c): register-staged, byte-granular gather.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 
 #include "../mhip.h"
 
@@ -618,7 +619,9 @@ static int launch_mfma(const mhip_conv_i8_t *p, long total_pix, int k64) {
     const size_t lds = BPX * 8 + 256 + (ring > tile ? ring : tile);
     // in_c a power of two and tap/kw small enough for the 16-bit reciprocal: shift-based K position
     int lg = -1;
-    if ((p->in_c & (p->in_c - 1)) == 0 && (long)p->kh * p->kw * (p->kw - 1) < 65536) {
+    static int nopow2 = -1;
+    if (nopow2 < 0) nopow2 = getenv("MARS_HIP_NOPOW2") ? 1 : 0;
+    if (!nopow2 && (p->in_c & (p->in_c - 1)) == 0 && (long)p->kh * p->kw * (p->kw - 1) < 65536) {
         lg = 0;
         while ((1 << lg) < p->in_c) lg++;
     }
@@ -634,7 +637,8 @@ template <int BPX, int BN>
 static int launch_mfma_auto(const mhip_conv_i8_t *p, long total_pix, int k64) {
     const int nks = k64 / BK;
     if (nks <= 2) return launch_mfma<BPX, BN, 2>(p, total_pix, k64);
-    return launch_mfma<BPX, BN, 3>(p, total_pix, k64);
+    if (nks == 3 || BPX * BN >= 128 * 128) return launch_mfma<BPX, BN, 3>(p, total_pix, k64);
+    return launch_mfma<BPX, BN, 4>(p, total_pix, k64);
 }
 
 template <int BN>
@@ -665,9 +669,18 @@ extern "C" int mhip_conv_i8(const mhip_conv_i8_t *p) {
     }
     if ((p->in_c % 16) == 0) {
         if (!mhip_zero_page()) return -1;
+        // pixel-tile policy for the narrow (BN <= 64) configurations: 256 pixels per workgroup halves the
+        // weight-tile traffic and per-workgroup overhead, 128 keeps one more workgroup per CU.
+        static int policy = -1; // 0 auto, 128, 256 (MARS_HIP_BPX, for experiments)
+        if (policy < 0) {
+            const char *e = getenv("MARS_HIP_BPX");
+            policy = e ? atoi(e) : 0;
+        }
+        const int nks = k64 / BK;
         if (oc_pad % 128 == 0) return launch_mfma_auto<128, 128>(p, total_pix, k64);
-        if (oc_pad % 64 == 0) return launch_mfma_auto<256, 64>(p, total_pix, k64);
-        return launch_mfma_auto<256, 32>(p, total_pix, k64);
+        const bool wide = policy == 256 || (policy == 0 && nks <= 2);
+        if (oc_pad % 64 == 0) return wide ? launch_mfma_auto<256, 64>(p, total_pix, k64) : launch_mfma_auto<128, 64>(p, total_pix, k64);
+        return wide ? launch_mfma_auto<256, 32>(p, total_pix, k64) : launch_mfma_auto<128, 32>(p, total_pix, k64);
     }
     if (oc_pad % 64 == 0) return launch_generic<64>(p, total_pix, k64);
     return launch_generic<32>(p, total_pix, k64);
