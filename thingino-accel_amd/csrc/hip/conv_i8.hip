@@ -222,6 +222,7 @@ __global__ __launch_bounds__(NTHREADS) void conv_i8_mfma(const mhip_conv_i8_t p,
                                                          const unsigned nblk, const int lg_inc, const unsigned kw_magic,
                                                          const fastdiv_t dhw, const fastdiv_t dow) {
     const bool POW2 = lg_inc >= 0; // in_c is a power of two: K position by shifts, else carried counters
+    const bool masked = p.kh * p.kw <= 32;
     constexpr int STAGE = (BPX + BN) * BK;
     constexpr int NWN = BN == 128 ? 2 : 1;       // waves along oc
     constexpr int NWM = 4 / NWN;                 // waves along pixels
@@ -249,7 +250,11 @@ __global__ __launch_bounds__(NTHREADS) void conv_i8_mfma(const mhip_conv_i8_t p,
     // ---- DMA assignment.  One wave-instruction fills 16 consecutive 64-byte rows; lane i
     // lands in row i/4, slot i%4, so it must FETCH chunk (slot ^ swizzle(row)).
     const int schunk = (lane & 3) ^ (((lane >> 4) & 1) << 1);
-    const int8_t *xbase[XI];
+    // Per row: pointer to the (possibly out-of-image) top-left input pixel of its window, and a bit mask
+    // of the kernel taps that fall inside the image (bit ky*kw+kx), so the K loop spends one bit test per
+    // row and step instead of four compares.  (kh*kw <= 32 is checked on the host; else MASKED is off.)
+    const int8_t *xwin[XI];
+    unsigned tapmask[XI];
     int iy0[XI], ix0[XI];
 #pragma unroll
     for (int j = 0; j < XI; j++) {
@@ -260,7 +265,18 @@ __global__ __launch_bounds__(NTHREADS) void conv_i8_mfma(const mhip_conv_i8_t p,
         const int oy = (int)fdiv(rem, dow), ox = (int)(rem - (unsigned)oy * (unsigned)p.out_w);
         iy0[j] = valid ? oy * p.stride_h - p.pad_top : -(1 << 28); // invalid rows fail every bounds test
         ix0[j] = ox * p.stride_w - p.pad_left;
-        xbase[j] = p.in + (size_t)f * p.in_stride;
+        xwin[j] = p.in + (size_t)f * p.in_stride + ((long)iy0[j] * p.in_w + ix0[j]) * p.in_c;
+        unsigned m = 0;
+        if (masked) {
+            // columns kx with 0 <= ix0+kx < in_w
+            const int kx_lo = ix0[j] < 0 ? -ix0[j] : 0, kx_hi = p.in_w - ix0[j] < p.kw ? p.in_w - ix0[j] : p.kw; // [lo, hi)
+            const unsigned colbits = kx_hi > kx_lo ? ((kx_hi >= 32 ? ~0u : (1u << kx_hi) - 1u) & ~((1u << kx_lo) - 1u)) : 0u;
+            for (int r = 0; r < p.kh; r++) {
+                const int iy = iy0[j] + r;
+                if (iy >= 0 && iy < p.in_h) m |= colbits << (r * p.kw);
+            }
+        }
+        tapmask[j] = m;
     }
     const int8_t *wsrc[LW];
     int wq[LW];
@@ -291,11 +307,18 @@ __global__ __launch_bounds__(NTHREADS) void conv_i8_mfma(const mhip_conv_i8_t p,
         } else {
             kvalid = ky < p.kh;
         }
+        const long koff = ((long)ky * p.in_w + kx) * p.in_c + rc; // same for every row of this lane
+        const int tap = ky * p.kw + kx;
 #pragma unroll
         for (int j = 0; j < XI; j++) {
-            const int iy = iy0[j] + ky, ix = ix0[j] + kx;
-            const bool ok = kvalid & (iy >= 0) & (iy < p.in_h) & (ix >= 0) & (ix < p.in_w);
-            const int8_t *src = ok ? xbase[j] + ((size_t)iy * p.in_w + ix) * p.in_c + rc : zeros;
+            bool ok;
+            if (masked) {
+                ok = kvalid & ((tapmask[j] >> tap) & 1u);
+            } else {
+                const int iy = iy0[j] + ky, ix = ix0[j] + kx;
+                ok = kvalid & (iy >= 0) & (iy < p.in_h) & (ix >= 0) & (ix < p.in_w);
+            }
+            const int8_t *src = ok ? xwin[j] + koff : zeros;
             glds16(src, sb + (wv * (BPX / 4) + j * 16) * BK);
         }
 #pragma unroll
