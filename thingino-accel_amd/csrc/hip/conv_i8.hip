@@ -121,7 +121,8 @@ __device__ __forceinline__ void fill_rowoff(const mhip_conv_i8_t &p, long *rowof
         long off = -1;
         if (pix >= 0) {
             const unsigned f = fdiv((unsigned)pix, dhw), rem = (unsigned)pix - f * hw;
-            off = (long)f * (long)p.out_stride + (p.out_nchw ? (long)rem : (long)rem * p.out_c);
+            off = (long)f * (long)p.out_stride +
+                  (p.out_nchw ? (long)rem : (long)rem * (p.out_pix_stride ? p.out_pix_stride : p.out_c) + p.out_ch_off);
         }
         rowoff[threadIdx.x] = off;
     }
@@ -152,7 +153,7 @@ __device__ __forceinline__ void epilogue_t(const mhip_conv_i8_t &p, v4i (&acc)[W
     }
     __syncthreads();
     const int ncols = p.out_c - oc0 < BN ? p.out_c - oc0 : BN; // valid channels of this tile
-    if (!p.out_nchw && (p.out_c & 15) == 0) {
+    if (!p.out_nchw && ((p.out_c | p.out_pix_stride | p.out_ch_off) & 15) == 0) {
         constexpr int CPR = BN / 16; // 16-byte chunks per pixel row
         for (int id = tid; id < BPX * CPR; id += NTHREADS) {
             const int row = id / CPR, c = id - row * CPR;
@@ -491,9 +492,9 @@ __global__ __launch_bounds__(NTHREADS) void conv_i8_smallc(const mhip_conv_i8_t 
     extern __shared__ __attribute__((aligned(16))) int8_t dyn[];
     const int wrow = k64 + 16;                       // padded weight row: conflict-free fragment reads
     int8_t *wl = dyn;                                // [BN][wrow]
-    int8_t *patch = wl + ((BN * wrow + 15) & ~15);   // [(PH+1)][PWp] dwords
+    int8_t *patch0 = wl + ((BN * wrow + 15) & ~15);  // 2 x [(PH+1)][PWp] dwords (double buffer)
     const int patch_bytes = ((PH + 1) * PWp * 4 + 15) & ~15;
-    int8_t *tile = patch + patch_bytes;              // [128][BN+OPAD]
+    int8_t *tile = patch0 + 2 * patch_bytes;         // [128][BN+OPAD]
     uint8_t *slut = (uint8_t *)tile + BP * (BN + OPAD);
     __shared__ long rowoff[BP];
 
@@ -504,7 +505,7 @@ __global__ __launch_bounds__(NTHREADS) void conv_i8_smallc(const mhip_conv_i8_t 
         const int row = i / (k64 / 16), c = i - row * (k64 / 16);
         *(v4i *)(wl + row * wrow + c * 16) = *(const v4i *)(p.w + (size_t)row * k64 + c * 16);
     }
-    for (int i = tid; i < patch_bytes / 4; i += NTHREADS) ((uint32_t *)patch)[i] = 0;
+    for (int i = tid; i < 2 * patch_bytes / 4; i += NTHREADS) ((uint32_t *)patch0)[i] = 0;
 
     // one staging unit = 4 consecutive patch pixels of one row -> one 16-byte LDS store.
     // in_c == 3: the 12 source bytes come from ONE unaligned 16-byte global load (gfx950 serves
@@ -548,7 +549,7 @@ __global__ __launch_bounds__(NTHREADS) void conv_i8_smallc(const mhip_conv_i8_t 
             pre[j] = v;
         }
     };
-    auto commit = [&]() {
+    auto commit = [&](int8_t *patch) {
 #pragma unroll
         for (int j = 0; j < 2; j++) {
             const int u = tid + j * NTHREADS;
@@ -559,13 +560,20 @@ __global__ __launch_bounds__(NTHREADS) void conv_i8_smallc(const mhip_conv_i8_t 
         }
     };
 
+    // Software pipeline over tiles with a double-buffered patch: the next tile's loads are issued
+    // before this tile's MFMAs and committed to the OTHER buffer before this tile's stores, so the
+    // (in-order) vmcnt wait for those loads never sits behind freshly issued stores.
     const int nks = k64 / BK;
     long t = blockIdx.x;
-    if (t < ntiles) fetch(t);
+    int buf = 0;
+    __syncthreads(); // zero fill of both patch buffers is complete
+    if (t < ntiles) {
+        fetch(t);
+        commit(patch0);
+    }
     for (; t < ntiles; t += gridDim.x) {
-        __syncthreads(); // previous tile fully consumed (patch reads and output tile copy-out)
-        commit();
-        __syncthreads();
+        __syncthreads(); // patch[buf] committed by everyone; previous copy-out (tile, rowoff) finished
+        const int8_t *patch = patch0 + buf * patch_bytes;
         const long tn = t + gridDim.x;
         if (tn < ntiles) fetch(tn); // next tile's bytes travel while this one is computed
 
@@ -588,6 +596,8 @@ __global__ __launch_bounds__(NTHREADS) void conv_i8_smallc(const mhip_conv_i8_t 
                 acc[s][1] = __builtin_amdgcn_mfma_i32_16x16x64_i8(wa, xb[1], acc[s][1], 0, 0, 0);
             }
         }
+        if (tn < ntiles) commit(patch0 + (buf ^ 1) * patch_bytes); // last read before the previous epilogue's barrier
+        buf ^= 1;
         const int tx = (int)(t % tiles_x), ty = (int)((t / tiles_x) % tiles_y);
         const long f = t / ((long)tiles_x * tiles_y);
         const int oy0 = ty * SC_TH, ox0 = tx * SC_TW, ow = p.out_w, oh = p.out_h;
@@ -624,7 +634,7 @@ static int launch_smallc(const mhip_conv_i8_t *p, int k64) {
     const int PWp = (PW + 8 + 3) & ~3;
     if ((long)PH * ((PW + 3) / 4) > 2 * NTHREADS) return -1;
     constexpr int BN = WOC * 16;
-    const size_t lds = (((size_t)BN * (k64 + 16) + 15) & ~(size_t)15) + ((((size_t)PH + 1) * PWp * 4 + 15) & ~(size_t)15) +
+    const size_t lds = (((size_t)BN * (k64 + 16) + 15) & ~(size_t)15) + 2 * ((((size_t)PH + 1) * PWp * 4 + 15) & ~(size_t)15) +
                        (size_t)BP * (BN + OPAD) + 256;
     if (lds > 64 * 1024) return -1;
     long grid = ntiles < 256L * 8 ? ntiles : 256L * 8;
@@ -675,6 +685,9 @@ static int launch_generic(const mhip_conv_i8_t *p, long total_pix, int k64) {
 extern "C" int mhip_conv_i8(const mhip_conv_i8_t *p) {
     // host-side shape checks: the kernels trust these (a faulting kernel can reset the node)
     if (!p || !p->in || !p->out || !p->w) return -1;
+    if (p->out_pix_stride < 0 || p->out_ch_off < 0 || (p->out_nchw && (p->out_pix_stride || p->out_ch_off)) ||
+        (p->out_pix_stride && p->out_pix_stride < p->out_ch_off + p->out_c))
+        return -1;
     if (p->frames <= 0 || p->in_h <= 0 || p->in_w <= 0 || p->in_c <= 0 || p->out_h <= 0 || p->out_w <= 0 ||
         p->out_c <= 0 || p->kh <= 0 || p->kw <= 0 || p->stride_h < 0 || p->stride_w < 0)
         return -1;

@@ -117,12 +117,26 @@ __device__ __forceinline__ int8_t binary_one(int is_mul, int8_t a, int8_t b, flo
 
 __global__ __launch_bounds__(EW_THREADS) void binary_i8_kernel(int is_mul, const int8_t *a, size_t as, const int8_t *b,
                                                                size_t bs, int8_t *out, size_t os, size_t n, float sa,
-                                                               float sb, float inv, int vec) {
+                                                               float sb, float inv, int vec, int run, int pstride,
+                                                               int choff) {
     const int8_t *pa = a + (size_t)blockIdx.y * as;
     const int8_t *pb = b + (size_t)blockIdx.y * bs;
     int8_t *po = out + (size_t)blockIdx.y * os;
     size_t i0 = ((size_t)blockIdx.x * EW_THREADS + threadIdx.x) * 16;
     if (i0 >= n) return;
+    if (run > 0) { // channel-slice output: element i -> pixel i/run, channel i%run of a wider tensor
+        const size_t pix = i0 / (size_t)run;
+        po += pix * (size_t)pstride + choff - pix * (size_t)run; // vec path: run % 16 == 0, a chunk never crosses a pixel
+        if (!vec) {
+            size_t e = i0 + 16 < n ? i0 + 16 : n;
+            for (size_t i = i0; i < e; i++) {
+                const size_t px = i / (size_t)run;
+                out[(size_t)blockIdx.y * os + px * (size_t)pstride + choff + (i - px * (size_t)run)] =
+                    binary_one(is_mul, pa[i], pb[i], sa, sb, inv);
+            }
+            return;
+        }
+    }
     if (vec && i0 + 16 <= n) {
         v4i x = *(const v4i *)(pa + i0), y = *(const v4i *)(pb + i0), o;
 #pragma unroll
@@ -145,12 +159,15 @@ __global__ __launch_bounds__(EW_THREADS) void binary_i8_kernel(int is_mul, const
 
 extern "C" int mhip_binary_i8(int is_mul, const int8_t *a, size_t a_stride, const int8_t *b, size_t b_stride,
                               int8_t *out, size_t out_stride, int frames, size_t n, float sa, float sb,
-                              float inv_so) {
-    if (!a || !b || !out || frames <= 0) return -1;
+                              float inv_so, int out_run, int out_pix_stride, int out_ch_off) {
+    if (!a || !b || !out || frames <= 0 || out_run < 0 || out_pix_stride < 0 || out_ch_off < 0) return -1;
+    if (out_run > 0 && (out_pix_stride < out_ch_off + out_run || n % (size_t)out_run != 0)) return -1;
     if (n == 0) return 0;
     int vec = (((uintptr_t)a | (uintptr_t)b | (uintptr_t)out | a_stride | b_stride | out_stride) & 15) == 0;
+    if (out_run > 0 && ((out_run | out_pix_stride | out_ch_off) & 15)) vec = 0;
     hipLaunchKernelGGL(binary_i8_kernel, ew_grid((n + 15) / 16, frames), dim3(EW_THREADS), 0, mhip_stream_native(),
-                       is_mul, a, a_stride, b, b_stride, out, out_stride, n, sa, sb, inv_so, vec);
+                       is_mul, a, a_stride, b, b_stride, out, out_stride, n, sa, sb, inv_so, vec, out_run,
+                       out_pix_stride, out_ch_off);
     return mhip_check(hipGetLastError(), "binary_i8");
 }
 

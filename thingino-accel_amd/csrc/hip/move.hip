@@ -28,7 +28,7 @@ static inline dim3 mv_grid(size_t work, int frames) {
 template <int VEC>
 __global__ __launch_bounds__(MV_THREADS) void maxpool_kernel(const int8_t *in, size_t is, int8_t *out, size_t os,
                                                              int in_h, int in_w, int ch, int out_h, int out_w, int kh,
-                                                             int kw, int sh, int sw) {
+                                                             int kw, int sh, int sw, int pstride, int choff) {
     const int cv = ch / VEC;
     size_t idx = (size_t)blockIdx.x * MV_THREADS + threadIdx.x;
     size_t total = (size_t)out_h * out_w * cv;
@@ -60,7 +60,7 @@ __global__ __launch_bounds__(MV_THREADS) void maxpool_kernel(const int8_t *in, s
             }
         }
     }
-    int8_t *dst = out + (size_t)blockIdx.y * os + pix * ch + c;
+    int8_t *dst = out + (size_t)blockIdx.y * os + pix * pstride + choff + c;
     if (VEC == 4) {
         *(uint32_t *)dst = (uint32_t)(best[0] & 255) | ((uint32_t)(best[1] & 255) << 8) |
                            ((uint32_t)(best[2] & 255) << 16) | ((uint32_t)(best[3] & 255) << 24);
@@ -75,7 +75,7 @@ __global__ __launch_bounds__(MV_THREADS) void maxpool_kernel(const int8_t *in, s
 typedef short s2v __attribute__((ext_vector_type(2)));
 __global__ __launch_bounds__(MV_THREADS) void maxpool16_kernel(const int8_t *in, size_t is, int8_t *out, size_t os,
                                                                int in_h, int in_w, int ch, int out_h, int out_w, int kh,
-                                                               int kw, int sh, int sw) {
+                                                               int kw, int sh, int sw, int pstride, int choff) {
     const int cv = ch >> 4;
     size_t idx = (size_t)blockIdx.x * MV_THREADS + threadIdx.x;
     if (idx >= (size_t)out_h * out_w * cv) return;
@@ -111,27 +111,30 @@ __global__ __launch_bounds__(MV_THREADS) void maxpool16_kernel(const int8_t *in,
         const s2v m = (ev[d] & (short)0xFF) | (s2v)(od[d] << (short)8);
         r[d] = *(const int *)&m;
     }
-    *(v4i *)(out + (size_t)blockIdx.y * os + pix * ch + c) = r;
+    *(v4i *)(out + (size_t)blockIdx.y * os + pix * pstride + choff + c) = r;
 }
 
 extern "C" int mhip_maxpool_i8(const int8_t *in, size_t in_stride, int8_t *out, size_t out_stride, int frames,
-                               int in_h, int in_w, int ch, int out_h, int out_w, int kh, int kw, int sh, int sw) {
+                               int in_h, int in_w, int ch, int out_h, int out_w, int kh, int kw, int sh, int sw,
+                               int out_pix_stride, int out_ch_off) {
     if (!in || !out || frames <= 0 || in_h < 0 || in_w < 0 || ch < 0 || out_h < 0 || out_w < 0 || kh < 0 || kw < 0 ||
-        sh < 0 || sw < 0)
+        sh < 0 || sw < 0 || out_pix_stride < 0 || out_ch_off < 0)
         return -1;
+    if (out_pix_stride && out_pix_stride < out_ch_off + ch) return -1;
+    const int pstride = out_pix_stride ? out_pix_stride : ch, choff = out_ch_off;
     size_t total = (size_t)out_h * out_w * ch;
     if (total == 0) return 0;
-    bool v16 = (ch % 16 == 0) && ((((uintptr_t)in | (uintptr_t)out | in_stride | out_stride) & 15) == 0);
-    bool v4 = (ch % 4 == 0) && ((((uintptr_t)in | (uintptr_t)out | in_stride | out_stride) & 3) == 0);
+    bool v16 = (ch % 16 == 0) && ((((uintptr_t)in | (uintptr_t)out | in_stride | out_stride | pstride | choff) & 15) == 0);
+    bool v4 = (ch % 4 == 0) && ((((uintptr_t)in | (uintptr_t)out | in_stride | out_stride | pstride | choff) & 3) == 0);
     if (v16)
         hipLaunchKernelGGL(maxpool16_kernel, mv_grid(total / 16, frames), dim3(MV_THREADS), 0, mhip_stream_native(), in,
-                           in_stride, out, out_stride, in_h, in_w, ch, out_h, out_w, kh, kw, sh, sw);
+                           in_stride, out, out_stride, in_h, in_w, ch, out_h, out_w, kh, kw, sh, sw, pstride, choff);
     else if (v4)
         hipLaunchKernelGGL((maxpool_kernel<4>), mv_grid(total / 4, frames), dim3(MV_THREADS), 0, mhip_stream_native(),
-                           in, in_stride, out, out_stride, in_h, in_w, ch, out_h, out_w, kh, kw, sh, sw);
+                           in, in_stride, out, out_stride, in_h, in_w, ch, out_h, out_w, kh, kw, sh, sw, pstride, choff);
     else
         hipLaunchKernelGGL((maxpool_kernel<1>), mv_grid(total, frames), dim3(MV_THREADS), 0, mhip_stream_native(), in,
-                           in_stride, out, out_stride, in_h, in_w, ch, out_h, out_w, kh, kw, sh, sw);
+                           in_stride, out, out_stride, in_h, in_w, ch, out_h, out_w, kh, kw, sh, sw, pstride, choff);
     return mhip_check(hipGetLastError(), "maxpool");
 }
 
@@ -171,7 +174,7 @@ extern "C" int mhip_concat_slice(const int8_t *in, size_t in_stride, int8_t *out
 template <int VEC>
 __global__ __launch_bounds__(MV_THREADS) void upsample_kernel(const int8_t *in, size_t is, int8_t *out, size_t os,
                                                               int in_h, int in_w, int ch, int out_h, int out_w,
-                                                              int scale_h, int scale_w) {
+                                                              int scale_h, int scale_w, int pstride, int choff) {
     const int cv = ch / VEC;
     size_t idx = (size_t)blockIdx.x * MV_THREADS + threadIdx.x;
     if (idx >= (size_t)out_h * out_w * cv) return;
@@ -182,26 +185,29 @@ __global__ __launch_bounds__(MV_THREADS) void upsample_kernel(const int8_t *in, 
     if (iy >= in_h) iy = in_h - 1;
     if (ix >= in_w) ix = in_w - 1;
     const int8_t *s = in + (size_t)blockIdx.y * is + ((size_t)iy * in_w + ix) * ch + c;
-    int8_t *d = out + (size_t)blockIdx.y * os + pix * ch + c;
+    int8_t *d = out + (size_t)blockIdx.y * os + pix * pstride + choff + c;
     if (VEC == 16) *(v4i *)d = *(const v4i *)s;
     else d[0] = s[0];
 }
 
 extern "C" int mhip_upsample_i8(const int8_t *in, size_t in_stride, int8_t *out, size_t out_stride, int frames,
-                                int in_h, int in_w, int ch, int out_h, int out_w, int scale_h, int scale_w) {
+                                int in_h, int in_w, int ch, int out_h, int out_w, int scale_h, int scale_w,
+                                int out_pix_stride, int out_ch_off) {
     if (!in || !out || frames <= 0 || in_h <= 0 || in_w <= 0 || ch < 0 || out_h < 0 || out_w < 0 || scale_h <= 0 ||
-        scale_w <= 0)
+        scale_w <= 0 || out_pix_stride < 0 || out_ch_off < 0)
         return -1;
+    if (out_pix_stride && out_pix_stride < out_ch_off + ch) return -1;
+    const int pstride = out_pix_stride ? out_pix_stride : ch, choff = out_ch_off;
     size_t total = (size_t)out_h * out_w * ch;
     if (total == 0) return 0;
-    bool v16 = (ch % 16 == 0) && ((((uintptr_t)in | (uintptr_t)out | in_stride | out_stride) & 15) == 0);
+    bool v16 = (ch % 16 == 0) && ((((uintptr_t)in | (uintptr_t)out | in_stride | out_stride | pstride | choff) & 15) == 0);
     if (v16)
         hipLaunchKernelGGL((upsample_kernel<16>), mv_grid(total / 16, frames), dim3(MV_THREADS), 0,
                            mhip_stream_native(), in, in_stride, out, out_stride, in_h, in_w, ch, out_h, out_w,
-                           scale_h, scale_w);
+                           scale_h, scale_w, pstride, choff);
     else
         hipLaunchKernelGGL((upsample_kernel<1>), mv_grid(total, frames), dim3(MV_THREADS), 0, mhip_stream_native(),
-                           in, in_stride, out, out_stride, in_h, in_w, ch, out_h, out_w, scale_h, scale_w);
+                           in, in_stride, out, out_stride, in_h, in_w, ch, out_h, out_w, scale_h, scale_w, pstride, choff);
     return mhip_check(hipGetLastError(), "upsample");
 }
 

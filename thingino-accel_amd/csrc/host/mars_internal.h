@@ -51,6 +51,7 @@ typedef struct {
     int nchw, relu, is_mul, is_f32, leaky, safe;
     int row_pad, oc_pad, c_pad;
     int ch_off, scale_h, scale_w, bn_n;
+    int out_pix_stride, out_ch_off; /* producer writes a channel slice of a wider tensor (zero-copy concat) */
     float cs, f0, f1, f2;
     size_t n;                 /* elements per frame for element-wise ops */
     size_t w_off, b_off, lut_off, s_off; /* offsets into the parameter arena */

@@ -541,6 +541,65 @@ static void fuse_silu(mars_model_ext_t *m) {
     free(writers);
 }
 
+/* ------------------------------------------------------------- zero-copy concat
+ * A concat input that (a) has exactly one producer launch of a kind that can write a channel slice
+ * (int8 NHWC conv, int8 add/mul, max-pool, upsample), (b) is read by nothing but that concat, and
+ * (c) has the concat's pixel grid, is produced directly inside the concat's output tensor: the
+ * producer gets (pixel stride = concat channels, channel offset) and the copy launch disappears.
+ * Same bytes end up in the concat output; the intermediate tensor is never materialised. */
+static void elide_concat(mars_model_ext_t *m) {
+    const int nt = (int)m->pub.header.num_tensors;
+    int *readers = (int *)calloc((size_t)nt + 1, sizeof(int));
+    int *writers = (int *)calloc((size_t)nt + 1, sizeof(int));
+    if (!readers || !writers) { free(readers); free(writers); return; }
+    for (int i = 0; i < m->n_ops; i++) {
+        for (int k = 0; k < m->ops[i].n_in; k++)
+            if (m->ops[i].t_in[k] >= 0) readers[m->ops[i].t_in[k]]++;
+        if (m->ops[i].t_out >= 0) writers[m->ops[i].t_out]++;
+    }
+    for (int i = 0; i < m->n_ops; i++) {
+        mars_op_t *cs = &m->ops[i];
+        if (cs->kind != OP_CONCAT_SLICE) continue;
+        const int ti = cs->t_in[0], to = cs->t_out;
+        const mtensor_t *mt = &m->mt[ti];
+        if (mt->is_weight || mt->io_in || mt->io_out || readers[ti] != 1 || writers[ti] != 1) continue;
+        int j = -1;
+        for (int k = 0; k < i; k++)
+            if (m->ops[k].t_out == ti) j = k;
+        if (j < 0) continue;
+        mars_op_t *pr = &m->ops[j];
+        if (pr->out_pix_stride) continue;
+        const size_t npix = (size_t)cs->out_h * cs->out_w;
+        int ok = 0;
+        if (pr->kind == OP_CONV_I8 && !pr->nchw) ok = (size_t)pr->out_h * pr->out_w == npix && pr->out_c == cs->in_c;
+        else if (pr->kind == OP_BINARY_I8) ok = pr->n == npix * (size_t)cs->in_c;
+        else if (pr->kind == OP_MAXPOOL || pr->kind == OP_UPSAMPLE) ok = (size_t)pr->out_h * pr->out_w == npix && pr->in_c == cs->in_c;
+        if (!ok || cs->ch_off + cs->in_c > cs->out_c) continue;
+        /* nothing between producer and the copy may touch the concat output except its other slices */
+        int clash = 0;
+        for (int k = j; k < i && !clash; k++) {
+            const mars_op_t *o = &m->ops[k];
+            for (int q = 0; q < o->n_in; q++)
+                if (o->t_in[q] == to) clash = 1;
+            if (o->t_out == to && o->kind != OP_CONCAT_SLICE && !o->out_pix_stride) clash = 1;
+        }
+        if (clash) continue;
+        pr->t_out = to;
+        pr->out_pix_stride = cs->out_c;
+        pr->out_ch_off = cs->ch_off;
+        if (pr->kind == OP_BINARY_I8) pr->in_c = cs->in_c; /* channel run of the slice */
+        pr->bytes += 0;
+        m->mt[ti].needed = 0;
+        cs->kind = -1; /* dropped below */
+    }
+    int w = 0;
+    for (int i = 0; i < m->n_ops; i++)
+        if (m->ops[i].kind != -1) m->ops[w++] = m->ops[i];
+    m->n_ops = w;
+    free(readers);
+    free(writers);
+}
+
 /* ------------------------------------------------------------------- load */
 static void free_device_state(mars_model_ext_t *m) {
     if (m->act_dev) mhip_free(m->act_dev);
@@ -601,7 +660,10 @@ static mars_error_t build_plan(mars_model_ext_t *m) {
     /* slot 0 of the arena: mirror of the raw blob (element-wise layers may read weight
      * tensors directly); sized after planning, so reserve generously now */
     for (uint32_t i = 0; i < nl; i++) plan_layer(m, (int)i);
-    if (m->fusion >= 1) fuse_silu(m);
+    if (m->fusion >= 1) {
+        fuse_silu(m);
+        elide_concat(m);
+    }
     return MARS_OK;
 }
 
@@ -830,6 +892,7 @@ static int launch_op(mars_model_ext_t *m, mars_op_t *op) {
             p.kh = op->kh; p.kw = op->kw; p.stride_h = op->sh; p.stride_w = op->sw; p.pad_top = op->pt; p.pad_left = op->pl;
             p.row_pad = op->row_pad; p.oc_pad = op->oc_pad; p.cs = op->cs; p.relu = op->relu; p.out_nchw = op->nchw;
             p.safe = op->safe;
+            p.out_pix_stride = op->out_pix_stride; p.out_ch_off = op->out_ch_off;
             return mhip_conv_i8(&p);
         }
         case OP_CONV_F32: {
@@ -853,7 +916,8 @@ static int launch_op(mars_model_ext_t *m, mars_op_t *op) {
         case OP_BINARY_I8:
             return mhip_binary_i8(op->is_mul, (const int8_t *)tdev(m, op->t_in[0]), tstride(m, op->t_in[0]),
                                   (const int8_t *)tdev(m, op->t_in[1]), tstride(m, op->t_in[1]),
-                                  (int8_t *)tdev(m, op->t_out), tstride(m, op->t_out), B, op->n, op->f0, op->f1, op->f2);
+                                  (int8_t *)tdev(m, op->t_out), tstride(m, op->t_out), B, op->n, op->f0, op->f1, op->f2,
+                                  op->out_pix_stride ? op->in_c : 0, op->out_pix_stride, op->out_ch_off);
         case OP_SIGMOID_F32:
             return mhip_sigmoid_f32((const float *)tdev(m, op->t_in[0]), tstride(m, op->t_in[0]),
                                     (float *)tdev(m, op->t_out), tstride(m, op->t_out), B, op->n);
@@ -878,7 +942,7 @@ static int launch_op(mars_model_ext_t *m, mars_op_t *op) {
         case OP_MAXPOOL:
             return mhip_maxpool_i8((const int8_t *)tdev(m, op->t_in[0]), tstride(m, op->t_in[0]), (int8_t *)tdev(m, op->t_out),
                                    tstride(m, op->t_out), B, op->in_h, op->in_w, op->in_c, op->out_h, op->out_w, op->kh,
-                                   op->kw, op->sh, op->sw);
+                                   op->kw, op->sh, op->sw, op->out_pix_stride, op->out_ch_off);
         case OP_CONCAT_SLICE:
             return mhip_concat_slice((const int8_t *)tdev(m, op->t_in[0]), tstride(m, op->t_in[0]),
                                      (int8_t *)tdev(m, op->t_out), tstride(m, op->t_out), B, op->out_h, op->out_w,
@@ -886,7 +950,7 @@ static int launch_op(mars_model_ext_t *m, mars_op_t *op) {
         case OP_UPSAMPLE:
             return mhip_upsample_i8((const int8_t *)tdev(m, op->t_in[0]), tstride(m, op->t_in[0]),
                                     (int8_t *)tdev(m, op->t_out), tstride(m, op->t_out), B, op->in_h, op->in_w, op->in_c,
-                                    op->out_h, op->out_w, op->scale_h, op->scale_w);
+                                    op->out_h, op->out_w, op->scale_h, op->scale_w, op->out_pix_stride, op->out_ch_off);
         default: return -1;
     }
 }

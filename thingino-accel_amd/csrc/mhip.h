@@ -62,6 +62,9 @@ typedef struct {
     int relu;                   /* clamp negative results to 0 (fused ReLU, byte semantics) */
     int out_nchw;               /* store [O][H][W] instead of [H][W][O] */
     int safe;                   /* host proved |acc*cs| < 2^31 and cs finite: skip the x86 overflow fix-up */
+    int out_pix_stride;         /* NHWC only: bytes between consecutive output pixels (0 = out_c); with out_ch_off
+                                   this writes straight into a channel slice of a wider tensor (zero-copy concat) */
+    int out_ch_off;
 } mhip_conv_i8_t;
 /* is the float->int conversion of acc*cs provably in range for every int32 accumulator? */
 int mhip_conv_i8_is_safe(float cs);
@@ -85,8 +88,11 @@ int mhip_conv_f32(const mhip_conv_f32_t *p);
 int mhip_lut_i8(const int8_t *in, size_t in_stride, int8_t *out, size_t out_stride, int frames,
                 size_t n, const uint8_t *lut_dev);
 int mhip_relu_bytes(int8_t *buf, size_t stride, int frames, size_t n);
+/* out_run > 0: the result is written as pixels of out_run channels into a wider tensor:
+ * element i goes to (i / out_run) * out_pix_stride + out_ch_off + i % out_run (zero-copy concat) */
 int mhip_binary_i8(int is_mul, const int8_t *a, size_t a_stride, const int8_t *b, size_t b_stride,
-                   int8_t *out, size_t out_stride, int frames, size_t n, float sa, float sb, float inv_so);
+                   int8_t *out, size_t out_stride, int frames, size_t n, float sa, float sb, float inv_so,
+                   int out_run, int out_pix_stride, int out_ch_off);
 int mhip_sigmoid_f32(const float *in, size_t in_stride, float *out, size_t out_stride, int frames, size_t n);
 int mhip_binary_f32(int op /*0 add,1 mul,2 sub*/, const float *a, size_t a_stride, const float *b,
                     size_t b_stride, float *out, size_t out_stride, int frames, size_t n);
@@ -98,12 +104,15 @@ int mhip_batchnorm_f32(const float *in, size_t in_stride, float *out, size_t out
                        int n, int c, int hw, const float *s, const float *b);
 
 /* ---- data movement (move.hip); all int8-byte semantics, NHWC index math */
+/* out_pix_stride (0 = ch) / out_ch_off: as for the conv */
 int mhip_maxpool_i8(const int8_t *in, size_t in_stride, int8_t *out, size_t out_stride, int frames,
-                    int in_h, int in_w, int ch, int out_h, int out_w, int kh, int kw, int sh, int sw);
+                    int in_h, int in_w, int ch, int out_h, int out_w, int kh, int kw, int sh, int sw,
+                    int out_pix_stride, int out_ch_off);
 int mhip_concat_slice(const int8_t *in, size_t in_stride, int8_t *out, size_t out_stride, int frames,
                       int out_h, int out_w, int in_c, int out_c, int ch_off);
 int mhip_upsample_i8(const int8_t *in, size_t in_stride, int8_t *out, size_t out_stride, int frames,
-                     int in_h, int in_w, int ch, int out_h, int out_w, int scale_h, int scale_w);
+                     int in_h, int in_w, int ch, int out_h, int out_w, int scale_h, int scale_w,
+                     int out_pix_stride, int out_ch_off);
 /* [C][HW] -> [HW][c_pad] with zero channel padding (feeds the NHWC conv kernel) */
 int mhip_nchw_to_nhwc_pad(const int8_t *in, size_t in_stride, int8_t *out, size_t out_stride,
                           int frames, int c, int hw, int c_pad);
