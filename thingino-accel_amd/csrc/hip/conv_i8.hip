@@ -482,21 +482,24 @@ __global__ __launch_bounds__(NTHREADS) void conv_i8_generic(const mhip_conv_i8_t
 // kernel row of a pixel is 32 contiguous LDS bytes (kw*4 used, the rest meets zero
 // weights) and one MFMA K step covers two kernel rows.  Weights ([oc][kh][32]) stay in
 // LDS for the lifetime of the (persistent) workgroup.  Input bytes are read once.
-#define SC_TH 8
+#define SC_TH 16
 #define SC_TW 16
+#define SC_BP (SC_TH * SC_TW)
 template <int WOC>
 __global__ __launch_bounds__(NTHREADS) void conv_i8_smallc(const mhip_conv_i8_t p, const int k64, const int tiles_x,
-                                                           const int tiles_y, const long ntiles, const int PH, const int PW,
-                                                           const int PWp, const fastdiv_t dhw) {
+                                                           const int tiles_y, const unsigned ntiles, const int PH,
+                                                           const int PW, const int PWp, const fastdiv_t dhw,
+                                                           const fastdiv_t dtx, const fastdiv_t dty, const fastdiv_t dgpr) {
     constexpr int BN = WOC * 16;
+    constexpr int WPX = SC_TH / 4; // tile rows (= pixel subtiles of 16) per wave
     extern __shared__ __attribute__((aligned(16))) int8_t dyn[];
     const int wrow = k64 + 16;                       // padded weight row: conflict-free fragment reads
     int8_t *wl = dyn;                                // [BN][wrow]
     int8_t *patch0 = wl + ((BN * wrow + 15) & ~15);  // 2 x [(PH+1)][PWp] dwords (double buffer)
     const int patch_bytes = ((PH + 1) * PWp * 4 + 15) & ~15;
-    int8_t *tile = patch0 + 2 * patch_bytes;         // [128][BN+OPAD]
-    uint8_t *slut = (uint8_t *)tile + BP * (BN + OPAD);
-    __shared__ long rowoff[BP];
+    int8_t *tile = patch0 + 2 * patch_bytes;         // [256][BN+OPAD]
+    uint8_t *slut = (uint8_t *)tile + SC_BP * (BN + OPAD);
+    __shared__ long rowoff[SC_BP];
 
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int hw = p.out_h * p.out_w;
@@ -512,21 +515,34 @@ __global__ __launch_bounds__(NTHREADS) void conv_i8_smallc(const mhip_conv_i8_t 
     // global accesses at any byte alignment) when all 4 pixels are inside the image.
     const int gpr = (PW + 3) >> 2;           // units per patch row
     const int nunits = PH * gpr;             // host guarantees nunits <= 2 * NTHREADS
+    // this thread's (at most 2) units never change: patch row r, pixel group g
+    int ur[2], ug[2];
+#pragma unroll
+    for (int j = 0; j < 2; j++) {
+        const unsigned u = (unsigned)(tid + j * NTHREADS);
+        ur[j] = (int)fdiv(u, dgpr);
+        ug[j] = (int)u - ur[j] * gpr;
+    }
     v4i pre[2];
-    auto fetch = [&](long t) {
-        const int tx = (int)(t % tiles_x), ty = (int)((t / tiles_x) % tiles_y);
-        const long f = t / ((long)tiles_x * tiles_y);
+    auto tile_xy = [&](unsigned t, int &tx, int &ty, unsigned &f) {
+        const unsigned q = fdiv(t, dtx);
+        tx = (int)(t - q * (unsigned)tiles_x);
+        f = fdiv(q, dty);
+        ty = (int)(q - f * (unsigned)tiles_y);
+    };
+    auto fetch = [&](unsigned t) {
+        int tx, ty;
+        unsigned f;
+        tile_xy(t, tx, ty, f);
         const int8_t *src = p.in + (size_t)f * p.in_stride;
         const int y0 = ty * SC_TH * p.stride_h - p.pad_top, x0 = tx * SC_TW * p.stride_w - p.pad_left;
 #pragma unroll
         for (int j = 0; j < 2; j++) {
-            const int u = tid + j * NTHREADS;
             v4i v = {0, 0, 0, 0};
-            if (u < nunits) {
-                const int r = u / gpr, g = u - r * gpr;
-                const int iy = y0 + r, ix = x0 + g * 4;
+            if (tid + j * NTHREADS < nunits) {
+                const int iy = y0 + ur[j], ix = x0 + ug[j] * 4;
                 if (iy >= 0 && iy < p.in_h) {
-                    const int8_t *q = src + ((size_t)iy * p.in_w + ix) * p.in_c;
+                    const int8_t *q = src + ((long)iy * p.in_w + ix) * p.in_c;
                     if (p.in_c == 3 && ix >= 0 && ix + 4 <= p.in_w) {
                         v4i raw;
                         __builtin_memcpy(&raw, q, 16); // unaligned dwordx4; the 4 bytes past the 12 used are discarded
@@ -551,20 +567,15 @@ __global__ __launch_bounds__(NTHREADS) void conv_i8_smallc(const mhip_conv_i8_t 
     };
     auto commit = [&](int8_t *patch) {
 #pragma unroll
-        for (int j = 0; j < 2; j++) {
-            const int u = tid + j * NTHREADS;
-            if (u < nunits) {
-                const int r = u / gpr, g = u - r * gpr;
-                *(v4i *)(patch + ((size_t)r * PWp + g * 4) * 4) = pre[j];
-            }
-        }
+        for (int j = 0; j < 2; j++)
+            if (tid + j * NTHREADS < nunits) *(v4i *)(patch + ((size_t)ur[j] * PWp + ug[j] * 4) * 4) = pre[j];
     };
 
     // Software pipeline over tiles with a double-buffered patch: the next tile's loads are issued
     // before this tile's MFMAs and committed to the OTHER buffer before this tile's stores, so the
     // (in-order) vmcnt wait for those loads never sits behind freshly issued stores.
     const int nks = k64 / BK;
-    long t = blockIdx.x;
+    unsigned t = blockIdx.x;
     int buf = 0;
     __syncthreads(); // zero fill of both patch buffers is complete
     if (t < ntiles) {
@@ -574,40 +585,41 @@ __global__ __launch_bounds__(NTHREADS) void conv_i8_smallc(const mhip_conv_i8_t 
     for (; t < ntiles; t += gridDim.x) {
         __syncthreads(); // patch[buf] committed by everyone; previous copy-out (tile, rowoff) finished
         const int8_t *patch = patch0 + buf * patch_bytes;
-        const long tn = t + gridDim.x;
+        const unsigned tn = t + gridDim.x;
         if (tn < ntiles) fetch(tn); // next tile's bytes travel while this one is computed
 
-        v4i acc[WOC][2];
-        init_acc<2, WOC>(p, acc, 0);
+        v4i acc[WOC][WPX];
+        init_acc<WPX, WOC>(p, acc, 0);
         const int px = lane & 15, c = lane >> 4;
         for (int ks = 0; ks < nks; ks++) {
             const int ky = 2 * ks + (c >> 1);
-            v4i xb[2];
+            v4i xb[WPX];
 #pragma unroll
-            for (int u = 0; u < 2; u++) {
-                const int py = wv * 2 + u;
+            for (int u = 0; u < WPX; u++) {
+                const int py = wv * WPX + u;
                 const uint32_t *q = (const uint32_t *)patch + (py * p.stride_h + ky) * PWp + px * p.stride_w + (c & 1) * 4;
                 xb[u] = (v4i){(int)q[0], (int)q[1], (int)q[2], (int)q[3]}; // row PH (odd-kh tail) exists and is zero
             }
 #pragma unroll
             for (int s = 0; s < WOC; s++) {
                 const v4i wa = *(const v4i *)(wl + (s * 16 + px) * wrow + ks * BK + c * 16);
-                acc[s][0] = __builtin_amdgcn_mfma_i32_16x16x64_i8(wa, xb[0], acc[s][0], 0, 0, 0);
-                acc[s][1] = __builtin_amdgcn_mfma_i32_16x16x64_i8(wa, xb[1], acc[s][1], 0, 0, 0);
+#pragma unroll
+                for (int u = 0; u < WPX; u++) acc[s][u] = __builtin_amdgcn_mfma_i32_16x16x64_i8(wa, xb[u], acc[s][u], 0, 0, 0);
             }
         }
         if (tn < ntiles) commit(patch0 + (buf ^ 1) * patch_bytes); // last read before the previous epilogue's barrier
         buf ^= 1;
-        const int tx = (int)(t % tiles_x), ty = (int)((t / tiles_x) % tiles_y);
-        const long f = t / ((long)tiles_x * tiles_y);
+        int tx, ty;
+        unsigned f;
+        tile_xy(t, tx, ty, f);
         const int oy0 = ty * SC_TH, ox0 = tx * SC_TW, ow = p.out_w, oh = p.out_h;
-        fill_rowoff<BP>(p, rowoff,
-                    [=](int row) {
-                        const int oy = oy0 + (row >> 4), ox = ox0 + (row & 15);
-                        return (oy < oh && ox < ow) ? f * hw + (long)oy * ow + ox : -1L;
-                    },
-                    (unsigned)hw, dhw); // consumed after the barrier inside epilogue(); rewritten after the loop-top barrier
-        epilogue<BP, BN, 2, WOC>(p, acc, tile, slut, rowoff, 0, wv * 32, 0, hw);
+        fill_rowoff<SC_BP>(p, rowoff,
+                           [=](int row) {
+                               const int oy = oy0 + (row >> 4), ox = ox0 + (row & 15);
+                               return (oy < oh && ox < ow) ? (long)f * hw + (long)oy * ow + ox : -1L;
+                           },
+                           (unsigned)hw, dhw); // consumed after the barrier inside epilogue(); rewritten after the loop-top barrier
+        epilogue<SC_BP, BN, WPX, WOC>(p, acc, tile, slut, rowoff, 0, wv * (WPX * 16), 0, hw);
     }
 }
 
@@ -632,14 +644,16 @@ static int launch_smallc(const mhip_conv_i8_t *p, int k64) {
     const long ntiles = (long)tiles_x * tiles_y * p->frames;
     const int PH = (SC_TH - 1) * p->stride_h + p->kh, PW = (SC_TW - 1) * p->stride_w + p->kw;
     const int PWp = (PW + 8 + 3) & ~3;
-    if ((long)PH * ((PW + 3) / 4) > 2 * NTHREADS) return -1;
+    const int gpr = (PW + 3) / 4;
+    if ((long)PH * gpr > 2 * NTHREADS || ntiles > 0x7fffffffL) return -1;
     constexpr int BN = WOC * 16;
     const size_t lds = (((size_t)BN * (k64 + 16) + 15) & ~(size_t)15) + 2 * ((((size_t)PH + 1) * PWp * 4 + 15) & ~(size_t)15) +
-                       (size_t)BP * (BN + OPAD) + 256;
+                       (size_t)SC_BP * (BN + OPAD) + 256;
     if (lds > 64 * 1024) return -1;
     long grid = ntiles < 256L * 8 ? ntiles : 256L * 8;
     hipLaunchKernelGGL((conv_i8_smallc<WOC>), dim3((unsigned)grid), dim3(NTHREADS), lds, mhip_stream_native(), *p, k64,
-                       tiles_x, tiles_y, ntiles, PH, PW, PWp, make_fastdiv((unsigned)(p->out_h * p->out_w)));
+                       tiles_x, tiles_y, (unsigned)ntiles, PH, PW, PWp, make_fastdiv((unsigned)(p->out_h * p->out_w)),
+                       make_fastdiv((unsigned)tiles_x), make_fastdiv((unsigned)tiles_y), make_fastdiv((unsigned)gpr));
     return mhip_check(hipGetLastError(), "conv_i8_smallc launch");
 }
 
@@ -699,7 +713,7 @@ extern "C" int mhip_conv_i8(const mhip_conv_i8_t *p) {
     if (total_pix <= 0 || total_pix > 0x7fffffffL || (total_pix + BP - 1) / BP * (oc_pad / 32) > 0x7fffffffL) return -1;
     if (mhip_conv_i8_small_c(p->in_c, p->kw, p->out_c)) {
         const int PH = (SC_TH - 1) * p->stride_h + p->kh, PW = (SC_TW - 1) * p->stride_w + p->kw;
-        if (p->stride_h >= 1 && p->stride_w >= 1 && (long)PH * ((PW + 3) / 4) <= 2 * NTHREADS)
+        if (p->stride_h >= 1 && p->stride_w >= 1 && (long)PH * ((PW + 3) / 4) <= 2 * NTHREADS && total_pix <= 0x7fffffffL)
             return oc_pad == 32 ? launch_smallc<2>(p, k64) : launch_smallc<4>(p, k64);
         return -1;
     }
