@@ -683,9 +683,11 @@ static int launch_mfma(const mhip_conv_i8_t *p, long total_pix, int k64) {
 template <int BPX, int BN>
 static int launch_mfma_auto(const mhip_conv_i8_t *p, long total_pix, int k64) {
     const int nks = k64 / BK;
-    if (nks <= 2) return launch_mfma<BPX, BN, 2>(p, total_pix, k64);
-    if (nks == 3 || BPX * BN >= 128 * 128) return launch_mfma<BPX, BN, 3>(p, total_pix, k64);
-    return launch_mfma<BPX, BN, 4>(p, total_pix, k64);
+    static int force = -1; // MARS_HIP_STAGES (experiments)
+    if (force < 0) force = getenv("MARS_HIP_STAGES") ? atoi(getenv("MARS_HIP_STAGES")) : 0;
+    if (nks <= 2 || force == 2) return launch_mfma<BPX, BN, 2>(p, total_pix, k64);
+    if (force == 4) return launch_mfma<BPX, BN, 4>(p, total_pix, k64);
+    return launch_mfma<BPX, BN, 3>(p, total_pix, k64); // measured: 3 stages beat 4 everywhere (occupancy > depth)
 }
 
 template <int BN>
@@ -727,7 +729,8 @@ extern "C" int mhip_conv_i8(const mhip_conv_i8_t *p) {
             policy = e ? atoi(e) : 0;
         }
         const int nks = k64 / BK;
-        if (oc_pad % 128 == 0) return launch_mfma_auto<128, 128>(p, total_pix, k64);
+        if (oc_pad % 128 == 0)
+            return (policy == 256 && nks > 2) ? launch_mfma_auto<256, 128>(p, total_pix, k64) : launch_mfma_auto<128, 128>(p, total_pix, k64);
         const bool wide = policy == 256 || (policy == 0 && nks <= 2);
         if (oc_pad % 64 == 0) return wide ? launch_mfma_auto<256, 64>(p, total_pix, k64) : launch_mfma_auto<128, 64>(p, total_pix, k64);
         return wide ? launch_mfma_auto<256, 32>(p, total_pix, k64) : launch_mfma_auto<128, 32>(p, total_pix, k64);
