@@ -118,4 +118,5 @@ SYNTH = [
     ("tiny_40", dict(tiny=True, input_hw=40, seed=3)),
     ("v5n_64_nchw", dict(width_x16=4, input_hw=64, nchw_int8=True, seed=4)),
     ("tiny_32_f32", dict(tiny=True, input_hw=32, float32=True, seed=5)),
+    ("v5n_64_f32", dict(width_x16=4, input_hw=64, float32=True, seed=6)),   # config 5 topology (yolov5 f32), small
 ]

@@ -69,8 +69,16 @@ def test_synthetic_models(gpu, orc, name, kw, fusion):
         for oi, ti in enumerate(hdr["outputs"]):
             want = g.tensor(ti)
             got = m.output_view(oi)[f]
+            if tin["dtype"] == 0:
+                # float32 graphs: the task's bar is |a-b| <= 1e-4*max(1,|b|); this build keeps the reference's
+                # summation order in the conv and restates libm's expf exactly (csrc/expf_exact.h), so the
+                # outputs are in fact bit-identical -- which matters, because byte-moving layers (max-pool on
+                # float BYTES) downstream of a sigmoid turn any last-bit difference into garbage
+                a, b = got.view(np.float32).astype(np.float64), want.view(np.float32).astype(np.float64)
+                ok = (np.isnan(a) & np.isnan(b)) | (a == b) | (np.abs(a - b) <= 1e-4 * np.maximum(1.0, np.abs(b)))
+                assert ok.all(), "frame %d output %d: %d values out of tolerance" % (f, oi, int((~ok).sum()))
             assert np.array_equal(got, want), "frame %d output %d: %d bytes differ" % (f, oi, int((got != want).sum()))
-        if fusion == 0 and f == 1:  # unfused plan materialises every tensor: check them all
+        if fusion == 0 and f == 1:  # unfused plan materialises every tensor: check them all, bit for bit
             for ti, t in enumerate(tensors):
                 if t["size"] == 0 and marsfile.tensor_nbytes(t):
                     try:

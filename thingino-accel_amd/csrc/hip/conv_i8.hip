@@ -128,16 +128,23 @@ __device__ __forceinline__ void fill_rowoff(const mhip_conv_i8_t &p, long *rowof
     }
 }
 
-template <int BPX, int BN, int WPX, int WOC, bool HAS_LUT, bool SAFE>
+// Output channels are PERMUTED inside each wave's channel range (host packer, mhip_conv_i8_oc_row): MFMA row
+// (lane>>4)*4 + r of oc-subtile s carries channel (lane>>4)*4*WOC + s*4 + r, so the WOC*4 results a lane holds
+// for one pixel are CONSECUTIVE channels.
+//  DIRECT (NHWC, 16-byte aligned rows): one 16-byte (WOC=4) / 8-byte (WOC=2) global store per pixel straight
+//  from registers -- no LDS tile, no barrier.  Otherwise the int8 tile is staged in LDS and copied out coalesced.
+template <int BPX, int BN, int WPX, int WOC, bool HAS_LUT, bool SAFE, bool DIRECT>
 __device__ __forceinline__ void epilogue_t(const mhip_conv_i8_t &p, v4i (&acc)[WOC][WPX], int8_t *tile, const uint8_t *slut,
                                            const long *rowoff, int oc0, int pxw, int ocw, int hw) {
     const int tid = threadIdx.x, lane = tid & 63;
     constexpr int ROW = BN + OPAD;
     const int lo = p.relu ? 0 : -128; // fused ReLU == raising the lower clamp
     const uint8_t *lut128 = slut + 128;
+    const int chan = ocw + (lane >> 4) * (4 * WOC); // first of this lane's WOC*4 consecutive channels (tile-relative)
 #pragma unroll
     for (int t = 0; t < WPX; t++) {
         const int prow = pxw + t * 16 + (lane & 15);
+        uint32_t pk[WOC];
 #pragma unroll
         for (int s = 0; s < WOC; s++) {
             int q[4];
@@ -146,11 +153,22 @@ __device__ __forceinline__ void epilogue_t(const mhip_conv_i8_t &p, v4i (&acc)[W
                 q[r] = requant<SAFE>(acc[s][t][r], p.cs, lo); // the bias is already inside the accumulator
                 if (HAS_LUT) q[r] = lut128[q[r]];
             }
-            const uint32_t pk = (uint32_t)(q[0] & 255) | ((uint32_t)(q[1] & 255) << 8) | ((uint32_t)(q[2] & 255) << 16) |
-                                ((uint32_t)q[3] << 24);
-            *(uint32_t *)(tile + prow * ROW + ocw + s * 16 + (lane >> 4) * 4) = pk;
+            pk[s] = (uint32_t)(q[0] & 255) | ((uint32_t)(q[1] & 255) << 8) | ((uint32_t)(q[2] & 255) << 16) |
+                    ((uint32_t)q[3] << 24);
+        }
+        if (DIRECT) {
+            const long off = rowoff[prow];
+            if (off >= 0 && oc0 + chan < p.out_c) {
+                int8_t *d = p.out + off + oc0 + chan;
+                if (WOC == 4) *(v4i *)d = (v4i){(int)pk[0], (int)pk[1], (int)pk[2], (int)pk[3]};
+                else *(uint2 *)d = make_uint2(pk[0], pk[WOC > 1 ? 1 : 0]);
+            }
+        } else {
+#pragma unroll
+            for (int s = 0; s < WOC; s++) *(uint32_t *)(tile + prow * ROW + chan + s * 4) = pk[s];
         }
     }
+    if (DIRECT) return;
     __syncthreads();
     const int ncols = p.out_c - oc0 < BN ? p.out_c - oc0 : BN; // valid channels of this tile
     if (!p.out_nchw && ((p.out_c | p.out_pix_stride | p.out_ch_off) & 15) == 0) {
@@ -191,13 +209,16 @@ __device__ __forceinline__ void epilogue_t(const mhip_conv_i8_t &p, v4i (&acc)[W
 template <int BPX, int BN, int WPX, int WOC>
 __device__ __forceinline__ void epilogue(const mhip_conv_i8_t &p, v4i (&acc)[WOC][WPX], int8_t *tile, const uint8_t *slut,
                                          const long *rowoff, int oc0, int pxw, int ocw, int hw) {
-    if (p.lut) {
-        if (p.safe) epilogue_t<BPX, BN, WPX, WOC, true, true>(p, acc, tile, slut, rowoff, oc0, pxw, ocw, hw);
-        else epilogue_t<BPX, BN, WPX, WOC, true, false>(p, acc, tile, slut, rowoff, oc0, pxw, ocw, hw);
+    const bool direct = !p.out_nchw && ((p.out_c | p.out_pix_stride | p.out_ch_off) & 15) == 0;
+#define EPI(L, S, D) epilogue_t<BPX, BN, WPX, WOC, L, S, D>(p, acc, tile, slut, rowoff, oc0, pxw, ocw, hw)
+    if (direct) {
+        if (p.lut) { if (p.safe) EPI(true, true, true); else EPI(true, false, true); }
+        else { if (p.safe) EPI(false, true, true); else EPI(false, false, true); }
     } else {
-        if (p.safe) epilogue_t<BPX, BN, WPX, WOC, false, true>(p, acc, tile, slut, rowoff, oc0, pxw, ocw, hw);
-        else epilogue_t<BPX, BN, WPX, WOC, false, false>(p, acc, tile, slut, rowoff, oc0, pxw, ocw, hw);
+        if (p.lut) { if (p.safe) EPI(true, true, false); else EPI(true, false, false); }
+        else { if (p.safe) EPI(false, true, false); else EPI(false, false, false); }
     }
+#undef EPI
 }
 
 // accumulators start at the bias: lane holds channels ocbase + s*16 + (lane>>4)*4 .. +3 of every pixel subtile
@@ -245,6 +266,11 @@ __global__ __launch_bounds__(NTHREADS) void conv_i8_mfma(const mhip_conv_i8_t p,
     const int oc0 = (int)(id % noc) * BN;
     const int hw = p.out_h * p.out_w;
 
+    // bias first: the loads travel while the index math below runs; consumed by the first MFMA
+    const int wm = wv % NWM, wn = wv / NWM;
+    const int pxw = wm * (WPX * 16), ocw = wn * (WOC * 16);
+    v4i acc[WOC][WPX];
+    init_acc<WPX, WOC>(p, acc, oc0 + ocw);
     if (p.lut && tid < 64) ((uint32_t *)slut)[tid] = ((const uint32_t *)p.lut)[tid];
     fill_rowoff<BPX>(p, rowoff, [=](int row) { long q = pix0 + row; return q < total_pix ? q : -1L; }, (unsigned)hw, dhw);
 
@@ -335,10 +361,6 @@ __global__ __launch_bounds__(NTHREADS) void conv_i8_mfma(const mhip_conv_i8_t p,
     for (int s = 0; s < STAGES - 1; s++)
         if (s < nks) issue(s, s);
 
-    const int wm = wv % NWM, wn = wv / NWM;
-    const int pxw = wm * (WPX * 16), ocw = wn * (WOC * 16);
-    v4i acc[WOC][WPX];
-    init_acc<WPX, WOC>(p, acc, oc0 + ocw);
     const int frow = lane & 15, fchunk = lane >> 4;
     int stage = 0, nstage = STAGES - 1;
     for (int ks = 0; ks < nks; ks++) {
@@ -618,9 +640,19 @@ __global__ __launch_bounds__(NTHREADS) void conv_i8_smallc(const mhip_conv_i8_t 
                                const int oy = oy0 + (row >> 4), ox = ox0 + (row & 15);
                                return (oy < oh && ox < ow) ? (long)f * hw + (long)oy * ow + ox : -1L;
                            },
-                           (unsigned)hw, dhw); // consumed after the barrier inside epilogue(); rewritten after the loop-top barrier
+                           (unsigned)hw, dhw); // rewritten only after the next loop-top barrier
+        __syncthreads();              // rowoff (and the committed next patch) visible to every wave
         epilogue<SC_BP, BN, WPX, WOC>(p, acc, tile, slut, rowoff, 0, wv * (WPX * 16), 0, hw);
     }
+}
+
+// packed weight / bias row that carries output channel `oc` (see epilogue_t): channels are permuted inside
+// groups of G = 64 (oc_pad % 64 == 0, waves own 4 oc-subtiles) or 32 (2 subtiles)
+extern "C" int mhip_conv_i8_oc_row(int oc, int oc_pad) {
+    const int G = (oc_pad % 64 == 0) ? 64 : 32, NS = G / 16;
+    const int g = oc / G, local = oc - g * G;
+    const int q = local / (4 * NS), rem = local - q * 4 * NS, s = rem >> 2, r = rem & 3;
+    return g * G + s * 16 + q * 4 + r;
 }
 
 extern "C" int mhip_conv_i8_is_safe(float cs) {
@@ -672,7 +704,7 @@ static int launch_mfma(const mhip_conv_i8_t *p, long total_pix, int k64) {
         lg = 0;
         while ((1 << lg) < p->in_c) lg++;
     }
-    const unsigned magic = (65536u + (unsigned)p->kw - 1u) / (unsigned)p->kw;
+    const unsigned magic = ((65536u + (unsigned)p->kw - 1u) / (unsigned)p->kw);
     hipLaunchKernelGGL((conv_i8_mfma<BPX, BN, STAGES>), dim3(nblk), dim3(NTHREADS), lds, mhip_stream_native(), *p, total_pix,
                        k64, (const int8_t *)mhip_zero_page(), noc, nblk, lg, magic,
                        make_fastdiv((unsigned)(p->out_h * p->out_w)), make_fastdiv((unsigned)p->out_w));

@@ -3,7 +3,8 @@
 //
 // Replaces the scalar loops of reference src/mars/mars_runtime.c:
 //   :700-707 fused-ReLU byte pass, :752-768 int8 sigmoid (here: 256-entry LUT
-//   built on the host with the host's libm, so bit-exact by construction),
+//   built on the host with the host's libm, so bit-exact by construction; the f32
+//   sigmoid uses expf_exact.h, a restatement of glibc's expf that matches it bit for bit),
 //   :818-835 / :885-902 int8 mul/add, :742-749 / :807-816 / :874-883 f32 forms,
 //   :1066-1086 relu / leaky relu, :1115-1154 batchnorm.
 // Float arithmetic is written so that every operation rounds once, in the
@@ -11,6 +12,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include "../expf_exact.h"
 #include "../mhip.h"
 
 extern "C" hipStream_t mhip_stream_native(void);
@@ -185,7 +187,7 @@ __global__ __launch_bounds__(EW_THREADS) void f32_kernel(int op, const float *a,
             case 0: r = x + pb[i]; break;
             case 1: r = x * pb[i]; break;
             case 2: r = x - pb[i]; break;
-            case 3: r = 1.0f / (1.0f + expf(-x)); break;
+            case 3: r = 1.0f / (1.0f + expf_exact(-x, expf_exact_tab)); break; // libm-exact expf: see expf_exact.h
             default: r = x > 0.0f ? x : x * alpha; break;
         }
         po[i] = r;

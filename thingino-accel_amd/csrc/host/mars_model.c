@@ -115,7 +115,7 @@ void mars_pack_conv_i8(const int8_t *w, size_t avail, int nchw, int out_c, int i
                     size_t src = nchw ? (((size_t)oc * in_c + ic) * kh + ky) * kw + kx
                                       : (((size_t)oc * kh + ky) * kw + kx) * in_c + ic;
                     int8_t v = src < avail ? w[src] : 0;
-                    dst[(size_t)oc * k64 + (size_t)ky * row_pad + (size_t)kx * c_pad + ic] = v;
+                    dst[(size_t)mhip_conv_i8_oc_row(oc, oc_pad) * k64 + (size_t)ky * row_pad + (size_t)kx * c_pad + ic] = v;
                 }
 }
 
@@ -273,8 +273,13 @@ static void plan_conv(mars_model_ext_t *m, int li) {
     }
     if (tb >= 0) { /* raw bytes reinterpreted as int32, whatever the tensor says it is (:645,656) */
         op->b_off = arena_reserve(m, (size_t)op->oc_pad * 4);
-        if (op->b_off != NO_OFF && !m->deferred)
-            blob_read(m, (size_t)m->pub.tensors[tb].desc.data_offset, (size_t)out_c * 4, m->arena_host + op->b_off);
+        if (op->b_off != NO_OFF && !m->deferred) {
+            int32_t *raw = (int32_t *)calloc((size_t)out_c, 4), *dstb = (int32_t *)(m->arena_host + op->b_off);
+            if (!raw) return;
+            blob_read(m, (size_t)m->pub.tensors[tb].desc.data_offset, (size_t)out_c * 4, raw);
+            for (int oc = 0; oc < out_c; oc++) dstb[mhip_conv_i8_oc_row(oc, op->oc_pad)] = raw[oc]; /* same row order as the weights */
+            free(raw);
+        }
     }
     op->cs = (in->scale * w->scale) / out->scale; /* float32, this order (mxu_conv.c:639,722) */
     op->safe = mhip_conv_i8_is_safe(op->cs);

@@ -74,7 +74,7 @@ static void conv_i8_host(int nchw, const signed char *input, int in_h, int in_w,
     if (!hw || !hb || !d) { fprintf(stderr, "%s: allocation failed\n", who); goto done; }
     mars_pack_conv_i8((const int8_t *)weight, (size_t)out_c * in_c * kh * kw, nchw, out_c, in_c, kh, kw, c_eff, row_pad,
                       oc_pad, hw);
-    if (bias) memcpy(hb, bias, (size_t)out_c * 4);
+    for (int oc = 0; bias && oc < out_c; oc++) hb[mhip_conv_i8_oc_row(oc, oc_pad)] = bias[oc];
     {
         int8_t *din = (int8_t *)d, *dout = din + A256(in_b), *dw = dout + A256(out_b);
         int32_t *db = (int32_t *)(dw + A256(w_b));

@@ -66,6 +66,9 @@ typedef struct {
                                    this writes straight into a channel slice of a wider tensor (zero-copy concat) */
     int out_ch_off;
 } mhip_conv_i8_t;
+/* row of the packed weights / bias that holds output channel oc (channels are permuted so that a lane's
+ * results are consecutive channels) */
+int mhip_conv_i8_oc_row(int oc, int oc_pad);
 /* is the float->int conversion of acc*cs provably in range for every int32 accumulator? */
 int mhip_conv_i8_is_safe(float cs);
 /* packing geometry shared by host packer and kernel */
