@@ -36,7 +36,7 @@ def test_expf_exact_matches_libm(tmp_path):
     src = tmp_path / "t.c"
     src.write_text(SRC)
     exe = tmp_path / "t"
-    subprocess.check_call(["gcc", "-O2", "-ffp-contract=off", "-std=gnu11", "-I",
+    subprocess.check_call(["gcc", "-O2", "-ffp-contract=off", "-mfma", "-std=gnu11", "-I",
                            os.path.join(ROOT, "thingino-accel_amd", "csrc"), str(src), "-o", str(exe), "-lm"])
     out = subprocess.check_output([str(exe)]).decode().strip()
     assert out == "0"
