@@ -42,6 +42,7 @@ extern "C" int mhip_check(hipError_t e, const char *what);
 extern "C" const void *mhip_zero_page(void);
 
 typedef int v4i __attribute__((ext_vector_type(4)));
+typedef int v2i __attribute__((ext_vector_type(2)));
 
 #define BP 128      // pixels per workgroup
 #define BK 64       // K bytes per step = one MFMA
@@ -390,6 +391,217 @@ __global__ __launch_bounds__(NTHREADS) void conv_i8_mfma(const mhip_conv_i8_t p,
 }
 
 // ---------------------------------------------------------------------------------
+// persistent form of the main kernel (the default for NHWC outputs with 16-byte aligned rows):
+// a workgroup owns ONE channel tile and walks a contiguous run of pixel tiles.  The K stages of
+// all its tiles form one stream through the LDS ring, so the loads of tile i+1 are in flight
+// while tile i is still in its MFMAs and its epilogue; bias, LUT and weight pointers are set up
+// once.  Results leave as raw buffer stores straight from registers (lanes outside the image get
+// an out-of-range offset, which the buffer unit drops) -- always WPX stores per wave and tile, so
+// the number of vector-memory operations younger than a given stage is known and vmcnt can be
+// counted across the stores.  (gfx9: loads and stores retire in order against one vmcnt.)
+template <int A, int B>
+__device__ __forceinline__ void wait_vmcnt_at_most(int n) { // largest known-safe immediate <= n
+    constexpr int HI = A > B ? A : B, LO = A > B ? B : A;
+    if (n >= A + B) wait_vmcnt<A + B>();
+    else if (n >= HI) wait_vmcnt<HI>();
+    else if (n >= LO) wait_vmcnt<LO>();
+    else wait_vmcnt<0>();
+}
+
+template <int BPX, int BN, int STAGES, bool HAS_LUT>
+__global__ __launch_bounds__(NTHREADS) void conv_i8_persist(const mhip_conv_i8_t p, const unsigned total_pix, const int k64,
+                                                            const int8_t *__restrict__ zeros, const unsigned noc,
+                                                            const unsigned npt, const unsigned ngrp, const int lg_inc,
+                                                            const unsigned kw_magic, const fastdiv_t dhw, const fastdiv_t dow,
+                                                            const unsigned out_bytes) {
+    constexpr int STAGE = (BPX + BN) * BK;
+    constexpr int NWN = BN == 128 ? 2 : 1;
+    constexpr int NWM = 4 / NWN;
+    constexpr int WPX = BPX / NWM / 16;
+    constexpr int WOC = BN / NWN / 16;
+    constexpr int XI = BPX / 64;
+    constexpr int LW = BN >= 128 ? 2 : 1;
+    constexpr int L = XI + LW;  // vector-memory instructions per wave per stage
+    constexpr int NST = WPX;    // ... and per tile epilogue
+    extern __shared__ __attribute__((aligned(16))) int8_t dynlds[];
+    uint8_t *slut = (uint8_t *)dynlds;
+    int8_t *lds = dynlds + 256;
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const unsigned id = xcd_remap(blockIdx.x, noc * ngrp);
+    const unsigned grp = id / noc;
+    const int oc0 = (int)(id - grp * noc) * BN;
+    const unsigned t0 = (unsigned)(((unsigned long long)grp * npt) / ngrp);
+    const unsigned t1 = (unsigned)(((unsigned long long)(grp + 1) * npt) / ngrp);
+    if (t0 >= t1) return;
+    const unsigned hw = (unsigned)(p.out_h * p.out_w);
+    const int wm = wv % NWM, wn = wv / NWM;
+    const int pxw = wm * (WPX * 16), ocw = wn * (WOC * 16);
+
+    v4i bias[WOC];
+#pragma unroll
+    for (int s = 0; s < WOC; s++)
+        bias[s] = p.bias ? *(const v4i *)(p.bias + oc0 + ocw + s * 16 + (lane >> 4) * 4) : (v4i){0, 0, 0, 0};
+    if (HAS_LUT) {
+        if (tid < 64) ((uint32_t *)slut)[tid] = ((const uint32_t *)p.lut)[tid];
+        __syncthreads();
+    }
+    const __amdgpu_buffer_rsrc_t orsrc = __builtin_amdgcn_make_buffer_rsrc(p.out, 0, (int)out_bytes, 0x00020000);
+
+    const int schunk = (lane & 3) ^ (((lane >> 4) & 1) << 1);
+    const int8_t *xwin[XI];
+    unsigned tapmask[XI];
+    auto setup_rows = [&](unsigned tile) { // window origin and in-image tap mask of the rows this lane fetches
+#pragma unroll
+        for (int j = 0; j < XI; j++) {
+            const unsigned pix = tile * BPX + wv * (BPX / 4) + j * 16 + (lane >> 2);
+            const bool valid = pix < total_pix;
+            const unsigned f = valid ? fdiv(pix, dhw) : 0u;
+            const unsigned rem = valid ? pix - f * hw : 0u;
+            const int oy = (int)fdiv(rem, dow), ox = (int)(rem - (unsigned)oy * (unsigned)p.out_w);
+            const int iy0 = oy * p.stride_h - p.pad_top, ix0 = ox * p.stride_w - p.pad_left;
+            xwin[j] = p.in + (size_t)f * p.in_stride + ((long)iy0 * p.in_w + ix0) * p.in_c;
+            const int kx_lo = ix0 < 0 ? -ix0 : 0, kx_hi = p.in_w - ix0 < p.kw ? p.in_w - ix0 : p.kw;
+            const unsigned colbits = kx_hi > kx_lo ? ((kx_hi >= 32 ? ~0u : (1u << kx_hi) - 1u) & ~((1u << kx_lo) - 1u)) : 0u;
+            unsigned m = 0;
+            for (int r = 0; r < p.kh; r++) {
+                const int iy = iy0 + r;
+                if (iy >= 0 && iy < p.in_h) m |= colbits << (r * p.kw);
+            }
+            tapmask[j] = valid ? m : 0u;
+        }
+    };
+    const int8_t *wsrc[LW];
+    int wq[LW];
+#pragma unroll
+    for (int j = 0; j < LW; j++) {
+        wq[j] = BN >= 64 ? wv * LW + j : (wv & 1);
+        wsrc[j] = p.w + (size_t)(oc0 + wq[j] * 16 + (lane >> 2)) * k64 + schunk * 16;
+    }
+    const int taps = p.kh * p.kw;
+    const int nks = k64 / BK;
+
+    auto issue = [&](int ks, int stage) {
+        int8_t *sb = lds + stage * STAGE;
+        const unsigned pos = (unsigned)(ks * BK + schunk * 16);
+        const unsigned tap = pos >> lg_inc;
+        const int rc = (int)(pos & ((1u << lg_inc) - 1u));
+        const int ky = (int)((tap * kw_magic) >> 16);
+        const int kx = (int)tap - ky * p.kw;
+        const bool kvalid = (int)tap < taps;
+        const long koff = ((long)ky * p.in_w + kx) * p.in_c + rc;
+#pragma unroll
+        for (int j = 0; j < XI; j++) {
+            const bool ok = kvalid & ((tapmask[j] >> tap) & 1u);
+            glds16(ok ? xwin[j] + koff : zeros, sb + (wv * (BPX / 4) + j * 16) * BK);
+        }
+#pragma unroll
+        for (int j = 0; j < LW; j++) glds16(wsrc[j] + ks * BK, sb + BPX * BK + wq[j] * 16 * BK);
+    };
+
+    // issue cursor over the (tile, k-step) stream; younger[i] = vector-memory instructions this wave has
+    // issued after the i-th oldest stage still in the ring (a stage that was not issued counts as empty)
+    unsigned itile = t0;
+    int iks = 0;
+    int younger[STAGES - 1];
+    setup_rows(t0);
+    int nstage = 0;
+#pragma unroll
+    for (int s = 0; s < STAGES - 1; s++) {
+        int n = 0;
+        if (itile < t1) {
+            issue(iks, nstage);
+            n = L;
+            if (++iks == nks) {
+                iks = 0;
+                if (++itile < t1) setup_rows(itile);
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < s; i++) younger[i] += n;
+        younger[s] = 0;
+        nstage++;
+    }
+    nstage = STAGES - 1;
+
+    const int frow = lane & 15, fchunk = lane >> 4;
+    const int chan = ocw + (lane >> 4) * (4 * WOC);
+    const int pstride = p.out_pix_stride ? p.out_pix_stride : p.out_c;
+    const int lo = p.relu ? 0 : -128;
+    const uint8_t *lut128 = slut + 128;
+    int stage = 0;
+    for (unsigned tile = t0; tile < t1; tile++) {
+        v4i acc[WOC][WPX];
+        for (int ks = 0; ks < nks; ks++) {
+            wait_vmcnt_at_most<(STAGES - 2) * L, NST>(younger[0]);
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
+            int n = 0;
+            if (itile < t1) {
+                issue(iks, nstage);
+                n = L;
+                if (++iks == nks) {
+                    iks = 0;
+                    if (++itile < t1) setup_rows(itile);
+                }
+            }
+#pragma unroll
+            for (int i = 0; i + 1 < STAGES - 1; i++) younger[i] = younger[i + 1] + n;
+            younger[STAGES - 2] = 0;
+            const int8_t *xs = lds + stage * STAGE, *ws = xs + BPX * BK;
+            v4i xb[WPX];
+#pragma unroll
+            for (int t = 0; t < WPX; t++) xb[t] = *(const v4i *)(xs + lds_off(pxw + t * 16 + frow, fchunk));
+            if (ks == 0) { // the first step of a tile takes the bias as its C operand: accumulators start there
+#pragma unroll
+                for (int s = 0; s < WOC; s++) {
+                    v4i wa = *(const v4i *)(ws + lds_off(ocw + s * 16 + frow, fchunk));
+#pragma unroll
+                    for (int t = 0; t < WPX; t++) acc[s][t] = __builtin_amdgcn_mfma_i32_16x16x64_i8(wa, xb[t], bias[s], 0, 0, 0);
+                }
+            } else {
+#pragma unroll
+                for (int s = 0; s < WOC; s++) {
+                    v4i wa = *(const v4i *)(ws + lds_off(ocw + s * 16 + frow, fchunk));
+#pragma unroll
+                    for (int t = 0; t < WPX; t++) acc[s][t] = __builtin_amdgcn_mfma_i32_16x16x64_i8(wa, xb[t], acc[s][t], 0, 0, 0);
+                }
+            }
+            stage = stage + 1 == STAGES ? 0 : stage + 1;
+            nstage = nstage + 1 == STAGES ? 0 : nstage + 1;
+        }
+        // epilogue: requantise, optional LUT, one buffer store per pixel subtile
+#pragma unroll
+        for (int t = 0; t < WPX; t++) {
+            const unsigned pix = tile * BPX + pxw + t * 16 + (lane & 15);
+            const unsigned f = fdiv(pix, dhw), rem = pix - f * hw;
+            const unsigned off = f * (unsigned)p.out_stride + rem * (unsigned)pstride + (unsigned)(p.out_ch_off + oc0 + chan);
+            const bool ok = pix < total_pix && oc0 + chan < p.out_c;
+            uint32_t pk[WOC];
+#pragma unroll
+            for (int s = 0; s < WOC; s++) {
+                int q[4];
+#pragma unroll
+                for (int r = 0; r < 4; r++) {
+                    q[r] = requant<true>(acc[s][t][r], p.cs, lo);
+                    if (HAS_LUT) q[r] = lut128[q[r]];
+                }
+                pk[s] = (uint32_t)(q[0] & 255) | ((uint32_t)(q[1] & 255) << 8) | ((uint32_t)(q[2] & 255) << 16) |
+                        ((uint32_t)q[3] << 24);
+            }
+            const int voff = ok ? (int)off : -1; // 0xffffffff >= num_records: dropped by the buffer unit
+            if (WOC == 4)
+                __builtin_amdgcn_raw_buffer_store_b128((v4i){(int)pk[0], (int)pk[1], (int)pk[2], (int)pk[3]}, orsrc, voff, 0, 0);
+            else
+                __builtin_amdgcn_raw_buffer_store_b64((v2i){(int)pk[0], (int)pk[WOC > 1 ? 1 : 0]}, orsrc, voff, 0, 0);
+        }
+#pragma unroll
+        for (int i = 0; i < STAGES - 1; i++) younger[i] += NST;
+    }
+}
+
+// ---------------------------------------------------------------------------------
 // generic kernel: any in_c (the 3-channel stem); register-staged byte gather
 template <int BN>
 __global__ __launch_bounds__(NTHREADS) void conv_i8_generic(const mhip_conv_i8_t p, const long total_pix, const int k64,
@@ -711,10 +923,74 @@ static int launch_mfma(const mhip_conv_i8_t *p, long total_pix, int k64) {
     return mhip_check(hipGetLastError(), "conv_i8_mfma launch");
 }
 
+static int env_int(const char *name, int dflt) {
+    const char *e = getenv(name);
+    return e ? atoi(e) : dflt;
+}
+
+// bytes from p->out to the end of the last pixel row the layer can write
+static long persist_out_bytes(const mhip_conv_i8_t *p) {
+    const long pstride = p->out_pix_stride ? p->out_pix_stride : p->out_c;
+    return (long)(p->frames - 1) * (long)p->out_stride + (long)p->out_h * p->out_w * pstride;
+}
+
+template <int BPX, int BN, int STAGES, bool HAS_LUT>
+static int launch_persist_t(const mhip_conv_i8_t *p, long total_pix, int k64, int lg, unsigned magic) {
+    const unsigned npt = (unsigned)((total_pix + BPX - 1) / BPX), noc = (unsigned)(p->oc_pad / BN);
+    const size_t lds = 256 + (size_t)STAGES * (BPX + BN) * BK;
+    static int slots = 0; // workgroups of this instantiation the device holds at once
+    if (!slots) {
+        int occ = 0, dev = 0;
+        hipDeviceProp_t prop;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, conv_i8_persist<BPX, BN, STAGES, HAS_LUT>, NTHREADS, lds) != hipSuccess ||
+            hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess)
+            return mhip_check(hipErrorUnknown, "conv_i8_persist occupancy query");
+        const int cap = env_int("MARS_HIP_POCC", 0);
+        if (cap > 0 && occ > cap) occ = cap;
+        slots = (occ > 0 ? occ : 1) * prop.multiProcessorCount;
+    }
+    unsigned ngrp = (unsigned)slots / noc;
+    if (ngrp < 1) ngrp = 1;
+    if (ngrp > npt) ngrp = npt;
+    hipLaunchKernelGGL((conv_i8_persist<BPX, BN, STAGES, HAS_LUT>), dim3(noc * ngrp), dim3(NTHREADS), lds, mhip_stream_native(),
+                       *p, (unsigned)total_pix, k64, (const int8_t *)mhip_zero_page(), noc, npt, ngrp, lg, magic,
+                       make_fastdiv((unsigned)(p->out_h * p->out_w)), make_fastdiv((unsigned)p->out_w),
+                       (unsigned)persist_out_bytes(p));
+    return mhip_check(hipGetLastError(), "conv_i8_persist launch");
+}
+
+// 1 = launched (rc in *rc), 0 = this layer is not eligible for the persistent kernel
+template <int BPX, int BN>
+static int try_persist(const mhip_conv_i8_t *p, long total_pix, int k64, int *rc) {
+    static int on = -1, stages = 0, maxk = 0;
+    if (on < 0) {
+        stages = env_int("MARS_HIP_PSTAGES", 2);
+        maxk = env_int("MARS_HIP_PERSIST_MAXK", 8); // measured: deeper K loops gain nothing from walking tiles
+        on = env_int("MARS_HIP_PERSIST", 1);
+    }
+    if (k64 / BK > maxk) return 0;
+    const bool direct = !p->out_nchw && ((p->out_c | p->out_pix_stride | p->out_ch_off) & 15) == 0;
+    if (!on || !direct || !p->safe || (p->in_c & (p->in_c - 1)) || p->kh * p->kw > 32 ||
+        (long)p->kh * p->kw * (p->kw - 1) >= 65536 || persist_out_bytes(p) > 0x7fffffffL)
+        return 0;
+    int lg = 0;
+    while ((1 << lg) < p->in_c) lg++;
+    const unsigned magic = ((65536u + (unsigned)p->kw - 1u) / (unsigned)p->kw);
+    if (stages == 2)
+        *rc = p->lut ? launch_persist_t<BPX, BN, 2, true>(p, total_pix, k64, lg, magic)
+                     : launch_persist_t<BPX, BN, 2, false>(p, total_pix, k64, lg, magic);
+    else
+        *rc = p->lut ? launch_persist_t<BPX, BN, 3, true>(p, total_pix, k64, lg, magic)
+                     : launch_persist_t<BPX, BN, 3, false>(p, total_pix, k64, lg, magic);
+    return 1;
+}
+
 // ring depth: as deep as the K loop can use
 template <int BPX, int BN>
 static int launch_mfma_auto(const mhip_conv_i8_t *p, long total_pix, int k64) {
     const int nks = k64 / BK;
+    int rc;
+    if (try_persist<BPX, BN>(p, total_pix, k64, &rc)) return rc;
     static int force = -1; // MARS_HIP_STAGES (experiments)
     if (force < 0) force = getenv("MARS_HIP_STAGES") ? atoi(getenv("MARS_HIP_STAGES")) : 0;
     if (nks <= 2 || force == 2) return launch_mfma<BPX, BN, 2>(p, total_pix, k64);
