@@ -52,6 +52,12 @@ mars_error_t mars_hip_write_tensor(mars_model_t *model, int tensor_index, int fr
  * Must be set before mars_hip_set_batch / first run; re-plans. */
 mars_error_t mars_hip_set_fusion(mars_model_t *model, int level);
 
+/* Launch-policy knob of the convolution kernels (process-wide): "persist" (0|1), "persist_stages"
+ * (2|3), "persist_maxk", "persist_slots" (0 = what the device holds at once), "stages", "bpx".
+ * The defaults are the measured optimum; tests use "persist_slots" to force the multi-tile walk
+ * of the persistent kernel on small inputs.  Results never depend on these.  0 = ok, -1 = unknown key. */
+int mars_hip_set_tuning(const char *key, int value);
+
 /* ------------------------------------------------------- per-layer timing */
 /* When on, every kernel launch is bracketed by HIP events on the library's
  * stream; read back after a run. */

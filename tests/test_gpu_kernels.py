@@ -52,6 +52,52 @@ def test_conv_i8_larger_shapes(gpu, orc):
         assert len(np.unique(a)) > 32  # not a saturated / all-zero comparison
 
 
+@pytest.mark.parametrize("slots,stages", [(1, 2), (3, 2), (5, 3), (0, 3)])
+def test_conv_i8_persistent_tile_walk(gpu, orc, slots, stages):
+    """the persistent kernel walking SEVERAL pixel tiles per workgroup (cross-tile prefetch, counted vmcnt
+    across the epilogue's buffer stores): force few workgroups so that small inputs exercise it; both ring
+    depths; K loops of 1, 2, 4, 9 and 18 steps; pixel counts that are not a multiple of the tile"""
+    shapes = [  # in_h, in_w, in_c, out_c, k, s
+        (64, 64, 32, 32, 1, 1), (40, 40, 64, 128, 3, 2), (37, 29, 128, 64, 1, 1), (23, 17, 128, 64, 3, 1),
+        (33, 31, 256, 256, 1, 1), (50, 50, 64, 64, 1, 1), (80, 80, 16, 48, 3, 1)]
+    try:
+        gpu.set_tuning("persist", 1)
+        gpu.set_tuning("persist_maxk", 1 << 20)
+        gpu.set_tuning("persist_slots", slots)
+        gpu.set_tuning("persist_stages", stages)
+        for i, (h, w, ic, oc, k, s) in enumerate(shapes):
+            oh, ow = (h + s - 1) // s, (w + s - 1) // s
+            ph = max((oh - 1) * s + k - h, 0) // 2
+            pw = max((ow - 1) * s + k - w, 0) // 2
+            case = ("walk%d" % i, 1, h, w, ic, oc, k, k, s, s, ph, pw, oh, ow, 0.03, 0.003 / (k * k * ic) ** 0.5 * 8, 0.05, True)
+            a = cases.conv_i8_call(gpu.conv2d_int8, case, 5)
+            b = cases.conv_i8_call(orc.conv2d_int8, case, 5)
+            assert np.array_equal(a, b), (case[0], int((a != b).sum()))
+            assert len(np.unique(a)) > 32
+        # a whole graph (fused SiLU LUT epilogues, zero-copy concat slices, strided outputs), several frames
+        import marsfile
+        from conftest import lcg_frame
+        d = gpu.synth_model(width_x16=4, input_hw=96, seed=21)
+        hdr, tensors, _ = marsfile.parse(d)
+        nb = marsfile.tensor_nbytes(tensors[hdr["inputs"][0]])
+        m = gpu.Model(d, batch=3)
+        xs = [lcg_frame(0xAB0000 + f, nb) for f in range(3)]
+        for f in range(3):
+            m.input_view(0)[f] = xs[f]
+        m.run()
+        for f in range(3):
+            g = orc.Graph(d)
+            g.set_input(0, xs[f].tobytes())
+            assert g.run() == 0
+            for oi, ti in enumerate(hdr["outputs"]):
+                assert np.array_equal(m.output_view(oi)[f], g.tensor(ti))
+        m.close()
+    finally:
+        gpu.set_tuning("persist_slots", 0)
+        gpu.set_tuning("persist_stages", 2)
+        gpu.set_tuning("persist_maxk", 8)
+
+
 def test_mxu_f32_elementwise(gpu):
     L = gpu.lib()
     n = 100003

@@ -34,6 +34,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdlib.h>
+#include <string.h>
 
 #include "../mhip.h"
 
@@ -882,6 +883,47 @@ extern "C" void mhip_conv_i8_pack_geom(int in_c, int kw, int out_c, int *row_pad
     if (c_eff) *c_eff = small ? 4 : in_c;
 }
 
+// launch policy knobs.  Defaults are the measured optimum on MI355X; the environment (read once) and
+// mhip_conv_i8_tune() (tests: force the multi-tile walk on small inputs) override them.
+struct tune_t {
+    int init;
+    int persist;        // MARS_HIP_PERSIST       1: persistent kernel where eligible
+    int persist_stages; // MARS_HIP_PSTAGES       ring depth of the persistent kernel (2 | 3)
+    int persist_maxk;   // MARS_HIP_PERSIST_MAXK  deepest K loop (64-byte steps) that still walks tiles
+    int persist_slots;  // MARS_HIP_PSLOTS        0: what the device holds at once, else this many workgroups
+    int stages;         // MARS_HIP_STAGES        0: auto, else ring depth of the one-tile kernel (2 | 3 | 4)
+    int bpx;            // MARS_HIP_BPX           0: auto, else pixels per workgroup (128 | 256)
+};
+static tune_t g_tune;
+static int env_int(const char *name, int dflt) {
+    const char *e = getenv(name);
+    return e ? atoi(e) : dflt;
+}
+static const tune_t &tune() {
+    if (!g_tune.init) {
+        g_tune.persist = env_int("MARS_HIP_PERSIST", 1);
+        g_tune.persist_stages = env_int("MARS_HIP_PSTAGES", 2);
+        g_tune.persist_maxk = env_int("MARS_HIP_PERSIST_MAXK", 8); // measured: deeper K loops gain nothing from walking tiles
+        g_tune.persist_slots = env_int("MARS_HIP_PSLOTS", 0);
+        g_tune.stages = env_int("MARS_HIP_STAGES", 0);
+        g_tune.bpx = env_int("MARS_HIP_BPX", 0);
+        g_tune.init = 1;
+    }
+    return g_tune;
+}
+extern "C" int mhip_conv_i8_tune(const char *key, int value) {
+    (void)tune();
+    struct { const char *k; int *v; } tab[] = {{"persist", &g_tune.persist}, {"persist_stages", &g_tune.persist_stages},
+                                               {"persist_maxk", &g_tune.persist_maxk}, {"persist_slots", &g_tune.persist_slots},
+                                               {"stages", &g_tune.stages}, {"bpx", &g_tune.bpx}};
+    for (auto &e : tab)
+        if (key && !strcmp(key, e.k)) {
+            *e.v = value;
+            return 0;
+        }
+    return -1;
+}
+
 template <int WOC>
 static int launch_smallc(const mhip_conv_i8_t *p, int k64) {
     const int tiles_x = (p->out_w + SC_TW - 1) / SC_TW, tiles_y = (p->out_h + SC_TH - 1) / SC_TH;
@@ -910,9 +952,7 @@ static int launch_mfma(const mhip_conv_i8_t *p, long total_pix, int k64) {
     const size_t lds = BPX * 8 + 256 + (ring > tile ? ring : tile);
     // in_c a power of two and tap/kw small enough for the 16-bit reciprocal: shift-based K position
     int lg = -1;
-    static int nopow2 = -1;
-    if (nopow2 < 0) nopow2 = getenv("MARS_HIP_NOPOW2") ? 1 : 0;
-    if (!nopow2 && (p->in_c & (p->in_c - 1)) == 0 && (long)p->kh * p->kw * (p->kw - 1) < 65536) {
+    if ((p->in_c & (p->in_c - 1)) == 0 && (long)p->kh * p->kw * (p->kw - 1) < 65536) {
         lg = 0;
         while ((1 << lg) < p->in_c) lg++;
     }
@@ -921,11 +961,6 @@ static int launch_mfma(const mhip_conv_i8_t *p, long total_pix, int k64) {
                        k64, (const int8_t *)mhip_zero_page(), noc, nblk, lg, magic,
                        make_fastdiv((unsigned)(p->out_h * p->out_w)), make_fastdiv((unsigned)p->out_w));
     return mhip_check(hipGetLastError(), "conv_i8_mfma launch");
-}
-
-static int env_int(const char *name, int dflt) {
-    const char *e = getenv(name);
-    return e ? atoi(e) : dflt;
 }
 
 // bytes from p->out to the end of the last pixel row the layer can write
@@ -945,11 +980,9 @@ static int launch_persist_t(const mhip_conv_i8_t *p, long total_pix, int k64, in
         if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, conv_i8_persist<BPX, BN, STAGES, HAS_LUT>, NTHREADS, lds) != hipSuccess ||
             hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess)
             return mhip_check(hipErrorUnknown, "conv_i8_persist occupancy query");
-        const int cap = env_int("MARS_HIP_POCC", 0);
-        if (cap > 0 && occ > cap) occ = cap;
         slots = (occ > 0 ? occ : 1) * prop.multiProcessorCount;
     }
-    unsigned ngrp = (unsigned)slots / noc;
+    unsigned ngrp = (unsigned)(tune().persist_slots > 0 ? tune().persist_slots : slots) / noc;
     if (ngrp < 1) ngrp = 1;
     if (ngrp > npt) ngrp = npt;
     hipLaunchKernelGGL((conv_i8_persist<BPX, BN, STAGES, HAS_LUT>), dim3(noc * ngrp), dim3(NTHREADS), lds, mhip_stream_native(),
@@ -962,13 +995,8 @@ static int launch_persist_t(const mhip_conv_i8_t *p, long total_pix, int k64, in
 // 1 = launched (rc in *rc), 0 = this layer is not eligible for the persistent kernel
 template <int BPX, int BN>
 static int try_persist(const mhip_conv_i8_t *p, long total_pix, int k64, int *rc) {
-    static int on = -1, stages = 0, maxk = 0;
-    if (on < 0) {
-        stages = env_int("MARS_HIP_PSTAGES", 2);
-        maxk = env_int("MARS_HIP_PERSIST_MAXK", 8); // measured: deeper K loops gain nothing from walking tiles
-        on = env_int("MARS_HIP_PERSIST", 1);
-    }
-    if (k64 / BK > maxk) return 0;
+    const int on = tune().persist, stages = tune().persist_stages;
+    if (k64 / BK > tune().persist_maxk) return 0;
     const bool direct = !p->out_nchw && ((p->out_c | p->out_pix_stride | p->out_ch_off) & 15) == 0;
     if (!on || !direct || !p->safe || (p->in_c & (p->in_c - 1)) || p->kh * p->kw > 32 ||
         (long)p->kh * p->kw * (p->kw - 1) >= 65536 || persist_out_bytes(p) > 0x7fffffffL)
@@ -991,8 +1019,7 @@ static int launch_mfma_auto(const mhip_conv_i8_t *p, long total_pix, int k64) {
     const int nks = k64 / BK;
     int rc;
     if (try_persist<BPX, BN>(p, total_pix, k64, &rc)) return rc;
-    static int force = -1; // MARS_HIP_STAGES (experiments)
-    if (force < 0) force = getenv("MARS_HIP_STAGES") ? atoi(getenv("MARS_HIP_STAGES")) : 0;
+    const int force = tune().stages;
     if (nks <= 2 || force == 2) return launch_mfma<BPX, BN, 2>(p, total_pix, k64);
     if (force == 4) return launch_mfma<BPX, BN, 4>(p, total_pix, k64);
     return launch_mfma<BPX, BN, 3>(p, total_pix, k64); // measured: 3 stages beat 4 everywhere (occupancy > depth)
@@ -1031,11 +1058,7 @@ extern "C" int mhip_conv_i8(const mhip_conv_i8_t *p) {
         if (!mhip_zero_page()) return -1;
         // pixel-tile policy for the narrow (BN <= 64) configurations: 256 pixels per workgroup halves the
         // weight-tile traffic and per-workgroup overhead, 128 keeps one more workgroup per CU.
-        static int policy = -1; // 0 auto, 128, 256 (MARS_HIP_BPX, for experiments)
-        if (policy < 0) {
-            const char *e = getenv("MARS_HIP_BPX");
-            policy = e ? atoi(e) : 0;
-        }
+        const int policy = tune().bpx; // 0 auto, 128, 256
         const int nks = k64 / BK;
         if (oc_pad % 128 == 0)
             return (policy == 256 && nks > 2) ? launch_mfma_auto<256, 128>(p, total_pix, k64) : launch_mfma_auto<128, 128>(p, total_pix, k64);

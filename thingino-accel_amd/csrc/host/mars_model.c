@@ -1066,6 +1066,8 @@ mars_error_t mars_hip_set_fusion(mars_model_t *model, int level) {
     return e;
 }
 
+int mars_hip_set_tuning(const char *key, int value) { return mhip_conv_i8_tune(key, value); }
+
 void *mars_hip_tensor_device(mars_model_t *model, int ti, size_t *frame_stride) {
     if (!model || ti < 0 || (uint32_t)ti >= model->header.num_tensors) return NULL;
     mars_model_ext_t *m = (mars_model_ext_t *)model;

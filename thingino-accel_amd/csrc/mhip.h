@@ -71,6 +71,7 @@ typedef struct {
 int mhip_conv_i8_oc_row(int oc, int oc_pad);
 /* is the float->int conversion of acc*cs provably in range for every int32 accumulator? */
 int mhip_conv_i8_is_safe(float cs);
+int mhip_conv_i8_tune(const char *key, int value); /* launch-policy knobs, see mars_hip_set_tuning */
 /* packing geometry shared by host packer and kernel */
 /* c_eff: bytes per input pixel in the packed K layout (4 in small-channel mode, else in_c) */
 void mhip_conv_i8_pack_geom(int in_c, int kw, int out_c, int *row_pad, int *oc_pad, int *c_eff);

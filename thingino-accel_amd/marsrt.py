@@ -101,7 +101,7 @@ EXPORTS = {
                    "mars_hip_tensor_device", "mars_hip_read_tensor", "mars_hip_write_tensor", "mars_hip_set_fusion",
                    "mars_hip_set_profiling", "mars_hip_num_ops", "mars_hip_op_info", "mars_hip_stream",
                    "mars_hip_load_memory_ex", "mars_hip_param_arena", "mars_yolo_parse_output", "mars_yolo_nms",
-                   "mars_hip_detect", "mars_hip_detect_device", "mars_synth_model"],
+                   "mars_hip_detect", "mars_hip_detect_device", "mars_synth_model", "mars_hip_set_tuning"],
 }
 
 _lib = None
@@ -149,6 +149,7 @@ def lib():
         getattr(L, n).argtypes = [P(MarsModel)]
     L.mars_hip_set_batch.argtypes = [P(MarsModel), C.c_int]
     L.mars_hip_set_fusion.argtypes = [P(MarsModel), C.c_int]
+    L.mars_hip_set_tuning.argtypes = [C.c_char_p, C.c_int]
     L.mars_hip_set_profiling.argtypes = [P(MarsModel), C.c_int]
     L.mars_hip_set_profiling.restype = None
     L.mars_hip_tensor_device.restype = C.c_void_p
@@ -187,6 +188,12 @@ class MarsError(RuntimeError):
         self.code = code
         msg = lib().mars_get_error_string(code).decode()
         super().__init__("%s: %s (%d)" % (what, msg, code))
+
+
+def set_tuning(key, value):
+    """Launch-policy knob of the conv kernels (mars_hip_set_tuning); results never depend on it."""
+    if lib().mars_hip_set_tuning(key.encode(), int(value)) != 0:
+        raise KeyError(key)
 
 
 def synth_model(width_x16=8, depth_x3=1, input_hw=640, float32=False, nchw_int8=False, seed=1, tiny=False):
