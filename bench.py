@@ -86,6 +86,22 @@ def cpu_baseline(model_bytes, frames, out_ids, budget_s=14.0, max_frames=16):
                 sample="%d frames of the same workload through %s, %.1f s of CPU time" % (n, how, spent)), outs
 
 
+def pmc_traffic(args):
+    """HBM bytes one step's conv launches move, from the committed rocprofv3 PMC passes (FETCH_SIZE doubled per
+    MI355X_MICROARCH.md, WRITE_SIZE; tools/pmc_summary.py) -- counters cannot be collected from inside this
+    process, so the number is the profiled one of the same workload, or None when no matching profile exists."""
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "pmc_traffic.json")
+    try:
+        with open(path) as fh:
+            d = json.load(fh)
+        if d["config"] != {"width": args.width, "hw": args.hw, "batch": args.batch}:
+            return None, None
+        c = d["conv_i8"]
+        return c["read_bytes_per_step"] + c["write_bytes_per_step"], "profiles/pmc_traffic.json (per step, all conv_i8 launches)"
+    except (OSError, KeyError, ValueError):
+        return None, None
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -197,6 +213,8 @@ def main():
         macs_per_img = sum(op["macs"] for op in model.ops() if op["kind"] == 0)
         bytes_per_img = sum(op["bytes"] for op in model.ops())
         achieved = conv_ops / (conv_ms * 1e-3) / 1e12 if conv_ms > 0 else 0.0
+        conv_bytes_per_img = sum(op["bytes"] for op in model.ops() if op["kind"] == 0)
+        traffic, traffic_src = pmc_traffic(args)
         peak = 5000.0  # dense int8 MFMA, TOP/s: 2x the ~2.5 PF bf16 dense peak (MI355X_MICROARCH.md, Matrix cores)
         result = {
             "metric": "images/sec yolov5s_int8 640x640 batch256",
@@ -218,7 +236,8 @@ def main():
                        "conv_gmac_per_image": macs_per_img / 1e9, "algorithmic_mb_per_image": bytes_per_img / 1e6},
             "roofline": {"bound": "mfma", "kernel": "conv_i8_kernel (%d launches per step)" % n_conv,
                          "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak,
-                         "traffic": None,
+                         "traffic": traffic, "traffic_source": traffic_src,
+                         "algorithmic_bytes": conv_bytes_per_img * args.batch,
                          "event_timed_steps": ev_steps,
                          "conv_ms_per_step": conv_ms / ev_steps,
                          "all_kernels_ms_per_step": all_ms / ev_steps,

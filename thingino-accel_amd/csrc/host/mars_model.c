@@ -584,6 +584,7 @@ static void elide_concat(mars_model_ext_t *m) {
         int clash = 0;
         for (int k = j; k < i && !clash; k++) {
             const mars_op_t *o = &m->ops[k];
+            if (o->kind == -1) continue; /* a slice copy already elided */
             for (int q = 0; q < o->n_in; q++)
                 if (o->t_in[q] == to) clash = 1;
             if (o->t_out == to && o->kind != OP_CONCAT_SLICE && !o->out_pix_stride) clash = 1;
