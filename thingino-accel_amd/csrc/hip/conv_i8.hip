@@ -74,6 +74,71 @@ __device__ __forceinline__ int requant(int acc, float cs, int lo) {
     return r;
 }
 
+// ---- the epilogue's value path, trimmed to the VALU floor.  The epilogue is VALU-issue bound (a wave64 VALU
+// instruction holds its SIMD for 4 cycles, and every output byte of the network passes through here), so each
+// instruction per value counts:
+//   v_cvt_f32_i32, v_mul_f32, v_bfi_b32 (copysign 0.5), v_add_f32, v_cvt_i32_f32, v_med3_i32   = 6 per value
+//   + 3 instructions per 4 values to pack bytes into a dword; the fused LUT costs no VALU at all: ds_read_u8 takes
+//   the clamped value (negative included: the LDS address is vaddr + offset modulo 2^32) with offset = LUT + 128.
+// LUT0: the 256-byte LUT sits at LDS byte address 0 (first in dynamic LDS of a kernel that owns no static LDS).
+__device__ __forceinline__ int requant_safe(int acc, float cs, int lo, int hi) {
+    const float scaled = (float)acc * cs;
+    const float half = __int_as_float((__float_as_int(scaled) & (int)0x80000000) | 0x3f000000);
+    const int r = (int)(scaled + half);
+    int m;
+    asm("v_med3_i32 %0, %1, %2, %3" : "=v"(m) : "v"(r), "v"(lo), "v"(hi)); // lo <= hi is not provable for the compiler
+    return m;
+}
+__device__ __forceinline__ uint32_t pack4(int q0, int q1, int q2, int q3) { // low bytes of four ints
+    const uint32_t a = __builtin_amdgcn_perm((uint32_t)q1, (uint32_t)q0, 0x0c0c0400u);
+    const uint32_t b = __builtin_amdgcn_perm((uint32_t)q3, (uint32_t)q2, 0x0c0c0400u);
+    return (b << 16) | a;
+}
+__device__ __forceinline__ void lut4_at0(int q0, int q1, int q2, int q3, int &v0, int &v1, int &v2, int &v3) {
+    asm volatile("ds_read_u8 %0, %4 offset:128\n\tds_read_u8 %1, %5 offset:128\n\t"
+                 "ds_read_u8 %2, %6 offset:128\n\tds_read_u8 %3, %7 offset:128"
+                 : "=&v"(v0), "=&v"(v1), "=&v"(v2), "=&v"(v3)
+                 : "v"(q0), "v"(q1), "v"(q2), "v"(q3)
+                 : "memory");
+}
+__device__ __forceinline__ void lds_base_must_be_zero(const void *dynamic_lds) {
+    unsigned a = (unsigned)(size_t)(const __attribute__((address_space(3))) void *)dynamic_lds;
+    asm volatile("" : "+s"(a)); // opaque: the optimiser assumes a global's address is never 0 and would fold the test
+    if (a != 0u) __builtin_trap();
+}
+// NV = 8 or 16 accumulators of one pixel (consecutive channels) -> NV/4 packed dwords
+template <int NV, bool HAS_LUT, bool SAFE, bool LUT0>
+__device__ __forceinline__ void requant_pack(const int (&a)[NV], float cs, int lo, const uint8_t *lut128, uint32_t (&pk)[NV / 4]) {
+    int q[NV];
+    const int hi = 127;
+#pragma unroll
+    for (int i = 0; i < NV; i++) q[i] = SAFE ? requant_safe(a[i], cs, lo, hi) : requant<false>(a[i], cs, lo);
+    if (HAS_LUT && LUT0) {
+        int v[NV];
+#pragma unroll
+        for (int g = 0; g < NV / 4; g++)
+            lut4_at0(q[4 * g], q[4 * g + 1], q[4 * g + 2], q[4 * g + 3], v[4 * g], v[4 * g + 1], v[4 * g + 2], v[4 * g + 3]);
+        // the compiler does not count LDS loads issued from asm: wait here, and thread the values through the wait
+        if (NV == 16)
+            asm volatile("s_waitcnt lgkmcnt(0)"
+                         : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]), "+v"(v[3]), "+v"(v[4]), "+v"(v[5]), "+v"(v[6]), "+v"(v[7]),
+                           "+v"(v[8 % NV]), "+v"(v[9 % NV]), "+v"(v[10 % NV]), "+v"(v[11 % NV]), "+v"(v[12 % NV]), "+v"(v[13 % NV]),
+                           "+v"(v[14 % NV]), "+v"(v[15 % NV]));
+        else
+            asm volatile("s_waitcnt lgkmcnt(0)"
+                         : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]), "+v"(v[3]), "+v"(v[4]), "+v"(v[5]), "+v"(v[6]), "+v"(v[7]));
+#pragma unroll
+        for (int g = 0; g < NV / 4; g++) pk[g] = pack4(v[4 * g], v[4 * g + 1], v[4 * g + 2], v[4 * g + 3]);
+    } else {
+        if (HAS_LUT) {
+#pragma unroll
+            for (int i = 0; i < NV; i++) q[i] = lut128[q[i]];
+        }
+#pragma unroll
+        for (int g = 0; g < NV / 4; g++) pk[g] = pack4(q[4 * g], q[4 * g + 1], q[4 * g + 2], q[4 * g + 3]);
+    }
+}
+
 // exact unsigned division by a launch-time constant (Granlund & Montgomery, N = 32):
 // q = mulhi(m, n); q = (q + ((n - q) >> s1)) >> s2
 struct fastdiv_t {
@@ -135,7 +200,7 @@ __device__ __forceinline__ void fill_rowoff(const mhip_conv_i8_t &p, long *rowof
 // for one pixel are CONSECUTIVE channels.
 //  DIRECT (NHWC, 16-byte aligned rows): one 16-byte (WOC=4) / 8-byte (WOC=2) global store per pixel straight
 //  from registers -- no LDS tile, no barrier.  Otherwise the int8 tile is staged in LDS and copied out coalesced.
-template <int BPX, int BN, int WPX, int WOC, bool HAS_LUT, bool SAFE, bool DIRECT>
+template <int BPX, int BN, int WPX, int WOC, bool HAS_LUT, bool SAFE, bool DIRECT, bool LUT0>
 __device__ __forceinline__ void epilogue_t(const mhip_conv_i8_t &p, v4i (&acc)[WOC][WPX], int8_t *tile, const uint8_t *slut,
                                            const long *rowoff, int oc0, int pxw, int ocw, int hw) {
     const int tid = threadIdx.x, lane = tid & 63;
@@ -147,17 +212,12 @@ __device__ __forceinline__ void epilogue_t(const mhip_conv_i8_t &p, v4i (&acc)[W
     for (int t = 0; t < WPX; t++) {
         const int prow = pxw + t * 16 + (lane & 15);
         uint32_t pk[WOC];
+        int a[WOC * 4]; // the bias is already inside the accumulators
 #pragma unroll
-        for (int s = 0; s < WOC; s++) {
-            int q[4];
+        for (int s = 0; s < WOC; s++)
 #pragma unroll
-            for (int r = 0; r < 4; r++) {
-                q[r] = requant<SAFE>(acc[s][t][r], p.cs, lo); // the bias is already inside the accumulator
-                if (HAS_LUT) q[r] = lut128[q[r]];
-            }
-            pk[s] = (uint32_t)(q[0] & 255) | ((uint32_t)(q[1] & 255) << 8) | ((uint32_t)(q[2] & 255) << 16) |
-                    ((uint32_t)q[3] << 24);
-        }
+            for (int r = 0; r < 4; r++) a[s * 4 + r] = acc[s][t][r];
+        requant_pack<WOC * 4, HAS_LUT, SAFE, LUT0>(a, p.cs, lo, lut128, pk);
         if (DIRECT) {
             const long off = rowoff[prow];
             if (off >= 0 && oc0 + chan < p.out_c) {
@@ -208,11 +268,11 @@ __device__ __forceinline__ void epilogue_t(const mhip_conv_i8_t &p, v4i (&acc)[W
     }
 }
 
-template <int BPX, int BN, int WPX, int WOC>
+template <int BPX, int BN, int WPX, int WOC, bool LUT0 = false>
 __device__ __forceinline__ void epilogue(const mhip_conv_i8_t &p, v4i (&acc)[WOC][WPX], int8_t *tile, const uint8_t *slut,
                                          const long *rowoff, int oc0, int pxw, int ocw, int hw) {
     const bool direct = !p.out_nchw && ((p.out_c | p.out_pix_stride | p.out_ch_off) & 15) == 0;
-#define EPI(L, S, D) epilogue_t<BPX, BN, WPX, WOC, L, S, D>(p, acc, tile, slut, rowoff, oc0, pxw, ocw, hw)
+#define EPI(L, S, D) epilogue_t<BPX, BN, WPX, WOC, L, S, D, LUT0>(p, acc, tile, slut, rowoff, oc0, pxw, ocw, hw)
     if (direct) {
         if (p.lut) { if (p.safe) EPI(true, true, true); else EPI(true, false, true); }
         else { if (p.safe) EPI(false, true, true); else EPI(false, false, true); }
@@ -255,10 +315,11 @@ __global__ __launch_bounds__(NTHREADS) void conv_i8_mfma(const mhip_conv_i8_t p,
     constexpr int XI = BPX / 64;                 // X-tile DMA instructions per wave (16 rows each)
     constexpr int LW = BN >= 128 ? 2 : 1;        // W-tile DMA instructions per wave
     constexpr int L = XI + LW;                   // DMA instructions per wave per stage
-    // dynamic LDS: [rowoff][lut 256 B][ring: min(nks, STAGES) stages, reused as the output tile]
+    // dynamic LDS: [lut 256 B][rowoff][ring: min(nks, STAGES) stages, reused as the output tile]
     extern __shared__ __attribute__((aligned(16))) int8_t dynlds[];
-    long *rowoff = (long *)dynlds;
-    uint8_t *slut = (uint8_t *)dynlds + BPX * 8;
+    uint8_t *slut = (uint8_t *)dynlds; // LDS byte address 0: this kernel owns no static LDS (requant_pack LUT0)
+    lds_base_must_be_zero(dynlds);
+    long *rowoff = (long *)(dynlds + 256);
     int8_t *lds = dynlds + BPX * 8 + 256;
 
     const int tid = threadIdx.x, lane = tid & 63;
@@ -388,7 +449,7 @@ __global__ __launch_bounds__(NTHREADS) void conv_i8_mfma(const mhip_conv_i8_t p,
         nstage = nstage + 1 == STAGES ? 0 : nstage + 1;
     }
     __syncthreads(); // every wave is done reading the ring: reuse it for the output tile
-    epilogue<BPX, BN, WPX, WOC>(p, acc, lds, slut, rowoff, oc0, pxw, ocw, hw);
+    epilogue<BPX, BN, WPX, WOC, true>(p, acc, lds, slut, rowoff, oc0, pxw, ocw, hw);
 }
 
 // ---------------------------------------------------------------------------------
@@ -425,8 +486,9 @@ __global__ __launch_bounds__(NTHREADS) void conv_i8_persist(const mhip_conv_i8_t
     constexpr int L = XI + LW;  // vector-memory instructions per wave per stage
     constexpr int NST = WPX;    // ... and per tile epilogue
     extern __shared__ __attribute__((aligned(16))) int8_t dynlds[];
-    uint8_t *slut = (uint8_t *)dynlds;
+    uint8_t *slut = (uint8_t *)dynlds; // LDS byte address 0 (requant_pack LUT0)
     int8_t *lds = dynlds + 256;
+    lds_base_must_be_zero(dynlds);
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -580,17 +642,12 @@ __global__ __launch_bounds__(NTHREADS) void conv_i8_persist(const mhip_conv_i8_t
             const unsigned off = f * (unsigned)p.out_stride + rem * (unsigned)pstride + (unsigned)(p.out_ch_off + oc0 + chan);
             const bool ok = pix < total_pix && oc0 + chan < p.out_c;
             uint32_t pk[WOC];
+            int a[WOC * 4];
 #pragma unroll
-            for (int s = 0; s < WOC; s++) {
-                int q[4];
+            for (int s = 0; s < WOC; s++)
 #pragma unroll
-                for (int r = 0; r < 4; r++) {
-                    q[r] = requant<true>(acc[s][t][r], p.cs, lo);
-                    if (HAS_LUT) q[r] = lut128[q[r]];
-                }
-                pk[s] = (uint32_t)(q[0] & 255) | ((uint32_t)(q[1] & 255) << 8) | ((uint32_t)(q[2] & 255) << 16) |
-                        ((uint32_t)q[3] << 24);
-            }
+                for (int r = 0; r < 4; r++) a[s * 4 + r] = acc[s][t][r];
+            requant_pack<WOC * 4, HAS_LUT, true, true>(a, p.cs, lo, lut128, pk);
             const int voff = ok ? (int)off : -1; // 0xffffffff >= num_records: dropped by the buffer unit
             if (WOC == 4)
                 __builtin_amdgcn_raw_buffer_store_b128((v4i){(int)pk[0], (int)pk[1], (int)pk[2], (int)pk[3]}, orsrc, voff, 0, 0);
@@ -729,12 +786,13 @@ __global__ __launch_bounds__(NTHREADS) void conv_i8_smallc(const mhip_conv_i8_t 
     constexpr int WPX = SC_TH / 4; // tile rows (= pixel subtiles of 16) per wave
     extern __shared__ __attribute__((aligned(16))) int8_t dyn[];
     const int wrow = k64 + 16;                       // padded weight row: conflict-free fragment reads
-    int8_t *wl = dyn;                                // [BN][wrow]
+    uint8_t *slut = (uint8_t *)dyn;                  // LDS byte address 0 (no static LDS here: requant_pack LUT0)
+    long *rowoff = (long *)(dyn + 256);              // [256]
+    int8_t *wl = dyn + 256 + SC_BP * 8;              // [BN][wrow]
     int8_t *patch0 = wl + ((BN * wrow + 15) & ~15);  // 2 x [(PH+1)][PWp] dwords (double buffer)
     const int patch_bytes = ((PH + 1) * PWp * 4 + 15) & ~15;
     int8_t *tile = patch0 + 2 * patch_bytes;         // [256][BN+OPAD]
-    uint8_t *slut = (uint8_t *)tile + SC_BP * (BN + OPAD);
-    __shared__ long rowoff[SC_BP];
+    lds_base_must_be_zero(dyn);
 
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int hw = p.out_h * p.out_w;
@@ -855,7 +913,7 @@ __global__ __launch_bounds__(NTHREADS) void conv_i8_smallc(const mhip_conv_i8_t 
                            },
                            (unsigned)hw, dhw); // rewritten only after the next loop-top barrier
         __syncthreads();              // rowoff (and the committed next patch) visible to every wave
-        epilogue<SC_BP, BN, WPX, WOC>(p, acc, tile, slut, rowoff, 0, wv * (WPX * 16), 0, hw);
+        epilogue<SC_BP, BN, WPX, WOC, true>(p, acc, tile, slut, rowoff, 0, wv * (WPX * 16), 0, hw);
     }
 }
 
@@ -934,7 +992,7 @@ static int launch_smallc(const mhip_conv_i8_t *p, int k64) {
     if ((long)PH * gpr > 2 * NTHREADS || ntiles > 0x7fffffffL) return -1;
     constexpr int BN = WOC * 16;
     const size_t lds = (((size_t)BN * (k64 + 16) + 15) & ~(size_t)15) + 2 * ((((size_t)PH + 1) * PWp * 4 + 15) & ~(size_t)15) +
-                       (size_t)SC_BP * (BN + OPAD) + 256;
+                       (size_t)SC_BP * (BN + OPAD) + 256 + (size_t)SC_BP * 8;
     if (lds > 64 * 1024) return -1;
     long grid = ntiles < 256L * 8 ? ntiles : 256L * 8;
     hipLaunchKernelGGL((conv_i8_smallc<WOC>), dim3((unsigned)grid), dim3(NTHREADS), lds, mhip_stream_native(), *p, k64,
