@@ -15,7 +15,7 @@
 //    strict left-to-right records one record-slot down.  Each pass is done here
 //    as one wave-wide (max, first-holder) scan over register-resident slots,
 //    reproducing the permutation exactly, ties included;
-//  * suppression: the pair relation is evaluated in parallel into an LDS bit
+//  * suppression: the pair relation is evaluated in parallel, 64 rows at a time, into an LDS bit
 //    matrix with the reference's float expression order, then applied greedily.
 #include <hip/hip_runtime.h>
 #include <math.h>
@@ -184,108 +184,105 @@ __global__ __launch_bounds__(64) void sort_kernel(det_rec *all, const int *count
 }
 
 // --------------------------------------------------------------- suppress
-// One 1024-thread workgroup per frame.  The pairwise "same class and IoU > t"
-// relation is evaluated for all j > i in parallel into a bit matrix in LDS
-// (128 KB for 1000 boxes), then one wave walks i = 0..n-1 greedily OR-ing rows,
-// which is exactly the reference's double loop (suppressed boxes suppress nothing).
-#define NMS_THREADS 1024
+// One 256-thread workgroup per frame, 32 KB of LDS, so that it shares a CU with the convolution workgroups of
+// the NEXT batch (the tail runs on the auxiliary stream; a 1024-thread / 148 KB version of this kernel evicted
+// every convolution workgroup from the chip while it ran).  The pairwise "same class and IoU > t" relation is
+// evaluated 64 rows at a time, for all j > i in parallel, into an 8 KB bit matrix; wave 0 then walks those rows
+// greedily OR-ing them into the removed set (suppressed boxes suppress nothing) -- exactly the reference's
+// double loop.  The float expression order of the IoU is the reference's.
+#define NMS_THREADS 256
+#define NMS_CHUNK 64
 __global__ __launch_bounds__(NMS_THREADS) void nms_kernel(det_rec *all, int *counts, float thresh) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    unsigned long long *mask = (unsigned long long *)smem;            // [n][16]
-    float *bx = (float *)(smem + (size_t)MAXD * 16 * 8), *by = bx + 1024, *bw = by + 1024, *bh = bw + 1024;
-    int *bc = (int *)(bh + 1024);
+    __shared__ float bx[1024], by[1024], bw[1024], bh[1024], bconf[1024];
+    __shared__ int bc[1024];
+    __shared__ unsigned long long mask[NMS_CHUNK][16];
     __shared__ unsigned long long removed_s[16];
+    __shared__ int wave_cnt[NMS_THREADS / 64];
 
-    const int f = blockIdx.x, tid = threadIdx.x;
+    const int f = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     det_rec *dets = all + (size_t)f * MAXD;
     int n = counts[f];
     if (n > MAXD) n = MAXD;
     if (n <= 0) return;
     for (int j = tid; j < n; j += NMS_THREADS) {
         det_rec d = dets[j];
-        bx[j] = d.x; by[j] = d.y; bw[j] = d.w; bh[j] = d.h; bc[j] = d.cls;
+        bx[j] = d.x; by[j] = d.y; bw[j] = d.w; bh[j] = d.h; bc[j] = d.cls; bconf[j] = d.conf;
     }
     __syncthreads();
     const int nw = (n + 63) >> 6;
-    for (int pair = tid; pair < n * nw; pair += NMS_THREADS) {
-        const int i = pair / nw, w = pair - i * nw;
-        unsigned long long bits = 0;
-        if (w * 64 + 63 > i) {
-            const float xi = bx[i], yi = by[i], wi = bw[i], hi = bh[i];
-            const int ci = bc[i];
-            const float ax1 = xi - wi / 2, ay1 = yi - hi / 2, ax2 = xi + wi / 2, ay2 = yi + hi / 2;
-            const float aarea = wi * hi;
-            const int j0 = w * 64 > i + 1 ? w * 64 : i + 1;
-            const int j1 = w * 64 + 64 < n ? w * 64 + 64 : n;
-            for (int j = j0; j < j1; j++) {
-                if (bc[j] != ci) continue;
-                const float xj = bx[j], yj = by[j], wj = bw[j], hj = bh[j];
-                float x1 = fmaxf(ax1, xj - wj / 2);
-                float y1 = fmaxf(ay1, yj - hj / 2);
-                float x2 = fminf(ax2, xj + wj / 2);
-                float y2 = fminf(ay2, yj + hj / 2);
-                float iw = fmaxf(0.0f, x2 - x1), ih = fmaxf(0.0f, y2 - y1);
-                float inter = iw * ih;
-                float barea = wj * hj;
-                float uni = aarea + barea;
-                uni = uni - inter;
-                uni = uni + 1e-6f;
-                if (inter / uni > thresh) bits |= 1ull << (j & 63);
+    unsigned long long removed = 0; // wave 0: lane w (< 16) holds word w of the removed set
+    for (int i0 = 0; i0 < n; i0 += NMS_CHUNK) {
+        const int rows = n - i0 < NMS_CHUNK ? n - i0 : NMS_CHUNK;
+        for (int pair = tid; pair < rows * nw; pair += NMS_THREADS) {
+            const int r = pair / nw, w = pair - r * nw, i = i0 + r;
+            unsigned long long bits = 0;
+            if (w * 64 + 63 > i) {
+                const float xi = bx[i], yi = by[i], wi = bw[i], hi = bh[i];
+                const int ci = bc[i];
+                const float ax1 = xi - wi / 2, ay1 = yi - hi / 2, ax2 = xi + wi / 2, ay2 = yi + hi / 2;
+                const float aarea = wi * hi;
+                const int j0 = w * 64 > i + 1 ? w * 64 : i + 1;
+                const int j1 = w * 64 + 64 < n ? w * 64 + 64 : n;
+                for (int j = j0; j < j1; j++) {
+                    if (bc[j] != ci) continue;
+                    const float xj = bx[j], yj = by[j], wj = bw[j], hj = bh[j];
+                    float x1 = fmaxf(ax1, xj - wj / 2);
+                    float y1 = fmaxf(ay1, yj - hj / 2);
+                    float x2 = fminf(ax2, xj + wj / 2);
+                    float y2 = fminf(ay2, yj + hj / 2);
+                    float iw = fmaxf(0.0f, x2 - x1), ih = fmaxf(0.0f, y2 - y1);
+                    float inter = iw * ih;
+                    float barea = wj * hj;
+                    float uni = aarea + barea;
+                    uni = uni - inter;
+                    uni = uni + 1e-6f;
+                    if (inter / uni > thresh) bits |= 1ull << (j & 63);
+                }
+            }
+            mask[r][w] = bits;
+        }
+        __syncthreads();
+        if (tid < 64) {
+            for (int r = 0; r < rows; r++) {
+                const int i = i0 + r;
+                const unsigned lo = __builtin_amdgcn_readlane((unsigned)removed, i >> 6);
+                const unsigned hi = __builtin_amdgcn_readlane((unsigned)(removed >> 32), i >> 6);
+                const unsigned long long word = ((unsigned long long)hi << 32) | lo;
+                if ((word >> (i & 63)) & 1ull) continue; // suppressed boxes suppress nothing
+                if (tid < nw) removed |= mask[r][tid];
             }
         }
-        mask[(size_t)i * 16 + w] = bits;
+        __syncthreads(); // the next chunk overwrites the bit matrix
     }
+    if (tid < 16) removed_s[tid] = tid < nw ? removed : ~0ull;
     __syncthreads();
-    if (tid < 64) {
-        unsigned long long removed = 0; // lane w (< 16) holds word w
-        for (int i = 0; i < n; i++) {
-            const unsigned lo = __builtin_amdgcn_readlane((unsigned)removed, i >> 6);
-            const unsigned hi = __builtin_amdgcn_readlane((unsigned)(removed >> 32), i >> 6);
-            const unsigned long long word = ((unsigned long long)hi << 32) | lo;
-            if ((word >> (i & 63)) & 1ull) continue; // suppressed boxes suppress nothing
-            if (tid < nw) removed |= mask[(size_t)i * 16 + tid];
+    // compact the survivors in order (a record only ever moves to a lower slot, 256 at a time)
+    int total = 0;
+    for (int base = 0; base < n; base += NMS_THREADS) {
+        const int idx = base + tid;
+        const bool keep = idx < n && !((removed_s[idx >> 6] >> (idx & 63)) & 1ull);
+        const unsigned long long m = __ballot(keep);
+        if (lane == 0) wave_cnt[wv] = __popcll(m);
+        __syncthreads();
+        int off = total;
+        for (int w = 0; w < wv; w++) off += wave_cnt[w];
+        const int slot = off + __popcll(m & ((1ull << lane) - 1ull));
+        if (keep) {
+            det_rec k;
+            k.x = bx[idx]; k.y = by[idx]; k.w = bw[idx]; k.h = bh[idx]; k.conf = bconf[idx]; k.cls = bc[idx];
+            dets[slot] = k;
         }
-        if (tid < 16) removed_s[tid] = tid < nw ? removed : ~0ull;
+        for (int w = 0; w < NMS_THREADS / 64; w++) total += wave_cnt[w];
+        __syncthreads();
     }
-    __syncthreads();
-    // compact the survivors in order
-    __shared__ int wave_cnt[16];
-    __shared__ int base_s;
-    if (tid == 0) base_s = 0;
-    __syncthreads();
-    const int lane = tid & 63, wv = tid >> 6;
-    det_rec keep_rec;
-    const bool in = tid < n;
-    const bool keep = in && !((removed_s[tid >> 6] >> (tid & 63)) & 1ull);
-    if (keep) { keep_rec.x = bx[tid]; keep_rec.y = by[tid]; keep_rec.w = bw[tid]; keep_rec.h = bh[tid]; keep_rec.cls = bc[tid]; keep_rec.conf = dets[tid].conf; }
-    const unsigned long long m = __ballot(keep);
-    if (lane == 0) wave_cnt[wv] = __popcll(m);
-    __syncthreads();
-    int off = 0;
-    for (int w = 0; w < wv; w++) off += wave_cnt[w];
-    const int slot = off + __popcll(m & ((1ull << lane) - 1ull));
-    __syncthreads(); // every conf has been read before any record is overwritten
-    if (keep) dets[slot] = keep_rec;
-    if (tid == 0) {
-        int total = 0;
-        for (int w = 0; w < 16; w++) total += wave_cnt[w];
-        counts[f] = total;
-    }
+    if (tid == 0) counts[f] = total;
 }
 
 static int launch_sort_nms(det_rec *dets, int *counts, int frames, float thresh) {
     hipLaunchKernelGGL(sort_kernel, dim3(frames), dim3(64), 0, mhip_stream_native(), dets, counts);
     int rc = mhip_check(hipGetLastError(), "sort");
     if (rc) return rc;
-    const size_t lds = (size_t)MAXD * 16 * 8 + 5 * 1024 * 4;
-    static bool attr_set = false;
-    if (!attr_set) {
-        rc = mhip_check(hipFuncSetAttribute((const void *)nms_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds),
-                        "nms LDS attribute");
-        if (rc) return rc;
-        attr_set = true;
-    }
-    hipLaunchKernelGGL(nms_kernel, dim3(frames), dim3(NMS_THREADS), lds, mhip_stream_native(), dets, counts, thresh);
+    hipLaunchKernelGGL(nms_kernel, dim3(frames), dim3(NMS_THREADS), 0, mhip_stream_native(), dets, counts, thresh);
     return mhip_check(hipGetLastError(), "nms");
 }
 
