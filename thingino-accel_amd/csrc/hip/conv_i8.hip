@@ -1040,7 +1040,9 @@ static int launch_persist_t(const mhip_conv_i8_t *p, long total_pix, int k64, in
             return mhip_check(hipErrorUnknown, "conv_i8_persist occupancy query");
         slots = (occ > 0 ? occ : 1) * prop.multiProcessorCount;
     }
-    unsigned ngrp = (unsigned)(tune().persist_slots > 0 ? tune().persist_slots : slots) / noc;
+    // 4 workgroups per device slot: short enough runs that a workgroup which has to wait for a slot (the detection
+    // tail of the previous batch shares the CUs) costs little, long enough to keep the cross-tile prefetch (measured)
+    unsigned ngrp = (unsigned)(tune().persist_slots > 0 ? tune().persist_slots : 4 * slots) / noc;
     if (ngrp < 1) ngrp = 1;
     if (ngrp > npt) ngrp = npt;
     hipLaunchKernelGGL((conv_i8_persist<BPX, BN, STAGES, HAS_LUT>), dim3(noc * ngrp), dim3(NTHREADS), lds, mhip_stream_native(),
