@@ -57,6 +57,10 @@ mars_error_t mars_hip_set_fusion(mars_model_t *model, int level);
  * The defaults are the measured optimum; tests use "persist_slots" to force the multi-tile walk
  * of the persistent kernel on small inputs.  Results never depend on these.  0 = ok, -1 = unknown key. */
 int mars_hip_set_tuning(const char *key, int value);
+/* Times the launch variants of every int8 convolution of `model` on the device at the current batch
+ * (`reps` launches each, <= 0: 3) and pins the fastest per layer until the plan is rebuilt
+ * (set_fusion); call after mars_hip_set_batch.  A one-time load cost; outputs are unaffected. */
+mars_error_t mars_hip_autotune(mars_model_t *model, int reps);
 
 /* ------------------------------------------------------- per-layer timing */
 /* When on, every kernel launch is bracketed by HIP events on the library's

@@ -235,3 +235,27 @@ def test_detect_on_model_outputs(gpu, orc):
     for f in range(B):
         assert again[f].tobytes() == dets[f].tobytes()
     m.close()
+
+
+def test_autotune_keeps_results(gpu, orc):
+    """mars_hip_autotune pins, per conv layer, the fastest of its launch variants; every variant writes the same
+    bytes, so outputs before and after (and the oracle's) are identical"""
+    d = gpu.synth_model(width_x16=4, input_hw=160, seed=5)
+    hdr, tensors, _ = marsfile.parse(d)
+    nb = marsfile.tensor_nbytes(tensors[hdr["inputs"][0]])
+    B = 4
+    m = gpu.Model(d, batch=B)
+    xs = [lcg_frame(0xC0FFEE00 + f, nb) for f in range(B)]
+    for f in range(B):
+        m.input_view(0)[f] = xs[f]
+    m.run()
+    before = [m.output_view(i).copy() for i in range(3)]
+    m.autotune(2)
+    m.run()
+    for i in range(3):
+        assert np.array_equal(before[i], m.output_view(i))
+    g, rc = run_oracle(orc, d, xs[2])
+    assert rc == 0
+    for i, ti in enumerate(hdr["outputs"]):
+        assert np.array_equal(g.tensor(ti), m.output_view(i)[2])
+    m.close()

@@ -1053,36 +1053,78 @@ static int launch_persist_t(const mhip_conv_i8_t *p, long total_pix, int k64, in
 }
 
 // 1 = launched (rc in *rc), 0 = this layer is not eligible for the persistent kernel
-template <int BPX, int BN>
-static int try_persist(const mhip_conv_i8_t *p, long total_pix, int k64, int *rc) {
-    const int on = tune().persist, stages = tune().persist_stages;
-    if (k64 / BK > tune().persist_maxk) return 0;
+// ---- launch variants of the in_c % 16 == 0 kernels.  A variant = (form, pixels per workgroup, ring depth); every
+// variant computes the same bytes.  p->variant == 0 takes the measured default policy below; the host can pin a
+// variant per layer after timing the candidates on the device (mars_hip_autotune).
+//   code = 1 + persist + 2*(bpx == 256) + 4*(stages == 3)
+struct variant_t {
+    int persist, bpx, stages;
+};
+static int variant_code(const variant_t &v) { return 1 + (v.persist ? 1 : 0) + (v.bpx == 256 ? 2 : 0) + (v.stages == 3 ? 4 : 0); }
+static variant_t variant_of(int code) {
+    const int c = code - 1;
+    return variant_t{c & 1, (c & 2) ? 256 : 128, (c & 4) ? 3 : 2};
+}
+static bool persist_eligible(const mhip_conv_i8_t *p) {
     const bool direct = !p->out_nchw && ((p->out_c | p->out_pix_stride | p->out_ch_off) & 15) == 0;
-    if (!on || !direct || !p->safe || (p->in_c & (p->in_c - 1)) || p->kh * p->kw > 32 ||
-        (long)p->kh * p->kw * (p->kw - 1) >= 65536 || persist_out_bytes(p) > 0x7fffffffL)
-        return 0;
-    int lg = 0;
-    while ((1 << lg) < p->in_c) lg++;
-    const unsigned magic = ((65536u + (unsigned)p->kw - 1u) / (unsigned)p->kw);
-    if (stages == 2)
-        *rc = p->lut ? launch_persist_t<BPX, BN, 2, true>(p, total_pix, k64, lg, magic)
-                     : launch_persist_t<BPX, BN, 2, false>(p, total_pix, k64, lg, magic);
-    else
-        *rc = p->lut ? launch_persist_t<BPX, BN, 3, true>(p, total_pix, k64, lg, magic)
-                     : launch_persist_t<BPX, BN, 3, false>(p, total_pix, k64, lg, magic);
-    return 1;
+    return direct && p->safe && (p->in_c & (p->in_c - 1)) == 0 && p->kh * p->kw <= 32 &&
+           (long)p->kh * p->kw * (p->kw - 1) < 65536 && persist_out_bytes(p) <= 0x7fffffffL;
+}
+static variant_t default_variant(const mhip_conv_i8_t *p, int nks) {
+    variant_t v;
+    // pixels per workgroup: 256 halves the weight-tile traffic and per-workgroup overhead of the narrow, shallow
+    // configurations; 128 keeps one more workgroup per CU everywhere else
+    v.bpx = tune().bpx ? tune().bpx : ((p->oc_pad % 128 != 0 && nks <= 2) ? 256 : 128);
+    v.persist = tune().persist && nks <= tune().persist_maxk && persist_eligible(p);
+    // ring depth: 3 stages beat 4 everywhere (occupancy > depth); the tile-walking form is best with 2
+    v.stages = v.persist ? tune().persist_stages : (tune().stages ? tune().stages : (nks <= 2 ? 2 : 3));
+    if (v.stages != 3) v.stages = 2;
+    return v;
 }
 
-// ring depth: as deep as the K loop can use
 template <int BPX, int BN>
-static int launch_mfma_auto(const mhip_conv_i8_t *p, long total_pix, int k64) {
-    const int nks = k64 / BK;
-    int rc;
-    if (try_persist<BPX, BN>(p, total_pix, k64, &rc)) return rc;
-    const int force = tune().stages;
-    if (nks <= 2 || force == 2) return launch_mfma<BPX, BN, 2>(p, total_pix, k64);
-    if (force == 4) return launch_mfma<BPX, BN, 4>(p, total_pix, k64);
-    return launch_mfma<BPX, BN, 3>(p, total_pix, k64); // measured: 3 stages beat 4 everywhere (occupancy > depth)
+static int launch_variant_t(const mhip_conv_i8_t *p, long total_pix, int k64, const variant_t &v) {
+    if (v.persist) {
+        if (!persist_eligible(p)) return -1;
+        int lg = 0;
+        while ((1 << lg) < p->in_c) lg++;
+        const unsigned magic = ((65536u + (unsigned)p->kw - 1u) / (unsigned)p->kw);
+        if (v.stages == 2)
+            return p->lut ? launch_persist_t<BPX, BN, 2, true>(p, total_pix, k64, lg, magic)
+                          : launch_persist_t<BPX, BN, 2, false>(p, total_pix, k64, lg, magic);
+        return p->lut ? launch_persist_t<BPX, BN, 3, true>(p, total_pix, k64, lg, magic)
+                      : launch_persist_t<BPX, BN, 3, false>(p, total_pix, k64, lg, magic);
+    }
+    return v.stages == 2 ? launch_mfma<BPX, BN, 2>(p, total_pix, k64) : launch_mfma<BPX, BN, 3>(p, total_pix, k64);
+}
+
+static int launch_variant(const mhip_conv_i8_t *p, long total_pix, int k64, const variant_t &v) {
+    const int bn = p->oc_pad % 128 == 0 ? 128 : (p->oc_pad % 64 == 0 ? 64 : 32);
+    if (v.bpx == 256) {
+        if (bn == 128) return launch_variant_t<256, 128>(p, total_pix, k64, v);
+        if (bn == 64) return launch_variant_t<256, 64>(p, total_pix, k64, v);
+        return launch_variant_t<256, 32>(p, total_pix, k64, v);
+    }
+    if (bn == 128) return launch_variant_t<128, 128>(p, total_pix, k64, v);
+    if (bn == 64) return launch_variant_t<128, 64>(p, total_pix, k64, v);
+    return launch_variant_t<128, 32>(p, total_pix, k64, v);
+}
+
+// candidate variant codes of a layer (0 when the layer is not served by these kernels), default first
+extern "C" int mhip_conv_i8_variants(const mhip_conv_i8_t *p, int *codes, int max) {
+    if (!p || (p->in_c % 16) != 0 || mhip_conv_i8_small_c(p->in_c, p->kw, p->out_c)) return 0;
+    const int k64 = (p->kh * p->row_pad + BK - 1) / BK * BK, nks = k64 / BK;
+    int n = 0;
+    const int dflt = variant_code(default_variant(p, nks));
+    if (n < max) codes[n++] = dflt;
+    for (int code = 1; code <= 8; code++) {
+        const variant_t v = variant_of(code);
+        if (code == dflt) continue;
+        if (v.persist && !persist_eligible(p)) continue;
+        if (!v.persist && v.stages == 3 && nks <= 2) continue; // identical to the 2-stage launch
+        if (n < max) codes[n++] = code;
+    }
+    return n;
 }
 
 template <int BN>
@@ -1116,15 +1158,9 @@ extern "C" int mhip_conv_i8(const mhip_conv_i8_t *p) {
     }
     if ((p->in_c % 16) == 0) {
         if (!mhip_zero_page()) return -1;
-        // pixel-tile policy for the narrow (BN <= 64) configurations: 256 pixels per workgroup halves the
-        // weight-tile traffic and per-workgroup overhead, 128 keeps one more workgroup per CU.
-        const int policy = tune().bpx; // 0 auto, 128, 256
         const int nks = k64 / BK;
-        if (oc_pad % 128 == 0)
-            return (policy == 256 && nks > 2) ? launch_mfma_auto<256, 128>(p, total_pix, k64) : launch_mfma_auto<128, 128>(p, total_pix, k64);
-        const bool wide = policy == 256 || (policy == 0 && nks <= 2);
-        if (oc_pad % 64 == 0) return wide ? launch_mfma_auto<256, 64>(p, total_pix, k64) : launch_mfma_auto<128, 64>(p, total_pix, k64);
-        return wide ? launch_mfma_auto<256, 32>(p, total_pix, k64) : launch_mfma_auto<128, 32>(p, total_pix, k64);
+        if (p->variant < 0 || p->variant > 8) return -1;
+        return launch_variant(p, total_pix, k64, p->variant ? variant_of(p->variant) : default_variant(p, nks));
     }
     if (oc_pad % 64 == 0) return launch_generic<64>(p, total_pix, k64);
     return launch_generic<32>(p, total_pix, k64);

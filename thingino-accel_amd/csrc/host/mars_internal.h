@@ -49,6 +49,7 @@ typedef struct {
     /* geometry (conv / pool / concat / upsample share these) */
     int in_h, in_w, in_c, out_h, out_w, out_c, kh, kw, sh, sw, pt, pl;
     int nchw, relu, is_mul, is_f32, leaky, safe;
+    int variant; /* conv_i8 launch variant pinned by mars_hip_autotune (0 = default policy) */
     int row_pad, oc_pad, c_pad;
     int ch_off, scale_h, scale_w, bn_n;
     int out_pix_stride, out_ch_off; /* producer writes a channel slice of a wider tensor (zero-copy concat) */

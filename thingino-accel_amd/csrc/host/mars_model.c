@@ -872,15 +872,32 @@ void mars_print_summary(mars_model_t *model) {
 static uint8_t *tdev(const mars_model_ext_t *m, int ti) { return ti >= 0 ? m->mt[ti].dev : NULL; }
 static size_t tstride(const mars_model_ext_t *m, int ti) { return ti >= 0 ? m->mt[ti].stride : 0; }
 
+static void conv_i8_params(const mars_model_ext_t *m, const mars_op_t *op, mhip_conv_i8_t *p) {
+    uint8_t *A = m->arena_dev;
+    memset(p, 0, sizeof(*p));
+    p->in = (const int8_t *)tdev(m, op->t_in[0]); p->in_stride = tstride(m, op->t_in[0]);
+    p->in_c = op->in_c;
+    p->out = (int8_t *)tdev(m, op->t_out); p->out_stride = tstride(m, op->t_out);
+    p->w = (const int8_t *)(A + op->w_off);
+    p->bias = op->b_off != NO_OFF ? (const int32_t *)(A + op->b_off) : NULL;
+    p->lut = op->lut_off != NO_OFF ? A + op->lut_off : NULL;
+    p->frames = m->batch;
+    p->in_h = op->in_h; p->in_w = op->in_w;
+    p->out_h = op->out_h; p->out_w = op->out_w; p->out_c = op->out_c;
+    p->kh = op->kh; p->kw = op->kw; p->stride_h = op->sh; p->stride_w = op->sw; p->pad_top = op->pt; p->pad_left = op->pl;
+    p->row_pad = op->row_pad; p->oc_pad = op->oc_pad; p->cs = op->cs; p->relu = op->relu; p->out_nchw = op->nchw;
+    p->safe = op->safe;
+    p->out_pix_stride = op->out_pix_stride; p->out_ch_off = op->out_ch_off;
+    p->variant = op->variant;
+}
+
 static int launch_op(mars_model_ext_t *m, mars_op_t *op) {
     const int B = m->batch;
     uint8_t *A = m->arena_dev;
     switch (op->kind) {
         case OP_CONV_I8: {
             mhip_conv_i8_t p;
-            memset(&p, 0, sizeof(p));
-            p.in = (const int8_t *)tdev(m, op->t_in[0]); p.in_stride = tstride(m, op->t_in[0]);
-            p.in_c = op->in_c;
+            conv_i8_params(m, op, &p);
             if (op->nchw) {
                 const size_t ss = ALIGN_UP(m->scratch_per_frame, 256);
                 int rc = mhip_nchw_to_nhwc_pad(p.in, p.in_stride, (int8_t *)m->scratch_dev, ss, B, op->in_c,
@@ -888,17 +905,6 @@ static int launch_op(mars_model_ext_t *m, mars_op_t *op) {
                 if (rc) return rc;
                 p.in = (const int8_t *)m->scratch_dev; p.in_stride = ss; p.in_c = op->c_pad;
             }
-            p.out = (int8_t *)tdev(m, op->t_out); p.out_stride = tstride(m, op->t_out);
-            p.w = (const int8_t *)(A + op->w_off);
-            p.bias = op->b_off != NO_OFF ? (const int32_t *)(A + op->b_off) : NULL;
-            p.lut = op->lut_off != NO_OFF ? A + op->lut_off : NULL;
-            p.frames = B;
-            p.in_h = op->in_h; p.in_w = op->in_w;
-            p.out_h = op->out_h; p.out_w = op->out_w; p.out_c = op->out_c;
-            p.kh = op->kh; p.kw = op->kw; p.stride_h = op->sh; p.stride_w = op->sw; p.pad_top = op->pt; p.pad_left = op->pl;
-            p.row_pad = op->row_pad; p.oc_pad = op->oc_pad; p.cs = op->cs; p.relu = op->relu; p.out_nchw = op->nchw;
-            p.safe = op->safe;
-            p.out_pix_stride = op->out_pix_stride; p.out_ch_off = op->out_ch_off;
             return mhip_conv_i8(&p);
         }
         case OP_CONV_F32: {
@@ -1068,6 +1074,48 @@ mars_error_t mars_hip_set_fusion(mars_model_t *model, int level) {
 }
 
 int mars_hip_set_tuning(const char *key, int value) { return mhip_conv_i8_tune(key, value); }
+
+/* Time every launch variant of every int8 convolution on the device, at the current batch, and pin the fastest
+ * (all variants write the same bytes; the layer's real buffers are used, so the tensors stay valid). */
+mars_error_t mars_hip_autotune(mars_model_t *model, int reps) {
+    if (!model) return MARS_ERR_INVALID_FILE;
+    mars_model_ext_t *m = (mars_model_ext_t *)model;
+    if (!m->act_dev || !m->arena_dev) return MARS_ERR_NNA_INIT_FAILED;
+    if (reps <= 0) reps = 3;
+    void *e0 = mhip_event_create(), *e1 = mhip_event_create();
+    if (!e0 || !e1) return MARS_ERR_ALLOC_FAILED;
+    mars_error_t err = MARS_OK;
+    if (mhip_sync()) err = MARS_ERR_LAYER_FAILED;
+    for (int i = 0; i < m->n_ops && err == MARS_OK; i++) {
+        mars_op_t *op = &m->ops[i];
+        if (op->kind != OP_CONV_I8 || op->nchw) continue;
+        mhip_conv_i8_t p;
+        conv_i8_params(m, op, &p);
+        int codes[8];
+        const int n = mhip_conv_i8_variants(&p, codes, 8);
+        float best = 0.0f;
+        int best_code = 0;
+        for (int k = 0; k < n && err == MARS_OK; k++) {
+            p.variant = codes[k];
+            int rc = mhip_conv_i8(&p); /* warm: code object load, occupancy query */
+            if (!rc) rc = mhip_event_record(e0);
+            for (int r = 0; r < reps && !rc; r++) rc = mhip_conv_i8(&p);
+            if (!rc) rc = mhip_event_record(e1);
+            if (rc || mhip_sync()) { err = MARS_ERR_LAYER_FAILED; break; }
+            const float ms = mhip_event_elapsed_ms(e0, e1);
+            if (best_code == 0 || ms < best) { best = ms; best_code = codes[k]; }
+        }
+        if (err == MARS_OK && best_code) {
+            if (getenv("MARS_VERBOSE"))
+                fprintf(stderr, "Mars: autotune layer %d: variant %d (%.1f us) of %d candidates, default %d\n", op->layer,
+                        best_code, best * 1000.0f / reps, n, n ? codes[0] : 0);
+            op->variant = best_code;
+        }
+    }
+    mhip_event_destroy(e0);
+    mhip_event_destroy(e1);
+    return err;
+}
 
 void *mars_hip_tensor_device(mars_model_t *model, int ti, size_t *frame_stride) {
     if (!model || ti < 0 || (uint32_t)ti >= model->header.num_tensors) return NULL;

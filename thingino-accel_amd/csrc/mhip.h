@@ -65,6 +65,7 @@ typedef struct {
     int out_pix_stride;         /* NHWC only: bytes between consecutive output pixels (0 = out_c); with out_ch_off
                                    this writes straight into a channel slice of a wider tensor (zero-copy concat) */
     int out_ch_off;
+    int variant;                /* 0 = default launch policy, else a code from mhip_conv_i8_variants() */
 } mhip_conv_i8_t;
 /* row of the packed weights / bias that holds output channel oc (channels are permuted so that a lane's
  * results are consecutive channels) */
@@ -72,6 +73,8 @@ int mhip_conv_i8_oc_row(int oc, int oc_pad);
 /* is the float->int conversion of acc*cs provably in range for every int32 accumulator? */
 int mhip_conv_i8_is_safe(float cs);
 int mhip_conv_i8_tune(const char *key, int value); /* launch-policy knobs, see mars_hip_set_tuning */
+/* launch variants that can run this layer (same bytes out, different speed), the default first; 0 if none */
+int mhip_conv_i8_variants(const mhip_conv_i8_t *p, int *codes, int max);
 /* packing geometry shared by host packer and kernel */
 /* c_eff: bytes per input pixel in the packed K layout (4 in small-channel mode, else in_c) */
 void mhip_conv_i8_pack_geom(int in_c, int kw, int out_c, int *row_pad, int *oc_pad, int *c_eff);

@@ -101,7 +101,7 @@ EXPORTS = {
                    "mars_hip_tensor_device", "mars_hip_read_tensor", "mars_hip_write_tensor", "mars_hip_set_fusion",
                    "mars_hip_set_profiling", "mars_hip_num_ops", "mars_hip_op_info", "mars_hip_stream",
                    "mars_hip_load_memory_ex", "mars_hip_param_arena", "mars_yolo_parse_output", "mars_yolo_nms",
-                   "mars_hip_detect", "mars_hip_detect_device", "mars_synth_model", "mars_hip_set_tuning"],
+                   "mars_hip_detect", "mars_hip_detect_device", "mars_synth_model", "mars_hip_set_tuning", "mars_hip_autotune"],
 }
 
 _lib = None
@@ -150,6 +150,7 @@ def lib():
     L.mars_hip_set_batch.argtypes = [P(MarsModel), C.c_int]
     L.mars_hip_set_fusion.argtypes = [P(MarsModel), C.c_int]
     L.mars_hip_set_tuning.argtypes = [C.c_char_p, C.c_int]
+    L.mars_hip_autotune.argtypes = [P(MarsModel), C.c_int]
     L.mars_hip_set_profiling.argtypes = [P(MarsModel), C.c_int]
     L.mars_hip_set_profiling.restype = None
     L.mars_hip_tensor_device.restype = C.c_void_p
@@ -304,6 +305,11 @@ class Model:
 
     def set_profiling(self, on):
         lib().mars_hip_set_profiling(self.p, int(on))
+
+    def autotune(self, reps=3):
+        rc = lib().mars_hip_autotune(self.p, reps)
+        if rc != 0:
+            raise MarsError(rc, "mars_hip_autotune")
 
     def ops(self):
         n = lib().mars_hip_num_ops(self.p)
