@@ -53,7 +53,8 @@ mars_error_t mars_hip_write_tensor(mars_model_t *model, int tensor_index, int fr
 mars_error_t mars_hip_set_fusion(mars_model_t *model, int level);
 
 /* Launch-policy knob of the convolution kernels (process-wide): "persist" (0|1), "persist_stages"
- * (2|3), "persist_maxk", "persist_slots" (0 = what the device holds at once), "stages", "bpx".
+ * (2|3), "persist_maxk", "persist_slots" (0 = what the device holds at once), "stages", "bpx", "variant"
+ * (force one launch variant wherever a layer has it).
  * The defaults are the measured optimum; tests use "persist_slots" to force the multi-tile walk
  * of the persistent kernel on small inputs.  Results never depend on these.  0 = ok, -1 = unknown key. */
 int mars_hip_set_tuning(const char *key, int value);

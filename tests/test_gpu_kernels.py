@@ -59,7 +59,9 @@ def test_conv_i8_persistent_tile_walk(gpu, orc, slots, stages):
     depths; K loops of 1, 2, 4, 9 and 18 steps; pixel counts that are not a multiple of the tile"""
     shapes = [  # in_h, in_w, in_c, out_c, k, s
         (64, 64, 32, 32, 1, 1), (40, 40, 64, 128, 3, 2), (37, 29, 128, 64, 1, 1), (23, 17, 128, 64, 3, 1),
-        (33, 31, 256, 256, 1, 1), (50, 50, 64, 64, 1, 1), (80, 80, 16, 48, 3, 1)]
+        (33, 31, 256, 256, 1, 1), (50, 50, 64, 64, 1, 1), (80, 80, 16, 48, 3, 1),
+        # ragged channel runs (unaligned rows, 8+4+2+1-byte tail stores): the 255-channel heads and odd widths
+        (16, 16, 512, 255, 1, 1), (21, 19, 64, 81, 1, 1), (20, 20, 32, 7, 3, 1), (17, 23, 128, 131, 1, 1)]
     try:
         gpu.set_tuning("persist", 1)
         gpu.set_tuning("persist_maxk", 1 << 20)
@@ -96,6 +98,49 @@ def test_conv_i8_persistent_tile_walk(gpu, orc, slots, stages):
         gpu.set_tuning("persist_slots", 0)
         gpu.set_tuning("persist_stages", 2)
         gpu.set_tuning("persist_maxk", 8)
+
+
+@pytest.mark.parametrize("variant", [9, 10, 11])
+def test_conv_i8_patch_staged(gpu, orc, variant):
+    """the patch-staged kernel (input patch of a tile staged once in LDS, weights resident, taps fed from LDS):
+    3x3 / 5x5 / 3x1 kernels, stride 1 and 2 (de-interleaved patch columns), in_c 32 / 64, partial tiles at the
+    right and bottom edges, SAME padding on every side, several tiles per workgroup"""
+    shapes = [  # in_h, in_w, in_c, out_c, kh, kw, s
+        (48, 48, 64, 64, 3, 3, 1), (64, 64, 32, 64, 3, 3, 2), (47, 45, 32, 32, 3, 3, 1), (61, 63, 64, 32, 3, 3, 2),
+        (32, 48, 32, 48, 5, 5, 1), (40, 32, 64, 16, 3, 1, 1), (64, 64, 32, 32, 1, 3, 2), (33, 31, 64, 128, 3, 3, 1)]
+    try:
+        gpu.set_tuning("variant", variant)
+        for slots in (0, 3):
+            gpu.set_tuning("persist_slots", slots)
+            for i, (h, w, ic, oc, kh, kw, s) in enumerate(shapes):
+                oh, ow = (h + s - 1) // s, (w + s - 1) // s
+                ph = max((oh - 1) * s + kh - h, 0) // 2
+                pw = max((ow - 1) * s + kw - w, 0) // 2
+                case = ("patch%d" % i, 1, h, w, ic, oc, kh, kw, s, s, ph, pw, oh, ow, 0.03, 0.003 / (kh * kw * ic) ** 0.5 * 8, 0.05, True)
+                a = cases.conv_i8_call(gpu.conv2d_int8, case, 6)
+                b = cases.conv_i8_call(orc.conv2d_int8, case, 6)
+                assert np.array_equal(a, b), (case[0], slots, int((a != b).sum()))
+                assert len(np.unique(a)) > 32
+        gpu.set_tuning("persist_slots", 0)
+        import marsfile
+        from conftest import lcg_frame
+        d = gpu.synth_model(width_x16=4, input_hw=256, seed=22)  # 128x128 / 64x64 maps: eligible layers exist
+        hdr, tensors, _ = marsfile.parse(d)
+        nb = marsfile.tensor_nbytes(tensors[hdr["inputs"][0]])
+        m = gpu.Model(d, batch=2)
+        xs = [lcg_frame(0xAC0000 + f, nb) for f in range(2)]
+        for f in range(2):
+            m.input_view(0)[f] = xs[f]
+        m.run()
+        g = orc.Graph(d)
+        g.set_input(0, xs[1].tobytes())
+        assert g.run() == 0
+        for oi, ti in enumerate(hdr["outputs"]):
+            assert np.array_equal(m.output_view(oi)[1], g.tensor(ti))
+        m.close()
+    finally:
+        gpu.set_tuning("variant", 0)
+        gpu.set_tuning("persist_slots", 0)
 
 
 def test_mxu_f32_elementwise(gpu):

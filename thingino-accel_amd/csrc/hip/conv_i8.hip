@@ -593,6 +593,7 @@ __global__ __launch_bounds__(NTHREADS) void conv_i8_persist(const mhip_conv_i8_t
     const int pstride = p.out_pix_stride ? p.out_pix_stride : p.out_c;
     const int lo = p.relu ? 0 : -128;
     const uint8_t *lut128 = slut + 128;
+    const bool ragged = (p.out_c % (WOC * 4)) != 0;
     int stage = 0;
     for (unsigned tile = t0; tile < t1; tile++) {
         v4i acc[WOC][WPX];
@@ -640,7 +641,8 @@ __global__ __launch_bounds__(NTHREADS) void conv_i8_persist(const mhip_conv_i8_t
             const unsigned pix = tile * BPX + pxw + t * 16 + (lane & 15);
             const unsigned f = fdiv(pix, dhw), rem = pix - f * hw;
             const unsigned off = f * (unsigned)p.out_stride + rem * (unsigned)pstride + (unsigned)(p.out_ch_off + oc0 + chan);
-            const bool ok = pix < total_pix && oc0 + chan < p.out_c;
+            const int nvalid = p.out_c - (oc0 + chan); // channels of this lane's run that exist
+            const bool ok = pix < total_pix && nvalid >= WOC * 4;
             uint32_t pk[WOC];
             int a[WOC * 4];
 #pragma unroll
@@ -653,9 +655,211 @@ __global__ __launch_bounds__(NTHREADS) void conv_i8_persist(const mhip_conv_i8_t
                 __builtin_amdgcn_raw_buffer_store_b128((v4i){(int)pk[0], (int)pk[1], (int)pk[2], (int)pk[3]}, orsrc, voff, 0, 0);
             else
                 __builtin_amdgcn_raw_buffer_store_b64((v2i){(int)pk[0], (int)pk[WOC > 1 ? 1 : 0]}, orsrc, voff, 0, 0);
+            if (ragged) {
+                // out_c is not a multiple of the run (the 255-channel heads): the lane that holds the last, partial
+                // run writes it as 8 + 4 + 2 + 1 bytes; every other lane's pieces go out of range.  Always the same
+                // number of store instructions, so the vmcnt bookkeeping stays exact.
+                const bool part = pix < total_pix && nvalid > 0 && nvalid < WOC * 4;
+                const int nv = part ? nvalid : 0;
+                const int o4 = nv & 8, o2 = nv & 12, o1 = nv & 14;
+                const uint32_t w4 = o4 ? pk[(WOC * 4 > 8) ? 2 : 0] : pk[0];
+                const int i2 = o2 >> 2, i1 = o1 >> 2;
+                uint32_t w2 = pk[0], w1 = pk[0];
+#pragma unroll
+                for (int q = 1; q < WOC; q++) {
+                    w2 = i2 == q ? pk[q] : w2;
+                    w1 = i1 == q ? pk[q] : w1;
+                }
+                w1 >>= (o1 & 2) * 8;
+                if (WOC == 4)
+                    __builtin_amdgcn_raw_buffer_store_b64((v2i){(int)pk[0], (int)pk[1]}, orsrc, (nv & 8) ? (int)off : -1, 0, 0);
+                __builtin_amdgcn_raw_buffer_store_b32((int)w4, orsrc, (nv & 4) ? (int)off + o4 : -1, 0, 0);
+                __builtin_amdgcn_raw_buffer_store_b16((short)w2, orsrc, (nv & 2) ? (int)off + o2 : -1, 0, 0);
+                __builtin_amdgcn_raw_buffer_store_b8((char)w1, orsrc, (nv & 1) ? (int)off + o1 : -1, 0, 0);
+            }
         }
 #pragma unroll
-        for (int i = 0; i < STAGES - 1; i++) younger[i] += NST;
+        for (int i = 0; i < STAGES - 1; i++) younger[i] += ragged ? NST * (WOC == 4 ? 5 : 4) : NST;
+    }
+}
+
+// ---------------------------------------------------------------------------------
+// patch-staged kernel: k x k convolutions on wide feature maps with few channels (the 160x160 / 80x80 layers of
+// yolov5: in_c 32..128).  The implicit-GEMM kernels above fetch every input pixel once per kernel tap through the
+// 64 B/clk L1 path, which is what bounds these layers (few output channels per fetched byte).  Here a workgroup
+// stages the input patch of a TH x 16 output tile ONCE in LDS (LDS-DMA, double buffered, next tile's patch in
+// flight while this one is computed), keeps the weights of its channel tile resident in LDS for its whole
+// (persistent) life, and feeds the MFMAs of all taps from LDS: HBM/L2 bytes are read once, the K loop has no
+// barrier and no global access at all.
+//   B operand of pixel (oy,ox), K chunk (ky,kx,c16) = patch[(oy*s+ky)][(ox*s+kx)][c16]: in NHWC a chunk never
+//   straddles pixels, so its LDS address is Ubase(oy,ox) + dU(ky,kx,c16) in 16-byte units, dU tabulated per K step.
+//   Stride 2: patch columns are stored de-interleaved (even columns, then odd), so 16 consecutive output pixels
+//   read 16 consecutive patch pixels for every tap.  Bank conflicts: 16-byte unit U goes to U ^ ((U>>3) & M),
+//   M = 0 / 2 / 6 for in_c = 32 / 64 / 128 -- with it the lane groups of ds_read_b128 touch 16 distinct
+//   16-byte bank groups for any tap (derivation: DESIGN.md section 5).
+#define PT_TW 16
+#define PT_NIMAX 10
+template <int TH, int BN, bool HAS_LUT>
+__global__ __launch_bounds__(NTHREADS) void conv_i8_patch(const mhip_conv_i8_t p, const int k64, const int tiles_x,
+                                                          const int tiles_y, const unsigned ntiles, const int PH,
+                                                          const int PW, const int PWP, const int PWH, const int ni,
+                                                          const int8_t *__restrict__ zeros, const fastdiv_t dtx,
+                                                          const fastdiv_t dty, const fastdiv_t dpwp, const unsigned out_bytes) {
+    constexpr int WPX = TH / 4;  // tile rows (16-pixel subtiles) per wave
+    constexpr int WOC = BN / 16; // every wave covers all BN channels of its rows
+    constexpr int NST = WPX;
+    extern __shared__ __attribute__((aligned(16))) int8_t dynlds[];
+    uint8_t *slut = (uint8_t *)dynlds; // LDS byte address 0 (requant_pack LUT0)
+    lds_base_must_be_zero(dynlds);
+    const int nks = k64 / BK;
+    int *dutab = (int *)(dynlds + 256);                    // [nks][4] unit offsets of the K chunks
+    int8_t *wl = dynlds + 256 + ((nks * 16 + 255) & ~255); // [nks][BN][64], swizzled like the ring tiles
+    const int patch_bytes = ni * 4096;                     // whole DMA instructions (4 waves x 1 KB)
+    int8_t *patch0 = wl + nks * BN * BK;
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int oc0 = blockIdx.y * BN;
+    const int C = p.in_c, lgc = 31 - __builtin_clz((unsigned)C), cpp = C >> 4, lgcpp = lgc - 4;
+    const int s = p.stride_w;
+    const unsigned M = C >= 128 ? 6u : (C >= 64 ? 2u : 0u);
+
+    v4i bias[WOC];
+#pragma unroll
+    for (int q = 0; q < WOC; q++) bias[q] = p.bias ? *(const v4i *)(p.bias + oc0 + q * 16 + (lane >> 4) * 4) : (v4i){0, 0, 0, 0};
+    if (HAS_LUT && tid < 64) ((uint32_t *)slut)[tid] = ((const uint32_t *)p.lut)[tid];
+    // K chunk table: chunk (ks, f) -> kernel row ky, column kx, channel chunk
+    const int rowbytes = p.kw * C, kbytes = p.kh * rowbytes;
+    for (int i = tid; i < nks * 4; i += NTHREADS) {
+        const int kb = i * 16;
+        int du = 0; // K padding meets zero weights: any valid address
+        if (kb < kbytes) {
+            const int ky = kb / rowbytes, rem = kb - ky * rowbytes, kx = rem >> lgc, cc = (rem & (C - 1)) >> 4;
+            const int dp = ky * PWP + (s == 2 ? (kx >> 1) + (kx & 1) * PWH : kx);
+            du = dp * cpp + cc;
+        }
+        dutab[i] = du;
+    }
+    // resident weights: rows oc0 .. oc0+BN-1, every K step (LDS-DMA, source-side swizzle as in the ring kernels)
+    {
+        const int schunk = (lane & 3) ^ (((lane >> 4) & 1) << 1);
+        for (int i = wv; i < nks * (BN / 16); i += 4) {
+            const int ks = i / (BN / 16), g = i - ks * (BN / 16);
+            glds16(p.w + (size_t)(oc0 + g * 16 + (lane >> 2)) * k64 + ks * BK + schunk * 16, wl + (ks * BN + g * 16) * BK);
+        }
+    }
+    // this lane's units of the patch DMA: instruction n of wave wv fills physical units (n*4+wv)*64 + lane
+    int uoff[PT_NIMAX], upos[PT_NIMAX]; // byte offset from the tile's first input pixel; (py << 16) | px, or -1
+#pragma unroll
+    for (int n = 0; n < PT_NIMAX; n++) {
+        uoff[n] = 0;
+        upos[n] = -1;
+        if (n < ni) {
+            const unsigned phys = (unsigned)((n * 4 + wv) * 64 + lane);
+            const unsigned U = phys ^ ((phys >> 3) & M);
+            const unsigned pp = U >> lgcpp, cc = U & (unsigned)(cpp - 1);
+            const unsigned py = fdiv(pp, dpwp), col = pp - py * (unsigned)PWP;
+            const int px = s == 2 ? ((int)col < PWH ? 2 * (int)col : 2 * ((int)col - PWH) + 1) : (int)col;
+            if ((int)py < PH && px < PW) {
+                uoff[n] = ((int)py * p.in_w + px) * C + (int)cc * 16;
+                upos[n] = ((int)py << 16) | px;
+            }
+        }
+    }
+    auto tile_xy = [&](unsigned t, int &tx, int &ty, unsigned &f) {
+        const unsigned q = fdiv(t, dtx);
+        tx = (int)(t - q * (unsigned)tiles_x);
+        f = fdiv(q, dty);
+        ty = (int)(q - f * (unsigned)tiles_y);
+    };
+    auto issue_patch = [&](unsigned t, int8_t *dst) {
+        int tx, ty;
+        unsigned f;
+        tile_xy(t, tx, ty, f);
+        const int iy0 = ty * TH * s - p.pad_top, ix0 = tx * PT_TW * s - p.pad_left;
+        const int8_t *base = p.in + (size_t)f * p.in_stride + ((long)iy0 * p.in_w + ix0) * C;
+#pragma unroll
+        for (int n = 0; n < PT_NIMAX; n++)
+            if (n < ni) {
+                const int py = upos[n] >> 16, px = upos[n] & 0xffff;
+                const bool ok = upos[n] >= 0 && (unsigned)(iy0 + py) < (unsigned)p.in_h && (unsigned)(ix0 + px) < (unsigned)p.in_w;
+                glds16(ok ? base + uoff[n] : zeros, dst + (n * 4 + wv) * 1024);
+            }
+    };
+
+    const __amdgpu_buffer_rsrc_t orsrc = __builtin_amdgcn_make_buffer_rsrc(p.out, 0, (int)out_bytes, 0x00020000);
+    const int frow = lane & 15, fchunk = lane >> 4;
+    const int chan = (lane >> 4) * (4 * WOC);
+    const int pstride = p.out_pix_stride ? p.out_pix_stride : p.out_c;
+    const int lo = p.relu ? 0 : -128;
+    const uint8_t *lut128 = slut + 128;
+    int ubase[WPX]; // 16-byte unit of (tile row, column frow), tap (0,0), channel 0
+#pragma unroll
+    for (int u = 0; u < WPX; u++) ubase[u] = ((wv * WPX + u) * s * PWP + frow) * cpp;
+
+    unsigned t = blockIdx.x;
+    int buf = 0;
+    if (t < ntiles) issue_patch(t, patch0);
+    bool first = true;
+    for (; t < ntiles; t += gridDim.x) {
+        // this tile's patch (and, the first time, the weights / tables) has landed; stores of the previous tile
+        // are younger than it and may stay in flight
+        if (first) wait_vmcnt<0>();
+        else wait_vmcnt<NST>();
+        __syncthreads();
+        first = false;
+        const unsigned tn = t + gridDim.x;
+        if (tn < ntiles) issue_patch(tn, patch0 + (buf ^ 1) * patch_bytes); // every wave is past its reads of that buffer
+        const int8_t *patch = patch0 + buf * patch_bytes;
+        v4i acc[WOC][WPX];
+        for (int ks = 0; ks < nks; ks++) {
+            const int du = dutab[ks * 4 + fchunk];
+            v4i xb[WPX];
+#pragma unroll
+            for (int u = 0; u < WPX; u++) {
+                const unsigned U = (unsigned)(ubase[u] + du);
+                xb[u] = *(const v4i *)(patch + ((U ^ ((U >> 3) & M)) << 4));
+            }
+            const int8_t *ws = wl + ks * BN * BK;
+            if (ks == 0) {
+#pragma unroll
+                for (int q = 0; q < WOC; q++) {
+                    const v4i wa = *(const v4i *)(ws + lds_off(q * 16 + frow, fchunk));
+#pragma unroll
+                    for (int u = 0; u < WPX; u++) acc[q][u] = __builtin_amdgcn_mfma_i32_16x16x64_i8(wa, xb[u], bias[q], 0, 0, 0);
+                }
+            } else {
+#pragma unroll
+                for (int q = 0; q < WOC; q++) {
+                    const v4i wa = *(const v4i *)(ws + lds_off(q * 16 + frow, fchunk));
+#pragma unroll
+                    for (int u = 0; u < WPX; u++) acc[q][u] = __builtin_amdgcn_mfma_i32_16x16x64_i8(wa, xb[u], acc[q][u], 0, 0, 0);
+                }
+            }
+        }
+        buf ^= 1;
+        int tx, ty;
+        unsigned f;
+        tile_xy(t, tx, ty, f);
+#pragma unroll
+        for (int u = 0; u < WPX; u++) {
+            const int oy = ty * TH + wv * WPX + u, ox = tx * PT_TW + frow;
+            const unsigned off = f * (unsigned)p.out_stride + (unsigned)(oy * p.out_w + ox) * (unsigned)pstride +
+                                 (unsigned)(p.out_ch_off + oc0 + chan);
+            const bool ok = oy < p.out_h && ox < p.out_w && oc0 + chan < p.out_c;
+            uint32_t pk[WOC];
+            int a[WOC * 4];
+#pragma unroll
+            for (int q = 0; q < WOC; q++)
+#pragma unroll
+                for (int r = 0; r < 4; r++) a[q * 4 + r] = acc[q][u][r];
+            requant_pack<WOC * 4, HAS_LUT, true, true>(a, p.cs, lo, lut128, pk);
+            const int voff = ok ? (int)off : -1;
+            if (WOC == 4)
+                __builtin_amdgcn_raw_buffer_store_b128((v4i){(int)pk[0], (int)pk[1], (int)pk[2], (int)pk[3]}, orsrc, voff, 0, 0);
+            else if (WOC == 2)
+                __builtin_amdgcn_raw_buffer_store_b64((v2i){(int)pk[0], (int)pk[WOC > 1 ? 1 : 0]}, orsrc, voff, 0, 0);
+        }
     }
 }
 
@@ -951,6 +1155,7 @@ struct tune_t {
     int persist_slots;  // MARS_HIP_PSLOTS        0: what the device holds at once, else this many workgroups
     int stages;         // MARS_HIP_STAGES        0: auto, else ring depth of the one-tile kernel (2 | 3 | 4)
     int bpx;            // MARS_HIP_BPX           0: auto, else pixels per workgroup (128 | 256)
+    int variant;        // MARS_HIP_VARIANT       0: policy, else this launch variant wherever the layer allows it (tests)
 };
 static tune_t g_tune;
 static int env_int(const char *name, int dflt) {
@@ -965,6 +1170,7 @@ static const tune_t &tune() {
         g_tune.persist_slots = env_int("MARS_HIP_PSLOTS", 0);
         g_tune.stages = env_int("MARS_HIP_STAGES", 0);
         g_tune.bpx = env_int("MARS_HIP_BPX", 0);
+        g_tune.variant = env_int("MARS_HIP_VARIANT", 0);
         g_tune.init = 1;
     }
     return g_tune;
@@ -973,7 +1179,7 @@ extern "C" int mhip_conv_i8_tune(const char *key, int value) {
     (void)tune();
     struct { const char *k; int *v; } tab[] = {{"persist", &g_tune.persist}, {"persist_stages", &g_tune.persist_stages},
                                                {"persist_maxk", &g_tune.persist_maxk}, {"persist_slots", &g_tune.persist_slots},
-                                               {"stages", &g_tune.stages}, {"bpx", &g_tune.bpx}};
+                                               {"stages", &g_tune.stages}, {"bpx", &g_tune.bpx}, {"variant", &g_tune.variant}};
     for (auto &e : tab)
         if (key && !strcmp(key, e.k)) {
             *e.v = value;
@@ -1057,21 +1263,93 @@ static int launch_persist_t(const mhip_conv_i8_t *p, long total_pix, int k64, in
 // variant computes the same bytes.  p->variant == 0 takes the measured default policy below; the host can pin a
 // variant per layer after timing the candidates on the device (mars_hip_autotune).
 //   code = 1 + persist + 2*(bpx == 256) + 4*(stages == 3)
+//   code = 9 / 10 / 11: patch-staged kernel with 8 / 16 / 4 tile rows
+#define NVARIANTS 11
 struct variant_t {
-    int persist, bpx, stages;
+    int persist, bpx, stages, patch;
 };
-static int variant_code(const variant_t &v) { return 1 + (v.persist ? 1 : 0) + (v.bpx == 256 ? 2 : 0) + (v.stages == 3 ? 4 : 0); }
-static variant_t variant_of(int code) {
-    const int c = code - 1;
-    return variant_t{c & 1, (c & 2) ? 256 : 128, (c & 4) ? 3 : 2};
+static int variant_code(const variant_t &v) {
+    if (v.patch) return v.patch == 16 ? 10 : (v.patch == 8 ? 9 : 11);
+    return 1 + (v.persist ? 1 : 0) + (v.bpx == 256 ? 2 : 0) + (v.stages == 3 ? 4 : 0);
 }
-static bool persist_eligible(const mhip_conv_i8_t *p) {
+static variant_t variant_of(int code) {
+    if (code >= 9) return variant_t{0, 0, 0, code == 10 ? 16 : (code == 9 ? 8 : 4)};
+    const int c = code - 1;
+    return variant_t{c & 1, (c & 2) ? 256 : 128, (c & 4) ? 3 : 2, 0};
+}
+
+// ---- patch-staged kernel: geometry, eligibility, launch
+struct patch_geom_t {
+    int bn, tiles_x, tiles_y, PH, PW, PWP, PWH, ni, nks;
+    size_t lds;
+};
+static bool patch_geom(const mhip_conv_i8_t *p, int th, patch_geom_t *g) {
     const bool direct = !p->out_nchw && ((p->out_c | p->out_pix_stride | p->out_ch_off) & 15) == 0;
-    return direct && p->safe && (p->in_c & (p->in_c - 1)) == 0 && p->kh * p->kw <= 32 &&
+    const int C = p->in_c, s = p->stride_w;
+    if (!direct || !p->safe || (C != 32 && C != 64 && C != 128) || (s != 1 && s != 2) || p->stride_h != s ||
+        p->kh > 7 || p->kw > 7 || p->kh * p->kw < 2 || p->row_pad != p->kw * C || persist_out_bytes(p) > 0x7fffffffL)
+        return false;
+    const int k64 = (p->kh * p->row_pad + BK - 1) / BK * BK;
+    g->nks = k64 / BK;
+    g->bn = p->oc_pad % 64 == 0 ? 64 : 32;
+    g->tiles_x = (p->out_w + PT_TW - 1) / PT_TW;
+    g->tiles_y = (p->out_h + th - 1) / th;
+    // mostly full tiles only: a tile computes th x 16 pixels whether the image has them or not
+    if ((double)p->out_h * p->out_w < 0.85 * (double)g->tiles_x * PT_TW * g->tiles_y * th) return false;
+    g->PH = (th - 1) * s + p->kh;
+    g->PW = (PT_TW - 1) * s + p->kw;
+    g->PWH = s == 2 ? (g->PW + 1) / 2 : 0;
+    g->PWP = s == 2 ? 2 * g->PWH : g->PW;
+    const long units = (long)g->PH * g->PWP * (C / 16);
+    g->ni = (int)((units + 255) / 256);
+    if (g->ni > PT_NIMAX) return false;
+    g->lds = 256 + (((size_t)g->nks * 16 + 255) & ~(size_t)255) + (size_t)g->nks * g->bn * BK + 2 * (size_t)g->ni * 4096;
+    if (g->lds > 80 * 1024) return false; // two workgroups per CU, or the prefetch has nothing to hide behind
+    if ((long)g->tiles_x * g->tiles_y * p->frames > 0x7fffffffL) return false;
+    return true;
+}
+
+template <int TH, int BN, bool HAS_LUT>
+static int launch_patch_t(const mhip_conv_i8_t *p, int k64, const patch_geom_t &g) {
+    static int slots = 0;
+    if (!slots) {
+        int occ = 0, dev = 0;
+        hipDeviceProp_t prop;
+        if (hipFuncSetAttribute((const void *)conv_i8_patch<TH, BN, HAS_LUT>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024) != hipSuccess ||
+            hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, conv_i8_patch<TH, BN, HAS_LUT>, NTHREADS, g.lds) != hipSuccess ||
+            hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess)
+            return mhip_check(hipErrorUnknown, "conv_i8_patch occupancy query");
+        slots = (occ > 0 ? occ : 1) * prop.multiProcessorCount;
+    }
+    const unsigned ntiles = (unsigned)((long)g.tiles_x * g.tiles_y * p->frames);
+    const unsigned noc = (unsigned)(p->oc_pad / BN);
+    unsigned gx = (unsigned)(tune().persist_slots > 0 ? tune().persist_slots : slots) / noc;
+    if (gx < 1) gx = 1;
+    if (gx > ntiles) gx = ntiles;
+    hipLaunchKernelGGL((conv_i8_patch<TH, BN, HAS_LUT>), dim3(gx, noc), dim3(NTHREADS), g.lds, mhip_stream_native(), *p, k64,
+                       g.tiles_x, g.tiles_y, ntiles, g.PH, g.PW, g.PWP, g.PWH, g.ni, (const int8_t *)mhip_zero_page(),
+                       make_fastdiv((unsigned)g.tiles_x), make_fastdiv((unsigned)g.tiles_y), make_fastdiv((unsigned)g.PWP),
+                       (unsigned)persist_out_bytes(p));
+    return mhip_check(hipGetLastError(), "conv_i8_patch launch");
+}
+
+static int launch_patch(const mhip_conv_i8_t *p, int k64, int th) {
+    patch_geom_t g;
+    if (!patch_geom(p, th, &g)) return -1;
+#define PATCH(T, B) (p->lut ? launch_patch_t<T, B, true>(p, k64, g) : launch_patch_t<T, B, false>(p, k64, g))
+    if (th == 16) return g.bn == 64 ? PATCH(16, 64) : PATCH(16, 32);
+    if (th == 8) return g.bn == 64 ? PATCH(8, 64) : PATCH(8, 32);
+    return g.bn == 64 ? PATCH(4, 64) : PATCH(4, 32);
+#undef PATCH
+}
+
+static bool persist_eligible(const mhip_conv_i8_t *p) {
+    return !p->out_nchw && p->safe && (p->in_c & (p->in_c - 1)) == 0 && p->kh * p->kw <= 32 &&
            (long)p->kh * p->kw * (p->kw - 1) < 65536 && persist_out_bytes(p) <= 0x7fffffffL;
 }
 static variant_t default_variant(const mhip_conv_i8_t *p, int nks) {
     variant_t v;
+    v.patch = 0;
     // pixels per workgroup: 256 halves the weight-tile traffic and per-workgroup overhead of the narrow, shallow
     // configurations; 128 keeps one more workgroup per CU everywhere else
     v.bpx = tune().bpx ? tune().bpx : ((p->oc_pad % 128 != 0 && nks <= 2) ? 256 : 128);
@@ -1099,6 +1377,7 @@ static int launch_variant_t(const mhip_conv_i8_t *p, long total_pix, int k64, co
 }
 
 static int launch_variant(const mhip_conv_i8_t *p, long total_pix, int k64, const variant_t &v) {
+    if (v.patch) return launch_patch(p, k64, v.patch);
     const int bn = p->oc_pad % 128 == 0 ? 128 : (p->oc_pad % 64 == 0 ? 64 : 32);
     if (v.bpx == 256) {
         if (bn == 128) return launch_variant_t<256, 128>(p, total_pix, k64, v);
@@ -1117,9 +1396,11 @@ extern "C" int mhip_conv_i8_variants(const mhip_conv_i8_t *p, int *codes, int ma
     int n = 0;
     const int dflt = variant_code(default_variant(p, nks));
     if (n < max) codes[n++] = dflt;
-    for (int code = 1; code <= 8; code++) {
+    for (int code = 1; code <= NVARIANTS; code++) {
         const variant_t v = variant_of(code);
         if (code == dflt) continue;
+        patch_geom_t g;
+        if (v.patch && !patch_geom(p, v.patch, &g)) continue;
         if (v.persist && !persist_eligible(p)) continue;
         if (!v.persist && v.stages == 3 && nks <= 2) continue; // identical to the 2-stage launch
         if (n < max) codes[n++] = code;
@@ -1159,8 +1440,15 @@ extern "C" int mhip_conv_i8(const mhip_conv_i8_t *p) {
     if ((p->in_c % 16) == 0) {
         if (!mhip_zero_page()) return -1;
         const int nks = k64 / BK;
-        if (p->variant < 0 || p->variant > 8) return -1;
-        return launch_variant(p, total_pix, k64, p->variant ? variant_of(p->variant) : default_variant(p, nks));
+        if (p->variant < 0 || p->variant > NVARIANTS) return -1;
+        int code = p->variant;
+        if (!code && tune().variant) { // forced from outside: only where this layer has that variant
+            int codes[NVARIANTS];
+            const int n = mhip_conv_i8_variants(p, codes, NVARIANTS);
+            for (int i = 0; i < n; i++)
+                if (codes[i] == tune().variant) code = codes[i];
+        }
+        return launch_variant(p, total_pix, k64, code ? variant_of(code) : default_variant(p, nks));
     }
     if (oc_pad % 64 == 0) return launch_generic<64>(p, total_pix, k64);
     return launch_generic<32>(p, total_pix, k64);

@@ -1091,8 +1091,12 @@ mars_error_t mars_hip_autotune(mars_model_t *model, int reps) {
         if (op->kind != OP_CONV_I8 || op->nchw) continue;
         mhip_conv_i8_t p;
         conv_i8_params(m, op, &p);
-        int codes[8];
-        const int n = mhip_conv_i8_variants(&p, codes, 8);
+        int codes[16];
+        const int n = mhip_conv_i8_variants(&p, codes, 16);
+        if (getenv("MARS_VERBOSE") && atoi(getenv("MARS_VERBOSE")) > 1)
+            fprintf(stderr, "Mars: autotune layer %d: %dx%dx%d -> %dx%dx%d k%dx%d s%d pixstride %d choff %d lut %d safe %d\n", op->layer,
+                    p.in_h, p.in_w, p.in_c, p.out_h, p.out_w, p.out_c, p.kh, p.kw, p.stride_w, p.out_pix_stride, p.out_ch_off,
+                    p.lut != NULL, p.safe);
         float best = 0.0f;
         int best_code = 0;
         for (int k = 0; k < n && err == MARS_OK; k++) {
@@ -1103,6 +1107,8 @@ mars_error_t mars_hip_autotune(mars_model_t *model, int reps) {
             if (!rc) rc = mhip_event_record(e1);
             if (rc || mhip_sync()) { err = MARS_ERR_LAYER_FAILED; break; }
             const float ms = mhip_event_elapsed_ms(e0, e1);
+            if (getenv("MARS_VERBOSE") && atoi(getenv("MARS_VERBOSE")) > 1)
+                fprintf(stderr, "Mars: autotune layer %d: candidate %d: %.1f us\n", op->layer, codes[k], ms * 1000.0f / reps);
             if (best_code == 0 || ms < best) { best = ms; best_code = codes[k]; }
         }
         if (err == MARS_OK && best_code) {
