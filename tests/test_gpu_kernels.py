@@ -67,6 +67,7 @@ def test_conv_i8_persistent_tile_walk(gpu, orc, slots, stages):
         gpu.set_tuning("persist_maxk", 1 << 20)
         gpu.set_tuning("persist_slots", slots)
         gpu.set_tuning("persist_stages", stages)
+        gpu.set_tuning("variant", 2 if stages == 2 else 6)  # the tile-walking form wherever a layer has it
         for i, (h, w, ic, oc, k, s) in enumerate(shapes):
             oh, ow = (h + s - 1) // s, (w + s - 1) // s
             ph = max((oh - 1) * s + k - h, 0) // 2
@@ -95,6 +96,7 @@ def test_conv_i8_persistent_tile_walk(gpu, orc, slots, stages):
                 assert np.array_equal(m.output_view(oi)[f], g.tensor(ti))
         m.close()
     finally:
+        gpu.set_tuning("variant", 0)
         gpu.set_tuning("persist_slots", 0)
         gpu.set_tuning("persist_stages", 2)
         gpu.set_tuning("persist_maxk", 8)
