@@ -470,7 +470,11 @@ __device__ __forceinline__ void wait_vmcnt_at_most(int n) { // largest known-saf
     else wait_vmcnt<0>();
 }
 
-template <int BPX, int BN, int STAGES, bool HAS_LUT>
+// SEG: the input is the channel concatenation of up to 4 tensors that was never materialised (1x1 convolutions only):
+// K step ks reads its 64 channels from the tensor(s) that own them.  Segment boundaries are multiples of 32 channels,
+// so the two 32-byte halves of a K step each lie in one segment and the choice is a scalar select plus one per-lane
+// select between the halves.
+template <int BPX, int BN, int STAGES, bool HAS_LUT, bool SEG = false>
 __global__ __launch_bounds__(NTHREADS) void conv_i8_persist(const mhip_conv_i8_t p, const unsigned total_pix, const int k64,
                                                             const int8_t *__restrict__ zeros, const unsigned noc,
                                                             const unsigned npt, const unsigned ngrp, const int lg_inc,
@@ -515,6 +519,7 @@ __global__ __launch_bounds__(NTHREADS) void conv_i8_persist(const mhip_conv_i8_t
     const int schunk = (lane & 3) ^ (((lane >> 4) & 1) << 1);
     const int8_t *xwin[XI];
     unsigned tapmask[XI];
+    unsigned rowf[SEG ? XI : 1], rowrem[SEG ? XI : 1]; // SEG: frame and pixel-in-frame of the rows this lane fetches
     auto setup_rows = [&](unsigned tile) { // window origin and in-image tap mask of the rows this lane fetches
 #pragma unroll
         for (int j = 0; j < XI; j++) {
@@ -522,6 +527,12 @@ __global__ __launch_bounds__(NTHREADS) void conv_i8_persist(const mhip_conv_i8_t
             const bool valid = pix < total_pix;
             const unsigned f = valid ? fdiv(pix, dhw) : 0u;
             const unsigned rem = valid ? pix - f * hw : 0u;
+            if (SEG) {
+                rowf[j] = f;
+                rowrem[j] = rem;
+                tapmask[j] = valid ? 1u : 0u;
+                continue;
+            }
             const int oy = (int)fdiv(rem, dow), ox = (int)(rem - (unsigned)oy * (unsigned)p.out_w);
             const int iy0 = oy * p.stride_h - p.pad_top, ix0 = ox * p.stride_w - p.pad_left;
             xwin[j] = p.in + (size_t)f * p.in_stride + ((long)iy0 * p.in_w + ix0) * p.in_c;
@@ -548,16 +559,34 @@ __global__ __launch_bounds__(NTHREADS) void conv_i8_persist(const mhip_conv_i8_t
     auto issue = [&](int ks, int stage) {
         int8_t *sb = lds + stage * STAGE;
         const unsigned pos = (unsigned)(ks * BK + schunk * 16);
-        const unsigned tap = pos >> lg_inc;
-        const int rc = (int)(pos & ((1u << lg_inc) - 1u));
-        const int ky = (int)((tap * kw_magic) >> 16);
-        const int kx = (int)tap - ky * p.kw;
-        const bool kvalid = (int)tap < taps;
-        const long koff = ((long)ky * p.in_w + kx) * p.in_c + rc;
+        if (SEG) {
+            // owner of channel c: the last segment that starts at or before it (unused segments start at INT_MAX)
+            auto owner = [&](int c) { return (c >= p.seg_c0[1]) + (c >= p.seg_c0[2]) + (c >= p.seg_c0[3]); };
+            const int sa = owner(ks * BK), sb2 = owner(ks * BK + 32); // uniform
+            const bool hi = schunk >= 2;
+            const int8_t *base = hi ? p.seg_in[sb2] : p.seg_in[sa];
+            const unsigned fstride = (unsigned)(hi ? p.seg_stride[sb2] : p.seg_stride[sa]);
+            const unsigned segc = (unsigned)(hi ? p.seg_c[sb2] : p.seg_c[sa]);
+            const unsigned coff = pos - (unsigned)(hi ? p.seg_c0[sb2] : p.seg_c0[sa]);
+            const bool kvalid = (int)pos < p.in_c;
 #pragma unroll
-        for (int j = 0; j < XI; j++) {
-            const bool ok = kvalid & ((tapmask[j] >> tap) & 1u);
-            glds16(ok ? xwin[j] + koff : zeros, sb + (wv * (BPX / 4) + j * 16) * BK);
+            for (int j = 0; j < XI; j++) {
+                const bool ok = kvalid & (tapmask[j] != 0u);
+                const int8_t *src = base + (size_t)rowf[j] * fstride + (size_t)rowrem[j] * segc + coff;
+                glds16(ok ? src : zeros, sb + (wv * (BPX / 4) + j * 16) * BK);
+            }
+        } else {
+            const unsigned tap = pos >> lg_inc;
+            const int rc = (int)(pos & ((1u << lg_inc) - 1u));
+            const int ky = (int)((tap * kw_magic) >> 16);
+            const int kx = (int)tap - ky * p.kw;
+            const bool kvalid = (int)tap < taps;
+            const long koff = ((long)ky * p.in_w + kx) * p.in_c + rc;
+#pragma unroll
+            for (int j = 0; j < XI; j++) {
+                const bool ok = kvalid & ((tapmask[j] >> tap) & 1u);
+                glds16(ok ? xwin[j] + koff : zeros, sb + (wv * (BPX / 4) + j * 16) * BK);
+            }
         }
 #pragma unroll
         for (int j = 0; j < LW; j++) glds16(wsrc[j] + ks * BK, sb + BPX * BK + wq[j] * 16 * BK);
@@ -1242,7 +1271,7 @@ static long persist_out_bytes(const mhip_conv_i8_t *p) {
     return (long)(p->frames - 1) * (long)p->out_stride + (long)p->out_h * p->out_w * pstride;
 }
 
-template <int BPX, int BN, int STAGES, bool HAS_LUT>
+template <int BPX, int BN, int STAGES, bool HAS_LUT, bool SEG = false>
 static int launch_persist_t(const mhip_conv_i8_t *p, long total_pix, int k64, int lg, unsigned magic) {
     const unsigned npt = (unsigned)((total_pix + BPX - 1) / BPX), noc = (unsigned)(p->oc_pad / BN);
     const size_t lds = 256 + (size_t)STAGES * (BPX + BN) * BK;
@@ -1250,7 +1279,7 @@ static int launch_persist_t(const mhip_conv_i8_t *p, long total_pix, int k64, in
     if (!slots) {
         int occ = 0, dev = 0;
         hipDeviceProp_t prop;
-        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, conv_i8_persist<BPX, BN, STAGES, HAS_LUT>, NTHREADS, lds) != hipSuccess ||
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, conv_i8_persist<BPX, BN, STAGES, HAS_LUT, SEG>, NTHREADS, lds) != hipSuccess ||
             hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess)
             return mhip_check(hipErrorUnknown, "conv_i8_persist occupancy query");
         slots = (occ > 0 ? occ : 1) * prop.multiProcessorCount;
@@ -1260,7 +1289,7 @@ static int launch_persist_t(const mhip_conv_i8_t *p, long total_pix, int k64, in
     unsigned ngrp = (unsigned)(tune().persist_slots > 0 ? tune().persist_slots : 4 * slots) / noc;
     if (ngrp < 1) ngrp = 1;
     if (ngrp > npt) ngrp = npt;
-    hipLaunchKernelGGL((conv_i8_persist<BPX, BN, STAGES, HAS_LUT>), dim3(noc * ngrp), dim3(NTHREADS), lds, mhip_stream_native(),
+    hipLaunchKernelGGL((conv_i8_persist<BPX, BN, STAGES, HAS_LUT, SEG>), dim3(noc * ngrp), dim3(NTHREADS), lds, mhip_stream_native(),
                        *p, (unsigned)total_pix, k64, (const int8_t *)mhip_zero_page(), noc, npt, ngrp, lg, magic,
                        make_fastdiv((unsigned)(p->out_h * p->out_w)), make_fastdiv((unsigned)p->out_w),
                        (unsigned)persist_out_bytes(p));
@@ -1355,6 +1384,22 @@ static int launch_patch(const mhip_conv_i8_t *p, int k64, int th) {
 #undef PATCH
 }
 
+// a convolution whose input is a virtual concatenation: 1x1, stride 1, unpadded, segments tile [0, in_c) in steps of 32
+static bool seg_valid(const mhip_conv_i8_t *p) {
+    if (p->nseg < 2 || p->nseg > 4 || p->kh != 1 || p->kw != 1 || p->stride_h != 1 || p->stride_w != 1 || p->pad_top ||
+        p->pad_left || p->in_h != p->out_h || p->in_w != p->out_w)
+        return false;
+    int c = 0;
+    for (int i = 0; i < 4; i++) {
+        if (i < p->nseg) {
+            if (!p->seg_in[i] || p->seg_c[i] <= 0 || (p->seg_c[i] & 31) || p->seg_c0[i] != c) return false;
+            c += p->seg_c[i];
+        } else if (p->seg_c0[i] != 0x7fffffff) {
+            return false;
+        }
+    }
+    return c == p->in_c;
+}
 static bool persist_eligible(const mhip_conv_i8_t *p) {
     return !p->out_nchw && p->safe && (p->in_c & (p->in_c - 1)) == 0 && p->kh * p->kw <= 32 &&
            (long)p->kh * p->kw * (p->kw - 1) < 65536 && persist_out_bytes(p) <= 0x7fffffffL;
@@ -1386,6 +1431,9 @@ static int launch_variant_t(const mhip_conv_i8_t *p, long total_pix, int k64, co
         int lg = 0;
         while ((1 << lg) < p->in_c) lg++;
         const unsigned magic = ((65536u + (unsigned)p->kw - 1u) / (unsigned)p->kw);
+        if (p->nseg > 1) // never-materialised concat input: the two-stage tile walker only
+            return p->lut ? launch_persist_t<BPX, BN, 2, true, true>(p, total_pix, k64, lg, magic)
+                          : launch_persist_t<BPX, BN, 2, false, true>(p, total_pix, k64, lg, magic);
         if (v.stages == 2)
             return p->lut ? launch_persist_t<BPX, BN, 2, true>(p, total_pix, k64, lg, magic)
                           : launch_persist_t<BPX, BN, 2, false>(p, total_pix, k64, lg, magic);
@@ -1408,11 +1456,20 @@ static int launch_variant(const mhip_conv_i8_t *p, long total_pix, int k64, cons
     return launch_variant_t<128, 32>(p, total_pix, k64, v);
 }
 
+extern "C" int mhip_conv_i8_seg_ok(const mhip_conv_i8_t *p) {
+    return p && (p->in_c % 16) == 0 && !mhip_conv_i8_small_c(p->in_c, p->kw, p->out_c) && seg_valid(p) && persist_eligible(p);
+}
+
 // candidate variant codes of a layer (0 when the layer is not served by these kernels), default first
 extern "C" int mhip_conv_i8_variants(const mhip_conv_i8_t *p, int *codes, int max) {
     if (!p || (p->in_c % 16) != 0 || mhip_conv_i8_small_c(p->in_c, p->kw, p->out_c)) return 0;
     const int k64 = (p->kh * p->row_pad + BK - 1) / BK * BK, nks = k64 / BK;
     int n = 0;
+    if (p->nseg > 1) { // one form only
+        if (max > 0) codes[n++] = 2;
+        if (max > 1) codes[n++] = 4;
+        return n;
+    }
     const int dflt = variant_code(default_variant(p, nks));
     if (n < max) codes[n++] = dflt;
     for (int code = 1; code <= NVARIANTS; code++) {
@@ -1461,6 +1518,12 @@ extern "C" int mhip_conv_i8(const mhip_conv_i8_t *p) {
         const int nks = k64 / BK;
         if (p->variant < 0 || p->variant > NVARIANTS) return -1;
         int code = p->variant;
+        if (p->nseg > 1) {
+            if (!seg_valid(p) || !persist_eligible(p)) return -1;
+            variant_t v = variant_of(code == 4 ? 4 : 2);
+            if (!code) v.bpx = default_variant(p, nks).bpx ? default_variant(p, nks).bpx : 128;
+            return launch_variant(p, total_pix, k64, v);
+        }
         if (!code && tune().variant) { // forced from outside: only where this layer has that variant
             int codes[NVARIANTS];
             const int n = mhip_conv_i8_variants(p, codes, NVARIANTS);

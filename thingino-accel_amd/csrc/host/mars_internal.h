@@ -50,6 +50,7 @@ typedef struct {
     int in_h, in_w, in_c, out_h, out_w, out_c, kh, kw, sh, sw, pt, pl;
     int nchw, relu, is_mul, is_f32, leaky, safe;
     int variant; /* conv_i8 launch variant pinned by mars_hip_autotune (0 = default policy) */
+    int nseg, seg_t[4], seg_c[4]; /* conv_i8 reading a never-materialised concat: its segments (tensor, channels) */
     int row_pad, oc_pad, c_pad;
     int ch_off, scale_h, scale_w, bn_n;
     int out_pix_stride, out_ch_off; /* producer writes a channel slice of a wider tensor (zero-copy concat) */
@@ -66,6 +67,7 @@ typedef struct {
 typedef struct {
     mars_model_t pub; /* MUST stay first */
     int batch, fusion, profiling, deferred;
+    int no_vconcat; /* virtual concat switched off (a batch too large for 32-bit buffer offsets) */
     mtensor_t *mt;
     mars_op_t *ops;
     int n_ops, cap_ops;

@@ -606,6 +606,78 @@ static void elide_concat(mars_model_ext_t *m) {
     free(writers);
 }
 
+/* Virtual concat: when every reader of a Concat output is a plain 1x1 convolution, the concat tensor is never
+ * written -- the convolution's K loop takes each run of channels straight from the tensor that owns it
+ * (conv_i8_persist<SEG>).  The slice copies disappear and every producer keeps writing dense rows.  Same bytes
+ * as the reference: the copy would have put pixel p, channels [off, off+in_c) of the concat tensor = pixel p of the
+ * input, which is exactly what the segmented read fetches (checked: nothing rewrites an input between the copy's
+ * position and the last reader). */
+static void virtual_concat(mars_model_ext_t *m) {
+    const int nt = (int)m->pub.header.num_tensors;
+    for (int T = 0; T < nt; T++) {
+        const mtensor_t *mt = &m->mt[T];
+        if (mt->is_weight || mt->io_in || mt->io_out) continue;
+        int sl[4], ns = 0, bad = 0, first_reader = -1, last_reader = -1, last_slice = -1;
+        for (int i = 0; i < m->n_ops && !bad; i++) {
+            const mars_op_t *o = &m->ops[i];
+            if (o->t_out == T) {
+                if (o->kind != OP_CONCAT_SLICE || ns >= 4) bad = 1;
+                else { sl[ns++] = i; last_slice = i; }
+            }
+            for (int k = 0; k < o->n_in; k++)
+                if (o->t_in[k] == T) {
+                    if (o->kind != OP_CONV_I8 || k != 0 || o->n_in != 1 || o->nchw || o->kh != 1 || o->kw != 1 || o->sh != 1 ||
+                        o->sw != 1 || o->pt || o->pl || !o->safe || o->nseg || (o->out_c & 15) || o->in_h != o->out_h ||
+                        o->in_w != o->out_w)
+                        bad = 1;
+                    if (first_reader < 0) first_reader = i;
+                    last_reader = i;
+                }
+        }
+        if (bad || ns < 2 || first_reader < 0 || last_slice > first_reader) continue;
+        /* slices in channel order, tiling [0, out_c) in multiples of 32, all over the same pixels */
+        for (int a = 0; a < ns; a++)
+            for (int b = a + 1; b < ns; b++)
+                if (m->ops[sl[b]].ch_off < m->ops[sl[a]].ch_off) { int t = sl[a]; sl[a] = sl[b]; sl[b] = t; }
+        int c = 0;
+        const mars_op_t *s0 = &m->ops[sl[0]];
+        for (int a = 0; a < ns && !bad; a++) {
+            const mars_op_t *o = &m->ops[sl[a]];
+            if (o->ch_off != c || (o->in_c & 31) || o->out_h != s0->out_h || o->out_w != s0->out_w || o->out_c != s0->out_c ||
+                o->t_in[0] == T || o->t_in[0] < 0)
+                bad = 1;
+            c += o->in_c;
+            /* the input must still hold at the last reader what it held where the copy stood */
+            for (int i = sl[a] + 1; i <= last_reader && !bad; i++)
+                if (m->ops[i].t_out == o->t_in[0]) bad = 1;
+        }
+        if (bad || c != s0->out_c) continue;
+        for (int i = 0; i < m->n_ops && !bad; i++) {
+            const mars_op_t *o = &m->ops[i];
+            if (o->kind == OP_CONV_I8 && o->n_in == 1 && o->t_in[0] == T &&
+                (o->in_c != c || (size_t)o->in_h * o->in_w != (size_t)s0->out_h * s0->out_w))
+                bad = 1;
+        }
+        if (bad) continue;
+        for (int i = 0; i < m->n_ops; i++) {
+            mars_op_t *o = &m->ops[i];
+            if (o->kind != OP_CONV_I8 || o->n_in != 1 || o->t_in[0] != T) continue;
+            o->nseg = ns;
+            o->n_in = ns;
+            for (int a = 0; a < ns; a++) {
+                o->seg_t[a] = o->t_in[a] = m->ops[sl[a]].t_in[0];
+                o->seg_c[a] = m->ops[sl[a]].in_c;
+            }
+        }
+        for (int a = 0; a < ns; a++) m->ops[sl[a]].kind = -1;
+        m->mt[T].needed = 0;
+    }
+    int w = 0;
+    for (int i = 0; i < m->n_ops; i++)
+        if (m->ops[i].kind != -1) m->ops[w++] = m->ops[i];
+    m->n_ops = w;
+}
+
 /* ------------------------------------------------------------------- load */
 static void free_device_state(mars_model_ext_t *m) {
     if (m->act_dev) mhip_free(m->act_dev);
@@ -668,6 +740,7 @@ static mars_error_t build_plan(mars_model_ext_t *m) {
     for (uint32_t i = 0; i < nl; i++) plan_layer(m, (int)i);
     if (m->fusion >= 1) {
         fuse_silu(m);
+        if (!m->no_vconcat) virtual_concat(m);
         elide_concat(m);
     }
     return MARS_OK;
@@ -696,6 +769,22 @@ static mars_error_t upload_params(mars_model_ext_t *m) {
 static mars_error_t alloc_batch(mars_model_ext_t *m, int n) {
     const uint32_t nt = m->pub.header.num_tensors;
     if (mhip_sync()) return MARS_ERR_LAYER_FAILED;
+    /* segmented (virtual concat) convolutions address their output with 32-bit buffer offsets: if this batch makes
+     * an output tensor of one of them 2 GiB or more, plan again with materialised concats */
+    if (!m->no_vconcat && !m->deferred)
+        for (int i = 0; i < m->n_ops; i++) {
+            const mars_op_t *op = &m->ops[i];
+            if (op->kind != OP_CONV_I8 || op->nseg < 2 || op->t_out < 0) continue;
+            const mtensor_t *t = &m->mt[op->t_out];
+            const size_t stride = ALIGN_UP(t->extent > t->bytes ? t->extent : t->bytes, 256);
+            if (stride * (size_t)n > 0x7fffffffu) {
+                m->no_vconcat = 1;
+                mars_error_t e = build_plan(m);
+                if (e == MARS_OK) e = upload_params(m);
+                if (e != MARS_OK) return e;
+                break;
+            }
+        }
     free_device_state(m);
     size_t per_frame = 0;
     for (uint32_t i = 0; i < nt; i++) {
@@ -889,6 +978,19 @@ static void conv_i8_params(const mars_model_ext_t *m, const mars_op_t *op, mhip_
     p->safe = op->safe;
     p->out_pix_stride = op->out_pix_stride; p->out_ch_off = op->out_ch_off;
     p->variant = op->variant;
+    p->nseg = op->nseg;
+    int c0 = 0;
+    for (int k = 0; k < 4; k++) {
+        p->seg_c0[k] = 0x7fffffff;
+        if (k < op->nseg) {
+            p->seg_in[k] = (const int8_t *)tdev(m, op->seg_t[k]);
+            p->seg_stride[k] = tstride(m, op->seg_t[k]);
+            p->seg_c[k] = op->seg_c[k];
+            p->seg_c0[k] = c0;
+            c0 += op->seg_c[k];
+        }
+    }
+    if (op->nseg > 1) p->in = p->seg_in[0];
 }
 
 static int launch_op(mars_model_ext_t *m, mars_op_t *op) {

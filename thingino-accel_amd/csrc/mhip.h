@@ -66,6 +66,13 @@ typedef struct {
                                    this writes straight into a channel slice of a wider tensor (zero-copy concat) */
     int out_ch_off;
     int variant;                /* 0 = default launch policy, else a code from mhip_conv_i8_variants() */
+    /* virtual concatenation (1x1 convolutions): when nseg > 1 the input pixel's in_c channels are the
+     * concatenation of nseg dense NHWC tensors; `in` is unused.  seg_c0 = first channel of a segment (unused
+     * entries 0x7fffffff), every seg_c a multiple of 32.  See mhip_conv_i8_seg_ok(). */
+    int nseg;
+    const int8_t *seg_in[4];
+    size_t seg_stride[4];
+    int seg_c[4], seg_c0[4];
 } mhip_conv_i8_t;
 /* row of the packed weights / bias that holds output channel oc (channels are permuted so that a lane's
  * results are consecutive channels) */
@@ -75,6 +82,8 @@ int mhip_conv_i8_is_safe(float cs);
 int mhip_conv_i8_tune(const char *key, int value); /* launch-policy knobs, see mars_hip_set_tuning */
 /* launch variants that can run this layer (same bytes out, different speed), the default first; 0 if none */
 int mhip_conv_i8_variants(const mhip_conv_i8_t *p, int *codes, int max);
+/* can this (shape-only: pointers may be dummies) segmented convolution run?  frames/out_stride as they will be */
+int mhip_conv_i8_seg_ok(const mhip_conv_i8_t *p);
 /* packing geometry shared by host packer and kernel */
 /* c_eff: bytes per input pixel in the packed K layout (4 in small-channel mode, else in_c) */
 void mhip_conv_i8_pack_geom(int in_c, int kw, int out_c, int *row_pad, int *oc_pad, int *c_eff);
