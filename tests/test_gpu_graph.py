@@ -259,3 +259,45 @@ def test_autotune_keeps_results(gpu, orc):
     for i, ti in enumerate(hdr["outputs"]):
         assert np.array_equal(g.tensor(ti), m.output_view(i)[2])
     m.close()
+
+
+@pytest.mark.parametrize("order", ["conv_first", "conv_second"])
+@pytest.mark.parametrize("ic,hw", [(32, 48), (64, 40), (128, 24)])
+def test_residual_add_folded_into_conv(gpu, orc, order, ic, hw):
+    """x -> conv1x1 -> t1 -> conv3x3 -> t2; out = Add(t1, t2) in either operand order (different scales per
+    operand): the fused plan folds the Add into the 3x3 convolution's epilogue (one launch fewer) and must produce
+    the reference's bytes; covers the patch-staged (32/64 channels, 48/40 wide) and the one-tile MFMA epilogue"""
+    rng = np.random.default_rng(ic + hw)
+    G = marsfile.Graph()
+    x = G.tensor([1, hw, hw, ic], scale=0.04)
+    t1 = G.tensor([1, hw, hw, ic], scale=0.031)
+    t2 = G.tensor([1, hw, hw, ic], scale=0.027)
+    o = G.tensor([1, hw, hw, ic], scale=0.045)
+    w1 = G.tensor([ic, 1, 1, ic], scale=0.02, data=rng.integers(-127, 128, (ic, 1, 1, ic), dtype=np.int8))
+    b1 = G.tensor([ic], dtype=marsfile.I32, data=rng.integers(-300, 300, ic, dtype=np.int32))
+    w2 = G.tensor([ic, 3, 3, ic], scale=0.01, data=rng.integers(-127, 128, (ic, 3, 3, ic), dtype=np.int8))
+    b2 = G.tensor([ic], dtype=marsfile.I32, data=rng.integers(-300, 300, ic, dtype=np.int32))
+    G.conv(x, t1, w1, b1, (1, 1), (1, 1))
+    G.conv(t1, t2, w2, b2, (3, 3), (1, 1))
+    G.layer(marsfile.ADD, [t2, t1] if order == "conv_first" else [t1, t2], [o])
+    d = G.serialise([x], [o])
+    B = 3
+    xs = [rng.integers(-128, 128, hw * hw * ic, dtype=np.int8).view(np.uint8) for _ in range(B)]
+    outs = {}
+    nops = {}
+    for fusion in (0, 1):
+        m = gpu.Model(d, batch=B, fusion=fusion)
+        for f in range(B):
+            m.input_view(0)[f] = xs[f]
+        m.run()
+        outs[fusion] = m.output_view(0).copy()
+        nops[fusion] = len(m.ops())
+        m.close()
+    assert nops[1] == nops[0] - 1  # the Add launch is gone
+    for f in range(B):
+        g, rc = run_oracle(orc, d, xs[f])
+        assert rc == 0
+        want = g.tensor(o)
+        assert len(np.unique(want)) > 32
+        assert np.array_equal(outs[0][f], want)
+        assert np.array_equal(outs[1][f], want)

@@ -95,8 +95,8 @@ __device__ __forceinline__ uint32_t pack4(int q0, int q1, int q2, int q3) { // l
     return (b << 16) | a;
 }
 __device__ __forceinline__ void lut4_at0(int q0, int q1, int q2, int q3, int &v0, int &v1, int &v2, int &v3) {
-    asm volatile("ds_read_u8 %0, %4 offset:128\n\tds_read_u8 %1, %5 offset:128\n\t"
-                 "ds_read_u8 %2, %6 offset:128\n\tds_read_u8 %3, %7 offset:128"
+    asm volatile("ds_read_i8 %0, %4 offset:128\n\tds_read_i8 %1, %5 offset:128\n\t" // sign-extending byte loads
+                 "ds_read_i8 %2, %6 offset:128\n\tds_read_i8 %3, %7 offset:128"
                  : "=&v"(v0), "=&v"(v1), "=&v"(v2), "=&v"(v3)
                  : "v"(q0), "v"(q1), "v"(q2), "v"(q3)
                  : "memory");
@@ -107,8 +107,24 @@ __device__ __forceinline__ void lds_base_must_be_zero(const void *dynamic_lds) {
     if (a != 0u) __builtin_trap();
 }
 // NV = 8 or 16 accumulators of one pixel (consecutive channels) -> NV/4 packed dwords
-template <int NV, bool HAS_LUT, bool SAFE, bool LUT0>
-__device__ __forceinline__ void requant_pack(const int (&a)[NV], float cs, int lo, const uint8_t *lut128, uint32_t (&pk)[NV / 4]) {
+// fused residual Add (reference mars_runtime.c:835-905, the ADD branch): out = sat8(trunc((v*s_conv + x*s_other)*inv + 0.5f))
+// with v the convolution's (LUT-mapped) int8 result and x the other operand's byte; the host fuses only when the
+// float -> int conversion is provably in range, so the clamp is a med3.
+struct add_args_t {
+    float s_conv, s_other, inv;
+};
+__device__ __forceinline__ int add_one(int v, uint32_t xword, int k, const add_args_t &g, int lo8, int hi8) {
+    const int x = __builtin_amdgcn_sbfe((int)xword, 8 * k, 8);
+    const float y = (float)v * g.s_conv + (float)x * g.s_other;
+    const float t = y * g.inv;
+    const int r = (int)(t + 0.5f);
+    int m;
+    asm("v_med3_i32 %0, %1, %2, %3" : "=v"(m) : "v"(r), "v"(lo8), "v"(hi8));
+    return m;
+}
+template <int NV, bool HAS_LUT, bool SAFE, bool LUT0, bool ADD = false>
+__device__ __forceinline__ void requant_pack(const int (&a)[NV], float cs, int lo, const uint8_t *lut128, uint32_t (&pk)[NV / 4],
+                                             const uint32_t *xw = nullptr, const add_args_t *ga = nullptr) {
     int q[NV];
     const int hi = 127;
 #pragma unroll
@@ -127,12 +143,22 @@ __device__ __forceinline__ void requant_pack(const int (&a)[NV], float cs, int l
         else
             asm volatile("s_waitcnt lgkmcnt(0)"
                          : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]), "+v"(v[3]), "+v"(v[4]), "+v"(v[5]), "+v"(v[6]), "+v"(v[7]));
+        if (ADD) {
+            const int lo8 = -128;
+#pragma unroll
+            for (int i = 0; i < NV; i++) v[i] = add_one(v[i], xw[i >> 2], i & 3, *ga, lo8, hi);
+        }
 #pragma unroll
         for (int g = 0; g < NV / 4; g++) pk[g] = pack4(v[4 * g], v[4 * g + 1], v[4 * g + 2], v[4 * g + 3]);
     } else {
         if (HAS_LUT) {
 #pragma unroll
-            for (int i = 0; i < NV; i++) q[i] = lut128[q[i]];
+            for (int i = 0; i < NV; i++) q[i] = (int8_t)lut128[q[i]];
+        }
+        if (ADD) {
+            const int lo8 = -128;
+#pragma unroll
+            for (int i = 0; i < NV; i++) q[i] = add_one(q[i], xw[i >> 2], i & 3, *ga, lo8, hi);
         }
 #pragma unroll
         for (int g = 0; g < NV / 4; g++) pk[g] = pack4(q[4 * g], q[4 * g + 1], q[4 * g + 2], q[4 * g + 3]);
@@ -217,7 +243,22 @@ __device__ __forceinline__ void epilogue_t(const mhip_conv_i8_t &p, v4i (&acc)[W
         for (int s = 0; s < WOC; s++)
 #pragma unroll
             for (int r = 0; r < 4; r++) a[s * 4 + r] = acc[s][t][r];
-        requant_pack<WOC * 4, HAS_LUT, SAFE, LUT0>(a, p.cs, lo, lut128, pk);
+        if (DIRECT && SAFE && p.add) { // fused residual Add: the other operand has the output's layout
+            const long off = rowoff[prow];
+            const bool ok = off >= 0 && oc0 + chan < p.out_c;
+            uint32_t xw[WOC];
+#pragma unroll
+            for (int s = 0; s < WOC; s++) xw[s] = 0;
+            if (ok) {
+                const int8_t *x = p.add + off + oc0 + chan;
+                if (WOC == 4) { const v4i t4 = *(const v4i *)x; xw[0] = t4[0]; xw[1] = t4[1]; xw[WOC > 2 ? 2 : 0] = t4[2]; xw[WOC > 3 ? 3 : 0] = t4[3]; }
+                else { const uint2 t2 = *(const uint2 *)x; xw[0] = t2.x; xw[WOC > 1 ? 1 : 0] = t2.y; }
+            }
+            const add_args_t ga = {p.add_s_conv, p.add_s_other, p.add_inv};
+            requant_pack<WOC * 4, HAS_LUT, true, LUT0, true>(a, p.cs, lo, lut128, pk, xw, &ga);
+        } else {
+            requant_pack<WOC * 4, HAS_LUT, SAFE, LUT0>(a, p.cs, lo, lut128, pk);
+        }
         if (DIRECT) {
             const long off = rowoff[prow];
             if (off >= 0 && oc0 + chan < p.out_c) {
@@ -849,6 +890,28 @@ __global__ __launch_bounds__(NTHREADS) void conv_i8_patch(const mhip_conv_i8_t p
         }
         first = false;
         const int8_t *patch = patch0 + buf * patch_bytes;
+        int tx, ty;
+        unsigned f;
+        tile_xy(t, tx, ty, f);
+        // output offsets of this lane's pixels; with a fused residual Add the other operand (same layout) is fetched
+        // now, ahead of the K loop, so its latency never shows
+        int voffs[WPX];
+        uint32_t xw[WPX][WOC];
+#pragma unroll
+        for (int u = 0; u < WPX; u++) {
+            const int oy = ty * TH + wv * WPX + u, ox = tx * PT_TW + frow;
+            const unsigned off = f * (unsigned)p.out_stride + (unsigned)(oy * p.out_w + ox) * (unsigned)pstride +
+                                 (unsigned)(p.out_ch_off + oc0 + chan);
+            const bool ok = oy < p.out_h && ox < p.out_w && oc0 + chan < p.out_c;
+            voffs[u] = ok ? (int)off : -1;
+#pragma unroll
+            for (int q = 0; q < WOC; q++) xw[u][q] = 0;
+            if (p.add && ok) {
+                const int8_t *x = p.add + off;
+                if (WOC == 4) { const v4i t4 = *(const v4i *)x; xw[u][0] = t4[0]; xw[u][1] = t4[1]; xw[u][WOC > 2 ? 2 : 0] = t4[2]; xw[u][WOC > 3 ? 3 : 0] = t4[3]; }
+                else { const uint2 t2 = *(const uint2 *)x; xw[u][0] = t2.x; xw[u][WOC > 1 ? 1 : 0] = t2.y; }
+            }
+        }
         v4i acc[WOC][WPX];
         for (int ks = 0; ks < nks; ks++) {
             const int du = dutab[ks * 4 + fchunk];
@@ -876,23 +939,21 @@ __global__ __launch_bounds__(NTHREADS) void conv_i8_patch(const mhip_conv_i8_t p
             }
         }
         if (dbl) buf ^= 1;
-        int tx, ty;
-        unsigned f;
-        tile_xy(t, tx, ty, f);
 #pragma unroll
         for (int u = 0; u < WPX; u++) {
-            const int oy = ty * TH + wv * WPX + u, ox = tx * PT_TW + frow;
-            const unsigned off = f * (unsigned)p.out_stride + (unsigned)(oy * p.out_w + ox) * (unsigned)pstride +
-                                 (unsigned)(p.out_ch_off + oc0 + chan);
-            const bool ok = oy < p.out_h && ox < p.out_w && oc0 + chan < p.out_c;
             uint32_t pk[WOC];
             int a[WOC * 4];
 #pragma unroll
             for (int q = 0; q < WOC; q++)
 #pragma unroll
                 for (int r = 0; r < 4; r++) a[q * 4 + r] = acc[q][u][r];
-            requant_pack<WOC * 4, HAS_LUT, true, true>(a, p.cs, lo, lut128, pk);
-            const int voff = ok ? (int)off : -1;
+            if (p.add) {
+                const add_args_t ga = {p.add_s_conv, p.add_s_other, p.add_inv};
+                requant_pack<WOC * 4, HAS_LUT, true, true, true>(a, p.cs, lo, lut128, pk, xw[u], &ga);
+            } else {
+                requant_pack<WOC * 4, HAS_LUT, true, true>(a, p.cs, lo, lut128, pk);
+            }
+            const int voff = voffs[u];
             if (WOC == 4)
                 __builtin_amdgcn_raw_buffer_store_b128((v4i){(int)pk[0], (int)pk[1], (int)pk[2], (int)pk[3]}, orsrc, voff, 0, 0);
             else if (WOC == 2)
@@ -1401,6 +1462,7 @@ static bool seg_valid(const mhip_conv_i8_t *p) {
     return c == p->in_c;
 }
 static bool persist_eligible(const mhip_conv_i8_t *p) {
+    if (p->add) return false; // the fused residual Add lives in the one-tile and patch-staged epilogues
     return !p->out_nchw && p->safe && (p->in_c & (p->in_c - 1)) == 0 && p->kh * p->kw <= 32 &&
            (long)p->kh * p->kw * (p->kw - 1) < 65536 && persist_out_bytes(p) <= 0x7fffffffL;
 }
@@ -1504,6 +1566,9 @@ extern "C" int mhip_conv_i8(const mhip_conv_i8_t *p) {
     int row_pad, oc_pad;
     mhip_conv_i8_pack_geom(p->in_c, p->kw, p->out_c, &row_pad, &oc_pad, nullptr);
     if (row_pad != p->row_pad || oc_pad != p->oc_pad) return -1;
+    if (p->add && (!p->safe || p->out_nchw || ((p->out_c | p->out_pix_stride | p->out_ch_off) & 15) || (p->in_c % 16) != 0 ||
+                   mhip_conv_i8_small_c(p->in_c, p->kw, p->out_c) || p->nseg > 1))
+        return -1;
     const long total_pix = (long)p->frames * p->out_h * p->out_w;
     const int k64 = (p->kh * p->row_pad + BK - 1) / BK * BK;
     if (total_pix <= 0 || total_pix > 0x7fffffffL || (total_pix + BP - 1) / BP * (oc_pad / 32) > 0x7fffffffL) return -1;

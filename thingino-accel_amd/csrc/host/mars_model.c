@@ -573,7 +573,7 @@ static void elide_concat(mars_model_ext_t *m) {
             if (m->ops[k].t_out == ti) j = k;
         if (j < 0) continue;
         mars_op_t *pr = &m->ops[j];
-        if (pr->out_pix_stride) continue;
+        if (pr->out_pix_stride || pr->add_t) continue; /* a folded Add needs its other operand laid out like the output */
         const size_t npix = (size_t)cs->out_h * cs->out_w;
         int ok = 0;
         if (pr->kind == OP_CONV_I8 && !pr->nchw) ok = (size_t)pr->out_h * pr->out_w == npix && pr->out_c == cs->in_c;
@@ -597,6 +597,77 @@ static void elide_concat(mars_model_ext_t *m) {
         pr->bytes += 0;
         m->mt[ti].needed = 0;
         cs->kind = -1; /* dropped below */
+    }
+    int w = 0;
+    for (int i = 0; i < m->n_ops; i++)
+        if (m->ops[i].kind != -1) m->ops[w++] = m->ops[i];
+    m->n_ops = w;
+    free(readers);
+    free(writers);
+}
+
+/* Residual Add folded into the convolution that produces one of its operands (the bottleneck shortcut of C3):
+ * out = Add(conv_result, x) is evaluated in the convolution's epilogue with the reference's float steps
+ * (mars_runtime.c ADD branch: (a*sa + b*sb) * (1/so) + 0.5f, truncated, saturated), reading x where the output
+ * goes.  Saves writing the convolution result and reading it back.  Conditions: the convolution result has no
+ * other reader, x and the Add output have the same dense layout and frame stride, nothing touches them in
+ * between, and the scales keep the float -> int conversion in range (so no x86 fix-up is needed). */
+static size_t planned_stride(const mtensor_t *t) {
+    size_t s = ALIGN_UP(t->extent > t->bytes ? t->extent : t->bytes, 256);
+    return s ? s : 256;
+}
+static void fuse_add(mars_model_ext_t *m) {
+    const int nt = (int)m->pub.header.num_tensors;
+    int *readers = (int *)calloc((size_t)nt + 1, sizeof(int));
+    int *writers = (int *)calloc((size_t)nt + 1, sizeof(int));
+    if (!readers || !writers) { free(readers); free(writers); return; }
+    for (int i = 0; i < m->n_ops; i++) {
+        for (int k = 0; k < m->ops[i].n_in; k++)
+            if (m->ops[i].t_in[k] >= 0) readers[m->ops[i].t_in[k]]++;
+        if (m->ops[i].t_out >= 0) writers[m->ops[i].t_out]++;
+    }
+    for (int j = 0; j < m->n_ops; j++) {
+        mars_op_t *ad = &m->ops[j];
+        if (ad->kind != OP_BINARY_I8 || ad->is_mul || ad->n_in != 2 || ad->out_pix_stride) continue;
+        for (int side = 0; side < 2; side++) {
+            const int A = ad->t_in[side], X = ad->t_in[1 - side], O = ad->t_out;
+            if (A < 0 || X < 0 || O < 0 || A == X || O == X || O == A) continue;
+            if (readers[A] != 1 || writers[A] != 1 || m->mt[A].io_in || m->mt[A].io_out || m->mt[A].is_weight) continue;
+            if (m->mt[X].is_weight || m->mt[O].is_weight || writers[O] != 1) continue;
+            int i = -1;
+            for (int k = 0; k < j; k++)
+                if (m->ops[k].t_out == A) i = k;
+            if (i < 0) continue;
+            mars_op_t *c = &m->ops[i];
+            if (c->kind != OP_CONV_I8 || c->nchw || !c->safe || c->out_pix_stride || (c->out_c & 15) || (c->in_c & 15) ||
+                c->nseg || c->add_t || c->n_in != 1)
+                continue;
+            if (ad->n != (size_t)c->out_h * c->out_w * c->out_c) continue;
+            if (planned_stride(&m->mt[X]) != planned_stride(&m->mt[O])) continue;
+            const float s_conv = side == 0 ? ad->f0 : ad->f1, s_other = side == 0 ? ad->f1 : ad->f0, inv = ad->f2;
+            const double bound = 128.0 * (fabs((double)s_conv) + fabs((double)s_other)) * fabs((double)inv) + 1.0;
+            if (!(bound < 2147483000.0)) continue; /* also rejects NaN / inf */
+            int clash = 0;
+            for (int k = i; k <= j && !clash; k++) {
+                const mars_op_t *o = &m->ops[k];
+                if (o->t_out == X) clash = 1; /* x must be complete before the convolution runs */
+                if (k > i && k < j) {
+                    if (o->t_out == O) clash = 1;
+                    for (int q = 0; q < o->n_in; q++)
+                        if (o->t_in[q] == O) clash = 1;
+                }
+            }
+            if (clash) continue;
+            c->t_out = O;
+            c->add_t = X + 1;
+            c->add_s_conv = s_conv; c->add_s_other = s_other; c->add_inv = inv;
+            c->t_in[c->n_in++] = X;
+            c->bytes += (double)ad->n;
+            m->mt[A].needed = 0;
+            ad->kind = -1;
+            readers[A] = 0;
+            break;
+        }
     }
     int w = 0;
     for (int i = 0; i < m->n_ops; i++)
@@ -740,6 +811,7 @@ static mars_error_t build_plan(mars_model_ext_t *m) {
     for (uint32_t i = 0; i < nl; i++) plan_layer(m, (int)i);
     if (m->fusion >= 1) {
         fuse_silu(m);
+        fuse_add(m);
         if (!m->no_vconcat) virtual_concat(m);
         elide_concat(m);
     }
@@ -978,6 +1050,10 @@ static void conv_i8_params(const mars_model_ext_t *m, const mars_op_t *op, mhip_
     p->safe = op->safe;
     p->out_pix_stride = op->out_pix_stride; p->out_ch_off = op->out_ch_off;
     p->variant = op->variant;
+    if (op->add_t && tstride(m, op->add_t - 1) == p->out_stride) {
+        p->add = (const int8_t *)tdev(m, op->add_t - 1);
+        p->add_s_conv = op->add_s_conv; p->add_s_other = op->add_s_other; p->add_inv = op->add_inv;
+    }
     p->nseg = op->nseg;
     int c0 = 0;
     for (int k = 0; k < 4; k++) {
@@ -1007,6 +1083,7 @@ static int launch_op(mars_model_ext_t *m, mars_op_t *op) {
                 if (rc) return rc;
                 p.in = (const int8_t *)m->scratch_dev; p.in_stride = ss; p.in_c = op->c_pad;
             }
+            if (op->add_t && !p.add) return -1; /* planner guaranteed equal strides */
             return mhip_conv_i8(&p);
         }
         case OP_CONV_F32: {

@@ -69,6 +69,11 @@ typedef struct {
     /* virtual concatenation (1x1 convolutions): when nseg > 1 the input pixel's in_c channels are the
      * concatenation of nseg dense NHWC tensors; `in` is unused.  seg_c0 = first channel of a segment (unused
      * entries 0x7fffffff), every seg_c a multiple of 32.  See mhip_conv_i8_seg_ok(). */
+    /* fused residual Add (ADD layer folded into this convolution's epilogue): `add` = the other operand, an int8
+     * tensor with exactly the output's layout and frame stride (NULL = none); out = sat8(trunc((conv*add_s_conv +
+     * other*add_s_other)*add_inv + 0.5f)).  Only the one-tile and patch-staged forms implement it. */
+    const int8_t *add;
+    float add_s_conv, add_s_other, add_inv;
     int nseg;
     const int8_t *seg_in[4];
     size_t seg_stride[4];
