@@ -18,19 +18,18 @@
 //   of one kernel row are CONTIGUOUS in the input, so a 16-byte K chunk of a
 //   pixel is one 16-byte global access -- there is no im2col buffer anywhere.
 //
-// Main kernel (in_c % 16 == 0): both tiles go HBM/L2 -> LDS by LDS-DMA
-// (global_load_lds_dwordx4, no VGPR round trip) in a 3/4-stage ring with
-// counted vmcnt and one raw s_barrier per K step; taps that fall outside the
-// image source a 16-byte zero page.  LDS rows are 64 bytes, XOR-swizzled on the
-// SOURCE side (LDS-DMA writes lane-linearly) so that the ds_read_b128 fragment
-// reads are bank-conflict free (verified: SQ_LDS_BANK_CONFLICT = 0).
-// Epilogue: bias from registers, float requantisation in-register, optional
-// ReLU and 256-entry LUT (fused conv->sigmoid->mul) from LDS, results staged
-// through LDS and written with coalesced 16-byte stores.
-//
-// Small-channel kernel (in_c <= 4: the RGB stem): input patch of an 8x16 output tile
-// staged once in LDS, pixels widened to 4 bytes, weights resident in LDS.
-// Generic kernel (any other in_c): register-staged, byte-granular gather.
+// Kernels (all share the LDS-DMA staging, the source-side XOR swizzle that makes the ds_read_b128 fragment reads
+// bank-conflict free, and the register epilogue: bias as the first MFMA's C operand, 6 VALU per value requantise,
+// LUT gather with an immediate offset, packed 16-byte stores of consecutive channels):
+//   conv_i8_mfma     in_c % 16 == 0, one BPX x BN tile per workgroup, 2-3 stage ring, counted vmcnt, one raw
+//                    s_barrier per K step                                   -> deep K loops (3x3, >= 64 channels)
+//   conv_i8_persist  the same inner loop walking a run of pixel tiles with cross-tile prefetch and buffer stores;
+//                    SEG: input = never-materialised concat of up to 4 tensors -> 1x1 layers
+//   conv_i8_patch    input patch of a tile staged once in LDS, weights resident, taps fed from LDS
+//                                                                           -> k x k layers on wide maps
+//   conv_i8_smallc   in_c <= 4 (RGB stem): patch with pixels widened to 4 bytes, weights resident
+//   conv_i8_generic  any other in_c: register-staged byte gather (fallback)
+// Launch variants / policy / autotune hooks: bottom of this file.  Design notes: DESIGN.md section 5.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdlib.h>
