@@ -560,6 +560,7 @@ __global__ __launch_bounds__(NTHREADS) void conv_i8_persist(const mhip_conv_i8_t
     const int8_t *xwin[XI];
     unsigned tapmask[XI];
     unsigned rowf[SEG ? XI : 1], rowrem[SEG ? XI : 1]; // SEG: frame and pixel-in-frame of the rows this lane fetches
+    unsigned rowrem_up[SEG ? XI : 1];                  // ... and the pixel a 2x nearest-upsampled segment reads instead
     auto setup_rows = [&](unsigned tile) { // window origin and in-image tap mask of the rows this lane fetches
 #pragma unroll
         for (int j = 0; j < XI; j++) {
@@ -570,6 +571,8 @@ __global__ __launch_bounds__(NTHREADS) void conv_i8_persist(const mhip_conv_i8_t
             if (SEG) {
                 rowf[j] = f;
                 rowrem[j] = rem;
+                const unsigned oy = fdiv(rem, dow), ox = rem - oy * (unsigned)p.out_w;
+                rowrem_up[j] = (oy >> 1) * ((unsigned)p.out_w >> 1) + (ox >> 1);
                 tapmask[j] = valid ? 1u : 0u;
                 continue;
             }
@@ -608,11 +611,12 @@ __global__ __launch_bounds__(NTHREADS) void conv_i8_persist(const mhip_conv_i8_t
             const unsigned fstride = (unsigned)(hi ? p.seg_stride[sb2] : p.seg_stride[sa]);
             const unsigned segc = (unsigned)(hi ? p.seg_c[sb2] : p.seg_c[sa]);
             const unsigned coff = pos - (unsigned)(hi ? p.seg_c0[sb2] : p.seg_c0[sa]);
+            const bool up = ((p.seg_up >> (hi ? sb2 : sa)) & 1) != 0; // segment = 2x nearest upsample of its tensor
             const bool kvalid = (int)pos < p.in_c;
 #pragma unroll
             for (int j = 0; j < XI; j++) {
                 const bool ok = kvalid & (tapmask[j] != 0u);
-                const int8_t *src = base + (size_t)rowf[j] * fstride + (size_t)rowrem[j] * segc + coff;
+                const int8_t *src = base + (size_t)rowf[j] * fstride + (size_t)(up ? rowrem_up[j] : rowrem[j]) * segc + coff;
                 glds16(ok ? src : zeros, sb + (wv * (BPX / 4) + j * 16) * BK);
             }
         } else {
@@ -1450,6 +1454,8 @@ static bool seg_valid(const mhip_conv_i8_t *p) {
         p->pad_left || p->in_h != p->out_h || p->in_w != p->out_w)
         return false;
     int c = 0;
+    if (p->seg_up && ((p->out_h | p->out_w) & 1)) return false;
+    if (p->seg_up >> p->nseg) return false;
     for (int i = 0; i < 4; i++) {
         if (i < p->nseg) {
             if (!p->seg_in[i] || p->seg_c[i] <= 0 || (p->seg_c[i] & 31) || p->seg_c0[i] != c) return false;

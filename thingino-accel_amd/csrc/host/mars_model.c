@@ -742,6 +742,41 @@ static void virtual_concat(mars_model_ext_t *m) {
         }
         for (int a = 0; a < ns; a++) m->ops[sl[a]].kind = -1;
         m->mt[T].needed = 0;
+        /* a segment that is a 2x2 nearest upsample (reference :1003-1044) of a half-size tensor, read by nothing
+         * else: the convolution reads the half-size tensor at pixel (y/2, x/2) and the upsample launch goes too */
+        for (int a = 0; a < ns; a++) {
+            const int S = m->ops[sl[a]].t_in[0];
+            int up = -1, nread = 0, nwrite = 0, ok = 1;
+            for (int i = 0; i < m->n_ops; i++) {
+                const mars_op_t *o = &m->ops[i];
+                if (o->kind == -1) continue;
+                if (o->t_out == S) { nwrite++; up = i; }
+                for (int k = 0; k < o->n_in; k++)
+                    if (o->t_in[k] == S && !(o->kind == OP_CONV_I8 && o->nseg == ns && o->seg_t[a] == S)) nread++;
+            }
+            if (nwrite != 1 || nread != 0 || up < 0 || m->mt[S].io_out || m->mt[S].io_in || m->mt[S].is_weight) continue;
+            const mars_op_t *u = &m->ops[up];
+            if (u->kind != OP_UPSAMPLE || u->out_pix_stride || u->scale_h != 2 || u->scale_w != 2 || u->out_h != 2 * u->in_h ||
+                u->out_w != 2 * u->in_w || u->in_c != m->ops[sl[a]].in_c || u->out_h != s0->out_h || u->out_w != s0->out_w)
+                continue;
+            const int U = u->t_in[0];
+            if (U < 0 || U == S) continue;
+            int last = -1;
+            for (int i = 0; i < m->n_ops; i++)
+                if (m->ops[i].kind == OP_CONV_I8 && m->ops[i].nseg == ns && m->ops[i].seg_t[a] == S) last = i;
+            for (int i = up; i <= last && ok; i++)
+                if (m->ops[i].kind != -1 && m->ops[i].t_out == U) ok = 0; /* the half-size tensor must stay as it was */
+            if (!ok) continue;
+            for (int i = 0; i < m->n_ops; i++) {
+                mars_op_t *o = &m->ops[i];
+                if (o->kind == OP_CONV_I8 && o->nseg == ns && o->seg_t[a] == S) {
+                    o->seg_t[a] = o->t_in[a] = U;
+                    o->seg_up |= 1 << a;
+                }
+            }
+            m->ops[up].kind = -1;
+            m->mt[S].needed = 0;
+        }
     }
     int w = 0;
     for (int i = 0; i < m->n_ops; i++)
@@ -1055,6 +1090,7 @@ static void conv_i8_params(const mars_model_ext_t *m, const mars_op_t *op, mhip_
         p->add_s_conv = op->add_s_conv; p->add_s_other = op->add_s_other; p->add_inv = op->add_inv;
     }
     p->nseg = op->nseg;
+    p->seg_up = op->seg_up;
     int c0 = 0;
     for (int k = 0; k < 4; k++) {
         p->seg_c0[k] = 0x7fffffff;

@@ -78,6 +78,7 @@ typedef struct {
     const int8_t *seg_in[4];
     size_t seg_stride[4];
     int seg_c[4], seg_c0[4];
+    int seg_up;                 /* bit k: segment k is read through a 2x2 nearest upsample (its tensor is out_h/2 x out_w/2) */
 } mhip_conv_i8_t;
 /* row of the packed weights / bias that holds output channel oc (channels are permuted so that a lane's
  * results are consecutive channels) */
