@@ -1091,11 +1091,10 @@ __global__ __launch_bounds__(NTHREADS) void conv_i8_smallc(const mhip_conv_i8_t 
     constexpr int BN = WOC * 16;
     constexpr int WPX = SC_TH / 4; // tile rows (= pixel subtiles of 16) per wave
     extern __shared__ __attribute__((aligned(16))) int8_t dyn[];
-    const int wrow = k64 + 16;                       // padded weight row: conflict-free fragment reads
     uint8_t *slut = (uint8_t *)dyn;                  // LDS byte address 0 (no static LDS here: requant_pack LUT0)
     long *rowoff = (long *)(dyn + 256);              // [256]
-    int8_t *wl = dyn + 256 + SC_BP * 8;              // [BN][wrow]
-    int8_t *patch0 = wl + ((BN * wrow + 15) & ~15);  // 2 x [(PH+1)][PWp] dwords (double buffer)
+    int8_t *wl = dyn + 256 + SC_BP * 8;              // [k64/64][BN][64], rows swizzled like the ring tiles (lds_off)
+    int8_t *patch0 = wl + BN * k64;                  // 2 x [(PH+1)][PWp] dwords (double buffer)
     const int patch_bytes = ((PH + 1) * PWp * 4 + 15) & ~15;
     int8_t *tile = patch0 + 2 * patch_bytes;         // [256][BN+OPAD]
     lds_base_must_be_zero(dyn);
@@ -1105,7 +1104,7 @@ __global__ __launch_bounds__(NTHREADS) void conv_i8_smallc(const mhip_conv_i8_t 
     if (p.lut && tid < 64) ((uint32_t *)slut)[tid] = ((const uint32_t *)p.lut)[tid];
     for (int i = tid; i < BN * (k64 / 16); i += NTHREADS) {
         const int row = i / (k64 / 16), c = i - row * (k64 / 16);
-        *(v4i *)(wl + row * wrow + c * 16) = *(const v4i *)(p.w + (size_t)row * k64 + c * 16);
+        *(v4i *)(wl + (c >> 2) * (BN * BK) + lds_off(row, c & 3)) = *(const v4i *)(p.w + (size_t)row * k64 + c * 16);
     }
     for (int i = tid; i < 2 * patch_bytes / 4; i += NTHREADS) ((uint32_t *)patch0)[i] = 0;
 
@@ -1190,18 +1189,26 @@ __global__ __launch_bounds__(NTHREADS) void conv_i8_smallc(const mhip_conv_i8_t 
         v4i acc[WOC][WPX];
         init_acc<WPX, WOC>(p, acc, 0);
         const int px = lane & 15, c = lane >> 4;
+        const bool even_sw = ((p.stride_w | PWp) & 1) == 0;
         for (int ks = 0; ks < nks; ks++) {
             const int ky = 2 * ks + (c >> 1);
             v4i xb[WPX];
 #pragma unroll
             for (int u = 0; u < WPX; u++) {
                 const int py = wv * WPX + u;
-                const uint32_t *q = (const uint32_t *)patch + (py * p.stride_h + ky) * PWp + px * p.stride_w + (c & 1) * 4;
-                xb[u] = (v4i){(int)q[0], (int)q[1], (int)q[2], (int)q[3]}; // row PH (odd-kh tail) exists and is zero
+                const int idx = (py * p.stride_h + ky) * PWp + px * p.stride_w + (c & 1) * 4; // dwords
+                if (even_sw) { // 8-byte aligned: two ds_read_b64, conflict-free for 16 lanes at an 8-byte stride
+                    const uint2 *q2 = (const uint2 *)((const uint32_t *)patch + (idx & ~1));
+                    const uint2 a0 = q2[0], a1 = q2[1];
+                    xb[u] = (v4i){(int)a0.x, (int)a0.y, (int)a1.x, (int)a1.y};
+                } else {
+                    const uint32_t *q = (const uint32_t *)patch + idx;
+                    xb[u] = (v4i){(int)q[0], (int)q[1], (int)q[2], (int)q[3]};
+                } // row PH (odd-kh tail) exists and is zero
             }
 #pragma unroll
             for (int s = 0; s < WOC; s++) {
-                const v4i wa = *(const v4i *)(wl + (s * 16 + px) * wrow + ks * BK + c * 16);
+                const v4i wa = *(const v4i *)(wl + ks * (BN * BK) + lds_off(s * 16 + px, c));
 #pragma unroll
                 for (int u = 0; u < WPX; u++) acc[s][u] = __builtin_amdgcn_mfma_i32_16x16x64_i8(wa, xb[u], acc[s][u], 0, 0, 0);
             }
@@ -1299,7 +1306,7 @@ static int launch_smallc(const mhip_conv_i8_t *p, int k64) {
     const int gpr = (PW + 3) / 4;
     if ((long)PH * gpr > 2 * NTHREADS || ntiles > 0x7fffffffL) return -1;
     constexpr int BN = WOC * 16;
-    const size_t lds = (((size_t)BN * (k64 + 16) + 15) & ~(size_t)15) + 2 * ((((size_t)PH + 1) * PWp * 4 + 15) & ~(size_t)15) +
+    const size_t lds = (size_t)BN * k64 + 2 * ((((size_t)PH + 1) * PWp * 4 + 15) & ~(size_t)15) +
                        (size_t)SC_BP * (BN + OPAD) + 256 + (size_t)SC_BP * 8;
     if (lds > 64 * 1024) return -1;
     long grid = ntiles < 256L * 8 ? ntiles : 256L * 8;
