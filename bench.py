@@ -125,9 +125,16 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     dist = None
-    if world > 1:
+    # BENCH_FORCE_DIST=1: take the multi-process path (process group, descriptor-only load is skipped on rank 0, arena
+    # broadcast, barriers, max over ranks) with however many ranks there are -- a one-GPU rehearsal of the N>1 code
+    multi = world > 1 or os.environ.get("BENCH_FORCE_DIST") == "1"
+    if multi:
         import torch
         import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
         torch.cuda.set_device(local_rank)
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
     os.environ.setdefault("MARS_HIP_DEVICE", str(local_rank))
@@ -141,12 +148,12 @@ def main():
     in_bytes = marsfile.tensor_nbytes(tensors[hdr["inputs"][0]])
     out_ids = list(hdr["outputs"])
 
-    if world > 1 and rank != 0:
+    if multi and rank != 0:
         # descriptors only; the packed parameters arrive by RCCL broadcast from rank 0
         model = M.Model(D.strip_weights(model_bytes), batch=args.batch, flags=1)
     else:
         model = M.Model(model_bytes, batch=args.batch)
-    if world > 1:
+    if multi:
         import torch
         ptr, nbytes = model.param_arena()
         t = torch.as_tensor(D.DeviceBuffer(ptr, nbytes), device="cuda")

@@ -45,8 +45,15 @@ extern "C" int mhip_init(int device_hint) {
         return -2;
     }
     if (mhip_check(hipSetDevice(dev), "hipSetDevice")) return -1;
-    if (mhip_check(hipStreamCreateWithFlags(&g_stream, hipStreamNonBlocking), "hipStreamCreate")) return -3;
-    if (mhip_check(hipStreamCreateWithFlags(&g_aux, hipStreamNonBlocking), "hipStreamCreate aux")) return -3;
+    // Main stream (the graph) and auxiliary stream (the detection tail of the previous batch) must sit on
+    // DIFFERENT hardware queues or the tail serialises with the next batch.  HIP multiplexes streams onto a few
+    // hardware queues round-robin (GPU_MAX_HW_QUEUES, default 4), so in a process that owns other streams (torch,
+    // RCCL) two plain streams can land on the same queue (measured: +0.9 ms per batch).  Streams of different
+    // priority come from different queue pools, which guarantees the separation.
+    int prio_lo = 0, prio_hi = 0;
+    if (hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi) != hipSuccess) prio_lo = prio_hi = 0;
+    if (mhip_check(hipStreamCreateWithPriority(&g_stream, hipStreamNonBlocking, prio_hi), "hipStreamCreate")) return -3;
+    if (mhip_check(hipStreamCreateWithPriority(&g_aux, hipStreamNonBlocking, prio_lo), "hipStreamCreate aux")) return -3;
     if (mhip_check(hipMalloc(&g_zero_page, 256), "hipMalloc zero page") ||
         mhip_check(hipMemset(g_zero_page, 0, 256), "hipMemset zero page"))
         return -3;
