@@ -301,3 +301,36 @@ def test_residual_add_folded_into_conv(gpu, orc, order, ic, hw):
         assert len(np.unique(want)) > 32
         assert np.array_equal(outs[0][f], want)
         assert np.array_equal(outs[1][f], want)
+
+
+def test_deferred_load_and_arena_copy(gpu):
+    """what every rank but 0 does in the multi-GPU job: load DESCRIPTORS only (weights blob zeroed,
+    MARS_HIP_LOAD_DEFER_WEIGHTS), receive rank 0's packed parameter arena byte for byte (here: a device-to-device
+    copy instead of the RCCL broadcast), run -- outputs must equal the fully loaded model's"""
+    import ctypes as C
+    import sys
+    sys.path.insert(0, os.path.join(HERE, "..", "thingino-accel_amd"))
+    import dist as D
+    d = gpu.synth_model(width_x16=4, input_hw=128, seed=31)
+    hdr, tensors, _ = marsfile.parse(d)
+    nb = marsfile.tensor_nbytes(tensors[hdr["inputs"][0]])
+    B = 2
+    full = gpu.Model(d, batch=B)
+    lazy = gpu.Model(D.strip_weights(d), batch=B, flags=1)
+    pa, na = full.param_arena()
+    pb, nbytes = lazy.param_arena()
+    assert na == nbytes and pa and pb and pa != pb  # identical layout on both "ranks"
+    hip = C.CDLL("libamdhip64.so")
+    hip.hipMemcpy.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
+    assert hip.hipMemcpy(pb, pa, na, 3) == 0  # hipMemcpyDeviceToDevice
+    for f in range(B):
+        x = lcg_frame(0xD15C0000 + f, nb)
+        full.input_view(0)[f] = x
+        lazy.input_view(0)[f] = x
+    full.run()
+    lazy.run()
+    for i in range(len(hdr["outputs"])):
+        assert np.array_equal(full.output_view(i), lazy.output_view(i))
+        assert full.output_view(i).any()
+    full.close()
+    lazy.close()
