@@ -474,17 +474,19 @@ __global__ __launch_bounds__(NTHREADS) void conv_i8_mfma(const mhip_conv_i8_t p,
         else wait_vmcnt<0>();
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
-        if (ks + STAGES - 1 < nks) issue(ks + STAGES - 1, nstage);
+        // all fragment reads of this step first, then the next stage's DMA (its address math hides the LDS latency),
+        // then the MFMAs
         const int8_t *xs = lds + stage * STAGE, *ws = xs + BPX * BK;
-        v4i xb[WPX];
+        v4i xb[WPX], wa[WOC];
 #pragma unroll
         for (int t = 0; t < WPX; t++) xb[t] = *(const v4i *)(xs + lds_off(pxw + t * 16 + frow, fchunk));
 #pragma unroll
-        for (int s = 0; s < WOC; s++) {
-            v4i wa = *(const v4i *)(ws + lds_off(ocw + s * 16 + frow, fchunk));
+        for (int s = 0; s < WOC; s++) wa[s] = *(const v4i *)(ws + lds_off(ocw + s * 16 + frow, fchunk));
+        if (ks + STAGES - 1 < nks) issue(ks + STAGES - 1, nstage);
 #pragma unroll
-            for (int t = 0; t < WPX; t++) acc[s][t] = __builtin_amdgcn_mfma_i32_16x16x64_i8(wa, xb[t], acc[s][t], 0, 0, 0);
-        }
+        for (int s = 0; s < WOC; s++)
+#pragma unroll
+            for (int t = 0; t < WPX; t++) acc[s][t] = __builtin_amdgcn_mfma_i32_16x16x64_i8(wa[s], xb[t], acc[s][t], 0, 0, 0);
         stage = stage + 1 == STAGES ? 0 : stage + 1;
         nstage = nstage + 1 == STAGES ? 0 : nstage + 1;
     }
@@ -674,6 +676,14 @@ __global__ __launch_bounds__(NTHREADS) void conv_i8_persist(const mhip_conv_i8_t
             wait_vmcnt_at_most<(STAGES - 2) * L, NST>(younger[0]);
             __builtin_amdgcn_s_barrier();
             asm volatile("" ::: "memory");
+            // all fragment reads of this step first, then the next stage's DMA (its address math hides the LDS
+            // latency), then the MFMAs
+            const int8_t *xs = lds + stage * STAGE, *ws = xs + BPX * BK;
+            v4i xb[WPX], wa[WOC];
+#pragma unroll
+            for (int t = 0; t < WPX; t++) xb[t] = *(const v4i *)(xs + lds_off(pxw + t * 16 + frow, fchunk));
+#pragma unroll
+            for (int s = 0; s < WOC; s++) wa[s] = *(const v4i *)(ws + lds_off(ocw + s * 16 + frow, fchunk));
             int n = 0;
             if (itile < t1) {
                 issue(iks, nstage);
@@ -686,24 +696,16 @@ __global__ __launch_bounds__(NTHREADS) void conv_i8_persist(const mhip_conv_i8_t
 #pragma unroll
             for (int i = 0; i + 1 < STAGES - 1; i++) younger[i] = younger[i + 1] + n;
             younger[STAGES - 2] = 0;
-            const int8_t *xs = lds + stage * STAGE, *ws = xs + BPX * BK;
-            v4i xb[WPX];
-#pragma unroll
-            for (int t = 0; t < WPX; t++) xb[t] = *(const v4i *)(xs + lds_off(pxw + t * 16 + frow, fchunk));
             if (ks == 0) { // the first step of a tile takes the bias as its C operand: accumulators start there
 #pragma unroll
-                for (int s = 0; s < WOC; s++) {
-                    v4i wa = *(const v4i *)(ws + lds_off(ocw + s * 16 + frow, fchunk));
+                for (int s = 0; s < WOC; s++)
 #pragma unroll
-                    for (int t = 0; t < WPX; t++) acc[s][t] = __builtin_amdgcn_mfma_i32_16x16x64_i8(wa, xb[t], bias[s], 0, 0, 0);
-                }
+                    for (int t = 0; t < WPX; t++) acc[s][t] = __builtin_amdgcn_mfma_i32_16x16x64_i8(wa[s], xb[t], bias[s], 0, 0, 0);
             } else {
 #pragma unroll
-                for (int s = 0; s < WOC; s++) {
-                    v4i wa = *(const v4i *)(ws + lds_off(ocw + s * 16 + frow, fchunk));
+                for (int s = 0; s < WOC; s++)
 #pragma unroll
-                    for (int t = 0; t < WPX; t++) acc[s][t] = __builtin_amdgcn_mfma_i32_16x16x64_i8(wa, xb[t], acc[s][t], 0, 0, 0);
-                }
+                    for (int t = 0; t < WPX; t++) acc[s][t] = __builtin_amdgcn_mfma_i32_16x16x64_i8(wa[s], xb[t], acc[s][t], 0, 0, 0);
             }
             stage = stage + 1 == STAGES ? 0 : stage + 1;
             nstage = nstage + 1 == STAGES ? 0 : nstage + 1;
