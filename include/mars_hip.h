@@ -124,6 +124,18 @@ typedef struct {
 /* returns the file size; writes at most cap bytes (call with cap 0 to size) */
 size_t mars_synth_model(const mars_synth_opts_t *opts, void *buf, size_t cap);
 
+/* ------------------------------------------------------- image front-end */
+/* The reference's load_image() (src/mars/mars_yolo_test.c:40-77) after the file decode, on the GPU: letterbox
+ * resize of a uint8 RGB image [h][w][3] to tw x th exactly as stbir_resize_uint8() of the vendored
+ * stb_image_resize.h does it (Catmull-Rom up / Mitchell down, clamped edges, linear), grey (-17) padding,
+ * px - 128.  out = int8 [th][tw][3] (nhwc != 0) or [3][th][tw].  Host pointers; 0 = ok, -1 = failure. */
+int mars_yolo_letterbox(const unsigned char *rgb, int w, int h, int tw, int th, int nhwc, signed char *out);
+/* Camera batch: `frames` RGB frames of w x h (host memory, contiguous) are letterboxed straight into frames
+ * [first_frame, first_frame + frames) of graph input `input_index` in HBM, in the layout its format tag asks for
+ * (mars_yolo_test.c:157-165); follow with mars_hip_run_device().  Input must be int8 with 3 channels. */
+mars_error_t mars_hip_preprocess(mars_model_t *model, int input_index, const unsigned char *rgb_frames, int w, int h,
+                                 int first_frame, int frames);
+
 #ifdef __cplusplus
 }
 #endif

@@ -180,3 +180,16 @@ def nms(dets, thresh=0.45):
 
 def trunc_x86(x):
     return lib().orc_trunc_x86(float(np.float32(x)))
+
+
+def letterbox(rgb, tw, th, nhwc):
+    """orc_letterbox: RGB uint8 [h][w][3] -> int8 letterboxed frame (reference load_image minus the decode)"""
+    rgb = np.ascontiguousarray(rgb, dtype=np.uint8)
+    h, w = rgb.shape[:2]
+    out = np.zeros(tw * th * 3, dtype=np.int8)
+    L = lib()
+    L.orc_letterbox.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]
+    rc = L.orc_letterbox(rgb.ctypes.data, w, h, tw, th, int(bool(nhwc)), out.ctypes.data)
+    if rc != 0:
+        raise RuntimeError("orc_letterbox failed")
+    return out

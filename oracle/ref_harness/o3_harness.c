@@ -16,3 +16,17 @@ int ref_o3_parse_output(const int8_t *data, int npred, float scale, void *dets, 
 }
 
 int ref_o3_nms(void *dets, int n, float thresh) { return nms((det_t *)dets, n, thresh); }
+
+/* Image front-end (reference src/mars/mars_yolo_test.c:40-77): load_image() is static there too and reads a FILE
+ * through stb_image; the caller hands this wrapper the path of a binary PPM it wrote, so the reference's own
+ * decode -> stbir_resize_uint8 -> letterbox -> (px - 128) sequence runs unmodified.  Returns 0 on success. */
+int ref_o3_load_image(const char *ppm_path, int tw, int th, int nhwc, int8_t *out, int *src_w, int *src_h) {
+    int ow = 0, oh = 0;
+    int8_t *img = load_image(ppm_path, tw, th, nhwc, &ow, &oh);
+    if (!img) return -1;
+    memcpy(out, img, (size_t)tw * th * 3);
+    free(img);
+    if (src_w) *src_w = ow;
+    if (src_h) *src_h = oh;
+    return 0;
+}

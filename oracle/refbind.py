@@ -164,3 +164,37 @@ def nms(dets, thresh=0.45):
     d = np.ascontiguousarray(dets, dtype=DET_DTYPE).copy()
     n = lib.ref_o3_nms(d.ctypes.data, len(d), thresh)
     return d[:n].copy()
+
+
+def load_image(rgb, tw, th, nhwc):
+    """the reference's load_image() (mars_yolo_test.c:40-77) on an RGB uint8 array [h][w][3]: the frame is written
+    as a binary PPM, decoded by the reference's stb_image, letterbox-resized by its stb_image_resize and converted"""
+    import tempfile
+    rgb = np.ascontiguousarray(rgb, dtype=np.uint8)
+    h, w = rgb.shape[:2]
+    lib = _lib("libref_o2.so")
+    lib.ref_o3_load_image.restype = C.c_int
+    lib.ref_o3_load_image.argtypes = [C.c_char_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
+    out = np.zeros(tw * th * 3, dtype=np.int8)
+    with tempfile.NamedTemporaryFile(suffix=".ppm", delete=False) as fh:
+        fh.write(b"P6\n%d %d\n255\n" % (w, h))
+        fh.write(rgb.tobytes())
+        path = fh.name
+    try:
+        sw, sh = C.c_int(), C.c_int()
+        # the reference prints two lines per image; keep the test log quiet
+        fd = os.dup(1)
+        devnull = os.open(os.devnull, os.O_WRONLY)
+        os.dup2(devnull, 1)
+        try:
+            rc = lib.ref_o3_load_image(path.encode(), tw, th, int(bool(nhwc)), out.ctypes.data, C.byref(sw), C.byref(sh))
+        finally:
+            C.CDLL(None).fflush(None)  # the reference's printf output is still in stdio's buffer
+            os.dup2(fd, 1)
+            os.close(fd)
+            os.close(devnull)
+    finally:
+        os.unlink(path)
+    if rc != 0 or (sw.value, sh.value) != (w, h):
+        raise RuntimeError("reference load_image failed")
+    return out

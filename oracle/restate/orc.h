@@ -101,6 +101,12 @@ double orc_graph_conv_macs(const orc_graph_t *g); /* sum over CONV2D layers, per
 int orc_run_frames(const void *file, size_t size, const void *inputs, size_t in_stride,
                    void *outputs, size_t out_stride, int out_index, int nframes, int nthreads);
 
+/* ---- image front-end (reference src/mars/mars_yolo_test.c:40-77 load_image, minus the file decode) */
+/* stbir_resize_uint8(in, w, h, 0, out, ow, oh, 0, 3) of the vendored stb_image_resize.h, restated */
+int orc_resize_rgb8(const uint8_t *in, int w, int h, uint8_t *out, int ow, int oh);
+/* RGB uint8 [h][w][3] -> letterboxed int8 (px - 128, pad -17) [th][tw][3] (nhwc) or [3][th][tw] */
+int orc_letterbox(const uint8_t *rgb, int w, int h, int tw, int th, int nhwc, int8_t *out);
+
 #ifdef __cplusplus
 }
 #endif

@@ -120,3 +120,30 @@ SYNTH = [
     ("tiny_32_f32", dict(tiny=True, input_hw=32, float32=True, seed=5)),
     ("v5n_64_f32", dict(width_x16=4, input_hw=64, float32=True, seed=6)),   # config 5 topology (yolov5 f32), small
 ]
+
+
+# image front-end: (name, src_w, src_h, target_w, target_h, nhwc, seed, kind)
+#   kind "noise" = uniform random bytes, "smooth" = low-frequency gradients + a few hard edges (exercises the
+#   negative lobes of both kernels against saturation), "flat" = constant colour
+LETTERBOX_CASES = [
+    ("down_4x3", 64, 48, 32, 32, 1, 1, "noise"), ("up_3x4", 48, 64, 128, 128, 0, 2, "noise"),
+    ("down_odd", 100, 75, 64, 64, 1, 3, "smooth"), ("up_odd", 33, 57, 96, 80, 0, 4, "smooth"),
+    ("vga_160", 640, 480, 160, 160, 1, 5, "noise"), ("tiny_up", 37, 41, 320, 320, 1, 6, "noise"),
+    ("same", 64, 64, 64, 64, 0, 7, "noise"), ("almost_same", 65, 64, 64, 64, 1, 8, "smooth"),
+    ("tall", 31, 200, 96, 96, 1, 9, "noise"), ("wide", 200, 31, 96, 96, 0, 10, "noise"),
+    ("primes", 17, 19, 23, 29, 1, 11, "noise"), ("flat", 50, 40, 64, 64, 1, 12, "flat"),
+    ("hd_640", 1280, 720, 640, 640, 1, 13, "smooth"),
+]
+
+
+def letterbox_image(case):
+    name, w, h, tw, th, nhwc, seed, kind = case
+    if kind == "noise":
+        return lcg_frame(0x1AA60000 + seed, w * h * 3).reshape(h, w, 3).copy()
+    if kind == "flat":
+        return np.full((h, w, 3), 200, dtype=np.uint8)
+    yy, xx = np.mgrid[0:h, 0:w]
+    img = np.stack([(xx * 255) // max(w - 1, 1), (yy * 255) // max(h - 1, 1), ((xx + yy) * 7) % 256], axis=2)
+    img[h // 3: h // 3 + 2, :, :] = 255   # hard edges: ringing of the cubic kernels must clamp like the reference
+    img[:, w // 2: w // 2 + 1, :] = 0
+    return img.astype(np.uint8)

@@ -251,3 +251,28 @@ def test_run_frames_threads(orc, marsrt):
     g = orc.Graph(d)
     g.set_input(0, x[3].tobytes())
     assert g.run() == 0 and np.array_equal(g.tensor(hdr["outputs"][0]), a[3])
+
+
+# ---------------------------------------------------------------- image front-end
+@pytest.mark.parametrize("case", cases.LETTERBOX_CASES, ids=lambda c: c[0])
+def test_letterbox_vs_golden(orc, case):
+    """the restated stb_image_resize + letterbox (oracle/restate/orc_resize.c) against what the reference's own
+    load_image() produced (golden.json, generated through oracle/_ref)"""
+    out = orc.letterbox(cases.letterbox_image(case), case[3], case[4], case[5])
+    assert cases.digest(out) == GOLD["letterbox"][case[0]]
+    assert (out == -17).any() or case[1] * case[4] == case[2] * case[3]  # padding present unless aspect ratios match
+
+
+def test_letterbox_vs_reference_sweep(orc, ref):
+    """many geometries (growing, shrinking, identical, extreme aspect ratios, odd sizes), both layouts"""
+    rng = np.random.default_rng(5)
+    for i in range(40):
+        w, h = int(rng.integers(5, 300)), int(rng.integers(5, 300))
+        tw, th = int(rng.integers(8, 200)), int(rng.integers(8, 200))
+        img = rng.integers(0, 256, (h, w, 3), dtype=np.uint8)
+        if min(int(w * min(tw / w, th / h)), int(h * min(tw / w, th / h))) < 1:
+            continue
+        nhwc = i & 1
+        a = ref.load_image(img, tw, th, nhwc)
+        b = orc.letterbox(img, tw, th, nhwc)
+        assert np.array_equal(a, b), (w, h, tw, th, nhwc, int((a != b).sum()))

@@ -154,6 +154,17 @@ typedef struct {
 int mhip_detect(const mhip_detect_t *p);
 int mhip_nms_only(void *dets_dev, int *count_dev, int n, float thresh);
 
+/* ---- image front-end (preproc.hip): letterbox resize + (px - 128); tables from csrc/host/mars_preproc.c */
+typedef struct {
+    const uint8_t *rgb; size_t rgb_stride;   /* [frames][h][w][3] uint8 on the device */
+    int8_t *out;        size_t out_stride;   /* [frames] x (tw*th*3) int8: [th][tw][3] (nhwc) or [3][th][tw] */
+    int frames, w, h, tw, th, nhwc;
+    int nw, nh, px, py;                      /* resized size and its offset inside the target */
+    const int *xstart, *xsrc; const float *xw; /* gather lists of the horizontal / vertical pass (device) */
+    const int *ystart, *ysrc; const float *yw;
+} mhip_letterbox_t;
+int mhip_letterbox(const mhip_letterbox_t *p);
+
 #ifdef __cplusplus
 }
 #endif

@@ -101,7 +101,8 @@ EXPORTS = {
                    "mars_hip_tensor_device", "mars_hip_read_tensor", "mars_hip_write_tensor", "mars_hip_set_fusion",
                    "mars_hip_set_profiling", "mars_hip_num_ops", "mars_hip_op_info", "mars_hip_stream",
                    "mars_hip_load_memory_ex", "mars_hip_param_arena", "mars_yolo_parse_output", "mars_yolo_nms",
-                   "mars_hip_detect", "mars_hip_detect_device", "mars_synth_model", "mars_hip_set_tuning", "mars_hip_autotune"],
+                   "mars_hip_detect", "mars_hip_detect_device", "mars_synth_model", "mars_hip_set_tuning", "mars_hip_autotune", "mars_yolo_letterbox",
+                   "mars_hip_preprocess"],
 }
 
 _lib = None
@@ -151,6 +152,8 @@ def lib():
     L.mars_hip_set_fusion.argtypes = [P(MarsModel), C.c_int]
     L.mars_hip_set_tuning.argtypes = [C.c_char_p, C.c_int]
     L.mars_hip_autotune.argtypes = [P(MarsModel), C.c_int]
+    L.mars_yolo_letterbox.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]
+    L.mars_hip_preprocess.argtypes = [P(MarsModel), C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int]
     L.mars_hip_set_profiling.argtypes = [P(MarsModel), C.c_int]
     L.mars_hip_set_profiling.restype = None
     L.mars_hip_tensor_device.restype = C.c_void_p
@@ -195,6 +198,16 @@ def set_tuning(key, value):
     """Launch-policy knob of the conv kernels (mars_hip_set_tuning); results never depend on it."""
     if lib().mars_hip_set_tuning(key.encode(), int(value)) != 0:
         raise KeyError(key)
+
+
+def letterbox(rgb, tw, th, nhwc=True):
+    """mars_yolo_letterbox: uint8 RGB [h][w][3] -> int8 letterboxed frame, on the GPU."""
+    rgb = np.ascontiguousarray(rgb, dtype=np.uint8)
+    h, w = rgb.shape[:2]
+    out = np.zeros(tw * th * 3, dtype=np.int8)
+    if lib().mars_yolo_letterbox(rgb.ctypes.data, w, h, tw, th, int(bool(nhwc)), out.ctypes.data) != 0:
+        raise RuntimeError("mars_yolo_letterbox failed")
+    return out
 
 
 def synth_model(width_x16=8, depth_x3=1, input_hw=640, float32=False, nchw_int8=False, seed=1, tiny=False):
@@ -305,6 +318,14 @@ class Model:
 
     def set_profiling(self, on):
         lib().mars_hip_set_profiling(self.p, int(on))
+
+    def preprocess(self, rgb_frames, first_frame=0, input_index=0):
+        """uint8 RGB frames [n][h][w][3] -> letterboxed int8 frames of the graph input, in HBM"""
+        a = np.ascontiguousarray(rgb_frames, dtype=np.uint8)
+        n, h, w = a.shape[:3]
+        rc = lib().mars_hip_preprocess(self.p, input_index, a.ctypes.data, w, h, first_frame, n)
+        if rc != MARS_OK:
+            raise MarsError(rc, "mars_hip_preprocess")
 
     def autotune(self, reps=3):
         rc = lib().mars_hip_autotune(self.p, reps)
