@@ -19,6 +19,9 @@ extern "C" hipStream_t mhip_stream_native(void);
 extern "C" int mhip_check(hipError_t e, const char *what);
 
 __global__ __launch_bounds__(256) void letterbox_kernel(const mhip_letterbox_t p) {
+    __shared__ float dec[256]; // value / 255 (IEEE division, once per workgroup instead of once per tap)
+    dec[threadIdx.x] = (float)threadIdx.x / 255.0f;
+    __syncthreads();
     const int x = blockIdx.x * 16 + (threadIdx.x & 15), y = blockIdx.y * 16 + (threadIdx.x >> 4);
     if (x >= p.tw || y >= p.th) return;
     const int f = blockIdx.z;
@@ -36,7 +39,7 @@ __global__ __launch_bounds__(256) void letterbox_kernel(const mhip_letterbox_t p
                 const uint8_t *q = row + p.xsrc[k] * 3;
                 const float wk = p.xw[k];
 #pragma unroll
-                for (int c = 0; c < 3; c++) h[c] = h[c] + ((float)q[c] / 255.0f) * wk;
+                for (int c = 0; c < 3; c++) h[c] = h[c] + dec[q[c]] * wk;
             }
             const float wj = p.yw[j];
 #pragma unroll
