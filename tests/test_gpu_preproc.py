@@ -38,6 +38,16 @@ def test_letterbox_sweep(gpu, orc):
         assert np.array_equal(got, want), (w, h, tw, th, i & 1, int((got != want).sum()))
 
 
+def test_letterbox_extreme_ratio_uses_the_direct_kernel(gpu, orc):
+    """a 40x reduction: the source region of a 16 x 16 output tile no longer fits in LDS, so the launcher falls back
+    to the direct (one thread per pixel, gathers from HBM) kernel -- same bytes"""
+    rng = np.random.default_rng(77)
+    img = rng.integers(0, 256, (1500, 2000, 3), dtype=np.uint8)
+    got = gpu.letterbox(img, 50, 50, 1)
+    want = orc.letterbox(img, 50, 50, 1)
+    assert np.array_equal(got, want), int((got != want).sum())
+
+
 def test_preprocess_into_model_input(gpu, orc):
     """camera batch: RGB frames -> letterboxed int8 frames of the graph input in HBM -> run; the input tensor and the
     graph outputs equal the oracle's for every frame (NHWC yolov5 twin)"""

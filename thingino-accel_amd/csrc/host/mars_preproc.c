@@ -180,6 +180,7 @@ done:
 /* ---- one cached geometry: tables on the device */
 typedef struct {
     int w, h, tw, th, nw, nh, px, py;
+    int max_cols, max_rows; /* largest source region of a 16 x 16 output tile (for the LDS-tiled kernel) */
     void *dev; /* [xstart][xsrc][xw][ystart][ysrc][yw] */
     size_t off[6];
 } geom_t;
@@ -196,6 +197,31 @@ static int geometry(int w, int h, int tw, int th, geom_t **out) {
     gather_t gx, gy;
     if (build_axis(w, nw, &gx)) return -1;
     if (build_axis(h, nh, &gy)) { gather_free(&gx); return -1; }
+    /* tiles start at multiples of 16 of the TARGET, i.e. at (16 i - pad) of the resized image */
+    const int px0 = (tw - nw) / 2, py0 = (th - nh) / 2;
+    int max_cols = 1, max_rows = 1;
+    for (int t0 = -(px0 % 16); t0 < nw; t0 += 16) {
+        const int a = t0 < 0 ? 0 : t0, b = t0 + 16 < nw ? t0 + 16 : nw;
+        if (b <= a) continue;
+        int lo = gx.src[gx.start[a]], hi = lo;
+        for (int o = a; o < b; o++) {
+            if (gx.src[gx.start[o]] < lo) lo = gx.src[gx.start[o]];
+            if (gx.src[gx.start[o + 1] - 1] > hi) hi = gx.src[gx.start[o + 1] - 1];
+        }
+        const int span = hi - lo + 1;
+        if (span > max_cols) max_cols = span;
+    }
+    for (int t0 = -(py0 % 16); t0 < nh; t0 += 16) {
+        const int a = t0 < 0 ? 0 : t0, b = t0 + 16 < nh ? t0 + 16 : nh;
+        if (b <= a) continue;
+        int lo = gy.src[gy.start[a]], hi = lo;
+        for (int o = a; o < b; o++) {
+            if (gy.src[gy.start[o]] < lo) lo = gy.src[gy.start[o]];
+            if (gy.src[gy.start[o + 1] - 1] > hi) hi = gy.src[gy.start[o + 1] - 1];
+        }
+        const int span = hi - lo + 1;
+        if (span > max_rows) max_rows = span;
+    }
     const size_t sz[6] = {sizeof(int) * ((size_t)nw + 1), sizeof(int) * (size_t)(gx.n_entries + 1), sizeof(float) * (size_t)(gx.n_entries + 1),
                           sizeof(int) * ((size_t)nh + 1), sizeof(int) * (size_t)(gy.n_entries + 1), sizeof(float) * (size_t)(gy.n_entries + 1)};
     const void *srcs[6] = {gx.start, gx.src, gx.w, gy.start, gy.src, gy.w};
@@ -221,6 +247,7 @@ static int geometry(int w, int h, int tw, int th, geom_t **out) {
     g_geom.w = w; g_geom.h = h; g_geom.tw = tw; g_geom.th = th;
     g_geom.nw = nw; g_geom.nh = nh;
     g_geom.px = (tw - nw) / 2; g_geom.py = (th - nh) / 2; /* :49 */
+    g_geom.max_cols = max_cols; g_geom.max_rows = max_rows;
     g_geom.dev = dev;
     memcpy(g_geom.off, off, sizeof(off));
     *out = &g_geom;
@@ -235,6 +262,7 @@ static int run_letterbox(const geom_t *g, const uint8_t *rgb_dev, size_t rgb_str
     p.out = out_dev; p.out_stride = out_stride;
     p.frames = frames; p.w = g->w; p.h = g->h; p.tw = g->tw; p.th = g->th; p.nhwc = nhwc;
     p.nw = g->nw; p.nh = g->nh; p.px = g->px; p.py = g->py;
+    p.max_cols = g->max_cols; p.max_rows = g->max_rows;
     const char *b = (const char *)g->dev;
     p.xstart = (const int *)(b + g->off[0]); p.xsrc = (const int *)(b + g->off[1]); p.xw = (const float *)(b + g->off[2]);
     p.ystart = (const int *)(b + g->off[3]); p.ysrc = (const int *)(b + g->off[4]); p.yw = (const float *)(b + g->off[5]);

@@ -162,6 +162,7 @@ typedef struct {
     int nw, nh, px, py;                      /* resized size and its offset inside the target */
     const int *xstart, *xsrc; const float *xw; /* gather lists of the horizontal / vertical pass (device) */
     const int *ystart, *ysrc; const float *yw;
+    int max_cols, max_rows;                  /* largest source region (columns, rows) any 16 x 16 output tile touches; 0 = unknown */
 } mhip_letterbox_t;
 int mhip_letterbox(const mhip_letterbox_t *p);
 
