@@ -334,3 +334,77 @@ def test_deferred_load_and_arena_copy(gpu):
         assert full.output_view(i).any()
     full.close()
     lazy.close()
+
+
+def test_nna_model_facade(gpu, orc, tmp_path):
+    """the reference's model-handle API (include/nna_model.h) over a .mars graph, used the way
+    examples/test_inference.c:142-238 uses it: load -> info -> get_input -> fill -> run -> get_output -> unload"""
+    import ctypes as C
+    L = gpu.lib()
+
+    class Shape(C.Structure):
+        _fields_ = [("dims", C.c_int32 * 4), ("ndim", C.c_int32)]
+
+    class Tensor(C.Structure):
+        _fields_ = [("data", C.c_void_p), ("shape", Shape), ("dtype", C.c_int), ("format", C.c_int), ("bytes", C.c_size_t),
+                    ("owns_data", C.c_int)]
+
+    class Info(C.Structure):
+        _fields_ = [("num_inputs", C.c_uint32), ("num_outputs", C.c_uint32), ("num_layers", C.c_uint32),
+                    ("model_size", C.c_size_t), ("forward_mem_req", C.c_size_t)]
+
+    class Opts(C.Structure):
+        _fields_ = [("use_file_mapping", C.c_int), ("enable_profiling", C.c_int), ("forward_memory", C.c_void_p),
+                    ("forward_mem_size", C.c_size_t)]
+
+    L.nna_model_load.restype = C.c_void_p
+    L.nna_model_load.argtypes = [C.c_char_p, C.POINTER(Opts)]
+    L.nna_model_load_from_memory.restype = C.c_void_p
+    L.nna_model_load_from_memory.argtypes = [C.c_void_p, C.c_size_t, C.POINTER(Opts)]
+    L.nna_model_get_info.argtypes = [C.c_void_p, C.POINTER(Info)]
+    for n in ("nna_model_get_input", "nna_model_get_output"):
+        getattr(L, n).restype = C.POINTER(Tensor)
+        getattr(L, n).argtypes = [C.c_void_p, C.c_uint32]
+    for n in ("nna_model_get_input_by_name", "nna_model_get_output_by_name"):
+        getattr(L, n).restype = C.POINTER(Tensor)
+        getattr(L, n).argtypes = [C.c_void_p, C.c_char_p]
+    L.nna_model_run.argtypes = [C.c_void_p]
+    L.nna_model_unload.argtypes = [C.c_void_p]
+
+    d = gpu.synth_model(width_x16=4, input_hw=96, seed=51)
+    hdr, tensors, _ = marsfile.parse(d)
+    path = tmp_path / "twin.mars"
+    path.write_bytes(d)
+    opts = Opts(0, 1, None, 0)
+    m = L.nna_model_load(str(path).encode(), C.byref(opts))
+    assert m
+    info = Info()
+    assert L.nna_model_get_info(m, C.byref(info)) == 0
+    assert (info.num_inputs, info.num_outputs, info.num_layers, info.model_size) == (1, 3, hdr["layers"], len(d))
+    assert info.forward_mem_req > 0
+    tin = L.nna_model_get_input(m, 0).contents
+    nb = marsfile.tensor_nbytes(tensors[hdr["inputs"][0]])
+    assert tin.bytes == nb and list(tin.shape.dims) == [1, 96, 96, 3] and tin.owns_data == 0
+    x = lcg_frame(0xFACADE, nb)
+    C.memmove(tin.data, x.ctypes.data, nb)
+    assert not L.nna_model_get_input(m, 1) and not L.nna_model_get_output(m, 3)
+    o = 76 + 124 * hdr["inputs"][0] + 4
+    name_in = bytes(d[o:o + 60]).split(b"\0")[0]
+    assert C.addressof(L.nna_model_get_input_by_name(m, name_in).contents) == C.addressof(L.nna_model_get_input(m, 0).contents)
+    assert not L.nna_model_get_input_by_name(m, b"no such tensor")
+    assert L.nna_model_run(m) == 0
+    g, rc = run_oracle(orc, d, x)
+    assert rc == 0
+    for i, ti in enumerate(hdr["outputs"]):
+        t = L.nna_model_get_output(m, i).contents
+        got = np.ctypeslib.as_array(C.cast(t.data, C.POINTER(C.c_uint8)), shape=(t.bytes,))
+        assert np.array_equal(got, g.tensor(ti))
+    L.nna_model_unload(m)  # prints the per-launch profile (enable_profiling)
+    buf = np.frombuffer(d, dtype=np.uint8).copy()
+    m2 = L.nna_model_load_from_memory(buf.ctypes.data, buf.size, None)
+    assert m2
+    L.nna_model_unload(m2)
+    assert not L.nna_model_load(b"/nonexistent.mgk", None)
+    junk = tmp_path / "model.mgk"
+    junk.write_bytes(b"\\x7fELF" + bytes(200))
+    assert not L.nna_model_load(str(junk).encode(), None)  # Venus .mgk models are not served here

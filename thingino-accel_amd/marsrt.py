@@ -91,6 +91,9 @@ EXPORTS = {
     "nna_tensor.h": ["nna_tensor_create", "nna_tensor_from_data", "nna_tensor_destroy", "nna_tensor_data",
                      "nna_tensor_shape", "nna_tensor_dtype", "nna_tensor_numel", "nna_tensor_bytes",
                      "nna_tensor_reshape", "nna_shape_make"],
+    "nna_model.h": ["nna_model_load", "nna_model_load_from_memory", "nna_model_get_info", "nna_model_get_input",
+                    "nna_model_get_input_by_name", "nna_model_get_output", "nna_model_get_output_by_name",
+                    "nna_model_run", "nna_model_unload"],
     "mars_runtime.h": ["mars_load_file", "mars_load_memory", "mars_free", "mars_get_input", "mars_get_output",
                        "mars_run", "mars_get_error_string", "mars_get_num_inputs", "mars_get_num_outputs",
                        "mars_print_summary"],
