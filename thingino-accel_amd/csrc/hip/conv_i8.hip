@@ -516,12 +516,27 @@ __device__ __forceinline__ void wait_vmcnt_at_most(int n) { // largest known-saf
 // K step ks reads its 64 channels from the tensor(s) that own them.  Segment boundaries are multiples of 32 channels,
 // so the two 32-byte halves of a K step each lie in one segment and the choice is a scalar select plus one per-lane
 // select between the halves.
-template <int BPX, int BN, int STAGES, bool HAS_LUT, bool SEG = false>
-__global__ __launch_bounds__(NTHREADS) void conv_i8_persist(const mhip_conv_i8_t p, const unsigned total_pix, const int k64,
+// PAIR: two convolutions over the SAME input and geometry (C3's cv1 and cv2) in one launch: channel tiles
+// [0, noc0) belong to the first, the rest to the second (`alt` = its output side).  The two workgroups that need a
+// pixel tile are neighbours in the XCD-aware block order, so the second one's input reads hit L2: the input is
+// read from HBM once instead of twice.
+struct conv_out_side_t {
+    int8_t *out;
+    size_t out_stride;
+    const int8_t *w;
+    const int32_t *bias;
+    const uint8_t *lut;
+    int out_c, relu, out_pix_stride, out_ch_off;
+    float cs;
+    unsigned out_bytes;
+};
+template <int BPX, int BN, int STAGES, bool HAS_LUT, bool SEG = false, bool PAIR = false>
+__global__ __launch_bounds__(NTHREADS) void conv_i8_persist(const mhip_conv_i8_t pin, const unsigned total_pix, const int k64,
                                                             const int8_t *__restrict__ zeros, const unsigned noc,
                                                             const unsigned npt, const unsigned ngrp, const int lg_inc,
                                                             const unsigned kw_magic, const fastdiv_t dhw, const fastdiv_t dow,
-                                                            const unsigned out_bytes) {
+                                                            const unsigned out_bytes_first, const conv_out_side_t alt,
+                                                            const unsigned noc0) {
     constexpr int STAGE = (BPX + BN) * BK;
     constexpr int NWN = BN == 128 ? 2 : 1;
     constexpr int NWM = 4 / NWN;
@@ -540,7 +555,17 @@ __global__ __launch_bounds__(NTHREADS) void conv_i8_persist(const mhip_conv_i8_t
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
     const unsigned id = xcd_remap(blockIdx.x, noc * ngrp);
     const unsigned grp = id / noc;
-    const int oc0 = (int)(id - grp * noc) * BN;
+    unsigned ot = id - grp * noc;
+    mhip_conv_i8_t p = pin; // uniform; the second convolution of a pair swaps in its output side
+    unsigned out_bytes = out_bytes_first;
+    if (PAIR && ot >= noc0) {
+        ot -= noc0;
+        p.out = alt.out; p.out_stride = alt.out_stride; p.w = alt.w; p.bias = alt.bias; p.lut = alt.lut;
+        p.out_c = alt.out_c; p.relu = alt.relu; p.out_pix_stride = alt.out_pix_stride; p.out_ch_off = alt.out_ch_off;
+        p.cs = alt.cs;
+        out_bytes = alt.out_bytes;
+    }
+    const int oc0 = (int)ot * BN;
     const unsigned t0 = (unsigned)(((unsigned long long)grp * npt) / ngrp);
     const unsigned t1 = (unsigned)(((unsigned long long)(grp + 1) * npt) / ngrp);
     if (t0 >= t1) return;
@@ -1344,15 +1369,24 @@ static long persist_out_bytes(const mhip_conv_i8_t *p) {
     return (long)(p->frames - 1) * (long)p->out_stride + (long)p->out_h * p->out_w * pstride;
 }
 
-template <int BPX, int BN, int STAGES, bool HAS_LUT, bool SEG = false>
-static int launch_persist_t(const mhip_conv_i8_t *p, long total_pix, int k64, int lg, unsigned magic) {
-    const unsigned npt = (unsigned)((total_pix + BPX - 1) / BPX), noc = (unsigned)(p->oc_pad / BN);
+template <int BPX, int BN, int STAGES, bool HAS_LUT, bool SEG = false, bool PAIR = false>
+static int launch_persist_t(const mhip_conv_i8_t *p, long total_pix, int k64, int lg, unsigned magic,
+                            const mhip_conv_i8_t *second = nullptr) {
+    const unsigned noc0 = (unsigned)(p->oc_pad / BN);
+    const unsigned npt = (unsigned)((total_pix + BPX - 1) / BPX), noc = noc0 + (PAIR ? (unsigned)(second->oc_pad / BN) : 0u);
+    conv_out_side_t alt;
+    memset(&alt, 0, sizeof(alt));
+    if (PAIR) {
+        alt.out = second->out; alt.out_stride = second->out_stride; alt.w = second->w; alt.bias = second->bias;
+        alt.lut = second->lut; alt.out_c = second->out_c; alt.relu = second->relu; alt.out_pix_stride = second->out_pix_stride;
+        alt.out_ch_off = second->out_ch_off; alt.cs = second->cs;
+    }
     const size_t lds = 256 + (size_t)STAGES * (BPX + BN) * BK;
     static int slots = 0; // workgroups of this instantiation the device holds at once
     if (!slots) {
         int occ = 0, dev = 0;
         hipDeviceProp_t prop;
-        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, conv_i8_persist<BPX, BN, STAGES, HAS_LUT, SEG>, NTHREADS, lds) != hipSuccess ||
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, conv_i8_persist<BPX, BN, STAGES, HAS_LUT, SEG, PAIR>, NTHREADS, lds) != hipSuccess ||
             hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess)
             return mhip_check(hipErrorUnknown, "conv_i8_persist occupancy query");
         slots = (occ > 0 ? occ : 1) * prop.multiProcessorCount;
@@ -1362,10 +1396,11 @@ static int launch_persist_t(const mhip_conv_i8_t *p, long total_pix, int k64, in
     unsigned ngrp = (unsigned)(tune().persist_slots > 0 ? tune().persist_slots : 4 * slots) / noc;
     if (ngrp < 1) ngrp = 1;
     if (ngrp > npt) ngrp = npt;
-    hipLaunchKernelGGL((conv_i8_persist<BPX, BN, STAGES, HAS_LUT, SEG>), dim3(noc * ngrp), dim3(NTHREADS), lds, mhip_stream_native(),
-                       *p, (unsigned)total_pix, k64, (const int8_t *)mhip_zero_page(), noc, npt, ngrp, lg, magic,
-                       make_fastdiv((unsigned)(p->out_h * p->out_w)), make_fastdiv((unsigned)p->out_w),
-                       (unsigned)persist_out_bytes(p));
+    if (PAIR) alt.out_bytes = (unsigned)persist_out_bytes(second);
+    hipLaunchKernelGGL((conv_i8_persist<BPX, BN, STAGES, HAS_LUT, SEG, PAIR>), dim3(noc * ngrp), dim3(NTHREADS), lds,
+                       mhip_stream_native(), *p, (unsigned)total_pix, k64, (const int8_t *)mhip_zero_page(), noc, npt, ngrp, lg,
+                       magic, make_fastdiv((unsigned)(p->out_h * p->out_w)), make_fastdiv((unsigned)p->out_w),
+                       (unsigned)persist_out_bytes(p), alt, noc0);
     return mhip_check(hipGetLastError(), "conv_i8_persist launch");
 }
 
@@ -1530,6 +1565,49 @@ static int launch_variant(const mhip_conv_i8_t *p, long total_pix, int k64, cons
     if (bn == 128) return launch_variant_t<128, 128>(p, total_pix, k64, v);
     if (bn == 64) return launch_variant_t<128, 64>(p, total_pix, k64, v);
     return launch_variant_t<128, 32>(p, total_pix, k64, v);
+}
+
+// Two convolutions over the same input in one launch (conv_i8_persist<PAIR>).  -2 = the pair is not eligible (the
+// caller launches them one after the other), otherwise the launch's return code.
+template <int BPX, int BN>
+static int launch_pair_t(const mhip_conv_i8_t *a, const mhip_conv_i8_t *b, long total_pix, int k64, int lg, unsigned magic) {
+    if (a->nseg > 1)
+        return launch_persist_t<BPX, BN, 2, true, true, true>(a, total_pix, k64, lg, magic, b);
+    return launch_persist_t<BPX, BN, 2, true, false, true>(a, total_pix, k64, lg, magic, b);
+}
+extern "C" int mhip_conv_i8_pair(const mhip_conv_i8_t *a, const mhip_conv_i8_t *b) {
+    if (!a || !b || !tune().persist || tune().variant) return -2;
+    // identical input side and geometry; both with a fused LUT; both eligible for the tile-walking form
+    if (a->in != b->in || a->in_stride != b->in_stride || a->frames != b->frames || a->in_h != b->in_h || a->in_w != b->in_w ||
+        a->in_c != b->in_c || a->out_h != b->out_h || a->out_w != b->out_w || a->kh != b->kh || a->kw != b->kw ||
+        a->stride_h != b->stride_h || a->stride_w != b->stride_w || a->pad_top != b->pad_top || a->pad_left != b->pad_left ||
+        a->row_pad != b->row_pad || a->nseg != b->nseg || a->seg_up != b->seg_up || !a->lut || !b->lut || a->add || b->add ||
+        a->out_nchw || b->out_nchw)
+        return -2;
+    for (int i = 0; i < a->nseg; i++)
+        if (a->seg_in[i] != b->seg_in[i] || a->seg_c[i] != b->seg_c[i] || a->seg_stride[i] != b->seg_stride[i]) return -2;
+    if ((a->in_c % 16) != 0 || mhip_conv_i8_small_c(a->in_c, a->kw, a->out_c) || mhip_conv_i8_small_c(b->in_c, b->kw, b->out_c))
+        return -2;
+    if (a->nseg > 1 && (!seg_valid(a) || !seg_valid(b))) return -2;
+    if (!persist_eligible(a) || !persist_eligible(b)) return -2;
+    const int bn = a->oc_pad % 128 == 0 ? 128 : (a->oc_pad % 64 == 0 ? 64 : 32);
+    const int bnb = b->oc_pad % 128 == 0 ? 128 : (b->oc_pad % 64 == 0 ? 64 : 32);
+    if (bn != bnb || !mhip_zero_page()) return -2;
+    const long total_pix = (long)a->frames * a->out_h * a->out_w;
+    const int k64 = (a->kh * a->row_pad + BK - 1) / BK * BK, nks = k64 / BK;
+    if (total_pix <= 0 || total_pix > 0x7fffffffL) return -2;
+    int lg = 0;
+    while ((1 << lg) < a->in_c) lg++;
+    const unsigned magic = ((65536u + (unsigned)a->kw - 1u) / (unsigned)a->kw);
+    const int bpx = default_variant(a, nks).bpx ? default_variant(a, nks).bpx : 128;
+    if (bpx == 256) {
+        if (bn == 128) return launch_pair_t<256, 128>(a, b, total_pix, k64, lg, magic);
+        if (bn == 64) return launch_pair_t<256, 64>(a, b, total_pix, k64, lg, magic);
+        return launch_pair_t<256, 32>(a, b, total_pix, k64, lg, magic);
+    }
+    if (bn == 128) return launch_pair_t<128, 128>(a, b, total_pix, k64, lg, magic);
+    if (bn == 64) return launch_pair_t<128, 64>(a, b, total_pix, k64, lg, magic);
+    return launch_pair_t<128, 32>(a, b, total_pix, k64, lg, magic);
 }
 
 extern "C" int mhip_conv_i8_seg_ok(const mhip_conv_i8_t *p) {

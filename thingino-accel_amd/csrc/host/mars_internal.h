@@ -51,7 +51,8 @@ typedef struct {
     int nchw, relu, is_mul, is_f32, leaky, safe;
     int variant; /* conv_i8 launch variant pinned by mars_hip_autotune (0 = default policy) */
     int add_t; float add_s_conv, add_s_other, add_inv; /* conv_i8 with a residual Add folded in: other operand (tensor index + 1, 0 = none) */
-    int nseg, seg_t[4], seg_c[4], seg_up; /* conv_i8 reading a never-materialised concat: its segments (tensor, channels) */
+    int nseg, seg_t[4], seg_c[4], seg_up;
+    int pair_next; /* conv_i8: launched together with the NEXT op (same input, same geometry: C3's cv1 + cv2) */ /* conv_i8 reading a never-materialised concat: its segments (tensor, channels) */
     int row_pad, oc_pad, c_pad;
     int ch_off, scale_h, scale_w, bn_n;
     int out_pix_stride, out_ch_off; /* producer writes a channel slice of a wider tensor (zero-copy concat) */

@@ -90,6 +90,9 @@ int mhip_conv_i8_tune(const char *key, int value); /* launch-policy knobs, see m
 int mhip_conv_i8_variants(const mhip_conv_i8_t *p, int *codes, int max);
 /* can this (shape-only: pointers may be dummies) segmented convolution run?  frames/out_stride as they will be */
 int mhip_conv_i8_seg_ok(const mhip_conv_i8_t *p);
+/* two convolutions over the same input in one launch (the second's input reads hit L2); -2 = not eligible as a
+ * pair (launch them separately), else the launch result */
+int mhip_conv_i8_pair(const mhip_conv_i8_t *a, const mhip_conv_i8_t *b);
 /* packing geometry shared by host packer and kernel */
 /* c_eff: bytes per input pixel in the packed K layout (4 in small-channel mode, else in_c) */
 void mhip_conv_i8_pack_geom(int in_c, int kw, int out_c, int *row_pad, int *oc_pad, int *c_eff);
