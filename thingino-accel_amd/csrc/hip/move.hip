@@ -138,6 +138,90 @@ extern "C" int mhip_maxpool_i8(const int8_t *in, size_t in_stride, int8_t *out, 
     return mhip_check(hipGetLastError(), "maxpool");
 }
 
+// A chain of up to three stride-1 max-pools with the same window over a small feature map (SPPF: 5x5 three times
+// on 20x20): one workgroup holds a whole frame of 16 channels in LDS, widened to packed int16 once, and evaluates
+// every pool separably (row maximum, then column maximum -- exact for integers), writing each stage's result.
+// Window semantics are the reference's (mars_runtime.c:908-960): anchored top-left, clipped at the right and
+// bottom edge, no padding.  One launch and one read of the input instead of three of each.
+typedef struct {
+    int8_t *out[3];
+    size_t stride[3];
+} pool_chain_outs_t;
+__global__ __launch_bounds__(MV_THREADS) void pool_chain_kernel(const int8_t *in, size_t is, pool_chain_outs_t outs, int n,
+                                                                int H, int W, int ch, int kh, int kw) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char pc_lds[];
+    const int hw = H * W;
+    s2v *A = (s2v *)pc_lds;           // [hw][8]: dwords 0-3 even bytes, 4-7 odd bytes of the 16 channels
+    s2v *T = A + (size_t)hw * 8;      // row maxima
+    const int c = blockIdx.x * 16, f = blockIdx.y;
+    const int8_t *src = in + (size_t)f * is + c;
+    for (int px = threadIdx.x; px < hw; px += MV_THREADS) {
+        const v4i v = *(const v4i *)(src + (size_t)px * ch);
+#pragma unroll
+        for (int d = 0; d < 4; d++) {
+            const int w = v[d];
+            const s2v x = *(const s2v *)&w;
+            A[px * 8 + d] = (s2v)(x << (short)8) >> (short)8;
+            A[px * 8 + 4 + d] = x >> (short)8;
+        }
+    }
+    __syncthreads();
+    for (int stage = 0; stage < n; stage++) {
+        for (int px = threadIdx.x; px < hw; px += MV_THREADS) { // row pass
+            const int y = px / W, x = px - y * W;
+            const int xe = x + kw < W ? x + kw : W;
+            s2v m[8];
+#pragma unroll
+            for (int d = 0; d < 8; d++) m[d] = A[px * 8 + d];
+            for (int xx = x + 1; xx < xe; xx++)
+#pragma unroll
+                for (int d = 0; d < 8; d++) m[d] = __builtin_elementwise_max(m[d], A[(y * W + xx) * 8 + d]);
+#pragma unroll
+            for (int d = 0; d < 8; d++) T[px * 8 + d] = m[d];
+        }
+        __syncthreads();
+        int8_t *dst = outs.out[stage] + (size_t)f * outs.stride[stage] + c;
+        for (int px = threadIdx.x; px < hw; px += MV_THREADS) { // column pass, result back into A and out to HBM
+            const int y = px / W, x = px - y * W;
+            const int ye = y + kh < H ? y + kh : H;
+            s2v m[8];
+#pragma unroll
+            for (int d = 0; d < 8; d++) m[d] = T[px * 8 + d];
+            for (int yy = y + 1; yy < ye; yy++)
+#pragma unroll
+                for (int d = 0; d < 8; d++) m[d] = __builtin_elementwise_max(m[d], T[(yy * W + x) * 8 + d]);
+            v4i r;
+#pragma unroll
+            for (int d = 0; d < 4; d++) {
+                A[px * 8 + d] = m[d];
+                A[px * 8 + 4 + d] = m[4 + d];
+                const s2v b = (m[d] & (short)0xFF) | (s2v)(m[4 + d] << (short)8);
+                r[d] = *(const int *)&b;
+            }
+            *(v4i *)(dst + (size_t)px * ch) = r;
+        }
+        __syncthreads();
+    }
+}
+
+extern "C" int mhip_pool_chain_i8(const int8_t *in, size_t in_stride, int8_t *const *outs, const size_t *out_strides, int n,
+                                  int frames, int h, int w, int ch, int kh, int kw) {
+    if (!in || !outs || !out_strides || n < 1 || n > 3 || frames <= 0 || frames > 65535 || h <= 0 || w <= 0 || ch <= 0 ||
+        (ch & 15) || kh <= 0 || kw <= 0)
+        return -1;
+    const size_t lds = (size_t)h * w * 8 * 4 * 2;
+    if (lds > 60 * 1024 || ((uintptr_t)in | in_stride) & 15) return -1;
+    pool_chain_outs_t o;
+    for (int i = 0; i < 3; i++) {
+        o.out[i] = i < n ? outs[i] : nullptr;
+        o.stride[i] = i < n ? out_strides[i] : 0;
+        if (i < n && (!outs[i] || (((uintptr_t)outs[i] | out_strides[i]) & 15))) return -1;
+    }
+    hipLaunchKernelGGL(pool_chain_kernel, dim3((unsigned)(ch / 16), (unsigned)frames), dim3(MV_THREADS), lds, mhip_stream_native(),
+                       in, in_stride, o, n, h, w, ch, kh, kw);
+    return mhip_check(hipGetLastError(), "pool chain");
+}
+
 // ------------------------------------------------------------ concat slice
 // out[(pix)*out_c + ch_off + c] = in[pix*in_c + c], pix over out_h*out_w
 template <int VEC>

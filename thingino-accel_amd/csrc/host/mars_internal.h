@@ -52,6 +52,7 @@ typedef struct {
     int variant; /* conv_i8 launch variant pinned by mars_hip_autotune (0 = default policy) */
     int add_t; float add_s_conv, add_s_other, add_inv; /* conv_i8 with a residual Add folded in: other operand (tensor index + 1, 0 = none) */
     int nseg, seg_t[4], seg_c[4], seg_up;
+    int chain_n, chain_out[3]; /* OP_MAXPOOL heading a fused chain of stride-1 pools: every stage's output tensor */
     int pair_next; /* conv_i8: launched together with the NEXT op (same input, same geometry: C3's cv1 + cv2) */ /* conv_i8 reading a never-materialised concat: its segments (tensor, channels) */
     int row_pad, oc_pad, c_pad;
     int ch_off, scale_h, scale_w, bn_n;

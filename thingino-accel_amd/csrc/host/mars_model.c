@@ -804,6 +804,12 @@ static int pairable(const mars_op_t *o) {
     return o->kind == OP_CONV_I8 && !o->nchw && !o->add_t && !o->nseg && o->safe && o->lut_off != NO_OFF && !o->pair_next &&
            (o->in_c & 15) == 0 && o->in_c > 4 && (o->out_c & 15) == 0 && !o->out_pix_stride;
 }
+static int op_writes(const mars_op_t *o, int t) {
+    if (o->t_out == t) return 1;
+    for (int k = 0; k < o->chain_n; k++)
+        if (o->chain_out[k] == t) return 1;
+    return 0;
+}
 static void pair_convs(mars_model_ext_t *m) {
     for (int i = 0; i + 1 < m->n_ops; i++) {
         mars_op_t *a = &m->ops[i];
@@ -816,11 +822,11 @@ static void pair_convs(mars_model_ext_t *m) {
                 if (b->t_in[k] == b->t_out || b->t_in[k] == a->t_out) ok = 0;
             for (int q = i + 1; q < j && ok; q++) {
                 const mars_op_t *o = &m->ops[q];
-                if (o->t_out == b->t_out) ok = 0;
+                if (op_writes(o, b->t_out)) ok = 0;
                 for (int k = 0; k < o->n_in; k++)
                     if (o->t_in[k] == b->t_out) ok = 0;
                 for (int k = 0; k < b->n_in; k++)
-                    if (o->t_out == b->t_in[k]) ok = 0;
+                    if (op_writes(o, b->t_in[k])) ok = 0;
             }
             if (!ok) continue;
             mars_op_t moved = *b;
@@ -830,6 +836,40 @@ static void pair_convs(mars_model_ext_t *m) {
             break;
         }
     }
+}
+
+/* SPPF: MaxPool -> MaxPool -> MaxPool, stride 1, same window, each feeding the next: one launch that keeps the
+ * frame in LDS (mhip_pool_chain_i8).  Every stage's tensor is still written (the concat / convolution reads them). */
+static void fuse_pool_chains(mars_model_ext_t *m) {
+    for (int i = 0; i + 1 < m->n_ops; i++) {
+        mars_op_t *a = &m->ops[i];
+        if (a->kind != OP_MAXPOOL || a->chain_n || a->sh != 1 || a->sw != 1 || a->out_pix_stride || (a->in_c & 15) ||
+            a->out_h != a->in_h || a->out_w != a->in_w || a->kh <= 0 || a->kw <= 0 || (size_t)a->in_h * a->in_w * 64 > 60 * 1024 ||
+            a->t_out < 0 || m->mt[a->t_out].io_out)
+            continue;
+        int n = 1;
+        a->chain_out[0] = a->t_out;
+        while (n < 3 && i + n < m->n_ops) {
+            const mars_op_t *b = &m->ops[i + n];
+            if (b->kind != OP_MAXPOOL || b->t_in[0] != a->chain_out[n - 1] || b->sh != 1 || b->sw != 1 || b->out_pix_stride ||
+                b->in_c != a->in_c || b->in_h != a->in_h || b->in_w != a->in_w || b->out_h != a->in_h || b->out_w != a->in_w ||
+                b->kh != a->kh || b->kw != a->kw || b->t_out < 0 || m->mt[b->t_out].io_out || b->t_out == a->t_in[0])
+                break;
+            a->chain_out[n] = b->t_out;
+            n++;
+        }
+        if (n < 2) continue;
+        a->chain_n = n;
+        for (int k = 1; k < n; k++) {
+            a->bytes += m->ops[i + k].bytes - (double)a->in_h * a->in_w * a->in_c; /* later stages re-read nothing */
+            m->ops[i + k].kind = -1;
+        }
+        a->t_out = a->chain_out[n - 1];
+    }
+    int w = 0;
+    for (int i = 0; i < m->n_ops; i++)
+        if (m->ops[i].kind != -1) m->ops[w++] = m->ops[i];
+    m->n_ops = w;
 }
 
 /* ------------------------------------------------------------------- load */
@@ -897,6 +937,7 @@ static mars_error_t build_plan(mars_model_ext_t *m) {
         fuse_add(m);
         if (!m->no_vconcat) virtual_concat(m);
         elide_concat(m);
+        fuse_pool_chains(m);
         pair_convs(m);
     }
     return MARS_OK;
@@ -1216,6 +1257,16 @@ static int launch_op(mars_model_ext_t *m, mars_op_t *op) {
                                      op->in_h * op->in_w, s, b, op->f0, op->f1);
         }
         case OP_MAXPOOL:
+            if (op->chain_n) {
+                int8_t *outs[3] = {NULL, NULL, NULL};
+                size_t strides[3] = {0, 0, 0};
+                for (int k = 0; k < op->chain_n; k++) {
+                    outs[k] = (int8_t *)tdev(m, op->chain_out[k]);
+                    strides[k] = tstride(m, op->chain_out[k]);
+                }
+                return mhip_pool_chain_i8((const int8_t *)tdev(m, op->t_in[0]), tstride(m, op->t_in[0]), outs, strides,
+                                          op->chain_n, B, op->in_h, op->in_w, op->in_c, op->kh, op->kw);
+            }
             return mhip_maxpool_i8((const int8_t *)tdev(m, op->t_in[0]), tstride(m, op->t_in[0]), (int8_t *)tdev(m, op->t_out),
                                    tstride(m, op->t_out), B, op->in_h, op->in_w, op->in_c, op->out_h, op->out_w, op->kh,
                                    op->kw, op->sh, op->sw, op->out_pix_stride, op->out_ch_off);

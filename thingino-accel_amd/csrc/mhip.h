@@ -133,6 +133,10 @@ int mhip_batchnorm_f32(const float *in, size_t in_stride, float *out, size_t out
 int mhip_maxpool_i8(const int8_t *in, size_t in_stride, int8_t *out, size_t out_stride, int frames,
                     int in_h, int in_w, int ch, int out_h, int out_w, int kh, int kw, int sh, int sw,
                     int out_pix_stride, int out_ch_off);
+/* n <= 3 chained stride-1 max-pools (same window, output size = input size, ch % 16 == 0, h*w*64 <= 60 KB of LDS):
+ * stage i reads stage i-1's result and writes outs[i] */
+int mhip_pool_chain_i8(const int8_t *in, size_t in_stride, int8_t *const *outs, const size_t *out_strides, int n,
+                       int frames, int h, int w, int ch, int kh, int kw);
 int mhip_concat_slice(const int8_t *in, size_t in_stride, int8_t *out, size_t out_stride, int frames,
                       int out_h, int out_w, int in_c, int out_c, int ch_off);
 int mhip_upsample_i8(const int8_t *in, size_t in_stride, int8_t *out, size_t out_stride, int frames,
