@@ -408,3 +408,36 @@ def test_nna_model_facade(gpu, orc, tmp_path):
     junk = tmp_path / "model.mgk"
     junk.write_bytes(b"\\x7fELF" + bytes(200))
     assert not L.nna_model_load(str(junk).encode(), None)  # Venus .mgk models are not served here
+
+
+@pytest.mark.parametrize("h,w,c,k", [(20, 20, 64, 5), (7, 9, 32, 3), (13, 6, 16, 4), (24, 24, 48, 9)])
+def test_pool_chain_fused(gpu, orc, h, w, c, k):
+    """three chained stride-1 max-pools (SPPF) run as one LDS-resident launch in the fused plan: every stage tensor
+    must equal the reference's (window anchored top-left, clipped right / bottom, odd and even windows)"""
+    G = marsfile.Graph()
+    x = G.tensor([1, h, w, c], scale=0.05)
+    p1 = G.tensor([1, h, w, c], scale=0.05)
+    p2 = G.tensor([1, h, w, c], scale=0.05)
+    p3 = G.tensor([1, h, w, c], scale=0.05)
+    o = G.tensor([1, h, w, c], scale=0.05)
+    G.pool(x, p1, (k, k), (1, 1))
+    G.pool(p1, p2, (k, k), (1, 1))
+    G.pool(p2, p3, (k, k), (1, 1))
+    G.layer(marsfile.RELU, [p3], [o])
+    d = G.serialise([x], [o])
+    B = 3
+    xs = [lcg_frame(0x900C0000 + f + h * w, h * w * c) for f in range(B)]
+    nops = {}
+    for fusion in (0, 1):
+        m = gpu.Model(d, batch=B, fusion=fusion)
+        for f in range(B):
+            m.input_view(0)[f] = xs[f]
+        m.run()
+        nops[fusion] = len(m.ops())
+        for f in range(B):
+            g, rc = run_oracle(orc, d, xs[f])
+            assert rc == 0
+            for t in (p1, p2, p3, o):
+                assert np.array_equal(m.read_tensor(t, frame=f), g.tensor(t)), (fusion, f, t)
+        m.close()
+    assert nops[1] == nops[0] - 2
