@@ -193,6 +193,12 @@ __device__ __forceinline__ void glds16(const void *gsrc, void *lds_wave_base) {
                                      (__attribute__((address_space(3))) void *)lds_wave_base, 16, 0, 0);
 }
 
+// LDS-DMA through a buffer resource: a lane whose offset is out of range delivers ZEROS to LDS (probed), so taps
+// outside the image need no zero page and no 64-bit address select; offsets are 32-bit.
+__device__ __forceinline__ void blds16(__amdgpu_buffer_rsrc_t rs, int voffset, int soffset, void *lds_wave_base) {
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (__attribute__((address_space(3))) void *)lds_wave_base, 16, voffset, soffset, 0, 0);
+}
+
 // XCD-aware block order: the 8 XCDs take consecutive dispatch ids round-robin; give each
 // XCD one contiguous range of logical tiles so tiles that share input rows / weight
 // panels share an L2 (bijective for any grid size).
@@ -349,7 +355,8 @@ template <int BPX, int BN, int STAGES>
 __global__ __launch_bounds__(NTHREADS) void conv_i8_mfma(const mhip_conv_i8_t p, const long total_pix, const int k64,
                                                          const int8_t *__restrict__ zeros, const unsigned noc,
                                                          const unsigned nblk, const int lg_inc, const unsigned kw_magic,
-                                                         const fastdiv_t dhw, const fastdiv_t dow) {
+                                                         const fastdiv_t dhw, const fastdiv_t dow, const int bufmode,
+                                                         const unsigned in_bytes) {
     const bool POW2 = lg_inc >= 0; // in_c is a power of two: K position by shifts, else carried counters
     const bool masked = p.kh * p.kw <= 32;
     constexpr int STAGE = (BPX + BN) * BK;
@@ -420,6 +427,18 @@ __global__ __launch_bounds__(NTHREADS) void conv_i8_mfma(const mhip_conv_i8_t p,
         wq[j] = BN >= 64 ? wv * LW + j : (wv & 1); // BN=32: waves 2,3 repeat 0,1 (same bytes, same place)
         wsrc[j] = p.w + (size_t)(oc0 + wq[j] * 16 + (lane >> 2)) * k64 + schunk * 16;
     }
+    // BUF (host: in_c >= 64 and a power of two, tensors < 2 GiB, tap masks in use): a 64-byte K step lies inside ONE
+    // tap, so tap / ky / kx / the step's byte offset are scalars, and the loads go through buffer resources with
+    // 32-bit per-lane offsets -- ~8 instead of ~40 vector instructions per step (the K loop is issue bound)
+    const __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc((void *)p.in, 0, (int)in_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t wrs = __builtin_amdgcn_make_buffer_rsrc((void *)p.w, 0, p.oc_pad * k64, 0x00020000);
+    int xvoff[XI], wvoff[LW];
+    if (bufmode) {
+#pragma unroll
+        for (int j = 0; j < XI; j++) xvoff[j] = (int)(xwin[j] - p.in) + schunk * 16; // may be negative: only used with in-image taps
+#pragma unroll
+        for (int j = 0; j < LW; j++) wvoff[j] = (oc0 + wq[j] * 16 + (lane >> 2)) * k64 + schunk * 16;
+    }
     // K position of this lane's chunk: kernel row ky, tap kx, byte rc inside the tap
     int ky = 0, kx = 0, rc = schunk * 16;
     if (!POW2) {
@@ -431,6 +450,20 @@ __global__ __launch_bounds__(NTHREADS) void conv_i8_mfma(const mhip_conv_i8_t p,
     const int nks = k64 / BK;
     auto issue = [&](int ks, int stage) {
         int8_t *sb = lds + stage * STAGE;
+        if (bufmode) {
+            const int utap = (ks * BK) >> lg_inc, urc = (ks * BK) & ((1 << lg_inc) - 1); // uniform
+            const int uky = (int)(((unsigned)utap * kw_magic) >> 16), ukx = utap - uky * p.kw;
+            const int ukoff = (uky * p.in_w + ukx) * p.in_c + urc;
+            const bool uvalid = utap < taps;
+#pragma unroll
+            for (int j = 0; j < XI; j++) {
+                const bool ok = uvalid & (((tapmask[j] >> utap) & 1u) != 0u);
+                blds16(xrs, ok ? xvoff[j] + ukoff : -1, 0, sb + (wv * (BPX / 4) + j * 16) * BK);
+            }
+#pragma unroll
+            for (int j = 0; j < LW; j++) blds16(wrs, wvoff[j], ks * BK, sb + BPX * BK + wq[j] * 16 * BK);
+            return;
+        }
         bool kvalid;
         if (POW2) {
             const unsigned pos = (unsigned)(ks * BK + schunk * 16);
@@ -541,7 +574,7 @@ __global__ __launch_bounds__(NTHREADS) void conv_i8_persist(const mhip_conv_i8_t
                                                             const unsigned npt, const unsigned ngrp, const int lg_inc,
                                                             const unsigned kw_magic, const fastdiv_t dhw, const fastdiv_t dow,
                                                             const unsigned out_bytes_first, const conv_out_side_t alt,
-                                                            const unsigned noc0) {
+                                                            const unsigned noc0, const int bufmode, const unsigned in_bytes) {
     constexpr int STAGE = (BPX + BN) * BK;
     constexpr int NWN = BN == 128 ? 2 : 1;
     constexpr int NWM = 4 / NWN;
@@ -593,6 +626,7 @@ __global__ __launch_bounds__(NTHREADS) void conv_i8_persist(const mhip_conv_i8_t
     unsigned tapmask[XI];
     unsigned rowf[SEG ? XI : 1], rowrem[SEG ? XI : 1]; // SEG: frame and pixel-in-frame of the rows this lane fetches
     unsigned rowrem_up[SEG ? XI : 1];                  // ... and the pixel a 2x nearest-upsampled segment reads instead
+    int xvoff[XI];
     auto setup_rows = [&](unsigned tile) { // window origin and in-image tap mask of the rows this lane fetches
 #pragma unroll
         for (int j = 0; j < XI; j++) {
@@ -611,6 +645,7 @@ __global__ __launch_bounds__(NTHREADS) void conv_i8_persist(const mhip_conv_i8_t
             const int oy = (int)fdiv(rem, dow), ox = (int)(rem - (unsigned)oy * (unsigned)p.out_w);
             const int iy0 = oy * p.stride_h - p.pad_top, ix0 = ox * p.stride_w - p.pad_left;
             xwin[j] = p.in + (size_t)f * p.in_stride + ((long)iy0 * p.in_w + ix0) * p.in_c;
+            xvoff[j] = (int)(f * (unsigned)p.in_stride) + (iy0 * p.in_w + ix0) * p.in_c + schunk * 16; // BUF mode (32-bit offsets)
             const int kx_lo = ix0 < 0 ? -ix0 : 0, kx_hi = p.in_w - ix0 < p.kw ? p.in_w - ix0 : p.kw;
             const unsigned colbits = kx_hi > kx_lo ? ((kx_hi >= 32 ? ~0u : (1u << kx_hi) - 1u) & ~((1u << kx_lo) - 1u)) : 0u;
             unsigned m = 0;
@@ -622,12 +657,15 @@ __global__ __launch_bounds__(NTHREADS) void conv_i8_persist(const mhip_conv_i8_t
         }
     };
     const int8_t *wsrc[LW];
-    int wq[LW];
+    int wq[LW], wvoff[LW];
 #pragma unroll
     for (int j = 0; j < LW; j++) {
         wq[j] = BN >= 64 ? wv * LW + j : (wv & 1);
         wsrc[j] = p.w + (size_t)(oc0 + wq[j] * 16 + (lane >> 2)) * k64 + schunk * 16;
+        wvoff[j] = (oc0 + wq[j] * 16 + (lane >> 2)) * k64 + schunk * 16;
     }
+    const __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc((void *)p.in, 0, (int)in_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t wrs = __builtin_amdgcn_make_buffer_rsrc((void *)p.w, 0, p.oc_pad * k64, 0x00020000);
     const int taps = p.kh * p.kw;
     const int nks = k64 / BK;
 
@@ -651,6 +689,19 @@ __global__ __launch_bounds__(NTHREADS) void conv_i8_persist(const mhip_conv_i8_t
                 const int8_t *src = base + (size_t)rowf[j] * fstride + (size_t)(up ? rowrem_up[j] : rowrem[j]) * segc + coff;
                 glds16(ok ? src : zeros, sb + (wv * (BPX / 4) + j * 16) * BK);
             }
+        } else if (bufmode) { // see conv_i8_mfma: scalar tap, buffer-addressed loads, zero fill by range check
+            const int utap = (ks * BK) >> lg_inc, urc = (ks * BK) & ((1 << lg_inc) - 1);
+            const int uky = (int)(((unsigned)utap * kw_magic) >> 16), ukx = utap - uky * p.kw;
+            const int ukoff = (uky * p.in_w + ukx) * p.in_c + urc;
+            const bool uvalid = utap < taps;
+#pragma unroll
+            for (int j = 0; j < XI; j++) {
+                const bool ok = uvalid & (((tapmask[j] >> utap) & 1u) != 0u);
+                blds16(xrs, ok ? xvoff[j] + ukoff : -1, 0, sb + (wv * (BPX / 4) + j * 16) * BK);
+            }
+#pragma unroll
+            for (int j = 0; j < LW; j++) blds16(wrs, wvoff[j], ks * BK, sb + BPX * BK + wq[j] * 16 * BK);
+            return;
         } else {
             const unsigned tap = pos >> lg_inc;
             const int rc = (int)(pos & ((1u << lg_inc) - 1u));
@@ -1297,6 +1348,7 @@ struct tune_t {
     int stages;         // MARS_HIP_STAGES        0: auto, else ring depth of the one-tile kernel (2 | 3 | 4)
     int bpx;            // MARS_HIP_BPX           0: auto, else pixels per workgroup (128 | 256)
     int variant;        // MARS_HIP_VARIANT       0: policy, else this launch variant wherever the layer allows it (tests)
+    int bufmode;        // MARS_HIP_BUFMODE       1: buffer-addressed K loop where eligible
 };
 static tune_t g_tune;
 static int env_int(const char *name, int dflt) {
@@ -1312,6 +1364,7 @@ static const tune_t &tune() {
         g_tune.stages = env_int("MARS_HIP_STAGES", 0);
         g_tune.bpx = env_int("MARS_HIP_BPX", 0);
         g_tune.variant = env_int("MARS_HIP_VARIANT", 0);
+        g_tune.bufmode = env_int("MARS_HIP_BUFMODE", 1);
         g_tune.init = 1;
     }
     return g_tune;
@@ -1320,7 +1373,7 @@ extern "C" int mhip_conv_i8_tune(const char *key, int value) {
     (void)tune();
     struct { const char *k; int *v; } tab[] = {{"persist", &g_tune.persist}, {"persist_stages", &g_tune.persist_stages},
                                                {"persist_maxk", &g_tune.persist_maxk}, {"persist_slots", &g_tune.persist_slots},
-                                               {"stages", &g_tune.stages}, {"bpx", &g_tune.bpx}, {"variant", &g_tune.variant}};
+                                               {"stages", &g_tune.stages}, {"bpx", &g_tune.bpx}, {"variant", &g_tune.variant}, {"bufmode", &g_tune.bufmode}};
     for (auto &e : tab)
         if (key && !strcmp(key, e.k)) {
             *e.v = value;
@@ -1348,6 +1401,17 @@ static int launch_smallc(const mhip_conv_i8_t *p, int k64) {
     return mhip_check(hipGetLastError(), "conv_i8_smallc launch");
 }
 
+// bytes from p->in to the end of the last frame's pixels (the buffer resource's range)
+static long in_extent_bytes(const mhip_conv_i8_t *p) {
+    return (long)(p->frames - 1) * (long)p->in_stride + (long)p->in_h * p->in_w * p->in_c;
+}
+// buffer-addressed K loop: a 64-byte step inside one tap (in_c >= 64, power of two), 31-bit offsets, tap masks
+static int buf_mode(const mhip_conv_i8_t *p, int k64) {
+    if (!tune().bufmode) return 0;
+    return p->in_c >= 64 && (p->in_c & (p->in_c - 1)) == 0 && p->kh * p->kw <= 32 && (long)p->kh * p->kw * (p->kw - 1) < 65536 &&
+           in_extent_bytes(p) <= 0x7fffffffL && (long)p->oc_pad * k64 <= 0x7fffffffL;
+}
+
 template <int BPX, int BN, int STAGES>
 static int launch_mfma(const mhip_conv_i8_t *p, long total_pix, int k64) {
     const unsigned npt = (unsigned)((total_pix + BPX - 1) / BPX), noc = (unsigned)(p->oc_pad / BN);
@@ -1364,7 +1428,8 @@ static int launch_mfma(const mhip_conv_i8_t *p, long total_pix, int k64) {
     const unsigned magic = ((65536u + (unsigned)p->kw - 1u) / (unsigned)p->kw);
     hipLaunchKernelGGL((conv_i8_mfma<BPX, BN, STAGES>), dim3(nblk), dim3(NTHREADS), lds, mhip_stream_native(), *p, total_pix,
                        k64, (const int8_t *)mhip_zero_page(), noc, nblk, lg, magic,
-                       make_fastdiv((unsigned)(p->out_h * p->out_w)), make_fastdiv((unsigned)p->out_w));
+                       make_fastdiv((unsigned)(p->out_h * p->out_w)), make_fastdiv((unsigned)p->out_w),
+                       lg >= 0 ? buf_mode(p, k64) : 0, (unsigned)in_extent_bytes(p));
     return mhip_check(hipGetLastError(), "conv_i8_mfma launch");
 }
 
@@ -1405,7 +1470,7 @@ static int launch_persist_t(const mhip_conv_i8_t *p, long total_pix, int k64, in
     hipLaunchKernelGGL((conv_i8_persist<BPX, BN, STAGES, HAS_LUT, SEG, PAIR>), dim3(noc * ngrp), dim3(NTHREADS), lds,
                        mhip_stream_native(), *p, (unsigned)total_pix, k64, (const int8_t *)mhip_zero_page(), noc, npt, ngrp, lg,
                        magic, make_fastdiv((unsigned)(p->out_h * p->out_w)), make_fastdiv((unsigned)p->out_w),
-                       (unsigned)persist_out_bytes(p), alt, noc0);
+                       (unsigned)persist_out_bytes(p), alt, noc0, SEG ? 0 : buf_mode(p, k64), (unsigned)in_extent_bytes(p));
     return mhip_check(hipGetLastError(), "conv_i8_persist launch");
 }
 
