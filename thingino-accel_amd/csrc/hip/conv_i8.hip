@@ -351,7 +351,9 @@ __device__ __forceinline__ void init_acc(const mhip_conv_i8_t &p, v4i (&acc)[WOC
 // 64-pixel x (32|64)-channel accumulator tile (BPX=256 for BN<=64, BPX=128 for BN=128).
 // POW2: in_c is a power of two (every yolov5 layer) -> the K position of a chunk is shifts and
 // one small multiply instead of carried counters.
-template <int BPX, int BN, int STAGES>
+// KS = 64-byte K slices per ring stage: 2 halves the barriers and waits per MFMA (one s_barrier per 128 bytes of K)
+// at twice the LDS per stage; the host picks it only for an even number of K steps.
+template <int BPX, int BN, int STAGES, int KS = 1>
 __global__ __launch_bounds__(NTHREADS) void conv_i8_mfma(const mhip_conv_i8_t p, const long total_pix, const int k64,
                                                          const int8_t *__restrict__ zeros, const unsigned noc,
                                                          const unsigned nblk, const int lg_inc, const unsigned kw_magic,
@@ -359,7 +361,8 @@ __global__ __launch_bounds__(NTHREADS) void conv_i8_mfma(const mhip_conv_i8_t p,
                                                          const unsigned in_bytes) {
     const bool POW2 = lg_inc >= 0; // in_c is a power of two: K position by shifts, else carried counters
     const bool masked = p.kh * p.kw <= 32;
-    constexpr int STAGE = (BPX + BN) * BK;
+    constexpr int SLICE = (BPX + BN) * BK;
+    constexpr int STAGE = KS * SLICE;
     constexpr int NWN = BN == 128 ? 2 : 1;       // waves along oc
     constexpr int NWM = 4 / NWN;                 // waves along pixels
     constexpr int WPX = BPX / NWM / 16;          // pixel subtiles per wave
@@ -449,7 +452,7 @@ __global__ __launch_bounds__(NTHREADS) void conv_i8_mfma(const mhip_conv_i8_t p,
 
     const int nks = k64 / BK;
     auto issue = [&](int ks, int stage) {
-        int8_t *sb = lds + stage * STAGE;
+        int8_t *sb = lds + stage * STAGE + (KS > 1 ? (ks % KS) * SLICE : 0);
         if (bufmode) {
             const int utap = (ks * BK) >> lg_inc, urc = (ks * BK) & ((1 << lg_inc) - 1); // uniform
             const int uky = (int)(((unsigned)utap * kw_magic) >> 16), ukx = utap - uky * p.kw;
@@ -498,33 +501,41 @@ __global__ __launch_bounds__(NTHREADS) void conv_i8_mfma(const mhip_conv_i8_t p,
         }
     };
 
+    const int nst = nks / KS; // ring stages to run (KS == 2: the host guarantees an even nks)
 #pragma unroll
     for (int s = 0; s < STAGES - 1; s++)
-        if (s < nks) issue(s, s);
+        if (s < nst)
+#pragma unroll
+            for (int u = 0; u < KS; u++) issue(s * KS + u, s);
 
     const int frow = lane & 15, fchunk = lane >> 4;
     int stage = 0, nstage = STAGES - 1;
-    for (int ks = 0; ks < nks; ks++) {
-        // tiles still allowed in flight once tile ks must have landed
-        const int ahead = nks - 1 - ks;
-        if (STAGES >= 4 && ahead >= 2) wait_vmcnt<2 * L>();
-        else if (STAGES >= 3 && ahead >= 1) wait_vmcnt<L>();
+    for (int st = 0; st < nst; st++) {
+        // stages still allowed in flight once stage st must have landed
+        const int ahead = nst - 1 - st;
+        if (STAGES >= 4 && ahead >= 2) wait_vmcnt<2 * L * KS>();
+        else if (STAGES >= 3 && ahead >= 1) wait_vmcnt<L * KS>();
         else wait_vmcnt<0>();
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
-        // all fragment reads of this step first, then the next stage's DMA (its address math hides the LDS latency),
-        // then the MFMAs
-        const int8_t *xs = lds + stage * STAGE, *ws = xs + BPX * BK;
-        v4i xb[WPX], wa[WOC];
 #pragma unroll
-        for (int t = 0; t < WPX; t++) xb[t] = *(const v4i *)(xs + lds_off(pxw + t * 16 + frow, fchunk));
+        for (int u = 0; u < KS; u++) {
+            // all fragment reads of this slice first, then the next stage's DMA (its address math hides the LDS
+            // latency), then the MFMAs
+            const int8_t *xs = lds + stage * STAGE + u * SLICE, *ws = xs + BPX * BK;
+            v4i xb[WPX], wa[WOC];
 #pragma unroll
-        for (int s = 0; s < WOC; s++) wa[s] = *(const v4i *)(ws + lds_off(ocw + s * 16 + frow, fchunk));
-        if (ks + STAGES - 1 < nks) issue(ks + STAGES - 1, nstage);
+            for (int t = 0; t < WPX; t++) xb[t] = *(const v4i *)(xs + lds_off(pxw + t * 16 + frow, fchunk));
 #pragma unroll
-        for (int s = 0; s < WOC; s++)
+            for (int s = 0; s < WOC; s++) wa[s] = *(const v4i *)(ws + lds_off(ocw + s * 16 + frow, fchunk));
+            if (u == 0 && st + STAGES - 1 < nst)
 #pragma unroll
-            for (int t = 0; t < WPX; t++) acc[s][t] = __builtin_amdgcn_mfma_i32_16x16x64_i8(wa[s], xb[t], acc[s][t], 0, 0, 0);
+                for (int v = 0; v < KS; v++) issue((st + STAGES - 1) * KS + v, nstage);
+#pragma unroll
+            for (int s = 0; s < WOC; s++)
+#pragma unroll
+                for (int t = 0; t < WPX; t++) acc[s][t] = __builtin_amdgcn_mfma_i32_16x16x64_i8(wa[s], xb[t], acc[s][t], 0, 0, 0);
+        }
         stage = stage + 1 == STAGES ? 0 : stage + 1;
         nstage = nstage + 1 == STAGES ? 0 : nstage + 1;
     }
@@ -1412,13 +1423,21 @@ static int buf_mode(const mhip_conv_i8_t *p, int k64) {
            in_extent_bytes(p) <= 0x7fffffffL && (long)p->oc_pad * k64 <= 0x7fffffffL;
 }
 
-template <int BPX, int BN, int STAGES>
+template <int BPX, int BN, int STAGES, int KS = 1>
 static int launch_mfma(const mhip_conv_i8_t *p, long total_pix, int k64) {
     const unsigned npt = (unsigned)((total_pix + BPX - 1) / BPX), noc = (unsigned)(p->oc_pad / BN);
     const unsigned nblk = npt * noc;
-    const int nks = k64 / BK, used = nks < STAGES ? nks : STAGES;
-    size_t ring = (size_t)used * (BPX + BN) * BK, tile = (size_t)BPX * (BN + OPAD);
+    const int nks = k64 / BK, nst = nks / KS, used = nst < STAGES ? nst : STAGES;
+    if (KS > 1 && (nks % KS) != 0) return -1;
+    size_t ring = (size_t)used * KS * (BPX + BN) * BK, tile = (size_t)BPX * (BN + OPAD);
     const size_t lds = BPX * 8 + 256 + (ring > tile ? ring : tile);
+    if (lds > 64 * 1024) {
+        static bool attr = false;
+        if (!attr && hipFuncSetAttribute((const void *)conv_i8_mfma<BPX, BN, STAGES, KS>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                         (int)(BPX * 8 + 256 + (size_t)STAGES * KS * (BPX + BN) * BK)) != hipSuccess)
+            return mhip_check(hipErrorUnknown, "conv_i8_mfma LDS attribute");
+        attr = true;
+    }
     // in_c a power of two and tap/kw small enough for the 16-bit reciprocal: shift-based K position
     int lg = -1;
     if ((p->in_c & (p->in_c - 1)) == 0 && (long)p->kh * p->kw * (p->kw - 1) < 65536) {
@@ -1426,7 +1445,7 @@ static int launch_mfma(const mhip_conv_i8_t *p, long total_pix, int k64) {
         while ((1 << lg) < p->in_c) lg++;
     }
     const unsigned magic = ((65536u + (unsigned)p->kw - 1u) / (unsigned)p->kw);
-    hipLaunchKernelGGL((conv_i8_mfma<BPX, BN, STAGES>), dim3(nblk), dim3(NTHREADS), lds, mhip_stream_native(), *p, total_pix,
+    hipLaunchKernelGGL((conv_i8_mfma<BPX, BN, STAGES, KS>), dim3(nblk), dim3(NTHREADS), lds, mhip_stream_native(), *p, total_pix,
                        k64, (const int8_t *)mhip_zero_page(), noc, nblk, lg, magic,
                        make_fastdiv((unsigned)(p->out_h * p->out_w)), make_fastdiv((unsigned)p->out_w),
                        lg >= 0 ? buf_mode(p, k64) : 0, (unsigned)in_extent_bytes(p));
@@ -1480,18 +1499,21 @@ static int launch_persist_t(const mhip_conv_i8_t *p, long total_pix, int k64, in
 // variant per layer after timing the candidates on the device (mars_hip_autotune).
 //   code = 1 + persist + 2*(bpx == 256) + 4*(stages == 3)
 //   code = 9 / 10 / 11: patch-staged kernel with 8 / 16 / 4 tile rows
-#define NVARIANTS 11
+//   code = 12: one tile per workgroup, 128 pixels, 2 ring stages of 128 K bytes each (even number of K steps)
+#define NVARIANTS 12
 struct variant_t {
-    int persist, bpx, stages, patch;
+    int persist, bpx, stages, patch, ks2;
 };
 static int variant_code(const variant_t &v) {
+    if (v.ks2) return 12;
     if (v.patch) return v.patch == 16 ? 10 : (v.patch == 8 ? 9 : 11);
     return 1 + (v.persist ? 1 : 0) + (v.bpx == 256 ? 2 : 0) + (v.stages == 3 ? 4 : 0);
 }
 static variant_t variant_of(int code) {
-    if (code >= 9) return variant_t{0, 0, 0, code == 10 ? 16 : (code == 9 ? 8 : 4)};
+    if (code == 12) return variant_t{0, 128, 2, 0, 1};
+    if (code >= 9) return variant_t{0, 0, 0, code == 10 ? 16 : (code == 9 ? 8 : 4), 0};
     const int c = code - 1;
-    return variant_t{c & 1, (c & 2) ? 256 : 128, (c & 4) ? 3 : 2, 0};
+    return variant_t{c & 1, (c & 2) ? 256 : 128, (c & 4) ? 3 : 2, 0, 0};
 }
 
 // ---- patch-staged kernel: geometry, eligibility, launch
@@ -1588,6 +1610,7 @@ static bool persist_eligible(const mhip_conv_i8_t *p) {
 static variant_t default_variant(const mhip_conv_i8_t *p, int nks) {
     variant_t v;
     v.patch = 0;
+    v.ks2 = 0;
     // wide, shallow k x k layers: the patch-staged kernel wins wherever its double-buffered form fits (measured on the
     // 160x160 and 80x80 layers of yolov5s: 1.25-1.9x over the implicit-GEMM forms)
     patch_geom_t g;
@@ -1624,6 +1647,7 @@ static int launch_variant_t(const mhip_conv_i8_t *p, long total_pix, int k64, co
         return p->lut ? launch_persist_t<BPX, BN, 3, true>(p, total_pix, k64, lg, magic)
                       : launch_persist_t<BPX, BN, 3, false>(p, total_pix, k64, lg, magic);
     }
+    if (v.ks2) return BPX == 128 && BN >= 64 ? launch_mfma<128, (BN >= 64 ? BN : 64), 2, 2>(p, total_pix, k64) : -1;
     return v.stages == 2 ? launch_mfma<BPX, BN, 2>(p, total_pix, k64) : launch_mfma<BPX, BN, 3>(p, total_pix, k64);
 }
 
@@ -1705,6 +1729,7 @@ extern "C" int mhip_conv_i8_variants(const mhip_conv_i8_t *p, int *codes, int ma
         patch_geom_t g;
         if (v.patch && !patch_geom(p, v.patch, &g)) continue;
         if (v.persist && !persist_eligible(p)) continue;
+        if (v.ks2 && ((nks & 1) || nks < 4 || p->oc_pad % 64 != 0)) continue;
         if (!v.persist && v.stages == 3 && nks <= 2) continue; // identical to the 2-stage launch
         if (n < max) codes[n++] = code;
     }
