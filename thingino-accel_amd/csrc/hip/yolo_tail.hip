@@ -136,40 +136,48 @@ __global__ __launch_bounds__(64) void sort_kernel(det_rec *all, const int *count
         c[k] = pos < n ? dets[pos].conf : -INFINITY;
         d[k] = pos;
     }
-    for (int i = 0; i + 1 < n; i++) {
-        const int rel = i - lane * 16; // slot k of this lane takes part iff k >= rel
-        // (1) this lane's (max, first holder) over its slots >= i  (selects, no branches)
-        float v = -INFINITY;
-        int id = -1;
+    // A slot that is final holds confidence -inf from then on (only its record id is needed), so no pass has to test
+    // "position >= i": finished slots can neither win the maximum nor be records.  Slot i itself turns into -inf by
+    // the chain shift of pass i (it is the first record, the running maximum before it is -inf), and receives the
+    // maximum's id explicitly.  Passes are unrolled by 16 so that the head slot index is a compile-time constant.
+    for (int i0 = 0; i0 + 1 < n; i0 += 16) {
+        const bool owner = lane == (i0 >> 4);
 #pragma unroll
-        for (int k = 0; k < 16; k++) {
-            const bool take = (k >= rel) & (c[k] > v);
-            v = take ? c[k] : v;
-            id = take ? d[k] : id;
-        }
-        // (2) inclusive scan across the wave
-        scan_step<DPP_ROW_SHR(1), 0xf>(v, id);
-        scan_step<DPP_ROW_SHR(2), 0xf>(v, id);
-        scan_step<DPP_ROW_SHR(4), 0xf>(v, id);
-        scan_step<DPP_ROW_SHR(8), 0xf>(v, id);
-        scan_step<DPP_ROW_BCAST15, 0xa>(v, id);
-        scan_step<DPP_ROW_BCAST31, 0xc>(v, id);
-        const float fv = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
-        const int fid = __builtin_amdgcn_readlane(id, 63);
-        // running (max, holder) BEFORE this lane's first slot
-        float rv = __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(-INFINITY), __float_as_int(v), DPP_WAVE_SHR1, 0xf, 0xf, false));
-        int rid = __builtin_amdgcn_update_dpp(-1, id, DPP_WAVE_SHR1, 0xf, 0xf, false);
-        // (3) shift the record chain, then drop the maximum into slot i
+        for (int k0 = 0; k0 < 16; k0++) {
+            if (i0 + k0 + 1 >= n) break; // uniform
+            // (1) this lane's (max, first holder)
+            float v = c[0];
+            int id = d[0];
 #pragma unroll
-        for (int k = 0; k < 16; k++) {
-            const bool rec = (k >= rel) & (c[k] > rv);
-            const bool head = k == rel;
-            const float tv = c[k];
-            const int td = d[k];
-            c[k] = head ? fv : (rec ? rv : tv);
-            d[k] = head ? fid : (rec ? rid : td);
-            rv = rec ? tv : rv;
-            rid = rec ? td : rid;
+            for (int k = 1; k < 16; k++) {
+                const bool take = c[k] > v; // strict: the earlier holder stays
+                v = take ? c[k] : v;
+                id = take ? d[k] : id;
+            }
+            // (2) inclusive scan across the wave
+            scan_step<DPP_ROW_SHR(1), 0xf>(v, id);
+            scan_step<DPP_ROW_SHR(2), 0xf>(v, id);
+            scan_step<DPP_ROW_SHR(4), 0xf>(v, id);
+            scan_step<DPP_ROW_SHR(8), 0xf>(v, id);
+            scan_step<DPP_ROW_BCAST15, 0xa>(v, id);
+            scan_step<DPP_ROW_BCAST31, 0xc>(v, id);
+            const int fid = __builtin_amdgcn_readlane(id, 63);
+            // running (max, holder) BEFORE this lane's first slot
+            float rv = __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(-INFINITY), __float_as_int(v), DPP_WAVE_SHR1, 0xf, 0xf, false));
+            int rid = __builtin_amdgcn_update_dpp(-1, id, DPP_WAVE_SHR1, 0xf, 0xf, false);
+            // (3) every strict left-to-right record takes the previous record's element
+#pragma unroll
+            for (int k = 0; k < 16; k++) {
+                const bool rec = c[k] > rv;
+                const float tv = c[k];
+                const int td = d[k];
+                c[k] = rec ? rv : tv;
+                d[k] = rec ? rid : td;
+                rv = rec ? tv : rv;
+                rid = rec ? td : rid;
+            }
+            // the maximum (first occurrence) lands in slot i
+            d[k0] = owner ? fid : d[k0];
         }
     }
     // gather the records in sorted order (read everything before anything is overwritten)
