@@ -441,3 +441,32 @@ def test_pool_chain_fused(gpu, orc, h, w, c, k):
                 assert np.array_equal(m.read_tensor(t, frame=f), g.tensor(t)), (fusion, f, t)
         m.close()
     assert nops[1] == nops[0] - 2
+
+
+def test_virtual_concat_falls_back_for_huge_batches(gpu, orc, monkeypatch):
+    """segmented (virtual concat) convolutions address their output with 32-bit offsets; a batch that would push an
+    output past 2 GiB makes set_batch plan again with materialised concats.  The limit is lowered through
+    MARS_HIP_VCONCAT_LIMIT so that a small batch takes that path; results must not change."""
+    d = gpu.synth_model(width_x16=4, input_hw=96, seed=61)
+    hdr, tensors, _ = marsfile.parse(d)
+    nb = marsfile.tensor_nbytes(tensors[hdr["inputs"][0]])
+    xs = [lcg_frame(0xB16B0000 + f, nb) for f in range(2)]
+    m = gpu.Model(d, batch=2)
+    n_virtual = len(m.ops())
+    for f in range(2):
+        m.input_view(0)[f] = xs[f]
+    m.run()
+    want = [m.output_view(i).copy() for i in range(3)]
+    monkeypatch.setenv("MARS_HIP_VCONCAT_LIMIT", "4096")
+    m.set_batch(2)  # re-plans: concat copies are back
+    assert len(m.ops()) > n_virtual
+    for f in range(2):
+        m.input_view(0)[f] = xs[f]
+    m.run()
+    for i in range(3):
+        assert np.array_equal(m.output_view(i), want[i])
+    g, rc = run_oracle(orc, d, xs[1])
+    assert rc == 0
+    for i, ti in enumerate(hdr["outputs"]):
+        assert np.array_equal(g.tensor(ti), want[i][1])
+    m.close()

@@ -974,7 +974,8 @@ static mars_error_t alloc_batch(mars_model_ext_t *m, int n) {
             if (op->kind != OP_CONV_I8 || op->nseg < 2 || op->t_out < 0) continue;
             const mtensor_t *t = &m->mt[op->t_out];
             const size_t stride = ALIGN_UP(t->extent > t->bytes ? t->extent : t->bytes, 256);
-            if (stride * (size_t)n > 0x7fffffffu) {
+            const char *lim = getenv("MARS_HIP_VCONCAT_LIMIT"); /* tests: exercise the fallback with a small batch */
+            if (stride * (size_t)n > (lim ? (size_t)strtoull(lim, NULL, 0) : (size_t)0x7fffffffu)) {
                 m->no_vconcat = 1;
                 mars_error_t e = build_plan(m);
                 if (e == MARS_OK) e = upload_params(m);
