@@ -13,7 +13,7 @@ sequence, NHWC/OHWI int8).  N>1: one process per GPU (torch.distributed.run), fr
 forward pass.
 
 Prints ONE JSON line (rank 0).  `roofline` is for the dominant kernel (conv_i8_kernel, the
-implicit-GEMM MFMA convolution): algorithmic int8 ops of all its launches / their summed
+implicit-GEMM MFMA convolution): algorithmic bytes (and, as `mfma_view`, int8 ops) of all its launches / their summed
 duration, measured with HIP events on the library's stream inside the timed region.
 `cpu_baseline` is the reference's own C code (oracle/_ref, -O3 -funroll-loops as in its
 Makefile:21) on one host core over a bounded sample (1 frame of the same workload); the GPU
@@ -247,10 +247,17 @@ def main():
                                    (args.width, args.hw, args.hw, args.batch, "off" if args.no_tail else "on"),
                        "frames_per_gpu": args.batch, "sharding": "frames", "collectives_in_forward": 0,
                        "autotuned_launch_variants": not args.no_autotune, "conv_gmac_per_image": macs_per_img / 1e9, "algorithmic_mb_per_image": bytes_per_img / 1e6},
-            "roofline": {"bound": "mfma", "kernel": "conv_i8_kernel (%d launches per step)" % n_conv,
-                         "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak,
+            # The conv family's arithmetic intensity (2*MAC / algorithmic byte ~ 260 op/B) is below the machine's ridge
+            # (5000 TOP/s / 8 TB/s = 625 op/B), so its roof is HBM: achieved = algorithmic bytes of the conv launches /
+            # their summed durations.  The matrix-roof view of the same launches is reported next to it.
+            "roofline": {"bound": "hbm", "kernel": "conv_i8_* (%d launches per step)" % n_conv,
+                         "achieved": conv_bytes_per_img * args.batch / (conv_ms / ev_steps * 1e-3) / 1e9 if conv_ms > 0 else 0.0,
+                         "peak": 8000.0, "unit": "GB/s",
+                         "frac": (conv_bytes_per_img * args.batch / (conv_ms / ev_steps * 1e-3) / 1e9 / 8000.0) if conv_ms > 0 else 0.0,
                          "traffic": traffic, "traffic_source": traffic_src,
                          "algorithmic_bytes": conv_bytes_per_img * args.batch,
+                         "intensity_ops_per_byte": 2.0 * macs_per_img / conv_bytes_per_img if conv_bytes_per_img else None,
+                         "mfma_view": {"achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak},
                          "event_timed_steps": ev_steps,
                          "conv_ms_per_step": conv_ms / ev_steps,
                          "all_kernels_ms_per_step": all_ms / ev_steps,
