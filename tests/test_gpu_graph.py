@@ -470,3 +470,30 @@ def test_virtual_concat_falls_back_for_huge_batches(gpu, orc, monkeypatch):
     for i, ti in enumerate(hdr["outputs"]):
         assert np.array_equal(g.tensor(ti), want[i][1])
     m.close()
+
+
+def test_c_program_links_and_runs(gpu, orc, tmp_path):
+    """tests/c/drop_in.c: a plain C caller (reference headers only) compiled with gcc, linked against the in-tree
+    libnna_mars.so, run as its own process on the GPU; its output checksum equals the oracle's for the same model"""
+    import subprocess
+    root = os.path.join(HERE, "..")
+    libdir = os.path.join(root, "thingino-accel_amd", "lib")
+    exe = tmp_path / "drop_in"
+    subprocess.run(["gcc", "-O1", "-Wall", "-I" + os.path.join(root, "include"), os.path.join(HERE, "c", "drop_in.c"), "-o", str(exe),
+                    "-L" + libdir, "-lnna_mars", "-Wl,-rpath," + libdir], check=True)
+    model = os.path.join(HERE, "golden", "models", "tiny_160_int8.mars")
+    out = subprocess.run([str(exe), model], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, (out.returncode, out.stderr[-1000:])
+    d = open(model, "rb").read()
+    hdr, tensors, _ = marsfile.parse(d)
+    n = marsfile.tensor_nbytes(tensors[hdr["inputs"][0]])
+    x = (np.arange(n) % 127).astype(np.int8).view(np.uint8)
+    g, rc = run_oracle(orc, d, x)
+    assert rc == 0
+    want = g.tensor(hdr["outputs"][0])
+    h = 0xCBF29CE484222325
+    for b in want.tobytes():
+        h = ((h ^ b) * 0x100000001B3) & 0xFFFFFFFFFFFFFFFF
+    lines = out.stdout.split()
+    assert lines[0] == "mars" and int(lines[1]) == want.size and lines[2] == "%016x" % h
+    assert lines[3] == "nna" and int(lines[4]) == want.size and lines[5] == "%016x" % h
