@@ -173,3 +173,41 @@ def test_synth_models(marsrt):
     assert marsrt.lib().mars_synth_model(None, None, 0) == 0
     with pytest.raises(ValueError):
         marsrt.synth_model(input_hw=100)  # not a multiple of 32
+
+
+def test_half_step_lut_guard(marsrt):
+    """mhip_conv_i8_lut2_ok(cs): the 4-instruction requantisation (index trunc(2*acc*cs) into a half-step LUT) equals
+    the reference's round-half-away for every float except |acc*cs| == 0x3EFFFFFF; the guard must refuse exactly the
+    scales for which some int32 accumulator produces that float (host code: no GPU needed)"""
+    import ctypes as C
+    L = marsrt.lib()
+    L.mhip_conv_i8_lut2_ok.argtypes = [C.c_float]
+    quirk = np.frombuffer(np.uint32(0x3EFFFFFF).tobytes(), dtype=np.float32)[0]
+
+    def brute(cs):
+        a = abs(np.float32(cs))
+        if not (a >= np.float32(1e-6)) or not (a < np.float32(0.99)):
+            return 0
+        a0 = int(float(quirk) / float(a))
+        for acc in range(max(a0 - 6, 1), a0 + 7):
+            if np.float32(np.float32(acc) * a) == quirk:
+                return 0
+        return 1
+
+    rng = np.random.default_rng(4)
+    refused = 0
+    for cs in np.exp(rng.uniform(np.log(2e-6), np.log(0.9), 4000)).astype(np.float32):
+        want = brute(cs)
+        assert L.mhip_conv_i8_lut2_ok(float(cs)) == want, float(cs)
+        refused += 1 - want
+    # constructed offenders: scales a few ulps around quirk / acc
+    hits = 0
+    for acc in (1, 3, 5, 7, 11, 100, 12345):
+        base = np.float32(float(quirk) / acc)
+        for ulps in range(-4, 5):
+            cs = np.frombuffer((base.view(np.uint32) + np.uint32(ulps % (1 << 32))).astype(np.uint32).tobytes(), dtype=np.float32)[0]
+            want = brute(cs)
+            assert L.mhip_conv_i8_lut2_ok(float(cs)) == want, (acc, ulps)
+            hits += 1 - want
+    assert hits > 0  # the guard does fire
+    assert L.mhip_conv_i8_lut2_ok(float("nan")) == 0 and L.mhip_conv_i8_lut2_ok(1.5) == 0 and L.mhip_conv_i8_lut2_ok(1e-9) == 0

@@ -48,6 +48,7 @@ typedef int v2i __attribute__((ext_vector_type(2)));
 #define BK 64       // K bytes per step = one MFMA
 #define NTHREADS 256
 #define OPAD 4      // padding of an epilogue LDS row (bytes): spreads pixel rows over banks
+#define LUTB 512    // bytes reserved at LDS address 0 for the fused LUT (256-entry, or the 512-entry half-step form)
 
 // LDS tile row = 64 bytes (4 chunks of 16).  XOR the chunk index with
 // ((row>>2)&1)<<1: conflict-free for the ds_read_b128 lane groups of gfx950
@@ -121,11 +122,52 @@ __device__ __forceinline__ int add_one(int v, uint32_t xword, int k, const add_a
     asm("v_med3_i32 %0, %1, %2, %3" : "=v"(m) : "v"(r), "v"(lo8), "v"(hi8));
     return m;
 }
-template <int NV, bool HAS_LUT, bool SAFE, bool LUT0, bool ADD = false>
+// FAST (host: p.lut2): the fused LUT in its half-step form.  round-half-away(x) = f(trunc(2x)) for every float except
+// +-0x3EFFFFFF (checked over all floats below 1000; that value rounds up inside the reference's float add), and the
+// host verifies no accumulator of the layer can produce it.  So requantise + clamp + LUT become: v_cvt_f32_i32,
+// v_mul_f32 (by 2*cs, exact doubling), v_cvt_i32_f32, v_med3_i32 to [-256, 255], ds_read_i8 from the 512-entry table
+// lut2[k + 256] = lut[clamp(f(k), lo, 127) + 128]: 4 instead of 6 VALU per value, the lower clamp folded into the table.
+__device__ __forceinline__ void lut4_fast(int q0, int q1, int q2, int q3, int &v0, int &v1, int &v2, int &v3) {
+    asm volatile("ds_read_i8 %0, %4 offset:256\n\tds_read_i8 %1, %5 offset:256\n\t"
+                 "ds_read_i8 %2, %6 offset:256\n\tds_read_i8 %3, %7 offset:256"
+                 : "=&v"(v0), "=&v"(v1), "=&v"(v2), "=&v"(v3)
+                 : "v"(q0), "v"(q1), "v"(q2), "v"(q3)
+                 : "memory");
+}
+template <int NV, bool HAS_LUT, bool SAFE, bool LUT0, bool ADD = false, bool FAST = false>
 __device__ __forceinline__ void requant_pack(const int (&a)[NV], float cs, int lo, const uint8_t *lut128, uint32_t (&pk)[NV / 4],
                                              const uint32_t *xw = nullptr, const add_args_t *ga = nullptr) {
     int q[NV];
     const int hi = 127;
+    if (FAST && HAS_LUT && LUT0 && SAFE) {
+        const float cs2 = cs * 2.0f;
+        const int klo = -256, khi = 255;
+        int v[NV];
+#pragma unroll
+        for (int i = 0; i < NV; i++) {
+            const int k = (int)((float)a[i] * cs2);
+            asm("v_med3_i32 %0, %1, %2, %3" : "=v"(q[i]) : "v"(k), "v"(klo), "v"(khi));
+        }
+#pragma unroll
+        for (int g = 0; g < NV / 4; g++)
+            lut4_fast(q[4 * g], q[4 * g + 1], q[4 * g + 2], q[4 * g + 3], v[4 * g], v[4 * g + 1], v[4 * g + 2], v[4 * g + 3]);
+        if (NV == 16)
+            asm volatile("s_waitcnt lgkmcnt(0)"
+                         : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]), "+v"(v[3]), "+v"(v[4]), "+v"(v[5]), "+v"(v[6]), "+v"(v[7]),
+                           "+v"(v[8 % NV]), "+v"(v[9 % NV]), "+v"(v[10 % NV]), "+v"(v[11 % NV]), "+v"(v[12 % NV]), "+v"(v[13 % NV]),
+                           "+v"(v[14 % NV]), "+v"(v[15 % NV]));
+        else
+            asm volatile("s_waitcnt lgkmcnt(0)"
+                         : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]), "+v"(v[3]), "+v"(v[4]), "+v"(v[5]), "+v"(v[6]), "+v"(v[7]));
+        if (ADD) {
+            const int lo8 = -128;
+#pragma unroll
+            for (int i = 0; i < NV; i++) v[i] = add_one(v[i], xw[i >> 2], i & 3, *ga, lo8, hi);
+        }
+#pragma unroll
+        for (int g = 0; g < NV / 4; g++) pk[g] = pack4(v[4 * g], v[4 * g + 1], v[4 * g + 2], v[4 * g + 3]);
+        return;
+    }
 #pragma unroll
     for (int i = 0; i < NV; i++) q[i] = SAFE ? requant_safe(a[i], cs, lo, hi) : requant<false>(a[i], cs, lo);
     if (HAS_LUT && LUT0) {
@@ -260,9 +302,11 @@ __device__ __forceinline__ void epilogue_t(const mhip_conv_i8_t &p, v4i (&acc)[W
                 else { const uint2 t2 = *(const uint2 *)x; xw[0] = t2.x; xw[WOC > 1 ? 1 : 0] = t2.y; }
             }
             const add_args_t ga = {p.add_s_conv, p.add_s_other, p.add_inv};
-            requant_pack<WOC * 4, HAS_LUT, true, LUT0, true>(a, p.cs, lo, lut128, pk, xw, &ga);
+            if (HAS_LUT && LUT0 && p.lut2) requant_pack<WOC * 4, HAS_LUT, true, LUT0, true, true>(a, p.cs, lo, lut128, pk, xw, &ga);
+            else requant_pack<WOC * 4, HAS_LUT, true, LUT0, true>(a, p.cs, lo, lut128, pk, xw, &ga);
         } else {
-            requant_pack<WOC * 4, HAS_LUT, SAFE, LUT0>(a, p.cs, lo, lut128, pk);
+            if (HAS_LUT && LUT0 && SAFE && p.lut2) requant_pack<WOC * 4, HAS_LUT, SAFE, LUT0, false, true>(a, p.cs, lo, lut128, pk);
+            else requant_pack<WOC * 4, HAS_LUT, SAFE, LUT0>(a, p.cs, lo, lut128, pk);
         }
         if (DIRECT) {
             const long off = rowoff[prow];
@@ -374,8 +418,8 @@ __global__ __launch_bounds__(NTHREADS) void conv_i8_mfma(const mhip_conv_i8_t p,
     extern __shared__ __attribute__((aligned(16))) int8_t dynlds[];
     uint8_t *slut = (uint8_t *)dynlds; // LDS byte address 0: this kernel owns no static LDS (requant_pack LUT0)
     lds_base_must_be_zero(dynlds);
-    long *rowoff = (long *)(dynlds + 256);
-    int8_t *lds = dynlds + BPX * 8 + 256;
+    long *rowoff = (long *)(dynlds + LUTB);
+    int8_t *lds = dynlds + BPX * 8 + LUTB;
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -389,7 +433,8 @@ __global__ __launch_bounds__(NTHREADS) void conv_i8_mfma(const mhip_conv_i8_t p,
     const int pxw = wm * (WPX * 16), ocw = wn * (WOC * 16);
     v4i acc[WOC][WPX];
     init_acc<WPX, WOC>(p, acc, oc0 + ocw);
-    if (p.lut && tid < 64) ((uint32_t *)slut)[tid] = ((const uint32_t *)p.lut)[tid];
+    if (p.lut2) { if (tid < 128) ((uint32_t *)slut)[tid] = ((const uint32_t *)p.lut2)[tid]; }
+    else if (p.lut && tid < 64) ((uint32_t *)slut)[tid] = ((const uint32_t *)p.lut)[tid];
     fill_rowoff<BPX>(p, rowoff, [=](int row) { long q = pix0 + row; return q < total_pix ? q : -1L; }, (unsigned)hw, dhw);
 
     // ---- DMA assignment.  One wave-instruction fills 16 consecutive 64-byte rows; lane i
@@ -597,7 +642,7 @@ __global__ __launch_bounds__(NTHREADS) void conv_i8_persist(const mhip_conv_i8_t
     constexpr int NST = WPX;    // ... and per tile epilogue
     extern __shared__ __attribute__((aligned(16))) int8_t dynlds[];
     uint8_t *slut = (uint8_t *)dynlds; // LDS byte address 0 (requant_pack LUT0)
-    int8_t *lds = dynlds + 256;
+    int8_t *lds = dynlds + LUTB;
     lds_base_must_be_zero(dynlds);
 
     const int tid = threadIdx.x, lane = tid & 63;
@@ -627,7 +672,8 @@ __global__ __launch_bounds__(NTHREADS) void conv_i8_persist(const mhip_conv_i8_t
     for (int s = 0; s < WOC; s++)
         bias[s] = p.bias ? *(const v4i *)(p.bias + oc0 + ocw + s * 16 + (lane >> 4) * 4) : (v4i){0, 0, 0, 0};
     if (HAS_LUT) {
-        if (tid < 64) ((uint32_t *)slut)[tid] = ((const uint32_t *)p.lut)[tid];
+        if (p.lut2) { if (tid < 128) ((uint32_t *)slut)[tid] = ((const uint32_t *)p.lut2)[tid]; }
+        else if (tid < 64) ((uint32_t *)slut)[tid] = ((const uint32_t *)p.lut)[tid];
         __syncthreads();
     }
     const __amdgpu_buffer_rsrc_t orsrc = __builtin_amdgcn_make_buffer_rsrc(p.out, 0, (int)out_bytes, 0x00020000);
@@ -816,7 +862,8 @@ __global__ __launch_bounds__(NTHREADS) void conv_i8_persist(const mhip_conv_i8_t
             for (int s = 0; s < WOC; s++)
 #pragma unroll
                 for (int r = 0; r < 4; r++) a[s * 4 + r] = acc[s][t][r];
-            requant_pack<WOC * 4, HAS_LUT, true, true>(a, p.cs, lo, lut128, pk);
+            if (HAS_LUT && p.lut2) requant_pack<WOC * 4, HAS_LUT, true, true, false, true>(a, p.cs, lo, lut128, pk);
+            else requant_pack<WOC * 4, HAS_LUT, true, true>(a, p.cs, lo, lut128, pk);
             const int voff = ok ? (int)off : -1; // 0xffffffff >= num_records: dropped by the buffer unit
             if (WOC == 4)
                 __builtin_amdgcn_raw_buffer_store_b128((v4i){(int)pk[0], (int)pk[1], (int)pk[2], (int)pk[3]}, orsrc, voff, 0, 0);
@@ -880,8 +927,8 @@ __global__ __launch_bounds__(NTHREADS) void conv_i8_patch(const mhip_conv_i8_t p
     uint8_t *slut = (uint8_t *)dynlds; // LDS byte address 0 (requant_pack LUT0)
     lds_base_must_be_zero(dynlds);
     const int nks = k64 / BK;
-    int *dutab = (int *)(dynlds + 256);                    // [nks][4] unit offsets of the K chunks
-    int8_t *wl = dynlds + 256 + ((nks * 16 + 255) & ~255); // [nks][BN][64], swizzled like the ring tiles
+    int *dutab = (int *)(dynlds + LUTB);                   // [nks][4] unit offsets of the K chunks
+    int8_t *wl = dynlds + LUTB + ((nks * 16 + 255) & ~255); // [nks][BN][64], swizzled like the ring tiles
     const int patch_bytes = ni * 4096;                     // whole DMA instructions (4 waves x 1 KB)
     int8_t *patch0 = wl + nks * BN * BK;
 
@@ -895,7 +942,10 @@ __global__ __launch_bounds__(NTHREADS) void conv_i8_patch(const mhip_conv_i8_t p
     v4i bias[WOC];
 #pragma unroll
     for (int q = 0; q < WOC; q++) bias[q] = p.bias ? *(const v4i *)(p.bias + oc0 + q * 16 + (lane >> 4) * 4) : (v4i){0, 0, 0, 0};
-    if (HAS_LUT && tid < 64) ((uint32_t *)slut)[tid] = ((const uint32_t *)p.lut)[tid];
+    if (HAS_LUT) {
+        if (p.lut2) { if (tid < 128) ((uint32_t *)slut)[tid] = ((const uint32_t *)p.lut2)[tid]; }
+        else if (tid < 64) ((uint32_t *)slut)[tid] = ((const uint32_t *)p.lut)[tid];
+    }
     // K chunk table: chunk (ks, f) -> kernel row ky, column kx, channel chunk
     const int rowbytes = p.kw * C, kbytes = p.kh * rowbytes;
     for (int i = tid; i < nks * 4; i += NTHREADS) {
@@ -1044,11 +1094,14 @@ __global__ __launch_bounds__(NTHREADS) void conv_i8_patch(const mhip_conv_i8_t p
             for (int q = 0; q < WOC; q++)
 #pragma unroll
                 for (int r = 0; r < 4; r++) a[q * 4 + r] = acc[q][u][r];
+            const bool fast = HAS_LUT && p.lut2 != nullptr;
             if (p.add) {
                 const add_args_t ga = {p.add_s_conv, p.add_s_other, p.add_inv};
-                requant_pack<WOC * 4, HAS_LUT, true, true, true>(a, p.cs, lo, lut128, pk, xw[u], &ga);
+                if (fast) requant_pack<WOC * 4, HAS_LUT, true, true, true, true>(a, p.cs, lo, lut128, pk, xw[u], &ga);
+                else requant_pack<WOC * 4, HAS_LUT, true, true, true>(a, p.cs, lo, lut128, pk, xw[u], &ga);
             } else {
-                requant_pack<WOC * 4, HAS_LUT, true, true>(a, p.cs, lo, lut128, pk);
+                if (fast) requant_pack<WOC * 4, HAS_LUT, true, true, false, true>(a, p.cs, lo, lut128, pk);
+                else requant_pack<WOC * 4, HAS_LUT, true, true>(a, p.cs, lo, lut128, pk);
             }
             const int voff = voffs[u];
             if (WOC == 4)
@@ -1186,8 +1239,8 @@ __global__ __launch_bounds__(NTHREADS) void conv_i8_smallc(const mhip_conv_i8_t 
     constexpr int WPX = SC_TH / 4; // tile rows (= pixel subtiles of 16) per wave
     extern __shared__ __attribute__((aligned(16))) int8_t dyn[];
     uint8_t *slut = (uint8_t *)dyn;                  // LDS byte address 0 (no static LDS here: requant_pack LUT0)
-    long *rowoff = (long *)(dyn + 256);              // [256]
-    int8_t *wl = dyn + 256 + SC_BP * 8;              // [k64/64][BN][64], rows swizzled like the ring tiles (lds_off)
+    long *rowoff = (long *)(dyn + LUTB);             // [256]
+    int8_t *wl = dyn + LUTB + SC_BP * 8;             // [k64/64][BN][64], rows swizzled like the ring tiles (lds_off)
     int8_t *patch0 = wl + BN * k64;                  // 2 x [(PH+1)][PWp] dwords (double buffer)
     const int patch_bytes = ((PH + 1) * PWp * 4 + 15) & ~15;
     int8_t *tile = patch0 + 2 * patch_bytes;         // [256][BN+OPAD]
@@ -1195,7 +1248,8 @@ __global__ __launch_bounds__(NTHREADS) void conv_i8_smallc(const mhip_conv_i8_t 
 
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int hw = p.out_h * p.out_w;
-    if (p.lut && tid < 64) ((uint32_t *)slut)[tid] = ((const uint32_t *)p.lut)[tid];
+    if (p.lut2) { if (tid < 128) ((uint32_t *)slut)[tid] = ((const uint32_t *)p.lut2)[tid]; }
+    else if (p.lut && tid < 64) ((uint32_t *)slut)[tid] = ((const uint32_t *)p.lut)[tid];
     for (int i = tid; i < BN * (k64 / 16); i += NTHREADS) {
         const int row = i / (k64 / 16), c = i - row * (k64 / 16);
         *(v4i *)(wl + (c >> 2) * (BN * BK) + lds_off(row, c & 3)) = *(const v4i *)(p.w + (size_t)row * k64 + c * 16);
@@ -1339,6 +1393,23 @@ extern "C" int mhip_conv_i8_is_safe(float cs) {
     return cs == cs && cs < 0.99f && cs > -0.99f;
 }
 
+extern "C" int mhip_conv_i8_lut2_ok(float cs) {
+    // round-half-away(x) == f(trunc(2x)) for every float except |x| = 0x3EFFFFFF (0.49999997), which the reference's
+    // float add rounds up to 1: refuse the half-step table when some int32 accumulator lands exactly there
+    if (!mhip_conv_i8_is_safe(cs)) return 0;
+    const float a = cs < 0 ? -cs : cs;
+    if (!(a >= 1e-6f)) return 0; // tiny scales: many accumulators crowd around any given product
+    const float quirk = 0.49999997f;
+    const double a0 = (double)quirk / (double)a;
+    for (int d = -3; d <= 3; d++) {
+        const double c = (double)(long long)(a0 + 0.5) + d;
+        if (c < 1.0 || c > 2147483647.0) continue;
+        volatile float prod = (float)(int)c * a;
+        if (prod == quirk) return 0;
+    }
+    return 1;
+}
+
 extern "C" int mhip_conv_i8_small_c(int in_c, int kw, int out_c) { return in_c <= 4 && kw <= 8 && out_c <= 64; }
 
 extern "C" void mhip_conv_i8_pack_geom(int in_c, int kw, int out_c, int *row_pad, int *oc_pad, int *c_eff) {
@@ -1403,7 +1474,7 @@ static int launch_smallc(const mhip_conv_i8_t *p, int k64) {
     if ((long)PH * gpr > 2 * NTHREADS || ntiles > 0x7fffffffL) return -1;
     constexpr int BN = WOC * 16;
     const size_t lds = (size_t)BN * k64 + 2 * ((((size_t)PH + 1) * PWp * 4 + 15) & ~(size_t)15) +
-                       (size_t)SC_BP * (BN + OPAD) + 256 + (size_t)SC_BP * 8;
+                       (size_t)SC_BP * (BN + OPAD) + LUTB + (size_t)SC_BP * 8;
     if (lds > 64 * 1024) return -1;
     long grid = ntiles < 256L * 8 ? ntiles : 256L * 8;
     hipLaunchKernelGGL((conv_i8_smallc<WOC>), dim3((unsigned)grid), dim3(NTHREADS), lds, mhip_stream_native(), *p, k64,
@@ -1430,11 +1501,11 @@ static int launch_mfma(const mhip_conv_i8_t *p, long total_pix, int k64) {
     const int nks = k64 / BK, nst = nks / KS, used = nst < STAGES ? nst : STAGES;
     if (KS > 1 && (nks % KS) != 0) return -1;
     size_t ring = (size_t)used * KS * (BPX + BN) * BK, tile = (size_t)BPX * (BN + OPAD);
-    const size_t lds = BPX * 8 + 256 + (ring > tile ? ring : tile);
+    const size_t lds = BPX * 8 + LUTB + (ring > tile ? ring : tile);
     if (lds > 64 * 1024) {
         static bool attr = false;
         if (!attr && hipFuncSetAttribute((const void *)conv_i8_mfma<BPX, BN, STAGES, KS>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                         (int)(BPX * 8 + 256 + (size_t)STAGES * KS * (BPX + BN) * BK)) != hipSuccess)
+                                         (int)(BPX * 8 + LUTB + (size_t)STAGES * KS * (BPX + BN) * BK)) != hipSuccess)
             return mhip_check(hipErrorUnknown, "conv_i8_mfma LDS attribute");
         attr = true;
     }
@@ -1470,7 +1541,7 @@ static int launch_persist_t(const mhip_conv_i8_t *p, long total_pix, int k64, in
         alt.lut = second->lut; alt.out_c = second->out_c; alt.relu = second->relu; alt.out_pix_stride = second->out_pix_stride;
         alt.out_ch_off = second->out_ch_off; alt.cs = second->cs;
     }
-    const size_t lds = 256 + (size_t)STAGES * (BPX + BN) * BK;
+    const size_t lds = LUTB + (size_t)STAGES * (BPX + BN) * BK;
     static int slots = 0; // workgroups of this instantiation the device holds at once
     if (!slots) {
         int occ = 0, dev = 0;
@@ -1542,7 +1613,7 @@ static bool patch_geom(const mhip_conv_i8_t *p, int th, patch_geom_t *g) {
     g->ni = (int)((units + 255) / 256);
     if (g->ni > PT_NIMAX) return false;
     // two workgroups per CU in any case (80 KB each): double-buffered patch if that fits, else one buffer
-    const size_t fixed = 256 + (((size_t)g->nks * 16 + 255) & ~(size_t)255) + (size_t)g->nks * g->bn * BK;
+    const size_t fixed = LUTB + (((size_t)g->nks * 16 + 255) & ~(size_t)255) + (size_t)g->nks * g->bn * BK;
     g->dbl = fixed + 2 * (size_t)g->ni * 4096 <= 80 * 1024;
     g->lds = fixed + (g->dbl ? 2 : 1) * (size_t)g->ni * 4096;
     if (g->lds > 80 * 1024) return false;

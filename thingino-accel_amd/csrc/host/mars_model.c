@@ -133,7 +133,7 @@ static mars_op_t *new_op(mars_model_ext_t *m, int kind, int layer) {
     op->kind = kind;
     op->layer = layer;
     op->t_in[0] = op->t_in[1] = op->t_in[2] = op->t_in[3] = op->t_out = -1;
-    op->w_off = op->b_off = op->lut_off = op->s_off = NO_OFF;
+    op->w_off = op->b_off = op->lut_off = op->lut2_off = op->s_off = NO_OFF;
     op->w_blob_off[0] = op->w_blob_off[1] = NO_OFF;
     op->prof_kind = 4;
     return op;
@@ -533,6 +533,19 @@ static void fuse_silu(mars_model_ext_t *m) {
                                         : binary_q(1, sg, q, d2->scale, d1->scale, d3->scale));
         }
         c->lut_off = lut_i8(m, tab);
+        if (mhip_conv_i8_lut2_ok(c->cs)) {
+            /* half-step form: index k = trunc(2 * acc * cs) in [-256, 255] determines round-half-away(acc * cs) =
+             * (k >= 0 ? (k+1)>>1 : -((1-k)>>1)) exactly (conv_i8.hip, requant_pack FAST); the ReLU clamp folds in */
+            int8_t tab2[512];
+            for (int k = -256; k < 256; k++) {
+                int r = k >= 0 ? (k + 1) >> 1 : -((1 - k) >> 1);
+                const int lo = c->relu ? 0 : -128;
+                r = r < lo ? lo : (r > 127 ? 127 : r);
+                tab2[k + 256] = tab[r + 128];
+            }
+            c->lut2_off = arena_reserve(m, 512);
+            if (c->lut2_off != NO_OFF) memcpy(m->arena_host + c->lut2_off, tab2, 512);
+        }
         c->t_out = q3;
         c->bytes += 0; /* same bytes written, to q3 instead of q1 */
         touch(m, q3, n1);
@@ -1168,6 +1181,7 @@ static void conv_i8_params(const mars_model_ext_t *m, const mars_op_t *op, mhip_
     p->w = (const int8_t *)(A + op->w_off);
     p->bias = op->b_off != NO_OFF ? (const int32_t *)(A + op->b_off) : NULL;
     p->lut = op->lut_off != NO_OFF ? A + op->lut_off : NULL;
+    p->lut2 = op->lut_off != NO_OFF && op->lut2_off != NO_OFF ? A + op->lut2_off : NULL;
     p->frames = m->batch;
     p->in_h = op->in_h; p->in_w = op->in_w;
     p->out_h = op->out_h; p->out_w = op->out_w; p->out_c = op->out_c;

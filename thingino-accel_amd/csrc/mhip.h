@@ -52,6 +52,8 @@ typedef struct {
     const int8_t *w;   /* packed: [oc_pad][kh][row_pad], see mhip_conv_i8_pack_geom */
     const int32_t *bias; /* [oc_pad] or NULL */
     const uint8_t *lut;  /* 256-entry post-requant map (index q+128) or NULL */
+    const uint8_t *lut2; /* optional 512-entry half-step form of `lut` (index trunc(2*acc*cs)+256, lower clamp folded in);
+                            only valid when mhip_conv_i8_lut2_ok(cs): enables the 4-instruction requantisation */
     int frames;
     int in_h, in_w, in_c;       /* input as NHWC */
     int out_h, out_w, out_c;
@@ -85,6 +87,8 @@ typedef struct {
 int mhip_conv_i8_oc_row(int oc, int oc_pad);
 /* is the float->int conversion of acc*cs provably in range for every int32 accumulator? */
 int mhip_conv_i8_is_safe(float cs);
+/* may the half-step LUT be used for this combined scale?  (no int32 accumulator may requantise to +-0x3EFFFFFF) */
+int mhip_conv_i8_lut2_ok(float cs);
 int mhip_conv_i8_tune(const char *key, int value); /* launch-policy knobs, see mars_hip_set_tuning */
 /* launch variants that can run this layer (same bytes out, different speed), the default first; 0 if none */
 int mhip_conv_i8_variants(const mhip_conv_i8_t *p, int *codes, int max);
