@@ -102,6 +102,28 @@ def test_conv_i8_persistent_tile_walk(gpu, orc, slots, stages):
         gpu.set_tuning("persist_maxk", 8)
 
 
+@pytest.mark.parametrize("variant", [12, 13])
+def test_conv_i8_wide_one_tile_forms(gpu, orc, variant):
+    """variant 12 (two K slices per ring stage) and 13 (256 x 128 tile on an 8-wave workgroup): deep K loops, 128 /
+    256 output channels, pixel counts that are not multiples of the tile, aligned and ragged (255) rows"""
+    shapes = [  # in_h, in_w, in_c, out_c, k, s
+        (40, 40, 128, 128, 3, 1), (23, 17, 256, 256, 3, 1), (33, 31, 128, 256, 1, 1), (20, 20, 512, 255, 1, 1),
+        (19, 21, 64, 128, 3, 2), (16, 16, 1024, 128, 1, 1)]
+    try:
+        gpu.set_tuning("variant", variant)
+        for i, (h, w, ic, oc, k, s) in enumerate(shapes):
+            oh, ow = (h + s - 1) // s, (w + s - 1) // s
+            ph = max((oh - 1) * s + k - h, 0) // 2
+            pw = max((ow - 1) * s + k - w, 0) // 2
+            case = ("wide%d" % i, 1, h, w, ic, oc, k, k, s, s, ph, pw, oh, ow, 0.03, 0.003 / (k * k * ic) ** 0.5 * 8, 0.05, True)
+            a = cases.conv_i8_call(gpu.conv2d_int8, case, 7)
+            b = cases.conv_i8_call(orc.conv2d_int8, case, 7)
+            assert np.array_equal(a, b), (case[0], int((a != b).sum()))
+            assert len(np.unique(a)) > 32
+    finally:
+        gpu.set_tuning("variant", 0)
+
+
 @pytest.mark.parametrize("variant", [9, 10, 11])
 def test_conv_i8_patch_staged(gpu, orc, variant):
     """the patch-staged kernel (input patch of a tile staged once in LDS, weights resident, taps fed from LDS):
