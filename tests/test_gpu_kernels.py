@@ -102,6 +102,49 @@ def test_conv_i8_persistent_tile_walk(gpu, orc, slots, stages):
         gpu.set_tuning("persist_maxk", 8)
 
 
+@pytest.mark.parametrize("slots,variant", [(1, 14), (3, 15), (0, 14), (0, 15)])
+def test_conv_i8_tile_walk_resident_weights(gpu, orc, slots, variant):
+    """variants 14 / 15: the tile walker with the weights of its channel tile fetched once and kept in LDS (the ring
+    carries pixel tiles only); few workgroups so that every one walks several tiles; K loops of 1..18 steps; ragged
+    rows; then a whole graph, whose never-materialised concat inputs take the same form"""
+    shapes = [  # in_h, in_w, in_c, out_c, k, s
+        (64, 64, 32, 32, 1, 1), (40, 40, 64, 128, 3, 2), (37, 29, 128, 64, 1, 1), (23, 17, 128, 64, 3, 1),
+        (33, 31, 256, 256, 1, 1), (50, 50, 64, 64, 1, 1), (16, 16, 512, 255, 1, 1), (21, 19, 64, 81, 1, 1),
+        (20, 20, 32, 7, 3, 1), (17, 23, 128, 131, 1, 1)]
+    try:
+        gpu.set_tuning("persist_slots", slots)
+        gpu.set_tuning("variant", variant)
+        for i, (h, w, ic, oc, k, s) in enumerate(shapes):
+            oh, ow = (h + s - 1) // s, (w + s - 1) // s
+            ph = max((oh - 1) * s + k - h, 0) // 2
+            pw = max((ow - 1) * s + k - w, 0) // 2
+            case = ("wres%d" % i, 1, h, w, ic, oc, k, k, s, s, ph, pw, oh, ow, 0.03, 0.003 / (k * k * ic) ** 0.5 * 8, 0.05, True)
+            a = cases.conv_i8_call(gpu.conv2d_int8, case, 9)
+            b = cases.conv_i8_call(orc.conv2d_int8, case, 9)
+            assert np.array_equal(a, b), (case[0], int((a != b).sum()))
+            assert len(np.unique(a)) > 32
+        import marsfile
+        from conftest import lcg_frame
+        d = gpu.synth_model(width_x16=4, input_hw=96, seed=22)
+        hdr, tensors, _ = marsfile.parse(d)
+        nb = marsfile.tensor_nbytes(tensors[hdr["inputs"][0]])
+        m = gpu.Model(d, batch=3)
+        xs = [lcg_frame(0xAC0000 + f, nb) for f in range(3)]
+        for f in range(3):
+            m.input_view(0)[f] = xs[f]
+        m.run()
+        for f in range(3):
+            g = orc.Graph(d)
+            g.set_input(0, xs[f].tobytes())
+            assert g.run() == 0
+            for oi, ti in enumerate(hdr["outputs"]):
+                assert np.array_equal(m.output_view(oi)[f], g.tensor(ti))
+        m.close()
+    finally:
+        gpu.set_tuning("variant", 0)
+        gpu.set_tuning("persist_slots", 0)
+
+
 @pytest.mark.parametrize("variant", [12, 13])
 def test_conv_i8_wide_one_tile_forms(gpu, orc, variant):
     """variant 12 (two K slices per ring stage) and 13 (256 x 128 tile on an 8-wave workgroup): deep K loops, 128 /

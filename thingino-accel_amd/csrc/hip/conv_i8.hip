@@ -635,8 +635,12 @@ __global__ __launch_bounds__(NTHREADS) void conv_i8_persist(const mhip_conv_i8_t
                                                             const unsigned npt, const unsigned ngrp, const int lg_inc,
                                                             const unsigned kw_magic, const fastdiv_t dhw, const fastdiv_t dow,
                                                             const unsigned out_bytes_first, const conv_out_side_t alt,
-                                                            const unsigned noc0, const int bufmode, const unsigned in_bytes) {
-    constexpr int STAGE = (BPX + BN) * BK;
+                                                            const unsigned noc0, const int bufmode, const unsigned in_bytes,
+                                                            const int wres) {
+    // wres (host: 2-stage ring only): the weights of this workgroup's channel tile, all K steps, are fetched ONCE
+    // into LDS behind the ring and stay there while the workgroup walks its pixel tiles; the ring then carries pixel
+    // tiles only -- for 1x1 layers that halves the LDS-DMA bytes per tile
+    const int STAGE = wres ? BPX * BK : (BPX + BN) * BK;
     constexpr int NWN = BN == 128 ? 2 : 1;
     constexpr int NWM = 4 / NWN;
     constexpr int WPX = BPX / NWM / 16;
@@ -761,8 +765,9 @@ __global__ __launch_bounds__(NTHREADS) void conv_i8_persist(const mhip_conv_i8_t
                 const bool ok = uvalid & (((tapmask[j] >> utap) & 1u) != 0u);
                 blds16(xrs, ok ? xvoff[j] + ukoff : -1, 0, sb + (wv * (BPX / 4) + j * 16) * BK);
             }
+            if (!wres)
 #pragma unroll
-            for (int j = 0; j < LW; j++) blds16(wrs, wvoff[j], ks * BK, sb + BPX * BK + wq[j] * 16 * BK);
+                for (int j = 0; j < LW; j++) blds16(wrs, wvoff[j], ks * BK, sb + BPX * BK + wq[j] * 16 * BK);
             return;
         } else {
             const unsigned tap = pos >> lg_inc;
@@ -777,12 +782,18 @@ __global__ __launch_bounds__(NTHREADS) void conv_i8_persist(const mhip_conv_i8_t
                 glds16(ok ? xwin[j] + koff : zeros, sb + (wv * (BPX / 4) + j * 16) * BK);
             }
         }
+        if (!wres)
 #pragma unroll
-        for (int j = 0; j < LW; j++) glds16(wsrc[j] + ks * BK, sb + BPX * BK + wq[j] * 16 * BK);
+            for (int j = 0; j < LW; j++) glds16(wsrc[j] + ks * BK, sb + BPX * BK + wq[j] * 16 * BK);
     };
 
     // issue cursor over the (tile, k-step) stream; younger[i] = vector-memory instructions this wave has
     // issued after the i-th oldest stage still in the ring (a stage that was not issued counts as empty)
+    int8_t *const wres_base = lds + STAGES * STAGE;
+    if (wres)
+        for (int ks = 0; ks < nks; ks++)
+#pragma unroll
+            for (int j = 0; j < LW; j++) glds16(wsrc[j] + ks * BK, wres_base + (ks * BN + wq[j] * 16) * BK);
     unsigned itile = t0;
     int iks = 0;
     int younger[STAGES - 1];
@@ -793,7 +804,7 @@ __global__ __launch_bounds__(NTHREADS) void conv_i8_persist(const mhip_conv_i8_t
         int n = 0;
         if (itile < t1) {
             issue(iks, nstage);
-            n = L;
+            n = wres ? XI : L;
             if (++iks == nks) {
                 iks = 0;
                 if (++itile < t1) setup_rows(itile);
@@ -821,7 +832,7 @@ __global__ __launch_bounds__(NTHREADS) void conv_i8_persist(const mhip_conv_i8_t
             asm volatile("" ::: "memory");
             // all fragment reads of this step first, then the next stage's DMA (its address math hides the LDS
             // latency), then the MFMAs
-            const int8_t *xs = lds + stage * STAGE, *ws = xs + BPX * BK;
+            const int8_t *xs = lds + stage * STAGE, *ws = wres ? wres_base + ks * (BN * BK) : xs + BPX * BK;
             v4i xb[WPX], wa[WOC];
 #pragma unroll
             for (int t = 0; t < WPX; t++) xb[t] = *(const v4i *)(xs + lds_off(pxw + t * 16 + frow, fchunk));
@@ -830,7 +841,7 @@ __global__ __launch_bounds__(NTHREADS) void conv_i8_persist(const mhip_conv_i8_t
             int n = 0;
             if (itile < t1) {
                 issue(iks, nstage);
-                n = L;
+                n = wres ? XI : L;
                 if (++iks == nks) {
                     iks = 0;
                     if (++itile < t1) setup_rows(itile);
@@ -1436,6 +1447,8 @@ struct tune_t {
     int bpx;            // MARS_HIP_BPX           0: auto, else pixels per workgroup (128 | 256)
     int variant;        // MARS_HIP_VARIANT       0: policy, else this launch variant wherever the layer allows it (tests)
     int bufmode;        // MARS_HIP_BUFMODE       1: buffer-addressed K loop where eligible
+    int wres;           // MARS_HIP_WRES          bit 0 / 1: the default policy may keep the weights resident in LDS (tile
+                        //                        walker) for single / paired launches
 };
 static tune_t g_tune;
 static int env_int(const char *name, int dflt) {
@@ -1452,6 +1465,7 @@ static const tune_t &tune() {
         g_tune.bpx = env_int("MARS_HIP_BPX", 0);
         g_tune.variant = env_int("MARS_HIP_VARIANT", 0);
         g_tune.bufmode = env_int("MARS_HIP_BUFMODE", 1);
+        g_tune.wres = env_int("MARS_HIP_WRES", 3);
         g_tune.init = 1;
     }
     return g_tune;
@@ -1459,7 +1473,7 @@ static const tune_t &tune() {
 extern "C" int mhip_conv_i8_tune(const char *key, int value) {
     (void)tune();
     struct { const char *k; int *v; } tab[] = {{"persist", &g_tune.persist}, {"persist_stages", &g_tune.persist_stages},
-                                               {"persist_maxk", &g_tune.persist_maxk}, {"persist_slots", &g_tune.persist_slots},
+                                               {"persist_maxk", &g_tune.persist_maxk}, {"persist_slots", &g_tune.persist_slots}, {"wres", &g_tune.wres},
                                                {"stages", &g_tune.stages}, {"bpx", &g_tune.bpx}, {"variant", &g_tune.variant}, {"bufmode", &g_tune.bufmode}};
     for (auto &e : tab)
         if (key && !strcmp(key, e.k)) {
@@ -1534,9 +1548,13 @@ static long persist_out_bytes(const mhip_conv_i8_t *p) {
     return (long)(p->frames - 1) * (long)p->out_stride + (long)p->out_h * p->out_w * pstride;
 }
 
+// LDS of the weights-resident form: LUT + 2 pixel-tile stages + every K step of one channel tile
+template <int BPX, int BN>
+static size_t wres_lds(int k64) { return LUTB + 2 * (size_t)BPX * BK + (size_t)(k64 / BK) * BN * BK; }
+
 template <int BPX, int BN, int STAGES, bool HAS_LUT, bool SEG = false, bool PAIR = false>
 static int launch_persist_t(const mhip_conv_i8_t *p, long total_pix, int k64, int lg, unsigned magic,
-                            const mhip_conv_i8_t *second = nullptr) {
+                            const mhip_conv_i8_t *second = nullptr, int wres = 0) {
     const unsigned noc0 = (unsigned)(p->oc_pad / BN);
     const unsigned npt = (unsigned)((total_pix + BPX - 1) / BPX), noc = noc0 + (PAIR ? (unsigned)(second->oc_pad / BN) : 0u);
     conv_out_side_t alt;
@@ -1546,7 +1564,30 @@ static int launch_persist_t(const mhip_conv_i8_t *p, long total_pix, int k64, in
         alt.lut = second->lut; alt.out_c = second->out_c; alt.relu = second->relu; alt.out_pix_stride = second->out_pix_stride;
         alt.out_ch_off = second->out_ch_off; alt.cs = second->cs;
     }
-    const size_t lds = LUTB + (size_t)STAGES * (BPX + BN) * BK;
+    if (PAIR) alt.out_bytes = (unsigned)persist_out_bytes(second);
+    if (wres && STAGES != 2) return -1;
+    const size_t lds = wres ? wres_lds<BPX, BN>(k64) : LUTB + (size_t)STAGES * (BPX + BN) * BK;
+    if (wres) { // its own occupancy (LDS differs per layer) and longer runs: the weight fetch must amortise
+        static bool attr = false;
+        if (!attr && hipFuncSetAttribute((const void *)conv_i8_persist<BPX, BN, STAGES, HAS_LUT, SEG, PAIR>,
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024) != hipSuccess)
+            return mhip_check(hipErrorUnknown, "conv_i8_persist LDS attribute");
+        attr = true;
+        int occ = 0, dev = 0;
+        hipDeviceProp_t prop;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, conv_i8_persist<BPX, BN, STAGES, HAS_LUT, SEG, PAIR>, NTHREADS, lds) != hipSuccess ||
+            hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess)
+            return mhip_check(hipErrorUnknown, "conv_i8_persist occupancy query");
+        unsigned g = (unsigned)((occ > 0 ? occ : 1) * prop.multiProcessorCount) / noc;
+        if (tune().persist_slots > 0) g = (unsigned)tune().persist_slots / noc;
+        if (g < 1) g = 1;
+        if (g > npt) g = npt;
+        hipLaunchKernelGGL((conv_i8_persist<BPX, BN, STAGES, HAS_LUT, SEG, PAIR>), dim3(noc * g), dim3(NTHREADS), lds,
+                           mhip_stream_native(), *p, (unsigned)total_pix, k64, (const int8_t *)mhip_zero_page(), noc, npt, g, lg,
+                           magic, make_fastdiv((unsigned)(p->out_h * p->out_w)), make_fastdiv((unsigned)p->out_w),
+                           (unsigned)persist_out_bytes(p), alt, noc0, SEG ? 0 : buf_mode(p, k64), (unsigned)in_extent_bytes(p), 1);
+        return mhip_check(hipGetLastError(), "conv_i8_persist (resident weights) launch");
+    }
     static int slots = 0; // workgroups of this instantiation the device holds at once
     if (!slots) {
         int occ = 0, dev = 0;
@@ -1561,11 +1602,10 @@ static int launch_persist_t(const mhip_conv_i8_t *p, long total_pix, int k64, in
     unsigned ngrp = (unsigned)(tune().persist_slots > 0 ? tune().persist_slots : 4 * slots) / noc;
     if (ngrp < 1) ngrp = 1;
     if (ngrp > npt) ngrp = npt;
-    if (PAIR) alt.out_bytes = (unsigned)persist_out_bytes(second);
     hipLaunchKernelGGL((conv_i8_persist<BPX, BN, STAGES, HAS_LUT, SEG, PAIR>), dim3(noc * ngrp), dim3(NTHREADS), lds,
                        mhip_stream_native(), *p, (unsigned)total_pix, k64, (const int8_t *)mhip_zero_page(), noc, npt, ngrp, lg,
                        magic, make_fastdiv((unsigned)(p->out_h * p->out_w)), make_fastdiv((unsigned)p->out_w),
-                       (unsigned)persist_out_bytes(p), alt, noc0, SEG ? 0 : buf_mode(p, k64), (unsigned)in_extent_bytes(p));
+                       (unsigned)persist_out_bytes(p), alt, noc0, SEG ? 0 : buf_mode(p, k64), (unsigned)in_extent_bytes(p), 0);
     return mhip_check(hipGetLastError(), "conv_i8_persist launch");
 }
 
@@ -1577,22 +1617,25 @@ static int launch_persist_t(const mhip_conv_i8_t *p, long total_pix, int k64, in
 //   code = 9 / 10 / 11: patch-staged kernel with 8 / 16 / 4 tile rows
 //   code = 12: one tile per workgroup, 128 pixels, 2 ring stages of 128 K bytes each (even number of K steps)
 //   code = 13: one 256 x 128 tile per 8-wave workgroup, 3 stages
-#define NVARIANTS 13
+//   code = 14 / 15: tile walker with the weights of its channel tile resident in LDS, 128 / 256 pixels
+#define NVARIANTS 15
 struct variant_t {
-    int persist, bpx, stages, patch, ks2, w8;
+    int persist, bpx, stages, patch, ks2, w8, wres;
 };
 static int variant_code(const variant_t &v) {
+    if (v.wres) return v.bpx == 256 ? 15 : 14;
     if (v.w8) return 13;
     if (v.ks2) return 12;
     if (v.patch) return v.patch == 16 ? 10 : (v.patch == 8 ? 9 : 11);
     return 1 + (v.persist ? 1 : 0) + (v.bpx == 256 ? 2 : 0) + (v.stages == 3 ? 4 : 0);
 }
 static variant_t variant_of(int code) {
-    if (code == 13) return variant_t{0, 256, 3, 0, 0, 1};
-    if (code == 12) return variant_t{0, 128, 2, 0, 1, 0};
-    if (code >= 9) return variant_t{0, 0, 0, code == 10 ? 16 : (code == 9 ? 8 : 4), 0, 0};
+    if (code == 14 || code == 15) return variant_t{1, code == 15 ? 256 : 128, 2, 0, 0, 0, 1};
+    if (code == 13) return variant_t{0, 256, 3, 0, 0, 1, 0};
+    if (code == 12) return variant_t{0, 128, 2, 0, 1, 0, 0};
+    if (code >= 9) return variant_t{0, 0, 0, code == 10 ? 16 : (code == 9 ? 8 : 4), 0, 0, 0};
     const int c = code - 1;
-    return variant_t{c & 1, (c & 2) ? 256 : 128, (c & 4) ? 3 : 2, 0, 0, 0};
+    return variant_t{c & 1, (c & 2) ? 256 : 128, (c & 4) ? 3 : 2, 0, 0, 0, 0};
 }
 
 // ---- patch-staged kernel: geometry, eligibility, launch
@@ -1686,17 +1729,35 @@ static bool persist_eligible(const mhip_conv_i8_t *p) {
     return !p->out_nchw && p->safe && (p->in_c & (p->in_c - 1)) == 0 && p->kh * p->kw <= 32 &&
            (long)p->kh * p->kw * (p->kw - 1) < 65536 && persist_out_bytes(p) <= 0x7fffffffL;
 }
+static bool wres_default(const mhip_conv_i8_t *p, int nks, int *bpx) {
+    if (!tune().wres || p->kh * p->kw != 1 || p->in_c < 64 || p->out_h * p->out_w > 6400) return false;
+    const int bn = p->oc_pad % 128 == 0 ? 128 : (p->oc_pad % 64 == 0 ? 64 : 32);
+    const int px = (bn == 64 && p->out_h * p->out_w >= 6400) ? 256 : 128;
+    if (LUTB + 2 * (size_t)px * BK + (size_t)nks * bn * BK > 80 * 1024) return false;
+    *bpx = px;
+    return true;
+}
+
 static variant_t default_variant(const mhip_conv_i8_t *p, int nks) {
     variant_t v;
     v.patch = 0;
     v.ks2 = 0;
     v.w8 = 0;
+    v.wres = 0;
     // wide, shallow k x k layers: the patch-staged kernel wins wherever its double-buffered form fits (measured on the
     // 160x160 and 80x80 layers of yolov5s: 1.25-1.9x over the implicit-GEMM forms)
     patch_geom_t g;
-    if (tune().persist && !tune().bpx && !tune().stages && patch_geom(p, 8, &g) && g.dbl) {
-        v.persist = 0; v.bpx = 0; v.stages = 0; v.patch = 8;
-        return v;
+    if (tune().persist && !tune().bpx && !tune().stages) {
+        // 16 output rows per workgroup wherever that patch fits at all (single-buffered included: the taller patch
+        // re-reads fewer halo rows, measured 5-40 % over 8 rows on the 160x160 / 80x80 layers), else 8 rows
+        if (patch_geom(p, 16, &g)) {
+            v.persist = 0; v.bpx = 0; v.stages = 0; v.patch = 16;
+            return v;
+        }
+        if (patch_geom(p, 8, &g) && g.dbl) {
+            v.persist = 0; v.bpx = 0; v.stages = 0; v.patch = 8;
+            return v;
+        }
     }
     // pixels per workgroup: 256 halves the weight-tile traffic and per-workgroup overhead of the narrow, shallow
     // configurations; 128 keeps one more workgroup per CU everywhere else
@@ -1708,11 +1769,18 @@ static variant_t default_variant(const mhip_conv_i8_t *p, int nks) {
     // ring depth: 3 stages beat 4 everywhere (occupancy > depth); the tile-walking form is best with 2
     v.stages = v.persist ? tune().persist_stages : (tune().stages ? tune().stages : (nks <= 4 ? 2 : 3));
     if (v.stages != 3) v.stages = 2;
+    // 1x1 layers of 64+ input channels on maps up to 80x80: the tile walker with its weights resident in LDS (the ring
+    // carries pixel tiles only -- half the LDS-DMA bytes; measured 5-25 % faster on every such layer of yolov5s, and
+    // no gain on the 160x160 maps)
+    if (v.persist && v.stages == 2 && !tune().bpx && wres_default(p, nks, &v.bpx)) v.wres = 1;
     // deep K loops with 128-channel tiles: the 8-wave 256 x 128 tile moves 25 % fewer DMA bytes per MAC (measured
     // 3-15 % faster on every such layer of yolov5s)
-    if (!v.persist && !tune().bpx && !tune().stages && p->oc_pad % 128 == 0 && nks > tune().persist_maxk) {
-        v.w8 = 1; v.bpx = 256; v.stages = 3;
+    if ((!v.persist || (!v.wres && nks >= 8 && p->nseg <= 1)) && !tune().bpx && !tune().stages && p->oc_pad % 128 == 0 &&
+        nks >= (tune().persist_maxk < 8 ? tune().persist_maxk + 1 : 8)) {
+        v.persist = 0; v.w8 = 1; v.bpx = 256; v.stages = 3;
     }
+    // never-materialised concat inputs (tile walker only) with 8+ K steps: 256 pixels per workgroup (measured 5-8 %)
+    if (p->nseg > 1 && !v.wres && !tune().bpx && nks >= 8) v.bpx = 256;
     return v;
 }
 
@@ -1723,9 +1791,13 @@ static int launch_variant_t(const mhip_conv_i8_t *p, long total_pix, int k64, co
         int lg = 0;
         while ((1 << lg) < p->in_c) lg++;
         const unsigned magic = ((65536u + (unsigned)p->kw - 1u) / (unsigned)p->kw);
+        if (v.wres && wres_lds<BPX, BN>(k64) > 80 * 1024) return -1;
         if (p->nseg > 1) // never-materialised concat input: the two-stage tile walker only
-            return p->lut ? launch_persist_t<BPX, BN, 2, true, true>(p, total_pix, k64, lg, magic)
-                          : launch_persist_t<BPX, BN, 2, false, true>(p, total_pix, k64, lg, magic);
+            return p->lut ? launch_persist_t<BPX, BN, 2, true, true>(p, total_pix, k64, lg, magic, nullptr, v.wres)
+                          : launch_persist_t<BPX, BN, 2, false, true>(p, total_pix, k64, lg, magic, nullptr, v.wres);
+        if (v.wres)
+            return p->lut ? launch_persist_t<BPX, BN, 2, true>(p, total_pix, k64, lg, magic, nullptr, 1)
+                          : launch_persist_t<BPX, BN, 2, false>(p, total_pix, k64, lg, magic, nullptr, 1);
         if (v.stages == 2)
             return p->lut ? launch_persist_t<BPX, BN, 2, true>(p, total_pix, k64, lg, magic)
                           : launch_persist_t<BPX, BN, 2, false>(p, total_pix, k64, lg, magic);
@@ -1753,10 +1825,11 @@ static int launch_variant(const mhip_conv_i8_t *p, long total_pix, int k64, cons
 // Two convolutions over the same input in one launch (conv_i8_persist<PAIR>).  -2 = the pair is not eligible (the
 // caller launches them one after the other), otherwise the launch's return code.
 template <int BPX, int BN>
-static int launch_pair_t(const mhip_conv_i8_t *a, const mhip_conv_i8_t *b, long total_pix, int k64, int lg, unsigned magic) {
+static int launch_pair_t(const mhip_conv_i8_t *a, const mhip_conv_i8_t *b, long total_pix, int k64, int lg, unsigned magic,
+                         int wres) {
     if (a->nseg > 1)
-        return launch_persist_t<BPX, BN, 2, true, true, true>(a, total_pix, k64, lg, magic, b);
-    return launch_persist_t<BPX, BN, 2, true, false, true>(a, total_pix, k64, lg, magic, b);
+        return launch_persist_t<BPX, BN, 2, true, true, true>(a, total_pix, k64, lg, magic, b, wres);
+    return launch_persist_t<BPX, BN, 2, true, false, true>(a, total_pix, k64, lg, magic, b, wres);
 }
 extern "C" int mhip_conv_i8_pair(const mhip_conv_i8_t *a, const mhip_conv_i8_t *b) {
     if (!a || !b || !tune().persist || tune().variant) return -2;
@@ -1782,15 +1855,16 @@ extern "C" int mhip_conv_i8_pair(const mhip_conv_i8_t *a, const mhip_conv_i8_t *
     int lg = 0;
     while ((1 << lg) < a->in_c) lg++;
     const unsigned magic = ((65536u + (unsigned)a->kw - 1u) / (unsigned)a->kw);
-    const int bpx = default_variant(a, nks).bpx ? default_variant(a, nks).bpx : 128;
+    const variant_t dv = default_variant(a, nks);
+    const int bpx = dv.bpx ? dv.bpx : 128, wres = dv.persist && dv.wres && (tune().wres & 2);
     if (bpx == 256) {
-        if (bn == 128) return launch_pair_t<256, 128>(a, b, total_pix, k64, lg, magic);
-        if (bn == 64) return launch_pair_t<256, 64>(a, b, total_pix, k64, lg, magic);
-        return launch_pair_t<256, 32>(a, b, total_pix, k64, lg, magic);
+        if (bn == 128) return launch_pair_t<256, 128>(a, b, total_pix, k64, lg, magic, wres);
+        if (bn == 64) return launch_pair_t<256, 64>(a, b, total_pix, k64, lg, magic, wres);
+        return launch_pair_t<256, 32>(a, b, total_pix, k64, lg, magic, wres);
     }
-    if (bn == 128) return launch_pair_t<128, 128>(a, b, total_pix, k64, lg, magic);
-    if (bn == 64) return launch_pair_t<128, 64>(a, b, total_pix, k64, lg, magic);
-    return launch_pair_t<128, 32>(a, b, total_pix, k64, lg, magic);
+    if (bn == 128) return launch_pair_t<128, 128>(a, b, total_pix, k64, lg, magic, wres);
+    if (bn == 64) return launch_pair_t<128, 64>(a, b, total_pix, k64, lg, magic, wres);
+    return launch_pair_t<128, 32>(a, b, total_pix, k64, lg, magic, wres);
 }
 
 extern "C" int mhip_conv_i8_seg_ok(const mhip_conv_i8_t *p) {
@@ -1802,9 +1876,15 @@ extern "C" int mhip_conv_i8_variants(const mhip_conv_i8_t *p, int *codes, int ma
     if (!p || (p->in_c % 16) != 0 || mhip_conv_i8_small_c(p->in_c, p->kw, p->out_c)) return 0;
     const int k64 = (p->kh * p->row_pad + BK - 1) / BK * BK, nks = k64 / BK;
     int n = 0;
-    if (p->nseg > 1) { // one form only
-        if (max > 0) codes[n++] = 2;
-        if (max > 1) codes[n++] = 4;
+    if (p->nseg > 1) { // the tile walker only: plain, or with resident weights where they fit
+        const int bn = p->oc_pad % 128 == 0 ? 128 : (p->oc_pad % 64 == 0 ? 64 : 32);
+        const variant_t dv = default_variant(p, nks);
+        const int dflt = dv.persist && dv.wres ? (dv.bpx == 256 ? 15 : 14) : (dv.bpx == 256 ? 4 : 2);
+        if (n < max) codes[n++] = dflt;
+        if (n < max && dflt != 2) codes[n++] = 2;
+        if (n < max && dflt != 4) codes[n++] = 4;
+        if (n < max && dflt != 14 && LUTB + 2 * (size_t)128 * BK + (size_t)nks * bn * BK <= 80 * 1024) codes[n++] = 14;
+        if (n < max && dflt != 15 && LUTB + 2 * (size_t)256 * BK + (size_t)nks * bn * BK <= 80 * 1024) codes[n++] = 15;
         return n;
     }
     const int dflt = variant_code(default_variant(p, nks));
@@ -1817,6 +1897,10 @@ extern "C" int mhip_conv_i8_variants(const mhip_conv_i8_t *p, int *codes, int ma
         if (v.persist && !persist_eligible(p)) continue;
         if (v.ks2 && ((nks & 1) || nks < 4 || p->oc_pad % 64 != 0)) continue;
         if (v.w8 && (p->oc_pad % 128 != 0 || nks < 3)) continue;
+        if (v.wres) {
+            const int bn = p->oc_pad % 128 == 0 ? 128 : (p->oc_pad % 64 == 0 ? 64 : 32);
+            if (LUTB + 2 * (size_t)v.bpx * BK + (size_t)nks * bn * BK > 80 * 1024) continue;
+        }
         if (!v.persist && v.stages == 3 && nks <= 2) continue; // identical to the 2-stage launch
         if (n < max) codes[n++] = code;
     }
@@ -1862,8 +1946,18 @@ extern "C" int mhip_conv_i8(const mhip_conv_i8_t *p) {
         int code = p->variant;
         if (p->nseg > 1) {
             if (!seg_valid(p) || !persist_eligible(p)) return -1;
-            variant_t v = variant_of(code == 4 ? 4 : 2);
-            if (!code) v.bpx = default_variant(p, nks).bpx ? default_variant(p, nks).bpx : 128;
+            if (!code && tune().variant) { // forced from outside, as below
+                int codes[NVARIANTS];
+                const int n = mhip_conv_i8_variants(p, codes, NVARIANTS);
+                for (int i = 0; i < n; i++)
+                    if (codes[i] == tune().variant) code = codes[i];
+            }
+            variant_t v = variant_of(code == 4 || code == 14 || code == 15 ? code : 2);
+            if (!code) {
+                const variant_t dv = default_variant(p, nks);
+                v.bpx = dv.bpx ? dv.bpx : 128;
+                v.wres = dv.persist && dv.wres;
+            }
             return launch_variant(p, total_pix, k64, v);
         }
         if (!code && tune().variant) { // forced from outside: only where this layer has that variant
