@@ -52,6 +52,24 @@ def test_conv_i8_larger_shapes(gpu, orc):
         assert len(np.unique(a)) > 32  # not a saturated / all-zero comparison
 
 
+def test_conv_i8_stem_edges(gpu, orc):
+    """the small-channel (RGB stem) kernel: tiles hanging over every image edge (its edge units load at a clamped
+    column and shift), widths below one 4-pixel unit and 1 / 2 / 4 channels (the per-byte path), several tiles per
+    workgroup, strides 1 and 2"""
+    shapes = [  # in_h, in_w, in_c, out_c, k, s
+        (37, 53, 3, 32, 6, 2), (70, 41, 3, 16, 3, 1), (9, 3, 3, 32, 3, 1), (33, 6, 3, 48, 6, 2), (18, 50, 1, 32, 5, 2),
+        (11, 13, 4, 64, 3, 1), (21, 35, 2, 16, 6, 2), (130, 131, 3, 32, 6, 2)]
+    for i, (h, w, ic, oc, k, s) in enumerate(shapes):
+        oh, ow = (h + s - 1) // s, (w + s - 1) // s
+        ph = max((oh - 1) * s + k - h, 0) // 2
+        pw = max((ow - 1) * s + k - w, 0) // 2
+        case = ("stem%d" % i, 1, h, w, ic, oc, k, k, s, s, ph, pw, oh, ow, 0.03, 0.003 / (k * k * ic) ** 0.5 * 8, 0.05, True)
+        a = cases.conv_i8_call(gpu.conv2d_int8, case, 6)
+        b = cases.conv_i8_call(orc.conv2d_int8, case, 6)
+        assert np.array_equal(a, b), (case[0], int((a != b).sum()))
+        assert len(np.unique(a)) > 32
+
+
 @pytest.mark.parametrize("slots,stages", [(1, 2), (3, 2), (5, 3), (0, 3)])
 def test_conv_i8_persistent_tile_walk(gpu, orc, slots, stages):
     """the persistent kernel walking SEVERAL pixel tiles per workgroup (cross-tile prefetch, counted vmcnt

@@ -1260,6 +1260,7 @@ __global__ __launch_bounds__(NTHREADS) void conv_i8_smallc(const mhip_conv_i8_t 
     int8_t *patch0 = wl + BN * k64;                  // 2 x [(PH+1)][PWp] dwords (double buffer)
     const int patch_bytes = ((PH + 1) * PWp * 4 + 15) & ~15;
     int8_t *tile = patch0 + 2 * patch_bytes;         // [256][BN+OPAD]
+    v4i *sbias = (v4i *)(tile + SC_BP * (BN + OPAD)); // [BN / 4]
     lds_base_must_be_zero(dyn);
 
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
@@ -1271,6 +1272,7 @@ __global__ __launch_bounds__(NTHREADS) void conv_i8_smallc(const mhip_conv_i8_t 
         *(v4i *)(wl + (c >> 2) * (BN * BK) + lds_off(row, c & 3)) = *(const v4i *)(p.w + (size_t)row * k64 + c * 16);
     }
     for (int i = tid; i < 2 * patch_bytes / 4; i += NTHREADS) ((uint32_t *)patch0)[i] = 0;
+    if (tid < BN) ((int *)sbias)[tid] = p.bias ? p.bias[tid] : 0;
 
     // one staging unit = 4 consecutive patch pixels of one row -> one 16-byte LDS store.
     // in_c == 3: the 12 source bytes come from ONE unaligned 16-byte global load (gfx950 serves
@@ -1286,6 +1288,9 @@ __global__ __launch_bounds__(NTHREADS) void conv_i8_smallc(const mhip_conv_i8_t 
         ug[j] = (int)u - ur[j] * gpr;
     }
     v4i pre[2];
+    int shf[2]; // fast path: column shift of the loaded pixels (PRE_ZERO: nothing of this unit is inside the image)
+    constexpr int PRE_ZERO = 8, PRE_DONE = -100;
+    const bool fast3 = p.in_c == 3 && p.in_w >= 4;
     auto tile_xy = [&](unsigned t, int &tx, int &ty, unsigned &f) {
         const unsigned q = fdiv(t, dtx);
         tx = (int)(t - q * (unsigned)tiles_x);
@@ -1298,6 +1303,21 @@ __global__ __launch_bounds__(NTHREADS) void conv_i8_smallc(const mhip_conv_i8_t 
         tile_xy(t, tx, ty, f);
         const int8_t *src = p.in + (size_t)f * p.in_stride;
         const int y0 = ty * SC_TH * p.stride_h - p.pad_top, x0 = tx * SC_TW * p.stride_w - p.pad_left;
+        if (fast3) {
+            // EVERY lane issues its loads unconditionally, from an address clamped into the image, and nothing looks
+            // at the bytes before commit(): the loads stay in flight across this tile's MFMAs (a load under a
+            // divergent branch is waited for inside the branch).  Units over the left / right edge load the 4 pixels
+            // at the clamped column and are shifted into place at commit (zeros move in).
+#pragma unroll
+            for (int j = 0; j < 2; j++) {
+                const int iy = y0 + ur[j], ix = x0 + ug[j] * 4;
+                const int iyc = iy < 0 ? 0 : (iy > p.in_h - 1 ? p.in_h - 1 : iy);
+                const int ixc = ix < 0 ? 0 : (ix > p.in_w - 4 ? p.in_w - 4 : ix);
+                __builtin_memcpy(&pre[j], src + ((long)iyc * p.in_w + ixc) * 3, 16); // unaligned dwordx4, 12 bytes used
+                shf[j] = (iy == iyc && tid + j * NTHREADS < nunits) ? ixc - ix : PRE_ZERO;
+            }
+            return;
+        }
 #pragma unroll
         for (int j = 0; j < 2; j++) {
             v4i v = {0, 0, 0, 0};
@@ -1305,32 +1325,41 @@ __global__ __launch_bounds__(NTHREADS) void conv_i8_smallc(const mhip_conv_i8_t 
                 const int iy = y0 + ur[j], ix = x0 + ug[j] * 4;
                 if (iy >= 0 && iy < p.in_h) {
                     const int8_t *q = src + ((long)iy * p.in_w + ix) * p.in_c;
-                    if (p.in_c == 3 && ix >= 0 && ix + 4 <= p.in_w) {
-                        v4i raw;
-                        __builtin_memcpy(&raw, q, 16); // unaligned dwordx4; the 4 bytes past the 12 used are discarded
-                        const uint32_t d0 = (uint32_t)raw[0], d1 = (uint32_t)raw[1], d2 = (uint32_t)raw[2];
-                        v[0] = (int)(d0 & 0xFFFFFFu);
-                        v[1] = (int)(((d0 >> 24) | (d1 << 8)) & 0xFFFFFFu);
-                        v[2] = (int)(((d1 >> 16) | (d2 << 16)) & 0xFFFFFFu);
-                        v[3] = (int)(d2 >> 8);
-                    } else {
 #pragma unroll
-                        for (int e = 0; e < 4; e++) {
-                            uint32_t w = 0;
-                            if (ix + e >= 0 && ix + e < p.in_w)
-                                for (int c = 0; c < p.in_c; c++) w |= (uint32_t)(uint8_t)q[e * p.in_c + c] << (8 * c);
-                            v[e] = (int)w;
-                        }
+                    for (int e = 0; e < 4; e++) {
+                        uint32_t w = 0;
+                        if (ix + e >= 0 && ix + e < p.in_w)
+                            for (int c = 0; c < p.in_c; c++) w |= (uint32_t)(uint8_t)q[e * p.in_c + c] << (8 * c);
+                        v[e] = (int)w;
                     }
                 }
             }
             pre[j] = v;
+            shf[j] = PRE_DONE;
         }
     };
     auto commit = [&](int8_t *patch) {
 #pragma unroll
-        for (int j = 0; j < 2; j++)
-            if (tid + j * NTHREADS < nunits) *(v4i *)(patch + ((size_t)ur[j] * PWp + ug[j] * 4) * 4) = pre[j];
+        for (int j = 0; j < 2; j++) {
+            v4i v = pre[j];
+            if (fast3) { // 4 x 3 packed bytes -> 4 pixels widened to a dword each
+                const uint32_t d0 = (uint32_t)v[0], d1 = (uint32_t)v[1], d2 = (uint32_t)v[2];
+                v4i l;
+                l[0] = (int)(d0 & 0xFFFFFFu);
+                l[1] = (int)(((d0 >> 24) | (d1 << 8)) & 0xFFFFFFu);
+                l[2] = (int)(((d1 >> 16) | (d2 << 16)) & 0xFFFFFFu);
+                l[3] = (int)(d2 >> 8);
+                v = l;
+                if (shf[j] != 0) { // patch pixel e is loaded pixel e - shift
+#pragma unroll
+                    for (int e = 0; e < 4; e++) {
+                        const int k = e - shf[j];
+                        v[e] = k == 0 ? l[0] : (k == 1 ? l[1] : (k == 2 ? l[2] : (k == 3 ? l[3] : 0)));
+                    }
+                }
+            }
+            if (tid + j * NTHREADS < nunits) *(v4i *)(patch + ((size_t)ur[j] * PWp + ug[j] * 4) * 4) = v;
+        }
     };
 
     // Software pipeline over tiles with a double-buffered patch: the next tile's loads are issued
@@ -1339,6 +1368,7 @@ __global__ __launch_bounds__(NTHREADS) void conv_i8_smallc(const mhip_conv_i8_t 
     const int nks = k64 / BK;
     unsigned t = blockIdx.x;
     int buf = 0;
+
     __syncthreads(); // zero fill of both patch buffers is complete
     if (t < ntiles) {
         fetch(t);
@@ -1351,7 +1381,14 @@ __global__ __launch_bounds__(NTHREADS) void conv_i8_smallc(const mhip_conv_i8_t 
         if (tn < ntiles) fetch(tn); // next tile's bytes travel while this one is computed
 
         v4i acc[WOC][WPX];
-        init_acc<WPX, WOC>(p, acc, 0);
+#pragma unroll
+        for (int s = 0; s < WOC; s++)
+        {   // the bias comes from LDS: a global reload per tile would put a vmcnt(0) wait (in-order counter) between
+            // the next tile's fetch and this tile's MFMAs and serialise the two
+            const v4i b = sbias[s * 4 + (lane >> 4)];
+#pragma unroll
+            for (int u = 0; u < WPX; u++) acc[s][u] = b;
+        }
         const int px = lane & 15, c = lane >> 4;
         const bool even_sw = ((p.stride_w | PWp) & 1) == 0;
         for (int ks = 0; ks < nks; ks++) {
@@ -1493,7 +1530,7 @@ static int launch_smallc(const mhip_conv_i8_t *p, int k64) {
     if ((long)PH * gpr > 2 * NTHREADS || ntiles > 0x7fffffffL) return -1;
     constexpr int BN = WOC * 16;
     const size_t lds = (size_t)BN * k64 + 2 * ((((size_t)PH + 1) * PWp * 4 + 15) & ~(size_t)15) +
-                       (size_t)SC_BP * (BN + OPAD) + LUTB + (size_t)SC_BP * 8;
+                       (size_t)SC_BP * (BN + OPAD) + LUTB + (size_t)SC_BP * 8 + (size_t)BN * 4;
     if (lds > 64 * 1024) return -1;
     long grid = ntiles < 256L * 8 ? ntiles : 256L * 8;
     hipLaunchKernelGGL((conv_i8_smallc<WOC>), dim3((unsigned)grid), dim3(NTHREADS), lds, mhip_stream_native(), *p, k64,
