@@ -39,6 +39,11 @@ mars_error_t mars_hip_sync(void);
 
 /* Device address / per-frame stride of any tensor (weights: stride 0). */
 void *mars_hip_tensor_device(mars_model_t *model, int tensor_index, size_t *frame_stride);
+/* Device layout of a tensor's pixel rows: 0 = dense (the reference's bytes).  Otherwise the tensor is a graph output
+ * whose [pixels][*row_bytes] rows sit at the returned pitch in HBM (the 255-channel YOLO heads are kept at a 256-byte
+ * pitch so that their convolutions store aligned rows); mars_get_output / mars_hip_read_tensor / the detection tail
+ * already account for it, only code that reads mars_hip_tensor_device() pointers itself has to. */
+int mars_hip_tensor_row_pitch(mars_model_t *model, int tensor_index, int *row_bytes);
 /* Copy `bytes` of frame `frame` of any tensor to host memory (debug/parity). */
 mars_error_t mars_hip_read_tensor(mars_model_t *model, int tensor_index, int frame, void *dst,
                                   size_t bytes);

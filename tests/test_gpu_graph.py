@@ -237,6 +237,50 @@ def test_detect_on_model_outputs(gpu, orc):
     m.close()
 
 
+@pytest.mark.parametrize("out_c", [255, 170, 100])
+def test_padded_output_rows(gpu, orc, out_c):
+    """graph outputs with ragged pixel rows are kept at a 16-byte-aligned pitch on the device (pad_output_rows):
+    mars_get_output bytes, mars_hip_read_tensor (whole and partial), mars_hip_write_tensor and the detection tail
+    (anchors per pixel, and the per-byte mapping of a channel count that is no multiple of 85) all see the
+    reference's dense layout"""
+    import ctypes as C
+    rng = np.random.default_rng(out_c)
+    G = marsfile.Graph()
+    x = G.tensor([1, 16, 16, 32], scale=0.03)
+    o = G.tensor([1, 16, 16, out_c], scale=0.07)
+    wt = G.tensor([out_c, 1, 1, 32], scale=0.004, data=rng.integers(-127, 128, (out_c, 1, 1, 32), dtype=np.int8))
+    b = G.tensor([out_c], dtype=marsfile.I32, scale=1.0, data=rng.integers(-3000, 3000, out_c, dtype=np.int32))
+    G.conv(x, o, wt, b, (1, 1), (1, 1))
+    d = G.serialise([x], [o])
+    hdr, tensors, _ = marsfile.parse(d)
+    ti = hdr["outputs"][0]
+    B = 3
+    m = gpu.Model(d, batch=B)
+    rb = C.c_int(0)
+    assert gpu.lib().mars_hip_tensor_row_pitch(m.p, ti, C.byref(rb)) == (out_c + 15) // 16 * 16 and rb.value == out_c
+    xs = [lcg_frame(0xFACE00 + f, 16 * 16 * 32) for f in range(B)]
+    for f in range(B):
+        m.input_view(0)[f] = xs[f]
+    m.run()
+    dets = m.detect(outputs=(0,), thresh=0.45)
+    for f in range(B):
+        g, rc = run_oracle(orc, d, xs[f])
+        assert rc == 0
+        want = g.tensor(ti)
+        assert np.array_equal(m.output_view(0)[f], want)
+        assert np.array_equal(m.read_tensor(ti, frame=f), want)
+        assert np.array_equal(m.read_tensor(ti, frame=f, nbytes=3 * out_c + 17), want[:3 * out_c + 17])
+        pred = want.view(np.int8)
+        raw = orc.parse_output(pred, len(pred) // 85, np.float32(0.07))
+        assert len(raw) > 5
+        assert dets[f].tobytes() == orc.nms(raw, 0.45).tobytes()
+    # write whole pixels back and read them again
+    fresh = rng.integers(0, 256, 16 * 16 * out_c, dtype=np.uint8)
+    assert gpu.lib().mars_hip_write_tensor(m.p, ti, 1, fresh.ctypes.data, fresh.size) == 0
+    assert np.array_equal(m.read_tensor(ti, frame=1), fresh)
+    m.close()
+
+
 def test_autotune_keeps_results(gpu, orc):
     """mars_hip_autotune pins, per conv layer, the fastest of its launch variants; every variant writes the same
     bytes, so outputs before and after (and the oracle's) are identical"""

@@ -50,18 +50,28 @@ __global__ __launch_bounds__(256) void decode_kernel(const mhip_detect_t p) {
         const int8_t *pred = p.pred[sgi] + (size_t)f * p.stride[sgi];
         const float *val = p.lut[sgi], *obj = val + 256, *den = val + 512;
         const int np = p.npred[sgi];
+        const int pc = p.pix_c[sgi], ps = p.pix_stride[sgi], apx = (ps && pc % ROW == 0) ? pc / ROW : 0;
         for (int base = 0; base < np && total < MAXD; base += 256) {
             const int r = base + tid;
             bool cand = false;
             det_rec d;
             if (r < np) {
-                const int8_t *row = pred + (size_t)r * ROW;
-                float o = obj[row[4] + 128];
+                // padded pixel rows (the model wrote its 255-channel rows at a 256-byte pitch): prediction r is anchor
+                // r % apx of pixel r / apx; a channel count that is no multiple of 85 takes the per-byte mapping
+                const int8_t *rowp = pred + (size_t)r * ROW;
+                if (ps && apx) rowp = pred + (size_t)(r / apx) * ps + (r % apx) * ROW;
+                const bool bytewise = ps && !apx;
+                auto at = [&](int k) -> int {
+                    if (!bytewise) return rowp[k];
+                    const size_t o = (size_t)r * ROW + k;
+                    return pred[(o / pc) * ps + (o % pc)];
+                };
+                float o = obj[at(4) + 128];
                 if (!(o < CONF_MIN)) {
                     int arg = 0, argq = -1000;
                     float top = -1e9f;
                     for (int c = 0; c < NCLS; c++) {
-                        int q = row[5 + c];
+                        int q = at(5 + c);
                         float s = val[q + 128];
                         if (s > top) { top = s; arg = c; argq = q; }
                     }
@@ -70,10 +80,10 @@ __global__ __launch_bounds__(256) void decode_kernel(const mhip_detect_t p) {
                     float conf = o / dn;
                     if (!(conf < CONF_MIN)) {
                         cand = true;
-                        d.x = val[row[0] + 128];
-                        d.y = val[row[1] + 128];
-                        d.w = val[row[2] + 128];
-                        d.h = val[row[3] + 128];
+                        d.x = val[at(0) + 128];
+                        d.y = val[at(1) + 128];
+                        d.w = val[at(2) + 128];
+                        d.h = val[at(3) + 128];
                         d.conf = conf;
                         d.cls = arg;
                     }
@@ -316,7 +326,7 @@ static int launch_sort_nms(det_rec *dets, int *counts, int frames, float thresh)
 extern "C" int mhip_detect(const mhip_detect_t *p) {
     if (!p || p->nseg <= 0 || p->nseg > 4 || p->frames <= 0 || !p->dets || !p->counts) return -1;
     for (int s = 0; s < p->nseg; s++)
-        if (!p->pred[s] || !p->lut[s] || p->npred[s] < 0) return -1;
+        if (!p->pred[s] || !p->lut[s] || p->npred[s] < 0 || (p->pix_stride[s] && (p->pix_c[s] <= 0 || p->pix_stride[s] < p->pix_c[s]))) return -1;
     hipLaunchKernelGGL(decode_kernel, dim3(p->frames), dim3(256), 0, mhip_stream_native(), *p);
     int rc = mhip_check(hipGetLastError(), "decode");
     if (rc || !p->do_nms) return rc;

@@ -41,6 +41,7 @@ typedef struct {
     int needed;      /* touched by an op, or graph input/output */
     int io_in, io_out; /* 1-based graph input / output slot, 0 if none */
     uint8_t *host;   /* pinned staging for graph I/O: batch * bytes */
+    int pix_c, pix_stride; /* pix_stride != 0: [pixels][pix_c] rows kept at a pix_stride-byte pitch on the device (pad_output_rows) */
 } mtensor_t;
 
 typedef struct {
@@ -57,6 +58,7 @@ typedef struct {
     int row_pad, oc_pad, c_pad;
     int ch_off, scale_h, scale_w, bn_n;
     int out_pix_stride, out_ch_off; /* producer writes a channel slice of a wider tensor (zero-copy concat) */
+    int store_c; /* conv_i8 writing padded pixel rows: channels stored per pixel (the padded count), 0 = out_c */
     float cs, f0, f1, f2;
     size_t n;                 /* elements per frame for element-wise ops */
     size_t w_off, b_off, lut_off, s_off; /* offsets into the parameter arena */

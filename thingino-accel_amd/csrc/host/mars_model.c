@@ -886,6 +886,44 @@ static void fuse_pool_chains(mars_model_ext_t *m) {
 }
 
 /* ------------------------------------------------------------------- load */
+/* Ragged pixel rows of graph outputs (the 255-channel YOLO heads) are kept at a 16-byte-aligned pitch on the device:
+ * the producing convolution then takes the aligned epilogue (16-byte stores straight from registers, every launch
+ * form) instead of the LDS-staged copy-out with 8+4+2+1-byte row tails.  Only tensors nothing in the graph reads:
+ * their readers are the detection tail (told the pitch) and the download / read entry points (2-D copies), so hosts
+ * still see the reference's dense [H][W][C] bytes.  The pad channels carry zero weights; their bytes are never read. */
+static void pad_output_rows(mars_model_ext_t *m) {
+    for (uint32_t i = 0; i < m->pub.header.num_tensors; i++) m->mt[i].pix_c = m->mt[i].pix_stride = 0;
+    if (getenv("MARS_HIP_NO_ROWPAD")) return;
+    for (int i = 0; i < m->n_ops; i++) {
+        mars_op_t *o = &m->ops[i];
+        if (o->kind != OP_CONV_I8 || o->nchw || o->out_pix_stride || o->out_ch_off || o->add_t || o->t_out < 0 ||
+            (o->out_c & 15) == 0 || (o->in_c & 15) != 0)
+            continue;
+        mtensor_t *t = &m->mt[o->t_out];
+        const int P = (o->out_c + 15) & ~15;
+        const size_t px = (size_t)o->out_h * o->out_w;
+        if (!t->io_out || t->io_in || P > o->oc_pad || t->bytes != px * (size_t)o->out_c || (px * P) % 256 != 0) continue;
+        int other = 0; /* any other op touching the tensor keeps it dense */
+        for (int j = 0; j < m->n_ops && !other; j++) {
+            if (j == i) continue;
+            if (m->ops[j].t_out == o->t_out) other = 1;
+            for (int k = 0; k < m->ops[j].n_in; k++)
+                if (m->ops[j].t_in[k] == o->t_out) other = 1;
+            for (int k = 0; k < m->ops[j].nseg; k++)
+                if (m->ops[j].seg_t[k] == o->t_out) other = 1;
+            if (m->ops[j].add_t - 1 == o->t_out) other = 1;
+            for (int k = 0; k < m->ops[j].chain_n; k++)
+                if (m->ops[j].chain_out[k] == o->t_out) other = 1;
+        }
+        if (other) continue;
+        o->out_pix_stride = P;
+        o->store_c = P;
+        t->pix_c = o->out_c;
+        t->pix_stride = P;
+        if (px * P > t->extent) t->extent = px * P;
+    }
+}
+
 static void free_device_state(mars_model_ext_t *m) {
     if (m->act_dev) mhip_free(m->act_dev);
     if (m->scratch_dev) mhip_free(m->scratch_dev);
@@ -940,6 +978,7 @@ static mars_error_t build_plan(mars_model_ext_t *m) {
     m->blob_mirror_bytes = m->pub.weights_size;
     for (uint32_t i = 0; i < nt; i++) {
         m->mt[i].extent = m->mt[i].bytes;
+        m->mt[i].pix_c = m->mt[i].pix_stride = 0;
         m->mt[i].needed = (m->mt[i].io_in || m->mt[i].io_out) ? 1 : 0;
     }
     /* slot 0 of the arena: mirror of the raw blob (element-wise layers may read weight
@@ -952,6 +991,7 @@ static mars_error_t build_plan(mars_model_ext_t *m) {
         elide_concat(m);
         fuse_pool_chains(m);
         pair_convs(m);
+        pad_output_rows(m);
     }
     return MARS_OK;
 }
@@ -1184,7 +1224,7 @@ static void conv_i8_params(const mars_model_ext_t *m, const mars_op_t *op, mhip_
     p->lut2 = op->lut_off != NO_OFF && op->lut2_off != NO_OFF ? A + op->lut2_off : NULL;
     p->frames = m->batch;
     p->in_h = op->in_h; p->in_w = op->in_w;
-    p->out_h = op->out_h; p->out_w = op->out_w; p->out_c = op->out_c;
+    p->out_h = op->out_h; p->out_w = op->out_w; p->out_c = op->store_c ? op->store_c : op->out_c;
     p->kh = op->kh; p->kw = op->kw; p->stride_h = op->sh; p->stride_w = op->sw; p->pad_top = op->pt; p->pad_left = op->pl;
     p->row_pad = op->row_pad; p->oc_pad = op->oc_pad; p->cs = op->cs; p->relu = op->relu; p->out_nchw = op->nchw;
     p->safe = op->safe;
@@ -1385,6 +1425,13 @@ mars_error_t mars_hip_download_outputs(mars_model_t *model) {
     for (uint32_t i = 0; i < model->header.num_tensors; i++) {
         mtensor_t *t = &m->mt[i];
         if (!t->io_out || !t->host || !t->dev || t->bytes == 0) continue;
+        if (t->pix_stride) { /* padded pixel rows (pad_output_rows): frames are exactly pixels x pitch, so one 2-D copy */
+            if (t->stride != (t->bytes / (size_t)t->pix_c) * (size_t)t->pix_stride) return MARS_ERR_LAYER_FAILED;
+            if (mhip_d2h_2d_async(t->host, (size_t)t->pix_c, t->dev, (size_t)t->pix_stride, (size_t)t->pix_c,
+                                  (t->bytes / (size_t)t->pix_c) * (size_t)m->batch))
+                return MARS_ERR_LAYER_FAILED;
+            continue;
+        }
         if (mhip_d2h_2d_async(t->host, t->bytes, t->dev, t->stride, t->bytes, (size_t)m->batch)) return MARS_ERR_LAYER_FAILED;
     }
     return mhip_sync() ? MARS_ERR_LAYER_FAILED : MARS_OK;
@@ -1479,6 +1526,13 @@ void *mars_hip_tensor_device(mars_model_t *model, int ti, size_t *frame_stride) 
     return m->mt[ti].dev;
 }
 
+int mars_hip_tensor_row_pitch(mars_model_t *model, int ti, int *row_bytes) {
+    if (!model || ti < 0 || (uint32_t)ti >= model->header.num_tensors) return 0;
+    const mtensor_t *t = &((mars_model_ext_t *)model)->mt[ti];
+    if (row_bytes) *row_bytes = t->pix_stride ? t->pix_c : 0;
+    return t->pix_stride;
+}
+
 mars_error_t mars_hip_read_tensor(mars_model_t *model, int ti, int frame, void *dst, size_t bytes) {
     if (!model || !dst || ti < 0 || (uint32_t)ti >= model->header.num_tensors) return MARS_ERR_INVALID_TENSOR;
     mars_model_ext_t *m = (mars_model_ext_t *)model;
@@ -1486,6 +1540,14 @@ mars_error_t mars_hip_read_tensor(mars_model_t *model, int ti, int frame, void *
     if (!t->dev || frame < 0 || (!t->is_weight && frame >= m->batch)) return MARS_ERR_INVALID_TENSOR;
     if (!t->is_weight && bytes > t->stride) return MARS_ERR_INVALID_TENSOR;
     if (mhip_sync()) return MARS_ERR_LAYER_FAILED;
+    if (t->pix_stride) { /* padded pixel rows: whole pixels, then the bytes of a last partial one */
+        const size_t rows = bytes / (size_t)t->pix_c, rest = bytes - rows * (size_t)t->pix_c;
+        const uint8_t *src = t->dev + (size_t)frame * t->stride;
+        if (bytes > t->bytes) return MARS_ERR_INVALID_TENSOR;
+        if (rows && mhip_d2h_2d_async(dst, (size_t)t->pix_c, src, (size_t)t->pix_stride, (size_t)t->pix_c, rows)) return MARS_ERR_LAYER_FAILED;
+        if (rest && mhip_d2h_async((uint8_t *)dst + rows * (size_t)t->pix_c, src + rows * (size_t)t->pix_stride, rest)) return MARS_ERR_LAYER_FAILED;
+        return mhip_sync() ? MARS_ERR_LAYER_FAILED : MARS_OK;
+    }
     if (mhip_d2h_async(dst, t->dev + (size_t)frame * t->stride, bytes) || mhip_sync()) return MARS_ERR_LAYER_FAILED;
     return MARS_OK;
 }
@@ -1495,6 +1557,13 @@ mars_error_t mars_hip_write_tensor(mars_model_t *model, int ti, int frame, const
     mars_model_ext_t *m = (mars_model_ext_t *)model;
     mtensor_t *t = &m->mt[ti];
     if (!t->dev || t->is_weight || frame < 0 || frame >= m->batch || bytes > t->stride) return MARS_ERR_INVALID_TENSOR;
+    if (t->pix_stride) { /* padded pixel rows: whole pixels only */
+        const size_t rows = bytes / (size_t)t->pix_c;
+        if (bytes > t->bytes || rows * (size_t)t->pix_c != bytes) return MARS_ERR_INVALID_TENSOR;
+        if (mhip_h2d_2d_async(t->dev + (size_t)frame * t->stride, (size_t)t->pix_stride, src, (size_t)t->pix_c, (size_t)t->pix_c, rows) || mhip_sync())
+            return MARS_ERR_LAYER_FAILED;
+        return MARS_OK;
+    }
     if (mhip_h2d_async(t->dev + (size_t)frame * t->stride, src, bytes) || mhip_sync()) return MARS_ERR_LAYER_FAILED;
     return MARS_OK;
 }

@@ -54,6 +54,7 @@ mars_error_t mars_hip_detect_device(mars_model_t *model, const int *output_indic
         if (!m->mt[ti].dev || t->desc.dtype != MARS_DTYPE_INT8) return MARS_ERR_INVALID_TENSOR;
         p.pred[s] = (const int8_t *)m->mt[ti].dev;
         p.stride[s] = m->mt[ti].stride;
+        p.pix_c[s] = m->mt[ti].pix_c; p.pix_stride[s] = m->mt[ti].pix_stride;
         p.npred[s] = (int)(m->mt[ti].bytes / 85); /* rows of 85 int8: x,y,w,h,obj,80 classes */
         p.lut[s] = m->det_lut_dev + s * 768;
         if (memcmp(&m->det_lut_scale[s], &t->desc.scale, sizeof(float)) != 0) lut_stale = 1;

@@ -153,6 +153,7 @@ int mhip_nchw_to_nhwc_pad(const int8_t *in, size_t in_stride, int8_t *out, size_
 /* ---- detection tail (yolo_tail.hip) */
 typedef struct {
     const int8_t *pred[4]; size_t stride[4]; int npred[4];
+    int pix_c[4], pix_stride[4]; /* pix_stride != 0: every pix_c prediction bytes sit at the start of a pix_stride-byte pixel row */
     const float *lut[4];   /* per segment, device: 3 x 256 floats: value[q], obj[q], den[q] */
     int nseg;
     int frames;

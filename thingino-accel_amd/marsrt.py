@@ -101,7 +101,7 @@ EXPORTS = {
                   "conv2d_int8_mxu", "conv2d_int8_nhwc_mxu", "conv2d_float32_mxu"],
     "mars_hip.h": ["mars_hip_set_batch", "mars_hip_get_batch", "mars_hip_upload_inputs", "mars_hip_run_device",
                    "mars_hip_run_device_async", "mars_hip_download_outputs", "mars_hip_sync",
-                   "mars_hip_tensor_device", "mars_hip_read_tensor", "mars_hip_write_tensor", "mars_hip_set_fusion",
+                   "mars_hip_tensor_device", "mars_hip_tensor_row_pitch", "mars_hip_read_tensor", "mars_hip_write_tensor", "mars_hip_set_fusion",
                    "mars_hip_set_profiling", "mars_hip_num_ops", "mars_hip_op_info", "mars_hip_stream",
                    "mars_hip_load_memory_ex", "mars_hip_param_arena", "mars_yolo_parse_output", "mars_yolo_nms",
                    "mars_hip_detect", "mars_hip_detect_device", "mars_synth_model", "mars_hip_set_tuning", "mars_hip_autotune", "mars_yolo_letterbox",
@@ -162,6 +162,7 @@ def lib():
     L.mars_hip_tensor_device.restype = C.c_void_p
     L.mars_hip_tensor_device.argtypes = [P(MarsModel), C.c_int, P(C.c_size_t)]
     L.mars_hip_read_tensor.argtypes = [P(MarsModel), C.c_int, C.c_int, C.c_void_p, C.c_size_t]
+    L.mars_hip_tensor_row_pitch.argtypes = [P(MarsModel), C.c_int, P(C.c_int)]
     L.mars_hip_write_tensor.argtypes = [P(MarsModel), C.c_int, C.c_int, C.c_void_p, C.c_size_t]
     L.mars_hip_op_info.argtypes = [P(MarsModel), C.c_int, P(C.c_int), P(C.c_int), P(C.c_double), P(C.c_double),
                                    P(C.c_float)]
