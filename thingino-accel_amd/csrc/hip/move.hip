@@ -148,12 +148,19 @@ typedef struct {
     size_t stride[3];
 } pool_chain_outs_t;
 __global__ __launch_bounds__(MV_THREADS) void pool_chain_kernel(const int8_t *in, size_t is, pool_chain_outs_t outs, int n,
-                                                                int H, int W, int ch, int kh, int kw) {
+                                                                int H, int W, int ch, int kh, int kw, int frames) {
     extern __shared__ __attribute__((aligned(16))) unsigned char pc_lds[];
     const int hw = H * W;
-    s2v *A = (s2v *)pc_lds;           // [hw][8]: dwords 0-3 even bytes, 4-7 odd bytes of the 16 channels
-    s2v *T = A + (size_t)hw * 8;      // row maxima
-    const int c = blockIdx.x * 16, f = blockIdx.y;
+    // [8][hw] dwords (plane d of pixel px at d*hw + px: consecutive lanes -> consecutive banks): planes 0-3 the even
+    // bytes, 4-7 the odd bytes of the 16 channels, widened to 16 bits for v_pk_max_i16
+    s2v *A = (s2v *)pc_lds;
+    s2v *T = A + (size_t)hw * 8;      // row maxima, same layout
+    // workgroup -> (frame, channel group): consecutive workgroup ids go round-robin over the 8 XCDs, each with its own
+    // L2.  All channel groups of a frame are given to ONE XCD (ids xcd, xcd + 8, ...), so the 16-byte pieces they
+    // write into the same 128-byte lines merge in that L2 instead of leaving 8 L2s with partial lines each
+    const int ncg = ch / 16, slot = blockIdx.x >> 3;
+    const int f = (slot / ncg) * 8 + (blockIdx.x & 7), c = (slot % ncg) * 16;
+    if (f >= frames) return;
     const int8_t *src = in + (size_t)f * is + c;
     for (int px = threadIdx.x; px < hw; px += MV_THREADS) {
         const v4i v = *(const v4i *)(src + (size_t)px * ch);
@@ -161,8 +168,8 @@ __global__ __launch_bounds__(MV_THREADS) void pool_chain_kernel(const int8_t *in
         for (int d = 0; d < 4; d++) {
             const int w = v[d];
             const s2v x = *(const s2v *)&w;
-            A[px * 8 + d] = (s2v)(x << (short)8) >> (short)8;
-            A[px * 8 + 4 + d] = x >> (short)8;
+            A[d * hw + px] = (s2v)(x << (short)8) >> (short)8;
+            A[(4 + d) * hw + px] = x >> (short)8;
         }
     }
     __syncthreads();
@@ -172,12 +179,12 @@ __global__ __launch_bounds__(MV_THREADS) void pool_chain_kernel(const int8_t *in
             const int xe = x + kw < W ? x + kw : W;
             s2v m[8];
 #pragma unroll
-            for (int d = 0; d < 8; d++) m[d] = A[px * 8 + d];
+            for (int d = 0; d < 8; d++) m[d] = A[d * hw + px];
             for (int xx = x + 1; xx < xe; xx++)
 #pragma unroll
-                for (int d = 0; d < 8; d++) m[d] = __builtin_elementwise_max(m[d], A[(y * W + xx) * 8 + d]);
+                for (int d = 0; d < 8; d++) m[d] = __builtin_elementwise_max(m[d], A[d * hw + y * W + xx]);
 #pragma unroll
-            for (int d = 0; d < 8; d++) T[px * 8 + d] = m[d];
+            for (int d = 0; d < 8; d++) T[d * hw + px] = m[d];
         }
         __syncthreads();
         int8_t *dst = outs.out[stage] + (size_t)f * outs.stride[stage] + c;
@@ -186,15 +193,15 @@ __global__ __launch_bounds__(MV_THREADS) void pool_chain_kernel(const int8_t *in
             const int ye = y + kh < H ? y + kh : H;
             s2v m[8];
 #pragma unroll
-            for (int d = 0; d < 8; d++) m[d] = T[px * 8 + d];
+            for (int d = 0; d < 8; d++) m[d] = T[d * hw + px];
             for (int yy = y + 1; yy < ye; yy++)
 #pragma unroll
-                for (int d = 0; d < 8; d++) m[d] = __builtin_elementwise_max(m[d], T[(yy * W + x) * 8 + d]);
+                for (int d = 0; d < 8; d++) m[d] = __builtin_elementwise_max(m[d], T[d * hw + yy * W + x]);
             v4i r;
 #pragma unroll
             for (int d = 0; d < 4; d++) {
-                A[px * 8 + d] = m[d];
-                A[px * 8 + 4 + d] = m[4 + d];
+                A[d * hw + px] = m[d];
+                A[(4 + d) * hw + px] = m[4 + d];
                 const s2v b = (m[d] & (short)0xFF) | (s2v)(m[4 + d] << (short)8);
                 r[d] = *(const int *)&b;
             }
@@ -206,7 +213,7 @@ __global__ __launch_bounds__(MV_THREADS) void pool_chain_kernel(const int8_t *in
 
 extern "C" int mhip_pool_chain_i8(const int8_t *in, size_t in_stride, int8_t *const *outs, const size_t *out_strides, int n,
                                   int frames, int h, int w, int ch, int kh, int kw) {
-    if (!in || !outs || !out_strides || n < 1 || n > 3 || frames <= 0 || frames > 65535 || h <= 0 || w <= 0 || ch <= 0 ||
+    if (!in || !outs || !out_strides || n < 1 || n > 3 || frames <= 0 || frames > (1 << 20) || h <= 0 || w <= 0 || ch <= 0 || ch > 65536 ||
         (ch & 15) || kh <= 0 || kw <= 0)
         return -1;
     const size_t lds = (size_t)h * w * 8 * 4 * 2;
@@ -217,8 +224,9 @@ extern "C" int mhip_pool_chain_i8(const int8_t *in, size_t in_stride, int8_t *co
         o.stride[i] = i < n ? out_strides[i] : 0;
         if (i < n && (!outs[i] || (((uintptr_t)outs[i] | out_strides[i]) & 15))) return -1;
     }
-    hipLaunchKernelGGL(pool_chain_kernel, dim3((unsigned)(ch / 16), (unsigned)frames), dim3(MV_THREADS), lds, mhip_stream_native(),
-                       in, in_stride, o, n, h, w, ch, kh, kw);
+    const unsigned groups = (unsigned)((frames + 7) / 8) * (unsigned)(ch / 16) * 8u;
+    hipLaunchKernelGGL(pool_chain_kernel, dim3(groups), dim3(MV_THREADS), lds, mhip_stream_native(),
+                       in, in_stride, o, n, h, w, ch, kh, kw, frames);
     return mhip_check(hipGetLastError(), "pool chain");
 }
 
