@@ -931,11 +931,11 @@ __global__ __launch_bounds__(NTHREADS) void conv_i8_persist(const mhip_conv_i8_t
 #define PT_NIMAX 10
 template <int TH, int BN, bool HAS_LUT>
 __global__ __launch_bounds__(NTHREADS) void conv_i8_patch(const mhip_conv_i8_t p, const int k64, const int tiles_x,
-                                                          const int tiles_y, const unsigned ntiles, const int PH,
+                                                          const int tiles_y, const unsigned ntiles_all, const int PH,
                                                           const int PW, const int PWP, const int PWH, const int ni,
                                                           const int8_t *__restrict__ zeros, const fastdiv_t dtx,
                                                           const fastdiv_t dty, const fastdiv_t dpwp, const unsigned out_bytes,
-                                                          const int dbl) {
+                                                          const int dbl, const int xmap) {
     constexpr int WPX = TH / 4;  // tile rows (16-pixel subtiles) per wave
     constexpr int WOC = BN / 16; // every wave covers all BN channels of its rows
     constexpr int NST = WPX;
@@ -1000,9 +1000,16 @@ __global__ __launch_bounds__(NTHREADS) void conv_i8_patch(const mhip_conv_i8_t p
             }
         }
     }
+    // xmap (the grid's x extent is a multiple of 8): workgroup ids go round-robin over the 8 XCDs, so XCD x is given the
+    // x-th eighth of the tile list and walks it in order: neighbouring tiles (shared halo rows and columns) meet in
+    // ONE L2.  Tile id t of a workgroup = 8 * (position in its XCD's range) + xcd.
+    const unsigned xcd = blockIdx.x & 7u;
+    const unsigned xstart = xmap ? (unsigned)(((unsigned long long)ntiles_all * xcd) >> 3) : 0u;
+    const unsigned xend = xmap ? (unsigned)(((unsigned long long)ntiles_all * (xcd + 1u)) >> 3) : 0u;
+    const unsigned ntiles = xmap ? (xend - xstart) * 8u + xcd : ntiles_all;
     auto tile_xy = [&](unsigned t, int &tx, int &ty, unsigned &f) {
-        const unsigned q = fdiv(t, dtx);
-        tx = (int)(t - q * (unsigned)tiles_x);
+        const unsigned j = xmap ? xstart + (t >> 3) : t, q = fdiv(j, dtx);
+        tx = (int)(j - q * (unsigned)tiles_x);
         f = fdiv(q, dty);
         ty = (int)(q - f * (unsigned)tiles_y);
     };
@@ -1248,7 +1255,7 @@ __global__ __launch_bounds__(NTHREADS) void conv_i8_generic(const mhip_conv_i8_t
 #define SC_BP (SC_TH * SC_TW)
 template <int WOC>
 __global__ __launch_bounds__(NTHREADS) void conv_i8_smallc(const mhip_conv_i8_t p, const int k64, const int tiles_x,
-                                                           const int tiles_y, const unsigned ntiles, const int PH,
+                                                           const int tiles_y, const unsigned ntiles_all, const int PH,
                                                            const int PW, const int PWp, const fastdiv_t dhw,
                                                            const fastdiv_t dtx, const fastdiv_t dty, const fastdiv_t dgpr) {
     constexpr int BN = WOC * 16;
@@ -1291,9 +1298,17 @@ __global__ __launch_bounds__(NTHREADS) void conv_i8_smallc(const mhip_conv_i8_t 
     int shf[2]; // fast path: column shift of the loaded pixels (PRE_ZERO: nothing of this unit is inside the image)
     constexpr int PRE_ZERO = 8, PRE_DONE = -100;
     const bool fast3 = p.in_c == 3 && p.in_w >= 4;
+    // Workgroup ids go round-robin over the 8 XCDs (the grid is a multiple of 8, so a workgroup's XCD is blockIdx.x & 7
+    // for its whole run): XCD x is given the x-th eighth of the tile list and walks it in order, so the workgroups
+    // that share patch halos and 128-byte input lines run side by side under ONE L2 (measured: the kernel fetched
+    // 4.5x its input when neighbouring tiles sat on different XCDs, 1.4x now).  Tile id t = 8 * (position in the
+    // XCD's range) + xcd; ids below `ntiles` are valid.
+    const unsigned xcd = blockIdx.x & 7u;
+    const unsigned xstart = (unsigned)(((unsigned long long)ntiles_all * xcd) >> 3);
+    const unsigned ntiles = ((unsigned)(((unsigned long long)ntiles_all * (xcd + 1u)) >> 3) - xstart) * 8u + xcd;
     auto tile_xy = [&](unsigned t, int &tx, int &ty, unsigned &f) {
-        const unsigned q = fdiv(t, dtx);
-        tx = (int)(t - q * (unsigned)tiles_x);
+        const unsigned j = xstart + (t >> 3), q = fdiv(j, dtx);
+        tx = (int)(j - q * (unsigned)tiles_x);
         f = fdiv(q, dty);
         ty = (int)(q - f * (unsigned)tiles_y);
     };
@@ -1532,7 +1547,8 @@ static int launch_smallc(const mhip_conv_i8_t *p, int k64) {
     const size_t lds = (size_t)BN * k64 + 2 * ((((size_t)PH + 1) * PWp * 4 + 15) & ~(size_t)15) +
                        (size_t)SC_BP * (BN + OPAD) + LUTB + (size_t)SC_BP * 8 + (size_t)BN * 4;
     if (lds > 64 * 1024) return -1;
-    long grid = ntiles < 256L * 8 ? ntiles : 256L * 8;
+    if (ntiles >= 0x0fffffffL) return -1; // tile ids reach 8 x the longest per-XCD range
+    long grid = ntiles < 256L * 8 ? (ntiles + 7) / 8 * 8 : 256L * 8; // a multiple of 8: a workgroup stays on its XCD's ids
     hipLaunchKernelGGL((conv_i8_smallc<WOC>), dim3((unsigned)grid), dim3(NTHREADS), lds, mhip_stream_native(), *p, k64,
                        tiles_x, tiles_y, (unsigned)ntiles, PH, PW, PWp, make_fastdiv((unsigned)(p->out_h * p->out_w)),
                        make_fastdiv((unsigned)tiles_x), make_fastdiv((unsigned)tiles_y), make_fastdiv((unsigned)gpr));
@@ -1726,10 +1742,12 @@ static int launch_patch_t(const mhip_conv_i8_t *p, int k64, const patch_geom_t &
     unsigned gx = (unsigned)(tune().persist_slots > 0 ? tune().persist_slots : slots) / noc;
     if (gx < 1) gx = 1;
     if (gx > ntiles) gx = ntiles;
+    const int xmap = gx >= 8 && ntiles < 0x0fffffffu; // ids reach 8 x the longest range
+    if (xmap) gx &= ~7u;
     hipLaunchKernelGGL((conv_i8_patch<TH, BN, HAS_LUT>), dim3(gx, noc), dim3(NTHREADS), g.lds, mhip_stream_native(), *p, k64,
                        g.tiles_x, g.tiles_y, ntiles, g.PH, g.PW, g.PWP, g.PWH, g.ni, (const int8_t *)mhip_zero_page(),
                        make_fastdiv((unsigned)g.tiles_x), make_fastdiv((unsigned)g.tiles_y), make_fastdiv((unsigned)g.PWP),
-                       (unsigned)persist_out_bytes(p), g.dbl);
+                       (unsigned)persist_out_bytes(p), g.dbl, xmap);
     return mhip_check(hipGetLastError(), "conv_i8_patch launch");
 }
 
