@@ -230,6 +230,35 @@ extern "C" int mhip_pool_chain_i8(const int8_t *in, size_t in_stride, int8_t *co
     return mhip_check(hipGetLastError(), "pool chain");
 }
 
+// ------------------------------------------------------- padded rows -> dense
+// dst[r * width + k] = src[r * pitch + k], k < width: graph outputs kept at an aligned row pitch (pad_output_rows of
+// the host) packed into the reference's dense bytes before they leave the device.  One thread per 16 source bytes.
+__global__ __launch_bounds__(MV_THREADS) void unpad_rows_kernel(const int8_t *src, int8_t *dst, size_t rows, int width, int pitch) {
+    const int cpr = (width + 15) / 16;
+    const size_t idx = (size_t)blockIdx.x * MV_THREADS + threadIdx.x;
+    if (idx >= rows * (size_t)cpr) return;
+    const size_t r = idx / (size_t)cpr;
+    const int c = (int)(idx - r * (size_t)cpr) * 16;
+    const v4i v = *(const v4i *)(src + r * (size_t)pitch + c);
+    int8_t *d = dst + r * (size_t)width + c;
+    if (c + 16 <= width) {
+        __builtin_memcpy(d, &v, 16); // unaligned dwordx4 store
+    } else {
+        const int8_t *b = (const int8_t *)&v;
+        for (int k = 0; k < width - c; k++) d[k] = b[k];
+    }
+}
+
+extern "C" int mhip_unpad_rows(const void *src, void *dst, size_t rows, int width, int pitch) {
+    if (!src || !dst || width <= 0 || pitch < width || (pitch & 15) || ((uintptr_t)src & 15)) return -1;
+    if (rows == 0) return 0;
+    const size_t n = rows * (size_t)((width + 15) / 16), blocks = (n + MV_THREADS - 1) / MV_THREADS;
+    if (blocks > 0x7fffffffu) return -1;
+    hipLaunchKernelGGL(unpad_rows_kernel, dim3((unsigned)blocks), dim3(MV_THREADS), 0, mhip_stream_native(), (const int8_t *)src,
+                       (int8_t *)dst, rows, width, pitch);
+    return mhip_check(hipGetLastError(), "unpad rows");
+}
+
 // ------------------------------------------------------------ concat slice
 // out[(pix)*out_c + ch_off + c] = in[pix*in_c + c], pix over out_h*out_w
 template <int VEC>

@@ -41,6 +41,7 @@ typedef struct {
     int needed;      /* touched by an op, or graph input/output */
     int io_in, io_out; /* 1-based graph input / output slot, 0 if none */
     uint8_t *host;   /* pinned staging for graph I/O: batch * bytes */
+    uint8_t *dense_dev; /* padded rows only: batch * bytes, the dense copy made on the device before a download */
     int pix_c, pix_stride; /* pix_stride != 0: [pixels][pix_c] rows kept at a pix_stride-byte pitch on the device (pad_output_rows) */
 } mtensor_t;
 

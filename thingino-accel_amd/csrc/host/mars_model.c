@@ -931,6 +931,8 @@ static void free_device_state(mars_model_ext_t *m) {
     for (uint32_t i = 0; m->mt && i < m->pub.header.num_tensors; i++) {
         if (m->mt[i].host) mhip_host_free(m->mt[i].host);
         m->mt[i].host = NULL;
+        if (m->mt[i].dense_dev) mhip_free(m->mt[i].dense_dev);
+        m->mt[i].dense_dev = NULL;
         if (!m->mt[i].is_weight) m->mt[i].dev = NULL;
     }
     if (m->det_dev) mhip_free(m->det_dev);
@@ -1067,6 +1069,10 @@ static mars_error_t alloc_batch(mars_model_ext_t *m, int n) {
             memset(t->host, 0, hb);
             rt->vaddr = t->host;
             rt->alloc_size = hb; /* what a caller may fill / read through vaddr (mars_test.c:73-84) */
+        }
+        if (t->pix_stride) {
+            t->dense_dev = (uint8_t *)mhip_malloc(t->bytes * (size_t)n);
+            if (!t->dense_dev) return MARS_ERR_ALLOC_FAILED;
         }
     }
     if (m->scratch_per_frame) {
@@ -1425,10 +1431,12 @@ mars_error_t mars_hip_download_outputs(mars_model_t *model) {
     for (uint32_t i = 0; i < model->header.num_tensors; i++) {
         mtensor_t *t = &m->mt[i];
         if (!t->io_out || !t->host || !t->dev || t->bytes == 0) continue;
-        if (t->pix_stride) { /* padded pixel rows (pad_output_rows): frames are exactly pixels x pitch, so one 2-D copy */
-            if (t->stride != (t->bytes / (size_t)t->pix_c) * (size_t)t->pix_stride) return MARS_ERR_LAYER_FAILED;
-            if (mhip_d2h_2d_async(t->host, (size_t)t->pix_c, t->dev, (size_t)t->pix_stride, (size_t)t->pix_c,
-                                  (t->bytes / (size_t)t->pix_c) * (size_t)m->batch))
+        if (t->pix_stride) { /* padded pixel rows (pad_output_rows): frames are exactly pixels x pitch; packed on the
+                              * device (a 2-D copy of millions of 255-byte rows runs at a few MB/s), then one copy */
+            const size_t rows = (t->bytes / (size_t)t->pix_c) * (size_t)m->batch;
+            if (!t->dense_dev || t->stride != (t->bytes / (size_t)t->pix_c) * (size_t)t->pix_stride) return MARS_ERR_LAYER_FAILED;
+            if (mhip_unpad_rows(t->dev, t->dense_dev, rows, t->pix_c, t->pix_stride) ||
+                mhip_d2h_async(t->host, t->dense_dev, t->bytes * (size_t)m->batch))
                 return MARS_ERR_LAYER_FAILED;
             continue;
         }
@@ -1540,13 +1548,13 @@ mars_error_t mars_hip_read_tensor(mars_model_t *model, int ti, int frame, void *
     if (!t->dev || frame < 0 || (!t->is_weight && frame >= m->batch)) return MARS_ERR_INVALID_TENSOR;
     if (!t->is_weight && bytes > t->stride) return MARS_ERR_INVALID_TENSOR;
     if (mhip_sync()) return MARS_ERR_LAYER_FAILED;
-    if (t->pix_stride) { /* padded pixel rows: whole pixels, then the bytes of a last partial one */
-        const size_t rows = bytes / (size_t)t->pix_c, rest = bytes - rows * (size_t)t->pix_c;
-        const uint8_t *src = t->dev + (size_t)frame * t->stride;
-        if (bytes > t->bytes) return MARS_ERR_INVALID_TENSOR;
-        if (rows && mhip_d2h_2d_async(dst, (size_t)t->pix_c, src, (size_t)t->pix_stride, (size_t)t->pix_c, rows)) return MARS_ERR_LAYER_FAILED;
-        if (rest && mhip_d2h_async((uint8_t *)dst + rows * (size_t)t->pix_c, src + rows * (size_t)t->pix_stride, rest)) return MARS_ERR_LAYER_FAILED;
-        return mhip_sync() ? MARS_ERR_LAYER_FAILED : MARS_OK;
+    if (t->pix_stride) { /* padded pixel rows: the frame is packed on the device first */
+        uint8_t *dense = t->dense_dev + (size_t)frame * t->bytes;
+        if (bytes > t->bytes || !t->dense_dev) return MARS_ERR_INVALID_TENSOR;
+        if (mhip_unpad_rows(t->dev + (size_t)frame * t->stride, dense, t->bytes / (size_t)t->pix_c, t->pix_c, t->pix_stride) ||
+            mhip_d2h_async(dst, dense, bytes) || mhip_sync())
+            return MARS_ERR_LAYER_FAILED;
+        return MARS_OK;
     }
     if (mhip_d2h_async(dst, t->dev + (size_t)frame * t->stride, bytes) || mhip_sync()) return MARS_ERR_LAYER_FAILED;
     return MARS_OK;

@@ -141,6 +141,7 @@ int mhip_maxpool_i8(const int8_t *in, size_t in_stride, int8_t *out, size_t out_
  * stage i reads stage i-1's result and writes outs[i] */
 int mhip_pool_chain_i8(const int8_t *in, size_t in_stride, int8_t *const *outs, const size_t *out_strides, int n,
                        int frames, int h, int w, int ch, int kh, int kw);
+int mhip_unpad_rows(const void *src, void *dst, size_t rows, int width, int pitch); /* device -> device */
 int mhip_concat_slice(const int8_t *in, size_t in_stride, int8_t *out, size_t out_stride, int frames,
                       int out_h, int out_w, int in_c, int out_c, int ch_off);
 int mhip_upsample_i8(const int8_t *in, size_t in_stride, int8_t *out, size_t out_stride, int frames,
