@@ -102,6 +102,9 @@ __device__ __forceinline__ void lut4_at0(int q0, int q1, int q2, int q3, int &v0
                  : "memory");
 }
 __device__ __forceinline__ void lds_base_must_be_zero(const void *dynamic_lds) {
+    // every convolution wave runs at raised issue priority: the detection tail of the previous batch shares the SIMDs
+    // (its serial sort wave otherwise takes issue slots from a wave its whole workgroup then waits for at the barrier)
+    __builtin_amdgcn_s_setprio(3);
     unsigned a = (unsigned)(size_t)(const __attribute__((address_space(3))) void *)dynamic_lds;
     asm volatile("" : "+s"(a)); // opaque: the optimiser assumes a global's address is never 0 and would fold the test
     if (a != 0u) __builtin_trap();
