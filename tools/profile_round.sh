@@ -7,9 +7,8 @@ TAG=${1:-r01}
 OUT=$PWD/gpurun_out
 mkdir -p $OUT
 W=2; K=4
-# --no-autotune: the autotuner would add ~4 launches of every variant of every layer to the counters and averages;
-# the default launch policy profiled here is within 2-3 % of the autotuned one
-BENCH="bench.py --no-cpu-baseline --no-autotune --steps $K --warmup $W"
+# the default launch policy (bench.py's default; --autotune would add ~4 launches of every variant of every layer)
+BENCH="bench.py --no-cpu-baseline --steps $K --warmup $W"
 export TMPDIR=/tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/${TAG}_trace -o t -- python3 $BENCH > $OUT/${TAG}_bench_line_under_rocprof.json 2> $OUT/${TAG}_trace.err
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/${TAG}_pmc_fetch -o f -- python3 $BENCH > /dev/null 2> $OUT/${TAG}_pmc_fetch.err
