@@ -1048,7 +1048,9 @@ static mars_error_t alloc_batch(mars_model_ext_t *m, int n) {
         per_frame += t->stride;
     }
     m->act_bytes = per_frame * (size_t)n;
-    m->act_dev = (uint8_t *)mhip_malloc(m->act_bytes);
+    /* + 256: vector loads may read up to 15 bytes past the last element they use (the stem's unaligned 16-byte loads
+     * of 12-byte pixel groups); the slack keeps that inside the allocation for the last tensor too */
+    m->act_dev = (uint8_t *)mhip_malloc(m->act_bytes + 256);
     if (!m->act_dev) return MARS_ERR_ALLOC_FAILED;
     if (mhip_memset_async(m->act_dev, 0, m->act_bytes)) return MARS_ERR_ALLOC_FAILED;
     size_t off = 0;
