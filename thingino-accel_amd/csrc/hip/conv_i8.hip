@@ -1290,12 +1290,14 @@ __global__ __launch_bounds__(NTHREADS) void conv_i8_smallc(const mhip_conv_i8_t 
     const int gpr = (PW + 3) >> 2;           // units per patch row
     const int nunits = PH * gpr;             // host guarantees nunits <= 2 * NTHREADS
     // this thread's (at most 2) units never change: patch row r, pixel group g
-    int ur[2], ug[2];
+    // (row << 8 | group) in one register each: the kernel sits at 112 VGPRs, one allocation granule below 120, so that
+    // 4 of its waves still fit beside a 64-register wave of the detection tail (measured: -2 % per batch at 115)
+    int urg[2];
 #pragma unroll
     for (int j = 0; j < 2; j++) {
         const unsigned u = (unsigned)(tid + j * NTHREADS);
-        ur[j] = (int)fdiv(u, dgpr);
-        ug[j] = (int)u - ur[j] * gpr;
+        const int r = (int)fdiv(u, dgpr);
+        urg[j] = (r << 8) | ((int)u - r * gpr);
     }
     v4i pre[2];
     int shf[2]; // fast path: column shift of the loaded pixels (PRE_ZERO: nothing of this unit is inside the image)
@@ -1328,7 +1330,7 @@ __global__ __launch_bounds__(NTHREADS) void conv_i8_smallc(const mhip_conv_i8_t 
             // at the clamped column and are shifted into place at commit (zeros move in).
 #pragma unroll
             for (int j = 0; j < 2; j++) {
-                const int iy = y0 + ur[j], ix = x0 + ug[j] * 4;
+                const int iy = y0 + (urg[j] >> 8), ix = x0 + (urg[j] & 255) * 4;
                 const int iyc = iy < 0 ? 0 : (iy > p.in_h - 1 ? p.in_h - 1 : iy);
                 const int ixc = ix < 0 ? 0 : (ix > p.in_w - 4 ? p.in_w - 4 : ix);
                 __builtin_memcpy(&pre[j], src + ((long)iyc * p.in_w + ixc) * 3, 16); // unaligned dwordx4, 12 bytes used
@@ -1340,7 +1342,7 @@ __global__ __launch_bounds__(NTHREADS) void conv_i8_smallc(const mhip_conv_i8_t 
         for (int j = 0; j < 2; j++) {
             v4i v = {0, 0, 0, 0};
             if (tid + j * NTHREADS < nunits) {
-                const int iy = y0 + ur[j], ix = x0 + ug[j] * 4;
+                const int iy = y0 + (urg[j] >> 8), ix = x0 + (urg[j] & 255) * 4;
                 if (iy >= 0 && iy < p.in_h) {
                     const int8_t *q = src + ((long)iy * p.in_w + ix) * p.in_c;
 #pragma unroll
@@ -1376,7 +1378,7 @@ __global__ __launch_bounds__(NTHREADS) void conv_i8_smallc(const mhip_conv_i8_t 
                     }
                 }
             }
-            if (tid + j * NTHREADS < nunits) *(v4i *)(patch + ((size_t)ur[j] * PWp + ug[j] * 4) * 4) = v;
+            if (tid + j * NTHREADS < nunits) *(v4i *)(patch + ((size_t)(urg[j] >> 8) * PWp + (urg[j] & 255) * 4) * 4) = v;
         }
     };
 
@@ -1384,6 +1386,14 @@ __global__ __launch_bounds__(NTHREADS) void conv_i8_smallc(const mhip_conv_i8_t 
     // before this tile's MFMAs and committed to the OTHER buffer before this tile's stores, so the
     // (in-order) vmcnt wait for those loads never sits behind freshly issued stores.
     const int nks = k64 / BK;
+    // MFMA operand addresses of this lane: B = pixel (row wv*WPX+u, column lane&15), K chunk c = lane>>4 -> kernel row
+    // 2*ks + (c>>1), pixel slots (c&1)*4..+3 of that row; A = weight row s*16 + (lane&15), chunk c (swizzled)
+    const bool even_sw = ((p.stride_w | PWp) & 1) == 0;
+    int xoff[WPX];
+#pragma unroll
+    for (int u = 0; u < WPX; u++)
+        xoff[u] = ((wv * WPX + u) * p.stride_h + (lane >> 5)) * PWp + (lane & 15) * p.stride_w + ((lane >> 4) & 1) * 4; // dwords
+    const int woff = lds_off(lane & 15, lane >> 4); // + s * 16 * BK for subtile s: 16 rows further the swizzle repeats
     unsigned t = blockIdx.x;
     int buf = 0;
 
@@ -1398,40 +1408,40 @@ __global__ __launch_bounds__(NTHREADS) void conv_i8_smallc(const mhip_conv_i8_t 
         const unsigned tn = t + gridDim.x;
         if (tn < ntiles) fetch(tn); // next tile's bytes travel while this one is computed
 
+        // K loop.  The accumulators start as the C operand of the first step's MFMAs = the bias, read from LDS (a
+        // global reload per tile would put a vmcnt(0) wait -- in-order counter -- between the next tile's fetch and
+        // this tile's MFMAs; copying it into 32 accumulator registers first costs 32 moves per tile).  Operand
+        // addresses: xoff[] (per lane, fixed for the whole run) + a scalar per (patch buffer, K step).
         v4i acc[WOC][WPX];
-#pragma unroll
-        for (int s = 0; s < WOC; s++)
-        {   // the bias comes from LDS: a global reload per tile would put a vmcnt(0) wait (in-order counter) between
-            // the next tile's fetch and this tile's MFMAs and serialise the two
-            const v4i b = sbias[s * 4 + (lane >> 4)];
-#pragma unroll
-            for (int u = 0; u < WPX; u++) acc[s][u] = b;
-        }
-        const int px = lane & 15, c = lane >> 4;
-        const bool even_sw = ((p.stride_w | PWp) & 1) == 0;
-        for (int ks = 0; ks < nks; ks++) {
-            const int ky = 2 * ks + (c >> 1);
+        auto kstep = [&](const int ks, const bool first) {
+            const uint32_t *rows = (const uint32_t *)patch + ks * 2 * PWp;
             v4i xb[WPX];
 #pragma unroll
             for (int u = 0; u < WPX; u++) {
-                const int py = wv * WPX + u;
-                const int idx = (py * p.stride_h + ky) * PWp + px * p.stride_w + (c & 1) * 4; // dwords
                 if (even_sw) { // 8-byte aligned: two ds_read_b64, conflict-free for 16 lanes at an 8-byte stride
-                    const uint2 *q2 = (const uint2 *)((const uint32_t *)patch + (idx & ~1));
+                    const uint2 *q2 = (const uint2 *)(rows + xoff[u]);
                     const uint2 a0 = q2[0], a1 = q2[1];
                     xb[u] = (v4i){(int)a0.x, (int)a0.y, (int)a1.x, (int)a1.y};
                 } else {
-                    const uint32_t *q = (const uint32_t *)patch + idx;
+                    const uint32_t *q = rows + xoff[u];
                     xb[u] = (v4i){(int)q[0], (int)q[1], (int)q[2], (int)q[3]};
                 } // row PH (odd-kh tail) exists and is zero
             }
 #pragma unroll
             for (int s = 0; s < WOC; s++) {
-                const v4i wa = *(const v4i *)(wl + ks * (BN * BK) + lds_off(s * 16 + px, c));
+                const v4i wa = *(const v4i *)(wl + ks * (BN * BK) + s * (16 * BK) + woff);
+                if (first) {
+                    const v4i b = sbias[s * 4 + (lane >> 4)];
 #pragma unroll
-                for (int u = 0; u < WPX; u++) acc[s][u] = __builtin_amdgcn_mfma_i32_16x16x64_i8(wa, xb[u], acc[s][u], 0, 0, 0);
+                    for (int u = 0; u < WPX; u++) acc[s][u] = __builtin_amdgcn_mfma_i32_16x16x64_i8(wa, xb[u], b, 0, 0, 0);
+                } else {
+#pragma unroll
+                    for (int u = 0; u < WPX; u++) acc[s][u] = __builtin_amdgcn_mfma_i32_16x16x64_i8(wa, xb[u], acc[s][u], 0, 0, 0);
+                }
             }
-        }
+        };
+        kstep(0, true);
+        for (int ks = 1; ks < nks; ks++) kstep(ks, false);
         if (tn < ntiles) commit(patch0 + (buf ^ 1) * patch_bytes); // last read before the previous epilogue's barrier
         buf ^= 1;
         int tx, ty;
