@@ -1740,15 +1740,27 @@ static bool patch_geom(const mhip_conv_i8_t *p, int th, patch_geom_t *g) {
 
 template <int TH, int BN, bool HAS_LUT>
 static int launch_patch_t(const mhip_conv_i8_t *p, int k64, const patch_geom_t &g) {
-    static int slots = 0;
-    if (!slots) {
-        int occ = 0, dev = 0;
+    // workgroups the device holds at once at THIS layer's LDS size (small patches fit 3-4 per CU), cached per size
+    static int cus = 0;
+    static size_t slots_lds[4];
+    static int slots_n[4], nslots = 0;
+    if (!cus) {
+        int dev = 0;
         hipDeviceProp_t prop;
         if (hipFuncSetAttribute((const void *)conv_i8_patch<TH, BN, HAS_LUT>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024) != hipSuccess ||
-            hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, conv_i8_patch<TH, BN, HAS_LUT>, NTHREADS, 80 * 1024) != hipSuccess ||
             hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess)
             return mhip_check(hipErrorUnknown, "conv_i8_patch occupancy query");
-        slots = (occ > 0 ? occ : 1) * prop.multiProcessorCount;
+        cus = prop.multiProcessorCount;
+    }
+    int slots = 0;
+    for (int i = 0; i < nslots; i++)
+        if (slots_lds[i] == g.lds) slots = slots_n[i];
+    if (!slots) {
+        int occ = 0;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, conv_i8_patch<TH, BN, HAS_LUT>, NTHREADS, g.lds) != hipSuccess)
+            return mhip_check(hipErrorUnknown, "conv_i8_patch occupancy query");
+        slots = (occ > 0 ? occ : 1) * cus;
+        if (nslots < 4) { slots_lds[nslots] = g.lds; slots_n[nslots++] = slots; }
     }
     const unsigned ntiles = (unsigned)((long)g.tiles_x * g.tiles_y * p->frames);
     const unsigned noc = (unsigned)(p->oc_pad / BN);
