@@ -237,6 +237,58 @@ def test_detect_on_model_outputs(gpu, orc):
     m.close()
 
 
+def _silu_conv(G, rng, x, in_c, out_c, hw, k, s_conv, s_sig, s_out, wscale=0.004):
+    """conv -> sigmoid -> mul with its own three scales (the plan folds the chain into the conv's LUT epilogue)"""
+    a = G.tensor([1, hw, hw, out_c], scale=s_conv)
+    g = G.tensor([1, hw, hw, out_c], scale=s_sig)
+    o = G.tensor([1, hw, hw, out_c], scale=s_out)
+    wt = G.tensor([out_c, k, k, in_c], scale=wscale, data=rng.integers(-127, 128, (out_c, k, k, in_c), dtype=np.int8))
+    b = G.tensor([out_c], dtype=marsfile.I32, scale=1.0, data=rng.integers(-2000, 2000, out_c, dtype=np.int32))
+    G.conv(x, a, wt, b, (k, k), (1, 1))
+    G.layer(marsfile.SIGMOID, [a], [g])
+    G.layer(marsfile.MUL, [a, g], [o])
+    return o
+
+
+@pytest.mark.parametrize("c,slots", [(32, 0), (64, 3), (128, 0), (128, 5), (256, 0)])
+def test_paired_convs_own_tables(gpu, orc, c, slots):
+    """C3 shape: cv1 and cv2 over one input run as one grid, each with its OWN fused SiLU table (different scales on
+    the two branches); a 1x1 follows cv1, a concat of both branches is read through (never materialised) by cv3 and
+    another 1x1 follows that"""
+    rng = np.random.default_rng(c + slots)
+    hw = 24
+    G = marsfile.Graph()
+    x = G.tensor([1, hw, hw, c], scale=0.04)
+    cv1 = _silu_conv(G, rng, x, c, c // 2 if c <= 128 else c, hw, 1, 0.05, 1.0 / 256, 0.03)
+    cv2 = _silu_conv(G, rng, x, c, c // 2 if c <= 128 else c, hw, 1, 0.09, 1.0 / 200, 0.07)
+    cm = c // 2 if c <= 128 else c
+    m1 = _silu_conv(G, rng, cv1, cm, cm, hw, 1, 0.06, 1.0 / 256, 0.045, wscale=0.01)
+    cat = G.tensor([1, hw, hw, 2 * cm], scale=0.05)
+    G.concat([m1, cv2], cat)
+    cv3 = _silu_conv(G, rng, cat, 2 * cm, cm, hw, 1, 0.07, 1.0 / 256, 0.05)      # reads the virtual concat
+    m2 = _silu_conv(G, rng, cv3, cm, cm, hw, 1, 0.05, 1.0 / 256, 0.04, wscale=0.01)  # chained behind it
+    d = G.serialise([x], [m2, cv1, cv3])
+    hdr, tensors, _ = marsfile.parse(d)
+    B = 3
+    try:
+        gpu.set_tuning("persist_slots", slots)
+        m = gpu.Model(d, batch=B)
+        xs = [lcg_frame(0xC4A100 + f, hw * hw * c) for f in range(B)]
+        for f in range(B):
+            m.input_view(0)[f] = xs[f]
+        m.run()
+        for f in range(B):
+            g, rc = run_oracle(orc, d, xs[f])
+            assert rc == 0
+            for oi, ti in enumerate(hdr["outputs"]):
+                want = g.tensor(ti)
+                assert np.array_equal(m.output_view(oi)[f], want), (c, f, oi, int((m.output_view(oi)[f] != want).sum()))
+                assert len(np.unique(want)) > 16
+        m.close()
+    finally:
+        gpu.set_tuning("persist_slots", 0)
+
+
 @pytest.mark.parametrize("out_c", [255, 170, 100])
 def test_padded_output_rows(gpu, orc, out_c):
     """graph outputs with ragged pixel rows are kept at a 16-byte-aligned pitch on the device (pad_output_rows):

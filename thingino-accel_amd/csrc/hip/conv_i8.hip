@@ -627,7 +627,7 @@ struct conv_out_side_t {
     size_t out_stride;
     const int8_t *w;
     const int32_t *bias;
-    const uint8_t *lut;
+    const uint8_t *lut, *lut2;
     int out_c, relu, out_pix_stride, out_ch_off;
     float cs;
     unsigned out_bytes;
@@ -666,6 +666,7 @@ __global__ __launch_bounds__(NTHREADS) void conv_i8_persist(const mhip_conv_i8_t
     unsigned out_bytes = out_bytes_first;
     if (PAIR && ot >= noc0) {
         ot -= noc0;
+        p.lut2 = alt.lut2; // its own half-step table (the two convolutions have different scales)
         p.out = alt.out; p.out_stride = alt.out_stride; p.w = alt.w; p.bias = alt.bias; p.lut = alt.lut;
         p.out_c = alt.out_c; p.relu = alt.relu; p.out_pix_stride = alt.out_pix_stride; p.out_ch_off = alt.out_ch_off;
         p.cs = alt.cs;
@@ -1627,7 +1628,7 @@ static int launch_persist_t(const mhip_conv_i8_t *p, long total_pix, int k64, in
     memset(&alt, 0, sizeof(alt));
     if (PAIR) {
         alt.out = second->out; alt.out_stride = second->out_stride; alt.w = second->w; alt.bias = second->bias;
-        alt.lut = second->lut; alt.out_c = second->out_c; alt.relu = second->relu; alt.out_pix_stride = second->out_pix_stride;
+        alt.lut = second->lut; alt.lut2 = second->lut2; alt.out_c = second->out_c; alt.relu = second->relu; alt.out_pix_stride = second->out_pix_stride;
         alt.out_ch_off = second->out_ch_off; alt.cs = second->cs;
     }
     if (PAIR) alt.out_bytes = (unsigned)persist_out_bytes(second);
