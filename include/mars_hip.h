@@ -125,6 +125,8 @@ typedef struct {
     int nchw_int8;   /* int8 only: emit NCHW/OIHW tags instead of NHWC/OHWI */
     unsigned seed;
     int tiny;        /* 1: 3-conv "tiny_160" chain instead of YOLOv5 */
+    int vary_scales; /* 1: every convolution gets its own output / sigmoid / SiLU scales (x0.75 .. x1.35 of the nominal
+                      * ones), so no two fused tables are equal; 0 keeps the files of earlier versions byte for byte */
 } mars_synth_opts_t;
 /* returns the file size; writes at most cap bytes (call with cap 0 to size) */
 size_t mars_synth_model(const mars_synth_opts_t *opts, void *buf, size_t cap);

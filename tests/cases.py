@@ -119,6 +119,10 @@ SYNTH = [
     ("v5n_64_nchw", dict(width_x16=4, input_hw=64, nchw_int8=True, seed=4)),
     ("tiny_32_f32", dict(tiny=True, input_hw=32, float32=True, seed=5)),
     ("v5n_64_f32", dict(width_x16=4, input_hw=64, float32=True, seed=6)),   # config 5 topology (yolov5 f32), small
+    # per-convolution scales: no two fused tables (or folded-Add factors) are equal, so a launch that picks up a
+    # neighbour's table shows (the plain twins share one scale per tensor kind and once hid exactly that in a pair)
+    ("v5n_64_vs", dict(width_x16=4, input_hw=64, seed=7, vary_scales=True)),
+    ("v5s_96_vs", dict(width_x16=8, input_hw=96, seed=8, vary_scales=True)),
 ]
 
 

@@ -47,6 +47,8 @@ struct Builder {
     static constexpr float kHeadScale = 0.05f;
     static constexpr float kInScale = 1.0f / 64.0f;
 
+    bool vary = false; // per-convolution scales (x0.75 .. x1.35 of the nominal ones): every fused table differs
+    float jit() { return vary ? 0.75f + 0.6f * rng.unit() : 1.0f; }
     Builder(bool f, bool n, unsigned seed) : f32(f), nchw(n || f), rng(seed) {}
 
     struct T { int id; int c, h, w; float rms; };
@@ -102,7 +104,7 @@ struct Builder {
         const std::string base = "conv" + std::to_string(layers.size());
         int wid, bid;
         float w_scale = 0.01f;
-        const float out_scale = out_scale_override > 0 ? out_scale_override : kConvOutScale;
+        const float out_scale = (out_scale_override > 0 ? out_scale_override : kConvOutScale) * jit();
         if (f32) {
             std::vector<float> w((size_t)cout * K);
             const float a = 1.7f / std::sqrt((float)K); // keeps unit-ish variance through the net
@@ -144,15 +146,15 @@ struct Builder {
         cp.weight_tensor_id = (uint32_t)wid;
         cp.bias_tensor_id = (uint32_t)bid;
         if (!silu) return q1;
-        T q2 = act(base + ".sig", cout, oh, ow, f32 ? 1.f : kSigScale, 80.f);
+        T q2 = act(base + ".sig", cout, oh, ow, f32 ? 1.f : kSigScale * jit(), 80.f);
         layer(MARS_LAYER_SIGMOID, {q1.id}, q2.id);
-        T q3 = act(base + ".silu", cout, oh, ow, f32 ? 1.f : kActScale, 33.f);
+        T q3 = act(base + ".silu", cout, oh, ow, f32 ? 1.f : kActScale * jit(), 33.f);
         layer(MARS_LAYER_MUL, {q1.id, q2.id}, q3.id);
         return q3;
     }
 
     T add(const T &a, const T &b) {
-        T o = act("add" + std::to_string(layers.size()), a.c, a.h, a.w, f32 ? 1.f : kActScale, 45.f);
+        T o = act("add" + std::to_string(layers.size()), a.c, a.h, a.w, f32 ? 1.f : kActScale * jit(), 45.f);
         layer(MARS_LAYER_ADD, {a.id, b.id}, o.id);
         return o;
     }
@@ -242,6 +244,7 @@ size_t build_tiny(const mars_synth_opts_t &o, void *buf, size_t cap) {
     // shape of the shipped tiny_160 models: 3->16->32->64,
     // k3, ReLU between; here SAME-padded and well-formed
     Builder b(o.float32 != 0, o.nchw_int8 != 0, o.seed);
+    b.vary = o.vary_scales != 0;
     const int hw = o.input_hw > 0 ? o.input_hw : 160;
     Builder::T x = b.act("input", 3, hw, hw, o.float32 ? 1.f : Builder::kInScale, 74.f);
     Builder::T y = b.conv(x, 16, 3, 1, false, true, Builder::kActScale);
@@ -254,6 +257,7 @@ size_t build_tiny(const mars_synth_opts_t &o, void *buf, size_t cap) {
 
 size_t build_yolov5(const mars_synth_opts_t &o, void *buf, size_t cap) {
     Builder b(o.float32 != 0, o.nchw_int8 != 0, o.seed);
+    b.vary = o.vary_scales != 0;
     const int hw = o.input_hw > 0 ? o.input_hw : 640;
     const int wm = o.width_x16 > 0 ? o.width_x16 : 8;
     const int dm = o.depth_x3 > 0 ? o.depth_x3 : 1;

@@ -77,7 +77,7 @@ class HwInfo(C.Structure):
 
 class SynthOpts(C.Structure):
     _fields_ = [("width_x16", C.c_int), ("depth_x3", C.c_int), ("input_hw", C.c_int), ("float32", C.c_int),
-                ("nchw_int8", C.c_int), ("seed", C.c_uint), ("tiny", C.c_int)]
+                ("nchw_int8", C.c_int), ("seed", C.c_uint), ("tiny", C.c_int), ("vary_scales", C.c_int)]
 
 
 assert C.sizeof(MarsHeader) == 76 and C.sizeof(MarsTensorDesc) == 124
@@ -214,9 +214,9 @@ def letterbox(rgb, tw, th, nhwc=True):
     return out
 
 
-def synth_model(width_x16=8, depth_x3=1, input_hw=640, float32=False, nchw_int8=False, seed=1, tiny=False):
+def synth_model(width_x16=8, depth_x3=1, input_hw=640, float32=False, nchw_int8=False, seed=1, tiny=False, vary_scales=False):
     """Bytes of a synthetic well-formed .mars graph (mars_synth_model)."""
-    o = SynthOpts(width_x16, depth_x3, input_hw, int(float32), int(nchw_int8), seed, int(tiny))
+    o = SynthOpts(width_x16, depth_x3, input_hw, int(float32), int(nchw_int8), seed, int(tiny), int(vary_scales))
     n = lib().mars_synth_model(C.byref(o), None, 0)
     if n == 0:
         raise ValueError("mars_synth_model rejected the options")
