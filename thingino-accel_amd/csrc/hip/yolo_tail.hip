@@ -208,7 +208,8 @@ __global__ __launch_bounds__(64) void sort_kernel(det_rec *all, const int *count
 // evaluated 64 rows at a time, inside class buckets, into an 8 KB bit matrix; wave 0 then walks those rows
 // greedily OR-ing them into the removed set (suppressed boxes suppress nothing) -- exactly the reference's
 // double loop.  The float expression order of the IoU is the reference's.
-#define NMS_THREADS 256
+#define NMS_THREADS 512
+#define NMS_SUBS (NMS_THREADS / NMS_CHUNK) // threads that share a row's bucket
 #define NMS_CHUNK 64
 #define NMS_BUCKETS 128
 __global__ __launch_bounds__(NMS_THREADS) void nms_kernel(det_rec *all, int *counts, float thresh) {
@@ -253,14 +254,14 @@ __global__ __launch_bounds__(NMS_THREADS) void nms_kernel(det_rec *all, int *cou
         for (int k = tid; k < NMS_CHUNK * 32; k += NMS_THREADS) ((unsigned int *)mask)[k] = 0;
         __syncthreads();
         {
-            const int r = tid >> 2, sub = tid & 3, i = i0 + r; // 4 threads share a row's bucket
+            const int r = tid / NMS_SUBS, sub = tid % NMS_SUBS, i = i0 + r;
             if (r < rows) {
                 const float xi = bx[i], yi = by[i], wi = bw[i], hi = bh[i];
                 const int ci = bc[i];
                 const float ax1 = xi - wi / 2, ay1 = yi - hi / 2, ax2 = xi + wi / 2, ay2 = yi + hi / 2;
                 const float aarea = wi * hi;
                 const int b = (unsigned)ci & (NMS_BUCKETS - 1);
-                for (int e = bstart[b] + sub; e < bstart[b + 1]; e += 4) {
+                for (int e = bstart[b] + sub; e < bstart[b + 1]; e += NMS_SUBS) {
                     const int j = blist[e];
                     if (j <= i || bc[j] != ci) continue;
                     const float xj = bx[j], yj = by[j], wj = bw[j], hj = bh[j];
