@@ -118,7 +118,7 @@ def main():
                          "(mars_hip_autotune; a load-time cost, outside the timed region).  Off by default: the default "
                          "launch policy was re-derived from the tuner's choices and is within 1 % of it")
     ap.add_argument("--no-autotune", action="store_true", help="(default; kept for older command lines)")
-    ap.add_argument("--event-steps", type=int, default=2,
+    ap.add_argument("--event-steps", type=int, default=1,
                     help="timed steps (the last ones) whose launches are bracketed by HIP events for the roofline; "
                          "each event pair costs a queue barrier, so not every step carries them")
     args = ap.parse_args()

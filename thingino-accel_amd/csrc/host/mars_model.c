@@ -1350,6 +1350,7 @@ mars_error_t mars_hip_run_device_async(mars_model_t *model) {
     mars_model_ext_t *m = (mars_model_ext_t *)model;
     if (!m->act_dev || !m->arena_dev) return MARS_ERR_NNA_INIT_FAILED;
     for (uint32_t i = 0; i < model->header.num_layers; i++) model->layers[i].is_executed = false;
+    void *prof_last = NULL;
     for (int i = 0; i < m->n_ops; i++) {
         mars_op_t *op = &m->ops[i];
         if (op->kind == OP_FAIL) {
@@ -1367,10 +1368,14 @@ mars_error_t mars_hip_run_device_async(mars_model_t *model) {
             mhip_stream_wait(0, m->ev_tail_done);
             m->tail_pending = 0;
         }
-        if (m->profiling) {
-            if (!op->ev0) op->ev0 = mhip_event_create();
+        if (m->profiling) { /* one event per launch: its stop event is the next launch's start event */
             if (!op->ev1) op->ev1 = mhip_event_create();
-            mhip_event_record(op->ev0);
+            if (!prof_last) {
+                if (!op->ev0) op->ev0 = mhip_event_create();
+                mhip_event_record(op->ev0);
+                prof_last = op->ev0;
+            }
+            op->ev_start = prof_last;
         }
         int rc;
         if (mate) { /* one grid for both (conv_i8_persist<PAIR>); -2 = not possible at this batch: one after the other */
@@ -1386,7 +1391,10 @@ mars_error_t mars_hip_run_device_async(mars_model_t *model) {
         } else {
             rc = launch_op(m, op);
         }
-        if (m->profiling) mhip_event_record(op->ev1);
+        if (m->profiling) {
+            mhip_event_record(op->ev1);
+            prof_last = op->ev1;
+        }
         if (rc != 0) {
             fprintf(stderr, "Mars: Layer %d launch failed: %s\n", op->layer, mhip_last_error());
             return MARS_ERR_LAYER_FAILED;
@@ -1410,7 +1418,7 @@ mars_error_t mars_hip_run_device(mars_model_t *model) {
     mars_model_ext_t *m = (mars_model_ext_t *)model;
     if (m->profiling)
         for (int i = 0; i < m->n_ops; i++)
-            if (m->ops[i].ev0 && m->ops[i].ev1) m->ops[i].last_ms = mhip_event_elapsed_ms(m->ops[i].ev0, m->ops[i].ev1);
+            if (m->ops[i].ev_start && m->ops[i].ev1) m->ops[i].last_ms = mhip_event_elapsed_ms(m->ops[i].ev_start, m->ops[i].ev1);
     model->total_inference_us += (uint64_t)(now_us() - t0);
     model->inference_count++;
     return MARS_OK;
@@ -1594,7 +1602,7 @@ int mars_hip_op_info(const mars_model_t *model, int i, int *layer, int *kind, do
     if (bytes) *bytes = m->ops[i].bytes;
     if (last_ms) { /* events of the most recent (completed) run; waits for the stop event */
         mars_op_t *op = (mars_op_t *)&m->ops[i];
-        if (m->profiling && op->ev0 && op->ev1) op->last_ms = mhip_event_elapsed_ms(op->ev0, op->ev1);
+        if (m->profiling && op->ev_start && op->ev1) op->last_ms = mhip_event_elapsed_ms(op->ev_start, op->ev1);
         *last_ms = op->last_ms;
     }
     return 0;
