@@ -111,6 +111,9 @@ def main():
     ap.add_argument("--hw", type=int, default=640)
     ap.add_argument("--width", type=int, default=8, help="channel multiple x16: 8 = yolov5s, 4 = yolov5n")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--vary-scales", action="store_true",
+                    help="check run, not the benchmark workload: the twin with per-convolution scales (every fused table "
+                         "differs); the CPU-baseline leg then compares its frames bit for bit as usual")
     ap.add_argument("--no-tail", action="store_true", help="graph only, skip decode+NMS")
     ap.add_argument("--ops", type=str, default="", help="write a per-launch table (last timed step) to this file")
     ap.add_argument("--autotune", action="store_true",
@@ -145,7 +148,7 @@ def main():
     D = load_dist_helpers()
     import marsfile
     M.nna_init()
-    model_bytes = M.synth_model(width_x16=args.width, input_hw=args.hw, seed=1)
+    model_bytes = M.synth_model(width_x16=args.width, input_hw=args.hw, seed=1, vary_scales=args.vary_scales)
     hdr, tensors, _ = marsfile.parse(model_bytes)
     in_bytes = marsfile.tensor_nbytes(tensors[hdr["inputs"][0]])
     out_ids = list(hdr["outputs"])
@@ -245,8 +248,9 @@ def main():
             "dtype": "int8",
             "data": "synthetic",
             "config": {"workload": "synthetic yolov5s_int8.mars twin (mars_synth_model width_x16=%d, seed 1), %dx%d int8 "
-                                   "NHWC frames, batch %d per GPU, decode+NMS tail %s" %
-                                   (args.width, args.hw, args.hw, args.batch, "off" if args.no_tail else "on"),
+                                   "NHWC frames, batch %d per GPU, decode+NMS tail %s%s" %
+                                   (args.width, args.hw, args.hw, args.batch, "off" if args.no_tail else "on",
+                                    ", per-convolution scales (check run)" if args.vary_scales else ""),
                        "frames_per_gpu": args.batch, "sharding": "frames", "collectives_in_forward": 0,
                        "autotuned_launch_variants": bool(args.autotune and not args.no_autotune), "conv_gmac_per_image": macs_per_img / 1e9, "algorithmic_mb_per_image": bytes_per_img / 1e6},
             # The conv family's arithmetic intensity (2*MAC / algorithmic byte ~ 260 op/B) is below the machine's ridge
