@@ -237,6 +237,33 @@ def test_detect_on_model_outputs(gpu, orc):
     m.close()
 
 
+@pytest.mark.parametrize("width,hw,seed,B", [(4, 128, 698702, 3), (8, 160, 911481, 2), (4, 224, 911456, 3), (8, 96, 335533, 5)])
+def test_varied_scale_twins_with_tail(gpu, orc, width, hw, seed, B):
+    """twins whose every convolution has its own scales, several frames: graph outputs and the detection tail (each head
+    decoded with ITS scale, candidates capped at 1000 in order) against the oracle"""
+    d = gpu.synth_model(width_x16=width, input_hw=hw, seed=seed, vary_scales=True)
+    hdr, tensors, _ = marsfile.parse(d)
+    nb = marsfile.tensor_nbytes(tensors[hdr["inputs"][0]])
+    m = gpu.Model(d, batch=B)
+    xs = [lcg_frame(seed * 16 + f, nb) for f in range(B)]
+    for f in range(B):
+        m.input_view(0)[f] = xs[f]
+    m.run()
+    dets = m.detect(outputs=(0, 1, 2), thresh=0.45)
+    for f in range(B):
+        g, rc = run_oracle(orc, d, xs[f])
+        assert rc == 0
+        parts = []
+        for oi, ti in enumerate(hdr["outputs"]):
+            assert np.array_equal(m.output_view(oi)[f], g.tensor(ti)), (f, oi)
+            pred = g.tensor(ti).view(np.int8)
+            parts.append(orc.parse_output(pred, len(pred) // 85, np.float32(tensors[ti]["scale"])))
+        raw = np.concatenate(parts)[:1000]
+        assert len(raw) > 10
+        assert dets[f].tobytes() == orc.nms(raw, 0.45).tobytes()
+    m.close()
+
+
 def _silu_conv(G, rng, x, in_c, out_c, hw, k, s_conv, s_sig, s_out, wscale=0.004):
     """conv -> sigmoid -> mul with its own three scales (the plan folds the chain into the conv's LUT epilogue)"""
     a = G.tensor([1, hw, hw, out_c], scale=s_conv)
