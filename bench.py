@@ -105,8 +105,8 @@ def pmc_traffic(args):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=30)
+    ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--batch", type=int, default=256, help="frames per GPU")
     ap.add_argument("--hw", type=int, default=640)
     ap.add_argument("--width", type=int, default=8, help="channel multiple x16: 8 = yolov5s, 4 = yolov5n")
@@ -200,7 +200,7 @@ def main():
     t0 = time.perf_counter()
     for k in range(args.steps):
         timed = k >= args.steps - ev_steps
-        model.set_profiling(timed)
+        model.set_profiling((1 if args.ops else 2) if timed else 0)  # 2: one event per run of same-kind launches
         step()
         if timed:
             for op in model.ops():

@@ -69,8 +69,10 @@ int mars_hip_set_tuning(const char *key, int value);
 mars_error_t mars_hip_autotune(mars_model_t *model, int reps);
 
 /* ------------------------------------------------------- per-layer timing */
-/* When on, every kernel launch is bracketed by HIP events on the library's
- * stream; read back after a run. */
+/* on = 1: every kernel launch is timed with HIP events on the library's stream (one event per launch: a launch's stop
+ * event is the next one's start); on = 2: one event per run of consecutive launches of the same kind -- the run's
+ * total is reported on its last launch, the others report 0 (a few events per graph instead of one per launch: what
+ * bench.py uses inside its timed region).  Read back after a run. */
 void mars_hip_set_profiling(mars_model_t *model, int on);
 int mars_hip_num_ops(const mars_model_t *model);
 /* kind: 0 conv_i8, 1 conv_f32, 2 elementwise, 3 data movement, 4 other */

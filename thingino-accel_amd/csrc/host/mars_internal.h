@@ -69,6 +69,7 @@ typedef struct {
     int prof_kind;
     float last_ms;
     void *ev0, *ev1;
+    int prof_rec;   /* profiling: this launch's stop event was recorded in the last run */
     void *ev_start; /* profiling: the event that marks this launch's start = the previous launch's ev1 (own ev0 for the first) */
 } mars_op_t;
 

@@ -1391,9 +1391,14 @@ mars_error_t mars_hip_run_device_async(mars_model_t *model) {
         } else {
             rc = launch_op(m, op);
         }
-        if (m->profiling) {
-            mhip_event_record(op->ev1);
-            prof_last = op->ev1;
+        if (m->profiling) { /* level 2: one event per run of launches of the same kind (their sum lands on the last one) */
+            const int nx = i + 1;
+            const int end = m->profiling != 2 || nx >= m->n_ops || m->ops[nx].prof_kind != op->prof_kind;
+            op->prof_rec = end;
+            if (end) {
+                mhip_event_record(op->ev1);
+                prof_last = op->ev1;
+            }
         }
         if (rc != 0) {
             fprintf(stderr, "Mars: Layer %d launch failed: %s\n", op->layer, mhip_last_error());
@@ -1418,7 +1423,7 @@ mars_error_t mars_hip_run_device(mars_model_t *model) {
     mars_model_ext_t *m = (mars_model_ext_t *)model;
     if (m->profiling)
         for (int i = 0; i < m->n_ops; i++)
-            if (m->ops[i].ev_start && m->ops[i].ev1) m->ops[i].last_ms = mhip_event_elapsed_ms(m->ops[i].ev_start, m->ops[i].ev1);
+            m->ops[i].last_ms = (m->ops[i].prof_rec && m->ops[i].ev_start && m->ops[i].ev1) ? mhip_event_elapsed_ms(m->ops[i].ev_start, m->ops[i].ev1) : 0.f;
     model->total_inference_us += (uint64_t)(now_us() - t0);
     model->inference_count++;
     return MARS_OK;
@@ -1602,7 +1607,7 @@ int mars_hip_op_info(const mars_model_t *model, int i, int *layer, int *kind, do
     if (bytes) *bytes = m->ops[i].bytes;
     if (last_ms) { /* events of the most recent (completed) run; waits for the stop event */
         mars_op_t *op = (mars_op_t *)&m->ops[i];
-        if (m->profiling && op->ev_start && op->ev1) op->last_ms = mhip_event_elapsed_ms(op->ev_start, op->ev1);
+        if (m->profiling) op->last_ms = (op->prof_rec && op->ev_start && op->ev1) ? mhip_event_elapsed_ms(op->ev_start, op->ev1) : 0.f;
         *last_ms = op->last_ms;
     }
     return 0;
