@@ -185,6 +185,45 @@ def test_conv_i8_wide_one_tile_forms(gpu, orc, variant):
         gpu.set_tuning("variant", 0)
 
 
+def test_conv_i8_patch_staged_streamed_weights(gpu, orc):
+    """variant 16: input patch staged once in LDS, weights streamed through a ring (8 waves, 16x16 pixels x 128
+    channels): 64 / 128 input channels, 128 / 256 output channels, 3x3 and 5x5, stride 1 and 2, sizes that are and are
+    not multiples of the tile, several frames in a graph with a folded residual Add"""
+    shapes = [  # in_h, in_w, in_c, out_c, k, s
+        (48, 48, 128, 128, 3, 1), (32, 48, 128, 256, 3, 1), (31, 30, 64, 128, 3, 1), (31, 31, 64, 128, 3, 2),
+        (16, 16, 64, 128, 5, 1), (47, 32, 128, 128, 3, 1), (40, 40, 128, 128, 3, 1)]  # the last one: not eligible (69 % fill)
+    try:
+        gpu.set_tuning("variant", 16)
+        for i, (h, w, ic, oc, k, s) in enumerate(shapes):
+            oh, ow = (h + s - 1) // s, (w + s - 1) // s
+            ph = max((oh - 1) * s + k - h, 0) // 2
+            pw = max((ow - 1) * s + k - w, 0) // 2
+            case = ("pws%d" % i, 1, h, w, ic, oc, k, k, s, s, ph, pw, oh, ow, 0.03, 0.003 / (k * k * ic) ** 0.5 * 8, 0.05, True)
+            a = cases.conv_i8_call(gpu.conv2d_int8, case, 11)
+            b = cases.conv_i8_call(orc.conv2d_int8, case, 11)
+            assert np.array_equal(a, b), (case[0], int((a != b).sum()))
+            assert len(np.unique(a)) > 32
+        import marsfile
+        from conftest import lcg_frame
+        d = gpu.synth_model(width_x16=8, input_hw=256, seed=23, vary_scales=True)  # 32x32x128 bottlenecks with folded Adds
+        hdr, tensors, _ = marsfile.parse(d)
+        nb = marsfile.tensor_nbytes(tensors[hdr["inputs"][0]])
+        m = gpu.Model(d, batch=2)
+        xs = [lcg_frame(0xAD0000 + f, nb) for f in range(2)]
+        for f in range(2):
+            m.input_view(0)[f] = xs[f]
+        m.run()
+        for f in range(2):
+            g = orc.Graph(d)
+            g.set_input(0, xs[f].tobytes())
+            assert g.run() == 0
+            for oi, ti in enumerate(hdr["outputs"]):
+                assert np.array_equal(m.output_view(oi)[f], g.tensor(ti))
+        m.close()
+    finally:
+        gpu.set_tuning("variant", 0)
+
+
 @pytest.mark.parametrize("variant", [9, 10, 11])
 def test_conv_i8_patch_staged(gpu, orc, variant):
     """the patch-staged kernel (input patch of a tile staged once in LDS, weights resident, taps fed from LDS):

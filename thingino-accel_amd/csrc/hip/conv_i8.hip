@@ -1140,6 +1140,166 @@ __global__ __launch_bounds__(NTHREADS) void conv_i8_patch(const mhip_conv_i8_t p
 }
 
 // ---------------------------------------------------------------------------------
+// patch-staged input, streamed weights: k x k convolutions with 64 / 128 input channels and 128+ output channels (the
+// deep 3x3 layers).  The implicit-GEMM forms move (256 + 128) x 64 bytes into LDS per K step and their K loop waits
+// for that DMA (20 B/clk/CU arrive, 47 would keep the MFMAs busy).  Here the input patch of a 16 x 16 output tile is
+// staged ONCE (as conv_i8_patch does) and serves all k*k taps from LDS; only the 128 x 64 weight bytes of a K step
+// stream through a 3-stage ring: 188 instead of 442 KB of LDS-DMA per tile of a 3x3 128 -> 128 layer.  8 waves
+// (4 pixel-row groups x 2 channel halves, 64 x 64 accumulators each), one tile per workgroup, two workgroups per CU.
+#define PWS_NIMAX 7
+template <bool HAS_LUT>
+__global__ __launch_bounds__(512) void conv_i8_patchw(const mhip_conv_i8_t p, const int k64, const int tiles_x, const int tiles_y,
+                                                       const unsigned nblk, const unsigned noc, const int PH, const int PW,
+                                                       const int PWP, const int PWH, const int ni,
+                                                       const int8_t *__restrict__ zeros, const fastdiv_t dtx,
+                                                       const fastdiv_t dty, const fastdiv_t dpwp, const unsigned out_bytes) {
+    constexpr int TH = 16, BN = 128, WPX = 4, WOC = 4, STG = 3;
+    extern __shared__ __attribute__((aligned(16))) int8_t dynlds[];
+    uint8_t *slut = (uint8_t *)dynlds; // LDS byte address 0 (requant_pack LUT0)
+    lds_base_must_be_zero(dynlds);
+    const int nks = k64 / BK;
+    int *dutab = (int *)(dynlds + LUTB);                     // [nks][4] unit offsets of the K chunks
+    int *sbias = (int *)(dynlds + LUTB + ((nks * 16 + 255) & ~255)); // [BN]
+    int8_t *wring = (int8_t *)(sbias + BN);                  // [STG][BN][64], rows swizzled like the ring tiles
+    int8_t *patch = wring + STG * BN * BK;                   // ni x 8 KB
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wv & 3, wn = wv >> 2;
+    const unsigned id = xcd_remap(blockIdx.x, nblk);
+    const unsigned t = id / noc;
+    const int oc0 = (int)(id - t * noc) * BN;
+    const int C = p.in_c, lgc = 31 - __builtin_clz((unsigned)C), cpp = C >> 4, lgcpp = lgc - 4;
+    const int s = p.stride_w;
+    const unsigned M = C >= 128 ? 6u : (C >= 64 ? 2u : 0u);
+
+    if (HAS_LUT) {
+        if (p.lut2) { if (tid < 128) ((uint32_t *)slut)[tid] = ((const uint32_t *)p.lut2)[tid]; }
+        else if (tid < 64) ((uint32_t *)slut)[tid] = ((const uint32_t *)p.lut)[tid];
+    }
+    if (tid < BN) sbias[tid] = p.bias ? p.bias[oc0 + tid] : 0;
+    const int rowbytes = p.kw * C, kbytes = p.kh * rowbytes;
+    for (int i = tid; i < nks * 4; i += 512) {
+        const int kb = i * 16;
+        int du = 0; // K padding meets zero weights: any valid address
+        if (kb < kbytes) {
+            const int ky = kb / rowbytes, rem = kb - ky * rowbytes, kx = rem >> lgc, cc = (rem & (C - 1)) >> 4;
+            const int dp = ky * PWP + (s == 2 ? (kx >> 1) + (kx & 1) * PWH : kx);
+            du = dp * cpp + cc;
+        }
+        dutab[i] = du;
+    }
+    __syncthreads(); // tables visible (the K loop uses raw barriers)
+    // tile, output offsets of this lane's pixels, residual operand (fetched first: the oldest vector-memory operations)
+    const unsigned q0 = fdiv(t, dtx);
+    const int tx = (int)(t - q0 * (unsigned)tiles_x);
+    const unsigned f = fdiv(q0, dty);
+    const int ty = (int)(q0 - f * (unsigned)tiles_y);
+    const int frow = lane & 15, fchunk = lane >> 4;
+    const int chan = wn * 64 + (lane >> 4) * (4 * WOC);
+    const int pstride = p.out_pix_stride ? p.out_pix_stride : p.out_c;
+    int voffs[WPX];
+    uint32_t xw[WPX][WOC];
+#pragma unroll
+    for (int u = 0; u < WPX; u++) {
+        const int oy = ty * TH + wm * WPX + u, ox = tx * PT_TW + frow;
+        const unsigned off = f * (unsigned)p.out_stride + (unsigned)(oy * p.out_w + ox) * (unsigned)pstride +
+                             (unsigned)(p.out_ch_off + oc0 + chan);
+        const bool ok = oy < p.out_h && ox < p.out_w && oc0 + chan < p.out_c;
+        voffs[u] = ok ? (int)off : -1;
+#pragma unroll
+        for (int q = 0; q < WOC; q++) xw[u][q] = 0;
+        if (p.add && ok) {
+            const v4i t4 = *(const v4i *)(p.add + off);
+            xw[u][0] = t4[0]; xw[u][1] = t4[1]; xw[u][2] = t4[2]; xw[u][3] = t4[3];
+        }
+    }
+    // input patch: instruction n of wave wv fills physical units (n*8 + wv)*64 + lane (unit = 16 bytes, swizzled)
+    {
+        const int iy0 = ty * TH * s - p.pad_top, ix0 = tx * PT_TW * s - p.pad_left;
+        const int8_t *base = p.in + (size_t)f * p.in_stride + ((long)iy0 * p.in_w + ix0) * C;
+#pragma unroll
+        for (int n = 0; n < PWS_NIMAX; n++)
+            if (n < ni) {
+                const unsigned phys = (unsigned)((n * 8 + wv) * 64 + lane);
+                const unsigned U = phys ^ ((phys >> 3) & M);
+                const unsigned pp = U >> lgcpp, cc = U & (unsigned)(cpp - 1);
+                const unsigned py = fdiv(pp, dpwp), col = pp - py * (unsigned)PWP;
+                const int px = s == 2 ? ((int)col < PWH ? 2 * (int)col : 2 * ((int)col - PWH) + 1) : (int)col;
+                const bool ok = (int)py < PH && px < PW && (unsigned)(iy0 + (int)py) < (unsigned)p.in_h &&
+                                (unsigned)(ix0 + px) < (unsigned)p.in_w;
+                glds16(ok ? base + ((long)py * p.in_w + px) * C + (int)cc * 16 : zeros, patch + (n * 8 + wv) * 1024);
+            }
+    }
+    // weight ring: wave wv fetches rows oc0 + wv*16 .. +15 of a K step (one instruction per wave and step)
+    const int schunk = (lane & 3) ^ (((lane >> 4) & 1) << 1);
+    const int8_t *wsrc = p.w + (size_t)(oc0 + wv * 16 + (lane >> 2)) * k64 + schunk * 16;
+    auto issue_w = [&](int ks) { glds16(wsrc + ks * BK, wring + (ks % STG) * (BN * BK) + wv * 16 * BK); };
+    issue_w(0);
+    if (nks > 1) issue_w(1);
+
+    const __amdgpu_buffer_rsrc_t orsrc = __builtin_amdgcn_make_buffer_rsrc(p.out, 0, (int)out_bytes, 0x00020000);
+    const int lo = p.relu ? 0 : -128;
+    const uint8_t *lut128 = slut + 128;
+    int ubase[WPX]; // 16-byte unit of (tile row, column frow), tap (0,0), channel 0
+#pragma unroll
+    for (int u = 0; u < WPX; u++) ubase[u] = ((wm * WPX + u) * s * PWP + frow) * cpp;
+
+    v4i acc[WOC][WPX];
+    for (int ks = 0; ks < nks; ks++) {
+        // K step ks has landed when at most the one younger step (ks + 1) is outstanding; the patch and the residual
+        // operand are older than every weight step
+        if (ks + 1 < nks) wait_vmcnt<1>();
+        else wait_vmcnt<0>();
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        const int du = dutab[ks * 4 + fchunk];
+        const int8_t *ws = wring + (ks % STG) * (BN * BK);
+        v4i xb[WPX], wa[WOC];
+#pragma unroll
+        for (int u = 0; u < WPX; u++) {
+            const unsigned U = (unsigned)(ubase[u] + du);
+            xb[u] = *(const v4i *)(patch + ((U ^ ((U >> 3) & M)) << 4));
+        }
+#pragma unroll
+        for (int q = 0; q < WOC; q++) wa[q] = *(const v4i *)(ws + lds_off(wn * 64 + q * 16 + frow, fchunk));
+        if (ks + 2 < nks) issue_w(ks + 2); // its slot was read in step ks - 1: every wave is past this step's barrier
+        if (ks == 0) {
+#pragma unroll
+            for (int q = 0; q < WOC; q++) {
+                const v4i b = *(const v4i *)(sbias + wn * 64 + q * 16 + (lane >> 4) * 4);
+#pragma unroll
+                for (int u = 0; u < WPX; u++) acc[q][u] = __builtin_amdgcn_mfma_i32_16x16x64_i8(wa[q], xb[u], b, 0, 0, 0);
+            }
+        } else {
+#pragma unroll
+            for (int q = 0; q < WOC; q++)
+#pragma unroll
+                for (int u = 0; u < WPX; u++) acc[q][u] = __builtin_amdgcn_mfma_i32_16x16x64_i8(wa[q], xb[u], acc[q][u], 0, 0, 0);
+        }
+    }
+#pragma unroll
+    for (int u = 0; u < WPX; u++) {
+        uint32_t pk[WOC];
+        int a[WOC * 4];
+#pragma unroll
+        for (int q = 0; q < WOC; q++)
+#pragma unroll
+            for (int r = 0; r < 4; r++) a[q * 4 + r] = acc[q][u][r];
+        const bool fast = HAS_LUT && p.lut2 != nullptr;
+        if (p.add) {
+            const add_args_t ga = {p.add_s_conv, p.add_s_other, p.add_inv};
+            if (fast) requant_pack<WOC * 4, HAS_LUT, true, true, true, true>(a, p.cs, lo, lut128, pk, xw[u], &ga);
+            else requant_pack<WOC * 4, HAS_LUT, true, true, true>(a, p.cs, lo, lut128, pk, xw[u], &ga);
+        } else {
+            if (fast) requant_pack<WOC * 4, HAS_LUT, true, true, false, true>(a, p.cs, lo, lut128, pk);
+            else requant_pack<WOC * 4, HAS_LUT, true, true>(a, p.cs, lo, lut128, pk);
+        }
+        __builtin_amdgcn_raw_buffer_store_b128((v4i){(int)pk[0], (int)pk[1], (int)pk[2], (int)pk[3]}, orsrc, voffs[u], 0, 0);
+    }
+}
+
+// ---------------------------------------------------------------------------------
 // generic kernel: any in_c (the 3-channel stem); register-staged byte gather
 template <int BN>
 __global__ __launch_bounds__(NTHREADS) void conv_i8_generic(const mhip_conv_i8_t p, const long total_pix, const int k64,
@@ -1690,11 +1850,13 @@ static int launch_persist_t(const mhip_conv_i8_t *p, long total_pix, int k64, in
 //   code = 12: one tile per workgroup, 128 pixels, 2 ring stages of 128 K bytes each (even number of K steps)
 //   code = 13: one 256 x 128 tile per 8-wave workgroup, 3 stages
 //   code = 14 / 15: tile walker with the weights of its channel tile resident in LDS, 128 / 256 pixels
-#define NVARIANTS 15
+//   code = 16: input patch staged once, weights streamed (8 waves, 16 x 16 pixels x 128 channels)
+#define NVARIANTS 16
 struct variant_t {
-    int persist, bpx, stages, patch, ks2, w8, wres;
+    int persist, bpx, stages, patch, ks2, w8, wres, pws;
 };
 static int variant_code(const variant_t &v) {
+    if (v.pws) return 16;
     if (v.wres) return v.bpx == 256 ? 15 : 14;
     if (v.w8) return 13;
     if (v.ks2) return 12;
@@ -1702,12 +1864,13 @@ static int variant_code(const variant_t &v) {
     return 1 + (v.persist ? 1 : 0) + (v.bpx == 256 ? 2 : 0) + (v.stages == 3 ? 4 : 0);
 }
 static variant_t variant_of(int code) {
-    if (code == 14 || code == 15) return variant_t{1, code == 15 ? 256 : 128, 2, 0, 0, 0, 1};
-    if (code == 13) return variant_t{0, 256, 3, 0, 0, 1, 0};
-    if (code == 12) return variant_t{0, 128, 2, 0, 1, 0, 0};
-    if (code >= 9) return variant_t{0, 0, 0, code == 10 ? 16 : (code == 9 ? 8 : 4), 0, 0, 0};
+    if (code == 16) return variant_t{0, 0, 0, 0, 0, 0, 0, 1};
+    if (code == 14 || code == 15) return variant_t{1, code == 15 ? 256 : 128, 2, 0, 0, 0, 1, 0};
+    if (code == 13) return variant_t{0, 256, 3, 0, 0, 1, 0, 0};
+    if (code == 12) return variant_t{0, 128, 2, 0, 1, 0, 0, 0};
+    if (code >= 9) return variant_t{0, 0, 0, code == 10 ? 16 : (code == 9 ? 8 : 4), 0, 0, 0, 0};
     const int c = code - 1;
-    return variant_t{c & 1, (c & 2) ? 256 : 128, (c & 4) ? 3 : 2, 0, 0, 0, 0};
+    return variant_t{c & 1, (c & 2) ? 256 : 128, (c & 4) ? 3 : 2, 0, 0, 0, 0, 0};
 }
 
 // ---- patch-staged kernel: geometry, eligibility, launch
@@ -1782,6 +1945,55 @@ static int launch_patch_t(const mhip_conv_i8_t *p, int k64, const patch_geom_t &
     return mhip_check(hipGetLastError(), "conv_i8_patch launch");
 }
 
+// ---- patch-staged input with streamed weights (conv_i8_patchw): geometry, eligibility, launch
+struct pws_geom_t {
+    int tiles_x, tiles_y, PH, PW, PWP, PWH, ni;
+    size_t lds;
+};
+static bool pws_geom(const mhip_conv_i8_t *p, pws_geom_t *g) {
+    const bool direct = !p->out_nchw && ((p->out_c | p->out_pix_stride | p->out_ch_off) & 15) == 0;
+    const int C = p->in_c, s = p->stride_w;
+    if (!direct || !p->safe || (C != 64 && C != 128) || (s != 1 && s != 2) || p->stride_h != s || p->kh > 7 || p->kw > 7 ||
+        p->kh * p->kw < 2 || p->row_pad != p->kw * C || p->oc_pad % 128 != 0 || persist_out_bytes(p) > 0x7fffffffL || p->nseg > 1)
+        return false;
+    const int k64 = (p->kh * p->row_pad + BK - 1) / BK * BK, nks = k64 / BK;
+    if (nks < 3) return false;
+    g->tiles_x = (p->out_w + PT_TW - 1) / PT_TW;
+    g->tiles_y = (p->out_h + 15) / 16;
+    // mostly full tiles only: a tile computes 16 x 16 pixels whether the map has them or not (40 x 40 maps fill 69 %:
+    // measured 90 vs 80 us against the 8-wave implicit-GEMM tile; 48 x 48 maps fill 100 %: 92 vs 105 us)
+    if ((double)p->out_h * p->out_w < 0.85 * (double)g->tiles_x * PT_TW * g->tiles_y * 16) return false;
+    g->PH = 15 * s + p->kh;
+    g->PW = (PT_TW - 1) * s + p->kw;
+    g->PWH = s == 2 ? (g->PW + 1) / 2 : 0;
+    g->PWP = s == 2 ? 2 * g->PWH : g->PW;
+    const long units = (long)g->PH * g->PWP * (C / 16);
+    g->ni = (int)((units + 511) / 512);
+    if (g->ni > PWS_NIMAX) return false;
+    g->lds = LUTB + (((size_t)nks * 16 + 255) & ~(size_t)255) + 128 * 4 + 3 * (size_t)128 * BK + (size_t)g->ni * 8192;
+    if (g->lds > 80 * 1024) return false;
+    if ((long)g->tiles_x * g->tiles_y * p->frames * (p->oc_pad / 128) > 0x7fffffffL) return false;
+    return true;
+}
+template <bool HAS_LUT>
+static int launch_pws_t(const mhip_conv_i8_t *p, int k64, const pws_geom_t &g) {
+    static bool attr = false;
+    if (!attr && hipFuncSetAttribute((const void *)conv_i8_patchw<HAS_LUT>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024) != hipSuccess)
+        return mhip_check(hipErrorUnknown, "conv_i8_patchw LDS attribute");
+    attr = true;
+    const unsigned ntiles = (unsigned)((long)g.tiles_x * g.tiles_y * p->frames), noc = (unsigned)(p->oc_pad / 128);
+    hipLaunchKernelGGL((conv_i8_patchw<HAS_LUT>), dim3(ntiles * noc), dim3(512), g.lds, mhip_stream_native(), *p, k64, g.tiles_x,
+                       g.tiles_y, ntiles * noc, noc, g.PH, g.PW, g.PWP, g.PWH, g.ni, (const int8_t *)mhip_zero_page(),
+                       make_fastdiv((unsigned)g.tiles_x), make_fastdiv((unsigned)g.tiles_y), make_fastdiv((unsigned)g.PWP),
+                       (unsigned)persist_out_bytes(p));
+    return mhip_check(hipGetLastError(), "conv_i8_patchw launch");
+}
+static int launch_pws(const mhip_conv_i8_t *p, int k64) {
+    pws_geom_t g;
+    if (!pws_geom(p, &g)) return -1;
+    return p->lut ? launch_pws_t<true>(p, k64, g) : launch_pws_t<false>(p, k64, g);
+}
+
 static int launch_patch(const mhip_conv_i8_t *p, int k64, int th) {
     patch_geom_t g;
     if (!patch_geom(p, th, &g)) return -1;
@@ -1830,6 +2042,7 @@ static variant_t default_variant(const mhip_conv_i8_t *p, int nks) {
     v.ks2 = 0;
     v.w8 = 0;
     v.wres = 0;
+    v.pws = 0;
     // wide, shallow k x k layers: the patch-staged kernel wins wherever its double-buffered form fits (measured on the
     // 160x160 and 80x80 layers of yolov5s: 1.25-1.9x over the implicit-GEMM forms)
     patch_geom_t g;
@@ -1896,6 +2109,7 @@ static int launch_variant_t(const mhip_conv_i8_t *p, long total_pix, int k64, co
 }
 
 static int launch_variant(const mhip_conv_i8_t *p, long total_pix, int k64, const variant_t &v) {
+    if (v.pws) return launch_pws(p, k64);
     if (v.patch) return launch_patch(p, k64, v.patch);
     const int bn = p->oc_pad % 128 == 0 ? 128 : (p->oc_pad % 64 == 0 ? 64 : 32);
     if (v.bpx == 256) {
@@ -1983,6 +2197,8 @@ extern "C" int mhip_conv_i8_variants(const mhip_conv_i8_t *p, int *codes, int ma
         if (v.persist && !persist_eligible(p)) continue;
         if (v.ks2 && ((nks & 1) || nks < 4 || p->oc_pad % 64 != 0)) continue;
         if (v.w8 && (p->oc_pad % 128 != 0 || nks < 3)) continue;
+        pws_geom_t pg;
+        if (v.pws && !pws_geom(p, &pg)) continue;
         if (v.wres) {
             const int bn = p->oc_pad % 128 == 0 ? 128 : (p->oc_pad % 64 == 0 ? 64 : 32);
             if (LUTB + 2 * (size_t)v.bpx * BK + (size_t)nks * bn * BK > 80 * 1024) continue;
