@@ -263,7 +263,7 @@ def main():
                          "traffic": traffic, "traffic_source": traffic_src,
                          "algorithmic_bytes": conv_bytes_per_img * args.batch,
                          "intensity_ops_per_byte": 2.0 * macs_per_img / conv_bytes_per_img if conv_bytes_per_img else None,
-                         "mfma_view": {"achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak},
+                         "mfma_view": {"achieved": achieved, "peak": peak, "unit": "TOP/s", "frac": achieved / peak},
                          "event_timed_steps": ev_steps,
                          "conv_ms_per_step": conv_ms / ev_steps,
                          "all_kernels_ms_per_step": all_ms / ev_steps,

@@ -26,9 +26,18 @@ extern "C" {
 /* ---------------------------------------------------------------- batching */
 /* Re-plans the model for `n` frames.  After the call mars_get_input()->vaddr
  * is a pinned host buffer of n * frame_bytes (frame-major, frames densely
- * packed), ->alloc_size says so; same for outputs.  Activations are re-zeroed. */
+ * packed; frame_bytes = mars_hip_tensor_frame_bytes), ->alloc_size says so; same for outputs.
+ * Activations are re-zeroed.  With n == 1 (also the state after mars_load_*) ->alloc_size is what the reference
+ * reports: the size of its shared working buffers, i.e. the largest 64-byte-rounded tensor_byte_size() of any
+ * activation (reference mars_runtime.c:250-334), and the staging buffer is that large. */
 mars_error_t mars_hip_set_batch(mars_model_t *model, int n);
 int mars_hip_get_batch(const mars_model_t *model);
+
+/* Bytes of one frame of a tensor by its shape and dtype (numel * element size). */
+size_t mars_hip_tensor_frame_bytes(const mars_model_t *model, int tensor_index);
+/* The reference's format-aware tensor size (static tensor_byte_size(), mars_runtime.c:80-124): NDHWC32 rounds
+ * channels up to 32, NMHWSOIB2 counts 1024-byte blocks, UINT4 packs two per byte.  Host-only. */
+size_t mars_hip_tensor_byte_size(const mars_tensor_t *desc);
 
 /* mars_run() = upload + run_device + download.  The three parts: */
 mars_error_t mars_hip_upload_inputs(mars_model_t *model);    /* pinned host -> HBM, waits */

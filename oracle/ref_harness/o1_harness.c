@@ -46,3 +46,20 @@ done:
     ref_quiet(0);
     return rc;
 }
+
+/* alloc_size the reference's public API reports for input 0 / output 0 after mars_load_file
+ * (reference mars_runtime.c:250-334); returns mars_error_t */
+long ref_o1_io_alloc(const char *path, size_t out[2]) {
+    ref_quiet(1);
+    mars_model_t *m = NULL;
+    nna_init();
+    mars_error_t e = mars_load_file(path, &m);
+    if (e == MARS_OK) {
+        mars_runtime_tensor_t *in = mars_get_input(m, 0), *o = mars_get_output(m, 0);
+        out[0] = in ? in->alloc_size : 0;
+        out[1] = o ? o->alloc_size : 0;
+        mars_free(m);
+    }
+    ref_quiet(0);
+    return e;
+}

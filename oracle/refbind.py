@@ -48,6 +48,18 @@ def o1_run_file(path, input_bytes, out_cap=64 << 20):
     return out[:rc].copy()
 
 
+def o1_io_alloc(path):
+    """(input 0, output 0) alloc_size as the reference's mars_load_file leaves them"""
+    lib = _lib("libref_o1.so")
+    lib.ref_o1_io_alloc.restype = C.c_long
+    lib.ref_o1_io_alloc.argtypes = [C.c_char_p, C.POINTER(C.c_size_t)]
+    out = (C.c_size_t * 2)()
+    rc = lib.ref_o1_io_alloc(path.encode(), out)
+    if rc != 0:
+        raise RuntimeError("reference mars_load_file failed: %d" % rc)
+    return int(out[0]), int(out[1])
+
+
 # ---------------------------------------------------------------- O2
 class O2Model:
     """Reference layer functions on a private non-aliased arena."""

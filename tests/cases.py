@@ -110,7 +110,7 @@ def yolo_pred(case):
     return np.ascontiguousarray(p.reshape(-1)), npred, np.float32(scale)
 
 
-SHIPPED = ["test_model", "test_simple", "tiny_160_int8", "tiny_160_f32", "yolov5n_int8"]
+SHIPPED = ["test_model", "test_simple", "tiny_160_int8", "tiny_160_f32", "yolov5n_int8", "yolov5nu", "yolov5n"]
 # synthetic graphs small enough for the CPU oracle: (name, synth kwargs)
 SYNTH = [
     ("v5n_64", dict(width_x16=4, input_hw=64, seed=1)),
@@ -151,3 +151,15 @@ def letterbox_image(case):
     img[h // 3: h // 3 + 2, :, :] = 255   # hard edges: ringing of the cubic kernels must clamp like the reference
     img[:, w // 2: w // 2 + 1, :] = 0
     return img.astype(np.uint8)
+
+
+# reference tensor_byte_size() (mars_runtime.c:80-124): (dtype, format tag, shape); formats: 0 NCHW, 1 NDHWC32, 2 HWIO,
+# 3 NMHWSOIB2, 4 NMC32, 5 D1, 6 OHWI, 7 NHWC, 8 OIHW; dtypes: 0 f32, 1 i32, 2 i16, 3 i8, 4 u8, 5 u4
+TBS_CASES = [
+    (3, 7, [1, 640, 640, 3]), (3, 0, [1, 3, 640, 640]), (0, 0, [1, 3, 160, 160]), (1, 5, [255]), (2, 7, [1, 7, 9, 5]),
+    (3, 1, [1, 3, 160, 160]), (3, 1, [1, 64, 154, 154]), (3, 1, [1, 33, 5, 7]), (0, 1, [1, 16, 80, 80]), (3, 1, [2, 32, 4, 4]),
+    (3, 1, [1, 25200, 85]),            # NDHWC32 with 3 dims: the plain product
+    (3, 3, [16, 3, 3, 3]), (3, 3, [255, 128, 1, 1]), (3, 3, [33, 65, 3, 3]), (0, 3, [64, 32, 3, 3]),
+    (5, 7, [1, 5, 5, 3]), (5, 7, [1, 4, 4, 4]), (5, 1, [1, 40, 6, 6]), (4, 8, [16, 3, 3, 3]), (7, 7, [1, 2, 3, 4]),
+    (3, 7, [0, 0, 0, 0]), (3, 7, []), (0, 6, [16, 6, 6, 3]), (3, 4, [1, 100, 32]),
+]

@@ -211,3 +211,31 @@ def test_half_step_lut_guard(marsrt):
             hits += 1 - want
     assert hits > 0  # the guard does fire
     assert L.mhip_conv_i8_lut2_ok(float("nan")) == 0 and L.mhip_conv_i8_lut2_ok(1.5) == 0 and L.mhip_conv_i8_lut2_ok(1e-9) == 0
+
+
+def test_tensor_byte_size_matches_reference(marsrt):
+    """row a3: the format-aware tensor size (reference mars_runtime.c:80-124) against what the reference's own
+    static function returned for bare descriptors and for every tensor of every shipped model (goldens made by
+    tests/golden/make_golden.py through oracle/_ref)"""
+    import ctypes as C
+    import json
+    import cases
+    import marsfile
+    gold = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "golden.json")))
+    L = marsrt.lib()
+
+    def tbs(dtype, fmt, shape):
+        d = marsrt.MarsTensorDesc()
+        d.dtype, d.format, d.ndims = dtype, fmt, len(shape)
+        for i, v in enumerate(shape):
+            d.shape[i] = v
+        return int(L.mars_hip_tensor_byte_size(C.byref(d)))
+
+    got = [tbs(*c) for c in cases.TBS_CASES]
+    assert got == gold["tensor_byte_size"]
+    for name in cases.SHIPPED:
+        data = open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "models", name + ".mars"), "rb").read()
+        _, tensors, _ = marsfile.parse(data)
+        want = gold["models"][name]["pattern"]["tensor_byte_size"]
+        assert [tbs(t["dtype"], t["fmt"], list(t["shape"])) for t in tensors] == want, name
+    assert L.mars_hip_tensor_byte_size(None) == 0

@@ -36,7 +36,11 @@ extern "C" int mhip_init(int device_hint) {
         snprintf(g_err, sizeof(g_err), "no HIP device visible");
         return -1;
     }
-    int dev = device_hint >= 0 ? device_hint % n : 0;
+    if (device_hint >= n) { // a wrong rank -> device mapping must not silently land on another rank's GPU
+        snprintf(g_err, sizeof(g_err), "device %d requested, %d visible", device_hint, n);
+        return -1;
+    }
+    int dev = device_hint >= 0 ? device_hint : 0;
     hipDeviceProp_t prop;
     if (mhip_check(hipGetDeviceProperties(&prop, dev), "hipGetDeviceProperties")) return -1;
     // the kernels are built for gfx950 only; refuse anything else loudly

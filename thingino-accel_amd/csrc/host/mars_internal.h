@@ -76,6 +76,7 @@ typedef struct {
 typedef struct {
     mars_model_t pub; /* MUST stay first */
     int batch, fusion, profiling, deferred;
+    int plan_err;   /* first allocation failure while planning (build_plan returns it; 0 = none) */
     int no_vconcat; /* virtual concat switched off (a batch too large for 32-bit buffer offsets) */
     mtensor_t *mt;
     mars_op_t *ops;

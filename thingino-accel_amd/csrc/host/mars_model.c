@@ -27,6 +27,8 @@
 #define ALIGN_UP(x, a) (((x) + (size_t)(a) - 1) & ~((size_t)(a) - 1))
 #define NO_TENSOR 0xFFFFFFFFu
 #define MAX_DIM_PRODUCT ((size_t)1 << 40)
+#define ARENA_MAX ((size_t)1 << 40) /* parameter arena: anything beyond is a corrupt file, not a model */
+#define MAX_CHANNELS 65536    /* per-tensor channel count the planners accept */
 
 static int verbose(void) {
     static int v = -1;
@@ -75,15 +77,67 @@ static size_t shape_numel(const mars_tensor_t *d) {
     return n;
 }
 
+/* Format-aware byte size of a tensor, reference mars_runtime.c:80-124 (`tensor_byte_size`): NDHWC32 rounds the
+ * channel count (shape[1]) up to 32, NMHWSOIB2 counts 1024-byte blocks, UINT4 packs two elements per byte; every
+ * other tag is numel * element size.  The reference evaluates the products in `int` and converts to size_t; the
+ * same wrap-around is kept by computing in 32-bit unsigned arithmetic and sign-extending. */
+size_t mars_hip_tensor_byte_size(const mars_tensor_t *t) {
+    if (!t) return 0;
+    size_t es;
+    switch (t->dtype) {
+        case MARS_DTYPE_FLOAT32: case MARS_DTYPE_INT32: es = 4; break;
+        case MARS_DTYPE_INT16: es = 2; break;
+        default: es = 1; break; /* INT8, UINT8, UINT4 (two per byte, handled below), unknown */
+    }
+    if (t->format == MARS_FORMAT_NDHWC32 && t->ndims >= 4) {
+        const uint32_t n = (uint32_t)t->shape[0], h = (uint32_t)t->shape[2], w = (uint32_t)t->shape[3];
+        const uint32_t d = (uint32_t)((t->shape[1] + 31) / 32);
+        return (size_t)(int32_t)(n * d * h * w * 32u) * es; /* int product, then * size_t (:101) */
+    }
+    if (t->format == MARS_FORMAT_NMHWSOIB2 && t->ndims >= 4) {
+        const uint32_t no = (uint32_t)((t->shape[0] + 31) / 32), mi = (uint32_t)((t->shape[1] + 31) / 32);
+        return (size_t)(int32_t)(no * mi * (uint32_t)t->shape[2] * (uint32_t)t->shape[3] * 1024u);
+    }
+    size_t numel = 1;
+    for (uint32_t i = 0; i < t->ndims && i < MARS_MAX_DIMS; i++) numel *= (size_t)(int64_t)t->shape[i];
+    if (t->dtype == MARS_DTYPE_UINT4) return (numel + 1) / 2;
+    return numel * es;
+}
+
+/* What the reference reports as `alloc_size` of every activation tensor (mars_runtime.c:250-334): all of them share
+ * working buffers of ONE size, the largest 64-byte-rounded tensor_byte_size of any activation -- or less when three,
+ * then two such buffers do not fit behind the weights in its 8 MiB arena.  Callers fill / scan `alloc_size` bytes
+ * through vaddr (mars_test.c:73-84, 117-127), so single-frame I/O tensors report the same number here and their
+ * staging is at least that large.  Where the reference would refuse to load (weights > 8 MiB, < 64 KiB per buffer)
+ * this build still loads and reports the unreduced size. */
+static size_t reference_buffer_size(const mars_model_ext_t *m) {
+    size_t max_sz = 0;
+    for (uint32_t i = 0; i < m->pub.header.num_tensors; i++) {
+        const mars_tensor_t *d = &m->pub.tensors[i].desc;
+        if (d->data_size != 0) continue;
+        size_t sz = ALIGN_UP(mars_hip_tensor_byte_size(d), 64);
+        if (sz > max_sz) max_sz = sz;
+    }
+    const size_t ddr = (size_t)8 << 20;
+    if (m->pub.weights_size > ddr) return max_sz;
+    const size_t remaining = ddr - m->pub.weights_size;
+    if (max_sz * 3 <= remaining || max_sz * 2 <= remaining) return max_sz;
+    const size_t reduced = (remaining / 2) & ~(size_t)63;
+    return reduced >= 65536 ? reduced : max_sz;
+}
+
 /* --------------------------------------------------------- parameter arena */
 static size_t arena_reserve(mars_model_ext_t *m, size_t bytes) {
+    /* any failure here fails the whole plan (build_plan returns plan_err): no op keeps an unset offset */
+    if (bytes > ARENA_MAX || m->arena_size > ARENA_MAX) { m->plan_err = MARS_ERR_ALLOC_FAILED; return NO_OFF; }
     size_t off = ALIGN_UP(m->arena_size, 256);
     size_t end = off + ALIGN_UP(bytes ? bytes : 1, 256);
+    if (end > ARENA_MAX) { m->plan_err = MARS_ERR_ALLOC_FAILED; return NO_OFF; }
     if (end > m->arena_cap) {
         size_t cap = m->arena_cap ? m->arena_cap : (1u << 20);
-        while (cap < end) cap *= 2;
+        while (cap < end) cap *= 2; /* end <= 2^40: cannot overflow */
         uint8_t *p = (uint8_t *)realloc(m->arena_host, cap);
-        if (!p) return NO_OFF;
+        if (!p) { m->plan_err = MARS_ERR_ALLOC_FAILED; return NO_OFF; }
         memset(p + m->arena_cap, 0, cap - m->arena_cap);
         m->arena_host = p;
         m->arena_cap = cap;
@@ -124,7 +178,7 @@ static mars_op_t *new_op(mars_model_ext_t *m, int kind, int layer) {
     if (m->n_ops == m->cap_ops) {
         int cap = m->cap_ops ? m->cap_ops * 2 : 64;
         mars_op_t *p = (mars_op_t *)realloc(m->ops, (size_t)cap * sizeof(mars_op_t));
-        if (!p) return NULL;
+        if (!p) { m->plan_err = MARS_ERR_ALLOC_FAILED; return NULL; }
         m->ops = p;
         m->cap_ops = cap;
     }
@@ -217,8 +271,12 @@ static void plan_conv(mars_model_ext_t *m, int li) {
         pl = pw / 2;
     }
     if (out_h <= 0 || out_w <= 0 || out_c <= 0) return; /* empty loops in the reference: nothing is written */
+    /* channel counts are bounded so that every packed-weight product below (kw * c_pad, kh * row_pad, oc_pad * k64)
+     * stays far inside int / size_t: a crafted in_c once wrapped kw * in_c and let the packer write past its slot */
     if (in_h <= 0 || in_w <= 0 || in_c <= 0 || kh <= 0 || kw <= 0 || sh < 0 || sw < 0 || kh > 64 || kw > 64 ||
-        (size_t)in_h * in_w * in_c > MAX_DIM_PRODUCT || (size_t)out_h * out_w * out_c > MAX_DIM_PRODUCT) {
+        in_c > MAX_CHANNELS || out_c > MAX_CHANNELS ||
+        (size_t)in_h * in_w * in_c > MAX_DIM_PRODUCT || (size_t)out_h * out_w * out_c > MAX_DIM_PRODUCT ||
+        (size_t)out_c * in_c * kh * kw > ((size_t)1 << 31)) {
         fail_op(m, li, MARS_ERR_LAYER_FAILED); /* degenerate geometry this build does not launch */
         return;
     }
@@ -245,7 +303,7 @@ static void plan_conv(mars_model_ext_t *m, int li) {
         if (!m->deferred) blob_read(m, (size_t)w->data_offset, wcount * 4, m->arena_host + op->w_off);
         if (tb >= 0) {
             op->b_off = arena_reserve(m, (size_t)out_c * 4);
-            if (!m->deferred)
+            if (op->b_off != NO_OFF && !m->deferred)
                 blob_read(m, (size_t)m->pub.tensors[tb].desc.data_offset, (size_t)out_c * 4, m->arena_host + op->b_off);
         }
         if (cp->activation == MARS_ACT_RELU) { /* byte-wise clamp over H*W*C BYTES of the f32 result (:700-707) */
@@ -265,7 +323,7 @@ static void plan_conv(mars_model_ext_t *m, int li) {
     if (op->w_off == NO_OFF) return;
     if (!m->deferred) {
         int8_t *tmp = (int8_t *)malloc(wcount ? wcount : 1);
-        if (!tmp) return;
+        if (!tmp) { m->plan_err = MARS_ERR_ALLOC_FAILED; return; }
         blob_read(m, (size_t)w->data_offset, wcount, tmp);
         mars_pack_conv_i8(tmp, wcount, op->nchw, out_c, in_c, kh, kw, c_eff, op->row_pad, op->oc_pad,
                           (int8_t *)m->arena_host + op->w_off);
@@ -275,7 +333,7 @@ static void plan_conv(mars_model_ext_t *m, int li) {
         op->b_off = arena_reserve(m, (size_t)op->oc_pad * 4);
         if (op->b_off != NO_OFF && !m->deferred) {
             int32_t *raw = (int32_t *)calloc((size_t)out_c, 4), *dstb = (int32_t *)(m->arena_host + op->b_off);
-            if (!raw) return;
+            if (!raw) { m->plan_err = MARS_ERR_ALLOC_FAILED; return; }
             blob_read(m, (size_t)m->pub.tensors[tb].desc.data_offset, (size_t)out_c * 4, raw);
             for (int oc = 0; oc < out_c; oc++) dstb[mhip_conv_i8_oc_row(oc, op->oc_pad)] = raw[oc]; /* same row order as the weights */
             free(raw);
@@ -449,7 +507,7 @@ static void plan_batchnorm(mars_model_ext_t *m, int li) {
     const mars_tensor_t *in = &m->pub.tensors[ti].desc, *out = &m->pub.tensors[to].desc;
     int n = in->shape[0] > 0 ? in->shape[0] : 1, c = in->shape[1] > 0 ? in->shape[1] : 1;
     int h = in->shape[2] > 0 ? in->shape[2] : 1, w = in->shape[3] > 0 ? in->shape[3] : 1;
-    if ((size_t)n * c * h * w > MAX_DIM_PRODUCT) { fail_op(m, li, MARS_ERR_LAYER_FAILED); return; }
+    if ((size_t)n * c * h * w > MAX_DIM_PRODUCT || c > MAX_CHANNELS) { fail_op(m, li, MARS_ERR_LAYER_FAILED); return; }
     const int f32 = in->dtype == MARS_DTYPE_FLOAT32;
     mars_op_t *op = new_op(m, OP_BN, li);
     if (!op) return;
@@ -521,6 +579,12 @@ static void fuse_silu(mars_model_ext_t *m) {
         const int fwd = mu->t_in[0] == q1 && mu->t_in[1] == q2, rev = mu->t_in[0] == q2 && mu->t_in[1] == q1;
         if (!fwd && !rev) continue;
         if (q1 == q2 || q2 == q3 || q1 == q3) continue;
+        { /* redirecting the result onto one of the convolution's own inputs would make a parallel launch run in place */
+            int inplace = 0;
+            for (int k = 0; k < c->n_in; k++)
+                if (c->t_in[k] == q3) inplace = 1;
+            if (inplace) continue;
+        }
         if (readers[q1] != 2 || readers[q2] != 1 || writers[q1] != 1 || writers[q2] != 1 || writers[q3] != 1) continue;
         if (m->mt[q1].io_out || m->mt[q2].io_out || m->mt[q1].io_in || m->mt[q2].io_in) continue;
         const size_t n1 = (size_t)c->out_h * c->out_w * c->out_c;
@@ -656,6 +720,7 @@ static void fuse_add(mars_model_ext_t *m) {
                 c->nseg || c->add_t || c->n_in != 1)
                 continue;
             if (ad->n != (size_t)c->out_h * c->out_w * c->out_c) continue;
+            if (c->t_in[0] == O) continue; /* add(conv(X), Y) -> X: sequential in the reference, a race when fused */
             if (planned_stride(&m->mt[X]) != planned_stride(&m->mt[O])) continue;
             const float s_conv = side == 0 ? ad->f0 : ad->f1, s_other = side == 0 ? ad->f1 : ad->f0, inv = ad->f2;
             const double bound = 128.0 * (fabs((double)s_conv) + fabs((double)s_other)) * fabs((double)inv) + 1.0;
@@ -977,6 +1042,7 @@ static mars_error_t build_plan(mars_model_ext_t *m) {
     m->arena_size = 0;
     if (m->arena_host) memset(m->arena_host, 0, m->arena_cap); /* re-plans must not see stale bytes */
     m->scratch_per_frame = 0;
+    m->plan_err = MARS_OK;
     m->blob_mirror_bytes = m->pub.weights_size;
     for (uint32_t i = 0; i < nt; i++) {
         m->mt[i].extent = m->mt[i].bytes;
@@ -985,7 +1051,8 @@ static mars_error_t build_plan(mars_model_ext_t *m) {
     }
     /* slot 0 of the arena: mirror of the raw blob (element-wise layers may read weight
      * tensors directly); sized after planning, so reserve generously now */
-    for (uint32_t i = 0; i < nl; i++) plan_layer(m, (int)i);
+    for (uint32_t i = 0; i < nl && m->plan_err == MARS_OK; i++) plan_layer(m, (int)i);
+    if (m->plan_err != MARS_OK) return (mars_error_t)m->plan_err;
     if (m->fusion >= 1) {
         fuse_silu(m);
         fuse_add(m);
@@ -995,7 +1062,7 @@ static mars_error_t build_plan(mars_model_ext_t *m) {
         pair_convs(m);
         pad_output_rows(m);
     }
-    return MARS_OK;
+    return (mars_error_t)m->plan_err;
 }
 
 static mars_error_t upload_params(mars_model_ext_t *m) {
@@ -1023,7 +1090,7 @@ static mars_error_t alloc_batch(mars_model_ext_t *m, int n) {
     if (mhip_sync()) return MARS_ERR_LAYER_FAILED;
     /* segmented (virtual concat) convolutions address their output with 32-bit buffer offsets: if this batch makes
      * an output tensor of one of them 2 GiB or more, plan again with materialised concats */
-    if (!m->no_vconcat && !m->deferred)
+    if (!m->no_vconcat) /* deferred (descriptor-only) ranks take the same decision: it depends on shapes and batch only */
         for (int i = 0; i < m->n_ops; i++) {
             const mars_op_t *op = &m->ops[i];
             if (op->kind != OP_CONV_I8 || op->nseg < 2 || op->t_out < 0) continue;
@@ -1065,12 +1132,16 @@ static mars_error_t alloc_batch(mars_model_ext_t *m, int n) {
         rt->paddr = t->dev;
         rt->alloc_size = t->stride * (size_t)n;
         if (t->io_in || t->io_out) {
-            size_t hb = t->bytes * (size_t)n;
-            t->host = (uint8_t *)mhip_host_alloc(hb ? hb : 64);
+            /* what a caller may fill / read through vaddr (mars_test.c:73-84): one frame = the reference's working
+             * buffer size; a batch (extension) = n densely packed frames */
+            const size_t hb = t->bytes * (size_t)n, ref = reference_buffer_size(m);
+            size_t cap = hb > ref ? hb : ref;
+            if (ref > ((size_t)1 << 32)) cap = hb; /* wrapped int products of a hostile descriptor: not honoured */
+            t->host = (uint8_t *)mhip_host_alloc(cap ? cap : 64);
             if (!t->host) return MARS_ERR_ALLOC_FAILED;
-            memset(t->host, 0, hb);
+            memset(t->host, 0, cap);
             rt->vaddr = t->host;
-            rt->alloc_size = hb; /* what a caller may fill / read through vaddr (mars_test.c:73-84) */
+            rt->alloc_size = n == 1 && cap >= ref ? ref : hb;
         }
         if (t->pix_stride) {
             t->dense_dev = (uint8_t *)mhip_malloc(t->bytes * (size_t)n);
@@ -1549,6 +1620,11 @@ void *mars_hip_tensor_device(mars_model_t *model, int ti, size_t *frame_stride) 
     return m->mt[ti].dev;
 }
 
+size_t mars_hip_tensor_frame_bytes(const mars_model_t *model, int ti) {
+    if (!model || ti < 0 || (uint32_t)ti >= model->header.num_tensors) return 0;
+    return ((const mars_model_ext_t *)model)->mt[ti].bytes;
+}
+
 int mars_hip_tensor_row_pitch(mars_model_t *model, int ti, int *row_bytes) {
     if (!model || ti < 0 || (uint32_t)ti >= model->header.num_tensors) return 0;
     const mtensor_t *t = &((mars_model_ext_t *)model)->mt[ti];
@@ -1562,6 +1638,11 @@ mars_error_t mars_hip_read_tensor(mars_model_t *model, int ti, int frame, void *
     mtensor_t *t = &m->mt[ti];
     if (!t->dev || frame < 0 || (!t->is_weight && frame >= m->batch)) return MARS_ERR_INVALID_TENSOR;
     if (!t->is_weight && bytes > t->stride) return MARS_ERR_INVALID_TENSOR;
+    if (t->is_weight) { /* weights: one copy for every frame, bounded by the blob mirror */
+        const size_t off = (size_t)m->pub.tensors[ti].desc.data_offset;
+        if (off > m->blob_mirror_bytes || bytes > m->blob_mirror_bytes - off) return MARS_ERR_INVALID_TENSOR;
+        frame = 0;
+    }
     if (mhip_sync()) return MARS_ERR_LAYER_FAILED;
     if (t->pix_stride) { /* padded pixel rows: the frame is packed on the device first */
         uint8_t *dense = t->dense_dev + (size_t)frame * t->bytes;

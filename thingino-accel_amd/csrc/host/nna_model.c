@@ -79,7 +79,12 @@ int nna_model_get_info(nna_model_t *model, nna_model_info_t *info) {
     return NNA_SUCCESS;
 }
 
-static nna_tensor_t *handle_for(const mars_runtime_tensor_t *rt) {
+/* bytes behind an I/O handle: every frame of the current batch, by shape (not the reference-style alloc_size) */
+static size_t io_bytes(mars_model_t *m, uint32_t tid) {
+    return mars_hip_tensor_frame_bytes(m, (int)tid) * (size_t)mars_hip_get_batch(m);
+}
+
+static nna_tensor_t *handle_for(const mars_runtime_tensor_t *rt, size_t bytes) {
     if (!rt || !rt->vaddr) return NULL;
     nna_shape_t shape;
     shape.ndim = (int32_t)(rt->desc.ndims > 4 ? 4 : rt->desc.ndims);
@@ -87,19 +92,19 @@ static nna_tensor_t *handle_for(const mars_runtime_tensor_t *rt) {
     /* the tensor borrows the staging buffer; its byte count is the buffer's (a batch > 1 makes it longer than the
      * shape says: frames are frame-major) */
     nna_tensor_t *t = nna_tensor_from_data(rt->vaddr, &shape, dtype_of(rt->desc.dtype), NNA_FORMAT_NHWC);
-    if (t) t->bytes = rt->alloc_size;
+    if (t) t->bytes = bytes;
     return t;
 }
 
 nna_tensor_t *nna_model_get_input(nna_model_t *model, uint32_t index) {
     if (!model || index >= model->mars->header.num_inputs) return NULL;
-    if (!model->in[index]) model->in[index] = handle_for(mars_get_input(model->mars, (int)index));
+    if (!model->in[index]) model->in[index] = handle_for(mars_get_input(model->mars, (int)index), io_bytes(model->mars, model->mars->header.input_tensor_ids[index]));
     return model->in[index];
 }
 
 const nna_tensor_t *nna_model_get_output(nna_model_t *model, uint32_t index) {
     if (!model || index >= model->mars->header.num_outputs) return NULL;
-    if (!model->out[index]) model->out[index] = handle_for(mars_get_output(model->mars, (int)index));
+    if (!model->out[index]) model->out[index] = handle_for(mars_get_output(model->mars, (int)index), io_bytes(model->mars, model->mars->header.output_tensor_ids[index]));
     return model->out[index];
 }
 

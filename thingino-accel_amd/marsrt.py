@@ -105,7 +105,7 @@ EXPORTS = {
                    "mars_hip_set_profiling", "mars_hip_num_ops", "mars_hip_op_info", "mars_hip_stream",
                    "mars_hip_load_memory_ex", "mars_hip_param_arena", "mars_yolo_parse_output", "mars_yolo_nms",
                    "mars_hip_detect", "mars_hip_detect_device", "mars_synth_model", "mars_hip_set_tuning", "mars_hip_autotune", "mars_yolo_letterbox",
-                   "mars_hip_preprocess"],
+                   "mars_hip_preprocess", "mars_hip_tensor_frame_bytes", "mars_hip_tensor_byte_size"],
 }
 
 _lib = None
@@ -148,6 +148,10 @@ def lib():
     L.mars_get_error_string.restype = C.c_char_p
     L.mars_get_error_string.argtypes = [C.c_int]
     L.mars_print_summary.argtypes = [P(MarsModel)]
+    L.mars_hip_tensor_frame_bytes.restype = C.c_size_t
+    L.mars_hip_tensor_frame_bytes.argtypes = [P(MarsModel), C.c_int]
+    L.mars_hip_tensor_byte_size.restype = C.c_size_t
+    L.mars_hip_tensor_byte_size.argtypes = [P(MarsTensorDesc)]
     for n in ("mars_hip_upload_inputs", "mars_hip_run_device", "mars_hip_run_device_async",
               "mars_hip_download_outputs", "mars_hip_get_batch", "mars_hip_num_ops"):
         getattr(L, n).argtypes = [P(MarsModel)]
@@ -261,16 +265,18 @@ class Model:
     def output(self, i=0):
         return lib().mars_get_output(self.p, i)
 
-    def _view(self, rt):
+    def _view(self, rt, tid):
+        # batch * frame bytes by shape; alloc_size is larger for a single frame (the reference's working-buffer size)
         t = rt.contents
-        return np.ctypeslib.as_array(C.cast(t.vaddr, C.POINTER(C.c_uint8)), shape=(t.alloc_size,))
+        n = lib().mars_hip_tensor_frame_bytes(self.p, tid) * self.batch
+        return np.ctypeslib.as_array(C.cast(t.vaddr, C.POINTER(C.c_uint8)), shape=(n,))
 
     def input_view(self, i=0):
         """uint8 view [batch, frame_bytes] of mars_get_input(i)->vaddr."""
-        return self._view(self.input(i)).reshape(self.batch, -1)
+        return self._view(self.input(i), self.header.input_tensor_ids[i]).reshape(self.batch, -1)
 
     def output_view(self, i=0):
-        return self._view(self.output(i)).reshape(self.batch, -1)
+        return self._view(self.output(i), self.header.output_tensor_ids[i]).reshape(self.batch, -1)
 
     def run(self):
         rc = lib().mars_run(self.p)
