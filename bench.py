@@ -8,9 +8,10 @@ SiLU-LUT epilogue, pooling, concat, upsample, add) and the decode + NMS detectio
 Workload at N=1 = the configuration BASELINE.json's metric is quoted on: yolov5s_int8,
 640x640, batch 256.  The reference repo does not ship that file (.MISSING_LARGE_BLOBS), so it
 is the seeded synthetic twin written by mars_synth_model() (same format, same YOLOv5s layer
-sequence, NHWC/OHWI int8).  N>1: one process per GPU (torch.distributed.run), frames sharded
-(256 per GPU, weak scaling), parameters broadcast once over RCCL, no collective in the
-forward pass.
+sequence, NHWC/OHWI int8).  N>1: one process per GPU (torch.distributed.run), frames sharded,
+parameters broadcast once over RCCL, no collective in the forward pass.  Frames per GPU: 256 at
+every N (weak scaling) -- except the default N=8 run, which is BASELINE config 4: 1024 frames in
+total = 128 per GPU (`--weak` keeps 256 per GPU there too; `--total-batch T` asks for any total).
 
 Prints ONE JSON line (rank 0).  `roofline` is for the dominant kernel (conv_i8_kernel, the
 implicit-GEMM MFMA convolution): algorithmic bytes (and, as `mfma_view`, int8 ops) of all its launches / their summed
@@ -86,6 +87,45 @@ def cpu_baseline(model_bytes, frames, out_ids, budget_s=14.0, max_frames=16):
                 sample="%d frames of the same workload through %s, %.1f s of CPU time" % (n, how, spent)), outs
 
 
+def cpu_baseline_parallel(model_bytes, frames, out_ids, nthreads, ref_outs):
+    """the same reference code, frames-parallel: one frame per thread, every host core this process may use (ctypes
+    releases the GIL; every thread owns its model instance).  One frame per thread, so ~one single-frame time."""
+    import threading
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    n = nthreads or len(os.sched_getaffinity(0))
+    n = max(1, min(n, len(frames)))
+    kind = "port"
+    try:
+        import refbind
+        use_ref = refbind.available()
+    except Exception:  # noqa: BLE001
+        use_ref = False
+    if use_ref:
+        kind = "reference"
+        mk = lambda: refbind.O2Model(model_bytes, slack_mult=1, slack_add=4096, fast=True)  # noqa: E731
+    else:
+        import orcbind
+        mk = lambda: orcbind.Graph(model_bytes, slack_mult=1, slack_add=4096)  # noqa: E731
+    runners = [mk() for _ in range(n)]
+    for i, r in enumerate(runners):
+        r.set_input(0, frames[i].tobytes())
+    rcs = [None] * n
+    th = [threading.Thread(target=lambda i=i: rcs.__setitem__(i, runners[i].run())) for i in range(n)]
+    t0 = time.time()
+    for t in th:
+        t.start()
+    for t in th:
+        t.join()
+    dt = time.time() - t0
+    if any(rc != 0 for rc in rcs):
+        raise RuntimeError("parallel cpu baseline failed: %r" % (rcs,))
+    same = all(np.array_equal(runners[f].tensor(ti), ref_outs[f][i]) for f in range(min(n, len(ref_outs))) for i, ti in enumerate(out_ids))
+    for r in runners:
+        r.close()
+    return dict(value=n / dt, unit="images/s", cores=n, kind=kind, matches_single_core_run=bool(same),
+                sample="%d frames at once, one per thread, %.1f s wall" % (n, dt))
+
+
 def pmc_traffic(args):
     """HBM bytes one step's conv launches move, from the committed rocprofv3 PMC passes (FETCH_SIZE doubled per
     MI355X_MICROARCH.md, WRITE_SIZE; tools/pmc_summary.py) -- counters cannot be collected from inside this
@@ -108,6 +148,12 @@ def main():
     ap.add_argument("--steps", type=int, default=30)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--batch", type=int, default=256, help="frames per GPU")
+    ap.add_argument("--total-batch", type=int, default=0,
+                    help="frames over ALL GPUs (split evenly; must divide by the GPU count).  Default: --batch per GPU, "
+                         "except 1024 in total at 8 GPUs (BASELINE config 4: 128 per GPU)")
+    ap.add_argument("--weak", action="store_true", help="--batch frames per GPU at every GPU count (also at 8)")
+    ap.add_argument("--cpu-threads", type=int, default=0,
+                    help="threads of the frames-parallel CPU baseline (0 = every core this process may run on)")
     ap.add_argument("--hw", type=int, default=640)
     ap.add_argument("--width", type=int, default=8, help="channel multiple x16: 8 = yolov5s, 4 = yolov5n")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -130,6 +176,12 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     dist = None
+    # frames per GPU: explicit total > config 4 at eight GPUs > --batch per GPU
+    total_batch = args.total_batch if args.total_batch > 0 else (1024 if world == 8 and not args.weak and args.batch == 256 else 0)
+    if total_batch:
+        if total_batch % world:
+            raise SystemExit("--total-batch %d does not divide over %d GPUs" % (total_batch, world))
+        args.batch = total_batch // world
     # BENCH_FORCE_DIST=1: take the multi-process path (process group, descriptor-only load is skipped on rank 0, arena
     # broadcast, barriers, max over ranks) with however many ranks there are -- a one-GPU rehearsal of the N>1 code
     multi = world > 1 or os.environ.get("BENCH_FORCE_DIST") == "1"
@@ -161,6 +213,13 @@ def main():
     if multi:
         import torch
         ptr, nbytes = model.param_arena()
+        sizes = [None] * dist.get_world_size()
+        dist.all_gather_object(sizes, int(nbytes))  # every rank planned the same arena (descriptors + batch decide it)
+        if len(set(sizes)) != 1:
+            raise RuntimeError("parameter arena sizes differ across ranks: %r" % (sizes,))
+        if rank == 0:
+            print("bench: %d ranks in the RCCL group, parameter arena %d bytes broadcast from rank 0" % (dist.get_world_size(), nbytes),
+                  file=sys.stderr)
         t = torch.as_tensor(D.DeviceBuffer(ptr, nbytes), device="cuda")
         dist.broadcast(t, src=0)  # the one collective of the path: weights over xGMI
         torch.cuda.synchronize()
@@ -233,9 +292,12 @@ def main():
         achieved = conv_ops / (conv_ms * 1e-3) / 1e12 if conv_ms > 0 else 0.0
         conv_bytes_per_img = sum(op["bytes"] for op in model.ops() if op["kind"] == 0)
         traffic, traffic_src = pmc_traffic(args)
+        floor_ms = sum(max(op["bytes"] * args.batch / 8e12, 2.0 * op["macs"] * args.batch / 5e15)
+                       for op in model.ops() if op["kind"] == 0) * 1e3
         peak = 5000.0  # dense int8 MFMA, TOP/s: 2x the ~2.5 PF bf16 dense peak (MI355X_MICROARCH.md, Matrix cores)
         result = {
-            "metric": "images/sec yolov5s_int8 640x640 batch256",
+            "metric": "images/sec %s_int8 %dx%d batch%d" % ("yolov5s" if args.width == 8 else "yolov5n" if args.width == 4 else
+                                                         "yolov5(width_x16=%d)" % args.width, args.hw, args.hw, args.batch),
             "value": world * args.batch * args.steps / dt,
             "unit": "images/s",
             "n_gpus": world,
@@ -243,7 +305,9 @@ def main():
             "warmup": args.warmup,
             "ms_per_step": dt / args.steps * 1e3,
             "higher_is_better": True,
-            "scaling": "weak",
+            # 256 (= --batch) frames on every GPU: weak.  The default 8-GPU run is BASELINE config 4 (1024 frames in all,
+            # 128 per GPU): the same total as 4 GPUs x 256, i.e. strong scaling from there
+            "scaling": "strong" if total_batch else "weak",
             "vs_baseline": None,
             "dtype": "int8",
             "data": "synthetic",
@@ -251,7 +315,10 @@ def main():
                                    "NHWC frames, batch %d per GPU, decode+NMS tail %s%s" %
                                    (args.width, args.hw, args.hw, args.batch, "off" if args.no_tail else "on",
                                     ", per-convolution scales (check run)" if args.vary_scales else ""),
-                       "frames_per_gpu": args.batch, "sharding": "frames", "collectives_in_forward": 0,
+                       "frames_per_gpu": args.batch, "frames_total": args.batch * world,
+                       "baseline_config": ("configs[3]: 1024 frames frame-sharded over 8 GPUs" if world == 8 and args.batch * world == 1024
+                                           else "configs[1]-class: the metric's batch 256 per GPU" if args.batch == 256 else "custom"),
+                       "ranks": world, "sharding": "frames", "collectives_in_forward": 0,
                        "autotuned_launch_variants": bool(args.autotune and not args.no_autotune), "conv_gmac_per_image": macs_per_img / 1e9, "algorithmic_mb_per_image": bytes_per_img / 1e6},
             # The conv family's arithmetic intensity (2*MAC / algorithmic byte ~ 260 op/B) is below the machine's ridge
             # (5000 TOP/s / 8 TB/s = 625 op/B), so its roof is HBM: achieved = algorithmic bytes of the conv launches /
@@ -264,6 +331,10 @@ def main():
                          "algorithmic_bytes": conv_bytes_per_img * args.batch,
                          "intensity_ops_per_byte": 2.0 * macs_per_img / conv_bytes_per_img if conv_bytes_per_img else None,
                          "mfma_view": {"achieved": achieved, "peak": peak, "unit": "TOP/s", "frac": achieved / peak},
+                         # what the same launches would take with every layer on its own roof: sum over the conv launches
+                         # of max(algorithmic bytes / 8 TB/s, 2*MAC / 5 POP/s); `frac_of_per_layer_floor` = that / measured
+                         "per_layer_floor_ms": floor_ms,
+                         "frac_of_per_layer_floor": (floor_ms / (conv_ms / ev_steps)) if conv_ms > 0 else 0.0,
                          "event_timed_steps": ev_steps,
                          "conv_ms_per_step": conv_ms / ev_steps,
                          "all_kernels_ms_per_step": all_ms / ev_steps,
@@ -277,6 +348,25 @@ def main():
             for _ in range(2):
                 model.run()
             result["pcie_inclusive_images_per_s"] = 2 * args.batch / (time.perf_counter() - t1)
+        if world == 1:
+            # the reference's real call pattern (mars_test.c:33-148): ONE frame per mars_run.  Latency of the graph alone
+            # (input resident) and through mars_run() (H2D + graph + D2H), median of 20
+            m1 = M.Model(model_bytes, batch=1)
+            m1.input_view(0)[0] = frames[0]
+            m1.upload()
+            lat = {}
+            for name, fn in (("graph_resident_ms", m1.run_device), ("mars_run_ms", m1.run)):
+                for _ in range(3):
+                    fn()
+                ts = []
+                for _ in range(20):
+                    t1 = time.perf_counter()
+                    fn()
+                    ts.append(time.perf_counter() - t1)
+                lat[name] = sorted(ts)[len(ts) // 2] * 1e3
+            lat["launches"] = len(m1.ops())
+            result["latency_batch1"] = lat
+            m1.close()
         if world == 1 and not args.no_cpu_baseline:
             base, ref_outs = cpu_baseline(model_bytes, frames, out_ids)
             model.download()
@@ -285,6 +375,8 @@ def main():
             base["gpu_matches_bit_exact"] = bool(same)
             base["frames_compared"] = len(ref_outs)
             result["cpu_baseline"] = base
+            # the fair node-level figure -- frames are independent, one frame per thread on every core
+            result["cpu_baseline_all_cores"] = cpu_baseline_parallel(model_bytes, frames, out_ids, args.cpu_threads, ref_outs)
     model.close()
     if dist is not None:
         dist.barrier()

@@ -8,6 +8,7 @@
  * lie and used as the parity oracle.
  */
 #include <fcntl.h>
+#include <pthread.h>
 #include <stdint.h>
 #include <stdio.h>
 #include <stdlib.h>
@@ -31,8 +32,16 @@ uint32_t nna_device_get_ddr_pbase(void) { return 0x06000000u; }
 void *nna_device_get_oram(void) { return g_oram; }
 
 /* The reference prints on every load step and every conv; tests silence it. */
-static int g_saved_out = -1, g_saved_err = -1;
+static int g_saved_out = -1, g_saved_err = -1, g_quiet_users = 0;
+static pthread_mutex_t g_quiet_lock = PTHREAD_MUTEX_INITIALIZER;
+/* counted: the frames-parallel CPU baseline runs one model per thread; the first user redirects, the last restores */
 void ref_quiet(int on) {
+    pthread_mutex_lock(&g_quiet_lock);
+    g_quiet_users += on ? 1 : -1;
+    if ((on && g_quiet_users != 1) || (!on && g_quiet_users != 0)) {
+        pthread_mutex_unlock(&g_quiet_lock);
+        return;
+    }
     fflush(stdout);
     fflush(stderr);
     if (on && g_saved_out < 0) {
@@ -49,4 +58,5 @@ void ref_quiet(int on) {
         close(g_saved_err);
         g_saved_out = g_saved_err = -1;
     }
+    pthread_mutex_unlock(&g_quiet_lock);
 }

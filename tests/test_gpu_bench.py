@@ -11,9 +11,10 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def run_bench(*extra):
+def run_bench(*extra, env=None):
     out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "3", "--warmup", "1",
-                          "--batch", "4", "--hw", "160", "--width", "4"] + list(extra), capture_output=True, text=True, timeout=600)
+                          "--batch", "4", "--hw", "160", "--width", "4"] + list(extra), capture_output=True, text=True, timeout=600,
+                         env=dict(os.environ, **(env or {})))
     assert out.returncode == 0, out.stderr[-2000:]
     lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1  # exactly one JSON line
@@ -37,9 +38,27 @@ def test_bench_line_has_the_contract_fields():
         assert k in c, k
     assert c["kind"] in ("reference", "port") and c["cores"] == 1 and c["value"] > 0
     assert c["gpu_matches_bit_exact"] is True and c["frames_compared"] >= 1
+    a = d["cpu_baseline_all_cores"]  # frames-parallel over the host cores, core count stated
+    assert a["cores"] >= 1 and a["value"] > 0 and a["kind"] == c["kind"] and a["matches_single_core_run"] is True
+    assert r["per_layer_floor_ms"] > 0 and 0 < r["frac_of_per_layer_floor"] <= 1.0
+    lat = d["latency_batch1"]
+    assert lat["graph_resident_ms"] > 0 and lat["mars_run_ms"] >= lat["graph_resident_ms"] * 0.5 and lat["launches"] > 0
+    assert d["config"]["frames_total"] == 4 and d["config"]["ranks"] == 1
 
 
 def test_bench_flags():
     d = run_bench("--no-cpu-baseline", "--no-tail", "--no-autotune")
     assert "cpu_baseline" not in d and "tail off" in d["config"]["workload"]
     assert d["config"]["autotuned_launch_variants"] is False
+
+
+def test_bench_multi_rank_path_with_one_rank():
+    """BENCH_FORCE_DIST=1: the N>1 code path (RCCL process group, equal-arena assertion, parameter-arena broadcast,
+    barriers, max over ranks) with one rank on this box's one GPU"""
+    d = run_bench("--no-cpu-baseline", env={"BENCH_FORCE_DIST": "1", "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": "29541"})
+    assert d["n_gpus"] == 1 and d["value"] > 0 and d["scaling"] == "weak"
+
+
+def test_bench_total_batch_flag():
+    d = run_bench("--no-cpu-baseline", "--total-batch", "6")
+    assert d["config"]["frames_per_gpu"] == 6 and d["config"]["frames_total"] == 6 and d["scaling"] == "strong"
