@@ -306,3 +306,48 @@ def test_decode_cap_and_maxd(gpu, orc):
     a = gpu.parse_output(pred, npred, scale, maxd=37)
     b = orc.parse_output(pred, npred, scale, maxd=37)
     assert len(a) == 37 and a.tobytes() == b.tobytes()
+
+
+def test_conv_i8_two_team_strip(gpu, orc):
+    """variant 17 (conv_i8_duo): one 16-wave workgroup = two teams half a tile apart on a shared weight ring, tiles of
+    256 flat pixels (straddling frames), input patch staged per 64-channel chunk.  3x3 / 5x5 stride-1 layers with 64,
+    128 and 256 input channels (1, 2, 4 chunks), 128 / 256 output channels, maps that do and do not divide into
+    256-pixel tiles, odd tile counts (team 1 idle at the end), several tiles per workgroup; through a graph with several
+    frames so that tiles straddle frame boundaries"""
+    import marsfile
+    from conftest import lcg_frame
+    rng = np.random.default_rng(5)
+    shapes = [  # h, w, ic, oc, k, frames, slots
+        (40, 40, 128, 128, 3, 3, 0), (20, 20, 256, 256, 3, 5, 0), (80, 80, 64, 128, 3, 1, 0), (17, 19, 64, 128, 3, 4, 0),
+        (16, 16, 128, 128, 5, 3, 0), (40, 40, 128, 128, 3, 7, 2), (23, 29, 256, 128, 3, 3, 3), (20, 20, 256, 256, 3, 16, 1)]
+    try:
+        gpu.set_tuning("variant", 17)
+        for i, (h, w, ic, oc, k, frames, slots) in enumerate(shapes):
+            gpu.set_tuning("persist_slots", slots)
+            G = marsfile.Graph()
+            x = G.tensor([1, h, w, ic], scale=4 / 127)
+            a = G.tensor([1, h, w, oc], scale=0.03125)
+            sg = G.tensor([1, h, w, oc], scale=1 / 127)
+            o = G.tensor([1, h, w, oc], scale=4 / 127)
+            wt = G.tensor([oc, k, k, ic], scale=0.0005, data=rng.integers(-127, 128, (oc, k, k, ic), dtype=np.int8))
+            b = G.tensor([oc], dtype=marsfile.I32, scale=1.0, data=rng.integers(-500, 500, oc, dtype=np.int32))
+            G.conv(x, a, wt, b, (k, k), (1, 1))
+            G.layer(marsfile.SIGMOID, [a], [sg])
+            G.layer(marsfile.MUL, [a, sg], [o])
+            d = G.serialise([x], [o])
+            m = gpu.Model(d, batch=frames)
+            xs = [lcg_frame(0xD00000 + 97 * i + f, h * w * ic) for f in range(frames)]
+            for f in range(frames):
+                m.input_view(0)[f] = xs[f]
+            m.run()
+            for f in sorted({0, frames // 2, frames - 1}):
+                g = orc.Graph(d)
+                g.set_input(0, xs[f].tobytes())
+                assert g.run() == 0
+                want, got = g.tensor(3), m.output_view(0)[f]
+                assert np.array_equal(want, got), (i, f, int((want != got).sum()))
+                assert len(np.unique(got)) > 32
+            m.close()
+    finally:
+        gpu.set_tuning("variant", 0)
+        gpu.set_tuning("persist_slots", 0)

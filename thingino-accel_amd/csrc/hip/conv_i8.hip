@@ -34,6 +34,7 @@
 #include <stdint.h>
 #include <stdlib.h>
 #include <string.h>
+#include <type_traits>
 
 #include "../mhip.h"
 
@@ -1300,6 +1301,325 @@ __global__ __launch_bounds__(512) void conv_i8_patchw(const mhip_conv_i8_t p, co
 }
 
 // ---------------------------------------------------------------------------------
+// two-team strip kernel: the deep k x k stride-1 layers (3x3 with 64 / 128 / 256 input channels on the 80x80 .. 20x20
+// maps).  What the counters say about the implicit-GEMM forms on these layers (profiles/r02_deep_sq_counters.md):
+// the 8-wave tile is bound by L2 -> LDS DMA throughput (24 KB per K step at the ~21 B/clk/CU this access shape
+// reaches), and conv_i8_patchw, which moves 2.3x fewer bytes, gains only 12 % because all workgroups of a round run in
+// lockstep -- prologue, K loop and epilogue of the two workgroups on a CU coincide instead of overlapping.  This kernel:
+//   * ONE 16-wave workgroup per CU = two TEAMS of 8 waves (4 pixel groups x 2 channel halves, 64 x 64 accumulators per
+//     wave as before).  Each team owns a tile of 256 output pixels x 128 channels; tiles are runs of 256 FLAT pixels
+//     (frame-major), so 40x40 and 20x20 maps fill every tile (a tile may straddle two frames: its input patch is then
+//     two row segments).
+//   * the teams run HALF A TILE apart: team 1 walks the K steps in rotated order (it starts at step H = nks / 2), so at
+//     any moment both teams need the SAME 128 x 64 weight bytes -- one weight ring serves both (half the weight DMA of
+//     two independent workgroups; int32 accumulation is order independent, so the rotation is exact), and one team's
+//     epilogue / tile set-up falls into the middle of the other's K loop.
+//   * the input patch of a tile is staged per 64-channel chunk (all taps of a chunk are served from LDS), double
+//     buffered per team: the next chunk (or the next tile's first chunk) streams in, one DMA instruction per wave
+//     and step, while the current one is computed.  Workgroups are persistent and walk a contiguous run of tiles.
+//   * every wave issues the same deterministic sequence of vector-memory instructions per step, so one counted
+//     s_waitcnt vmcnt(N) + one s_barrier per K step orders everything (loads, LDS-DMA and stores retire in order).
+// LDS: [LUT 512][bias 512][weight ring 3 x 8 KB][team 0: 2 patch buffers][team 1: 2 patch buffers].
+struct duo_args_t {
+    int k64, taps, nchunk, nks, H, cH; // K steps (chunk-major: step = chunk * taps + tap); team 1 starts at step H, chunk cH
+    int PWP, ni, patch_bytes;          // patch row pitch in positions; DMA instructions per wave and chunk; bytes per buffer
+    unsigned total_pix, ntiles, noc, ngrp;
+    fastdiv_t dhw, dow, dpwp;
+    unsigned out_bytes, in_bytes, kw_magic;
+};
+__device__ __forceinline__ void wait_vmcnt_dyn(int n) { // n is wave-uniform; any immediate <= n is safe
+    if (n == 1) wait_vmcnt<1>();       // the common case first: every compare + branch costs a scalar issue slot
+    else if (n == 2) wait_vmcnt<2>();
+    else if (n == 0) wait_vmcnt<0>();
+    else if (n >= 6) wait_vmcnt<6>();
+    else if (n == 5) wait_vmcnt<5>();
+    else if (n == 4) wait_vmcnt<4>();
+    else wait_vmcnt<3>();
+}
+// Scalar instructions are the scarce resource of a 16-wave workgroup (one scalar ALU per CU: 16 waves x ~120 scalar
+// instructions per K step made the first version of this kernel scalar-bound at 3500 cycles per step).  So the K loop
+// runs in EPOCHS of TAPS = 9 steps (one 64-channel chunk of a 3x3 kernel) with the step body unrolled: tap index,
+// ring slot and the tap's offset inside the patch are compile-time constants, all tile / epoch bookkeeping happens
+// once per epoch, and a step carries ~20 scalar instructions.
+template <bool HAS_LUT, bool HAS_ADD>
+__global__ __launch_bounds__(1024) void conv_i8_duo(const mhip_conv_i8_t p, const duo_args_t g) {
+    constexpr int BN = 128, WPX = 4, WOC = 4, STG = 3, P = 256, TAPS = 9;
+    extern __shared__ __attribute__((aligned(16))) int8_t dynlds[];
+    uint8_t *slut = (uint8_t *)dynlds; // LDS byte address 0 (requant_pack LUT0)
+    lds_base_must_be_zero(dynlds);
+    int *sbias = (int *)(dynlds + LUTB);
+    int8_t *wring = dynlds + LUTB + BN * 4;
+    int8_t *patches = wring + STG * BN * BK;
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    // waves go to SIMDs round-robin, so waves w, w+4, w+8, w+12 share one: two of each team
+    const int team = (wv >> 2) & 1, tw = (wv & 3) | ((wv >> 3) << 2);
+    const int wm = tw & 3, wn = tw >> 2;
+    int8_t *const mypatch = patches + team * 2 * g.patch_bytes;
+
+    const unsigned id = xcd_remap(blockIdx.x, g.noc * g.ngrp);
+    const unsigned grp = id / g.noc;
+    const int oc0 = (int)(id - grp * g.noc) * BN;
+    const unsigned t0 = (unsigned)(((unsigned long long)grp * g.ntiles) / g.ngrp);
+    const unsigned t1 = (unsigned)(((unsigned long long)(grp + 1) * g.ntiles) / g.ngrp);
+    if (t0 >= t1) return; // uniform for the workgroup
+    const int nchunk = g.nchunk, nks = g.nks;
+    const int n0 = (int)((t1 - t0 + 1) >> 1), n1 = (int)((t1 - t0) >> 1); // tiles of team 0 (t0, t0+2, ..) and team 1 (t0+1, ..)
+    const int G0 = n0 * nks, G1 = n1 ? g.H + n1 * nks : 0;
+    const int G = G0 > G1 ? G0 : G1;                 // steps until both teams have finished
+    const int NE = (G + TAPS - 1) / TAPS;            // epochs (the last one may be partial: its idle steps only pass barriers)
+    const int nmine = team ? n1 : n0;
+    const int gstart = team ? g.H : 0;               // first step at which this team works
+    const int startc = team ? g.cH : 0;              // ... the chunk its tiles start with
+    const int kstart = gstart % TAPS;                // ... and the tap (0, or 4 for team 1 of a one-chunk layer)
+    const int kend = kstart == 0 ? TAPS - 1 : kstart - 1;
+
+    if (HAS_LUT) {
+        if (p.lut2) { if (tid < 128) ((uint32_t *)slut)[tid] = ((const uint32_t *)p.lut2)[tid]; }
+        else if (tid < 64) ((uint32_t *)slut)[tid] = ((const uint32_t *)p.lut)[tid];
+    }
+    if (tid < BN) sbias[tid] = p.bias ? p.bias[oc0 + tid] : 0;
+
+    const int C = p.in_c, hw = p.out_h * p.out_w;
+    const int frow = lane & 15, fchunk = lane >> 4;
+    const int chan = wn * 64 + (lane >> 4) * (4 * WOC);
+    const int pstride = p.out_pix_stride ? p.out_pix_stride : p.out_c;
+    const int lo = p.relu ? 0 : -128;
+    const uint8_t *lut128 = slut + 128;
+    const __amdgpu_buffer_rsrc_t orsrc = __builtin_amdgcn_make_buffer_rsrc(p.out, 0, (int)g.out_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc((void *)p.in, 0, (int)g.in_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t wrs = __builtin_amdgcn_make_buffer_rsrc((void *)p.w, 0, p.oc_pad * g.k64, 0x00020000);
+
+    // the row segments of a tile (uniform): flat pixels [tile*P, tile*P + P) touch one frame (segment A only) or two
+    struct seg_t { unsigned fA, fB; int oyA0, iyA0, nA, nB; };
+    auto segments = [&](unsigned tile) {
+        seg_t s;
+        const unsigned g0 = tile * P, gl = (g0 + P < g.total_pix ? g0 + P : g.total_pix) - 1u;
+        s.fA = fdiv(g0, g.dhw);
+        s.fB = fdiv(gl, g.dhw);
+        s.oyA0 = (int)fdiv(g0 - s.fA * (unsigned)hw, g.dow);
+        const int oyB1 = (int)fdiv(gl - s.fB * (unsigned)hw, g.dow);
+        const bool two = s.fA != s.fB;
+        const int oyA1 = two ? p.out_h - 1 : oyB1;
+        s.iyA0 = s.oyA0 * p.stride_h - p.pad_top;
+        s.nA = (oyA1 - s.oyA0) * p.stride_h + p.kh;
+        s.nB = two ? oyB1 * p.stride_h + p.kh : 0;
+        return s;
+    };
+    // One DMA instruction of a patch chunk: instruction n of team wave tw fills 16-byte units (n*8 + tw)*64 + lane of the
+    // buffer (unit = position * 4 + 16-byte piece of the 64-channel chunk, swizzled as in conv_i8_patch for C = 64).
+    // This lane's unit of instruction n is position pos0 + n*128, piece cc: both fixed for the whole run.
+    const unsigned lane_sw = (unsigned)lane ^ (((unsigned)lane >> 3) & 2u);
+    const unsigned pos0 = (unsigned)tw * 16u + (lane_sw >> 2), ccoff = (lane_sw & 3u) * 16u;
+    auto issue_patch = [&](const seg_t &s, unsigned fA_off, unsigned fB_off, int chunk64, int n, int8_t *dst) {
+        const unsigned pos = pos0 + (unsigned)n * 128u;
+        const unsigned prow = fdiv(pos, g.dpwp), px = pos - prow * (unsigned)g.PWP;
+        const bool inA = (int)prow < s.nA;
+        const int iy = inA ? s.iyA0 + (int)prow : (int)prow - s.nA - p.pad_top;
+        const int ix = (int)px - p.pad_left;
+        const bool ok = (inA || (int)prow - s.nA < s.nB) && (unsigned)iy < (unsigned)p.in_h && (unsigned)ix < (unsigned)p.in_w;
+        const unsigned off = (inA ? fA_off : fB_off) + (unsigned)((iy * p.in_w + ix) * C + chunk64) + ccoff;
+        blds16(xrs, ok ? (int)off : -1, 0, dst + (n * 8 + tw) * 1024);
+    };
+    // weights of one K step (chunk, tap): bytes [tap * C + chunk * 64, + 64) of every row; each of the 16 waves fetches
+    // 8 rows (lanes 0..31), the same source-side swizzle as the ring kernels
+    const int schunk = (lane & 3) ^ (((lane >> 4) & 1) << 1);
+    const int wvoff = (oc0 + wv * 8 + ((lane >> 2) & 7)) * g.k64 + schunk * 16;
+
+    // ---- per-team tile state
+    int ubase[WPX];
+    v4i acc[WOC][WPX];
+    auto out_off = [&](unsigned tile, int u) { // output byte offset of this lane's pixel of subtile u, or -1
+        const unsigned gp = tile * P + (unsigned)((wm * WPX + u) * 16 + frow);
+        const bool valid = gp < g.total_pix;
+        const unsigned gq = valid ? gp : 0u;
+        const unsigned f = fdiv(gq, g.dhw), rem = gq - f * (unsigned)hw;
+        const unsigned off = f * (unsigned)p.out_stride + rem * (unsigned)pstride + (unsigned)(p.out_ch_off + oc0 + chan);
+        return valid && oc0 + chan < p.out_c ? (int)off : -1;
+    };
+    auto setup_tile = [&](unsigned tile) {
+        const seg_t s = segments(tile);
+#pragma unroll
+        for (int u = 0; u < WPX; u++) {
+            const unsigned gp = tile * P + (unsigned)((wm * WPX + u) * 16 + frow);
+            const bool valid = gp < g.total_pix;
+            const unsigned gq = valid ? gp : 0u;
+            const unsigned f = fdiv(gq, g.dhw), rem = gq - f * (unsigned)hw;
+            const int oy = (int)fdiv(rem, g.dow), ox = (int)rem - oy * p.out_w;
+            const int prow = f == s.fA ? (oy - s.oyA0) * p.stride_h : s.nA + oy * p.stride_h;
+            ubase[u] = valid ? (prow * g.PWP + ox * p.stride_w) * 4 + fchunk : fchunk;
+        }
+        // accumulators start at the bias (lane holds channels wn*64 + q*16 + (lane>>4)*4 .. +3 of every pixel subtile)
+#pragma unroll
+        for (int q = 0; q < WOC; q++) {
+            const v4i b = *(const v4i *)(sbias + wn * 64 + q * 16 + (lane >> 4) * 4);
+#pragma unroll
+            for (int u = 0; u < WPX; u++) acc[q][u] = b;
+        }
+    };
+
+    // ---- prologue: the first patch epoch of each team, then the weights of steps 0 and 1
+    __syncthreads(); // LUT / bias visible
+    unsigned mytile = t0 + (unsigned)team;
+    if (nmine > 0) {
+        const seg_t s = segments(mytile);
+        for (int n = 0; n < g.ni; n++)
+            issue_patch(s, s.fA * (unsigned)p.in_stride, s.fB * (unsigned)p.in_stride, startc * 64, n, mypatch);
+    }
+    if (lane < 32) blds16(wrs, wvoff, 0, wring + wv * 512);                              // step 0: chunk 0, tap 0
+    if (G > 1 && lane < 32) blds16(wrs, wvoff + C, 0, wring + BN * BK + wv * 512);       // step 1: chunk 0, tap 1
+
+    bool working = false, pvalid = false, have = false;
+    int lc = 0, ebuf = 0, tdone = 0; // lc: chunks of the current tile done so far (in this team's order)
+    seg_t pseg = {};                 // next patch epoch (being prefetched): segments, frame offsets, chunk * 64
+    unsigned pfA = 0, pfB = 0;
+    int pck = 0;
+    int8_t *pdst = mypatch;
+    const int8_t *pb = mypatch;
+    const int rowoff1 = g.PWP * 4, rowoff2 = g.PWP * 8; // 16-byte units per patch row (ky = 1, 2)
+    int gs = 0, kc = 0; // global step and the chunk of the current epoch
+    int kc64 = 0, kn64 = nchunk > 1 ? 64 : 0; // chunk * 64 of this epoch and of the next
+    // vmcnt bookkeeping (per wave, in issue order): the wait of step gs must see the weight piece this wave issued in
+    // step gs-1 landed (the weights of step gs+1).  Younger than that piece: what the wave issued between it and this
+    // step's weight piece (va), this step's weight piece, and what it has issued since (vx)
+    int va = 0, vx = 0;
+    v4i xb[WPX], wa[WOC];
+
+    // The two teams work in opposite PHASES: while one reads its MFMA operands from LDS and does its bookkeeping (LOAD),
+    // the other runs its 16 MFMAs per wave (COMPUTE).  Both execute the same code, LOAD(gs) then COMPUTE(gs), but the
+    // step's barrier sits at a different place: team 0 meets it AFTER its compute, team 1 BETWEEN its load and its
+    // compute.  Between two rendezvous team 0 therefore does [weights DMA, LOAD(gs+1), COMPUTE(gs+1)] and team 1
+    // [COMPUTE(gs), weights DMA, LOAD(gs+1)]: one team's MFMAs always run beside the other's load.  (With every wave in
+    // the same phase -- the first version -- the matrix pipe idled through everyone's load: 38 % busy.)
+    auto load = [&](auto KTc) __attribute__((always_inline)) {
+        constexpr int KT = decltype(KTc)::value;
+        if ((KT == 0 || KT == 4) && KT == kstart) { // a patch epoch of this team begins
+            if (!working) {
+                if (gs == gstart && nmine > 0) { working = true; lc = 0; }
+            } else {
+                ebuf ^= 1; // the prefetch filled the other buffer
+            }
+            if (working) {
+                pb = mypatch + ebuf * g.patch_bytes;
+                pdst = mypatch + (ebuf ^ 1) * g.patch_bytes;
+                if (lc == 0) setup_tile(mytile);
+                // the epoch to prefetch: the next chunk of this tile, or the first chunk of this team's next tile
+                const unsigned ptile = lc + 1 == nchunk ? mytile + 2 : mytile;
+                pvalid = ptile < t1;
+                if (pvalid) {
+                    pseg = segments(ptile);
+                    pfA = pseg.fA * (unsigned)p.in_stride;
+                    pfB = pseg.fB * (unsigned)p.in_stride;
+                    pck = (kc + 1 == nchunk ? 0 : kc + 1) * 64;
+                }
+            }
+        }
+        if (working) { // fragment reads of this wave's 16 MFMAs
+            constexpr int KY = KT / 3, KX = KT % 3;
+            const int du = (KY == 0 ? 0 : (KY == 1 ? rowoff1 : rowoff2)) + KX * 4;
+            const int8_t *ws = wring + (KT % STG) * (BN * BK) + lds_off(wn * 64 + frow, fchunk);
+#pragma unroll
+            for (int u = 0; u < WPX; u++) {
+                const unsigned U = (unsigned)(ubase[u] + du);
+                xb[u] = *(const v4i *)(pb + ((U ^ ((U >> 3) & 2u)) << 4));
+            }
+#pragma unroll
+            for (int q = 0; q < WOC; q++) wa[q] = *(const v4i *)(ws + q * 16 * BK); // 16 rows further the swizzle repeats
+            have = true;
+            // the data must be in registers before the barrier: after it the other waves may start DMA into these bytes
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        }
+    };
+    auto compute = [&](auto KTc) __attribute__((always_inline)) { // KT = the tap of the step whose operands were loaded
+        constexpr int KT = decltype(KTc)::value;
+        if (!have) return;
+        have = false;
+#pragma unroll
+        for (int q = 0; q < WOC; q++)
+#pragma unroll
+            for (int u = 0; u < WPX; u++) acc[q][u] = __builtin_amdgcn_mfma_i32_16x16x64_i8(wa[q], xb[u], acc[q][u], 0, 0, 0);
+        // one piece of the next epoch's patch per step (first ni steps of an epoch), after the MFMAs have been issued: its
+        // address arithmetic then reuses the registers of the fragments instead of competing with them
+        __builtin_amdgcn_sched_barrier(0);
+        if (pvalid) {
+            int n = KT - kstart;
+            if (n < 0) n += TAPS;
+            asm volatile("" : "+s"(n)); // opaque: otherwise the per-piece lane arithmetic of all nine steps is hoisted out of
+                                        // the epoch loop and its results are kept (and spilled) across it
+            if (n < g.ni) {
+                issue_patch(pseg, pfA, pfB, pck, n, pdst);
+                vx += 1;
+            }
+        }
+        if ((KT == TAPS - 1 || KT == 3) && KT == kend) { // a patch epoch of this team ends
+            if (++lc == nchunk) { // ... and with it the tile: requantise, LUT, store
+#pragma unroll
+                for (int u = 0; u < WPX; u++) {
+                    uint32_t pk[WOC];
+                    int a[WOC * 4];
+#pragma unroll
+                    for (int q = 0; q < WOC; q++)
+#pragma unroll
+                        for (int r = 0; r < 4; r++) a[q * 4 + r] = acc[q][u][r];
+                    if (HAS_LUT && p.lut2 != nullptr) requant_pack<WOC * 4, HAS_LUT, true, true, false, true>(a, p.cs, lo, lut128, pk);
+                    else requant_pack<WOC * 4, HAS_LUT, true, true>(a, p.cs, lo, lut128, pk);
+                    __builtin_amdgcn_raw_buffer_store_b128((v4i){(int)pk[0], (int)pk[1], (int)pk[2], (int)pk[3]}, orsrc, out_off(mytile, u), 0, 0);
+                }
+                vx += WPX;
+                lc = 0;
+                mytile += 2;
+                if (++tdone >= nmine) { working = false; pvalid = false; } // (ebuf flips where the next tile begins)
+            }
+        }
+    };
+    auto step = [&](auto KTc) __attribute__((always_inline)) {
+        constexpr int KT = decltype(KTc)::value;
+        // every wave fetches its piece of the weights of step gs + 2 (into the ring slot step gs - 1 used)
+        const bool more = gs + 2 < G;
+        if (more) {
+            constexpr int T2 = (KT + 2) % TAPS, SLOT = (KT + 2) % STG; // epochs are 9 steps: slot = tap mod 3
+            const int ck = KT + 2 >= TAPS ? kn64 : kc64;
+            if (lane < 32) blds16(wrs, wvoff + T2 * C + ck, 0, wring + SLOT * (BN * BK) + wv * 512);
+            va = vx;
+            vx = 0;
+        }
+        load(KTc);
+        if (team == 1) {
+            wait_vmcnt_dyn(more ? va + 1 + vx : 0);
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
+        }
+        compute(KTc);
+        if (team == 0) {
+            wait_vmcnt_dyn(more ? va + 1 + vx : 0);
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
+        }
+        gs++;
+    };
+
+    wait_vmcnt<1>(); // the patch and the weights of step 0 (only the piece of step 1 may still be in flight) ...
+    __builtin_amdgcn_s_barrier(); // ... of every wave
+    asm volatile("" ::: "memory");
+    for (int e = 0; e < NE; e++) {
+        step(std::integral_constant<int, 0>{});
+        step(std::integral_constant<int, 1>{});
+        step(std::integral_constant<int, 2>{});
+        step(std::integral_constant<int, 3>{});
+        step(std::integral_constant<int, 4>{});
+        step(std::integral_constant<int, 5>{});
+        step(std::integral_constant<int, 6>{});
+        step(std::integral_constant<int, 7>{});
+        step(std::integral_constant<int, 8>{});
+        kc = kc + 1 == nchunk ? 0 : kc + 1;
+        kc64 = kc * 64;
+        kn64 = (kc + 1 == nchunk ? 0 : kc + 1) * 64;
+    }
+    wait_vmcnt<0>(); // nothing of this workgroup may still be writing LDS when it ends
+}
+
+// ---------------------------------------------------------------------------------
 // generic kernel: any in_c (the 3-channel stem); register-staged byte gather
 template <int BN>
 __global__ __launch_bounds__(NTHREADS) void conv_i8_generic(const mhip_conv_i8_t p, const long total_pix, const int k64,
@@ -1851,11 +2171,13 @@ static int launch_persist_t(const mhip_conv_i8_t *p, long total_pix, int k64, in
 //   code = 13: one 256 x 128 tile per 8-wave workgroup, 3 stages
 //   code = 14 / 15: tile walker with the weights of its channel tile resident in LDS, 128 / 256 pixels
 //   code = 16: input patch staged once, weights streamed (8 waves, 16 x 16 pixels x 128 channels)
-#define NVARIANTS 16
+//   code = 17: two-team strip kernel (16 waves: two 256-pixel x 128-channel tiles half a tile apart, shared weight ring)
+#define NVARIANTS 17
 struct variant_t {
-    int persist, bpx, stages, patch, ks2, w8, wres, pws;
+    int persist, bpx, stages, patch, ks2, w8, wres, pws, duo;
 };
 static int variant_code(const variant_t &v) {
+    if (v.duo) return 17;
     if (v.pws) return 16;
     if (v.wres) return v.bpx == 256 ? 15 : 14;
     if (v.w8) return 13;
@@ -1864,13 +2186,14 @@ static int variant_code(const variant_t &v) {
     return 1 + (v.persist ? 1 : 0) + (v.bpx == 256 ? 2 : 0) + (v.stages == 3 ? 4 : 0);
 }
 static variant_t variant_of(int code) {
-    if (code == 16) return variant_t{0, 0, 0, 0, 0, 0, 0, 1};
-    if (code == 14 || code == 15) return variant_t{1, code == 15 ? 256 : 128, 2, 0, 0, 0, 1, 0};
-    if (code == 13) return variant_t{0, 256, 3, 0, 0, 1, 0, 0};
-    if (code == 12) return variant_t{0, 128, 2, 0, 1, 0, 0, 0};
-    if (code >= 9) return variant_t{0, 0, 0, code == 10 ? 16 : (code == 9 ? 8 : 4), 0, 0, 0, 0};
+    if (code == 17) return variant_t{0, 0, 0, 0, 0, 0, 0, 0, 1};
+    if (code == 16) return variant_t{0, 0, 0, 0, 0, 0, 0, 1, 0};
+    if (code == 14 || code == 15) return variant_t{1, code == 15 ? 256 : 128, 2, 0, 0, 0, 1, 0, 0};
+    if (code == 13) return variant_t{0, 256, 3, 0, 0, 1, 0, 0, 0};
+    if (code == 12) return variant_t{0, 128, 2, 0, 1, 0, 0, 0, 0};
+    if (code >= 9) return variant_t{0, 0, 0, code == 10 ? 16 : (code == 9 ? 8 : 4), 0, 0, 0, 0, 0};
     const int c = code - 1;
-    return variant_t{c & 1, (c & 2) ? 256 : 128, (c & 4) ? 3 : 2, 0, 0, 0, 0, 0};
+    return variant_t{c & 1, (c & 2) ? 256 : 128, (c & 4) ? 3 : 2, 0, 0, 0, 0, 0, 0};
 }
 
 // ---- patch-staged kernel: geometry, eligibility, launch
@@ -1994,6 +2317,98 @@ static int launch_pws(const mhip_conv_i8_t *p, int k64) {
     return p->lut ? launch_pws_t<true>(p, k64, g) : launch_pws_t<false>(p, k64, g);
 }
 
+// ---- two-team strip kernel (conv_i8_duo): geometry, eligibility, launch
+struct duo_geom_t {
+    duo_args_t a;
+    size_t lds;
+    unsigned grid;
+};
+static int device_cus() {
+    static int cus = 0;
+    if (!cus) {
+        int dev = 0;
+        hipDeviceProp_t prop;
+        if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return 256;
+        cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    }
+    return cus;
+}
+static bool duo_geom(const mhip_conv_i8_t *p, duo_geom_t *g) {
+    const bool direct = !p->out_nchw && ((p->out_c | p->out_pix_stride | p->out_ch_off) & 15) == 0;
+    const int C = p->in_c, hw = p->out_h * p->out_w, taps = p->kh * p->kw;
+    if (!direct || !p->safe || (C != 64 && C != 128 && C != 256) || p->stride_w != 1 || p->stride_h != 1 || p->kh != 3 || p->kw != 3 || p->row_pad != p->kw * C || p->oc_pad % 128 != 0 || p->nseg > 1 || hw < 256 || p->add || persist_out_bytes(p) > 0x7fffffffL ||
+        in_extent_bytes(p) > 0x7fffffffL)
+        return false;
+    const long total = (long)p->frames * hw;
+    const int k64 = p->kh * p->row_pad; // = taps * C, a multiple of 64
+    if (total <= 0 || total > 0x7fffffffL - 512 || (long)p->oc_pad * k64 > 0x7fffffffL || (k64 & 63)) return false;
+    duo_args_t &a = g->a;
+    memset(&a, 0, sizeof(a));
+    a.k64 = k64;
+    a.taps = taps;
+    a.nchunk = C / 64;
+    a.nks = taps * a.nchunk;
+    a.cH = a.nchunk / 2;
+    a.H = a.nchunk == 1 ? a.nks / 2 : a.cH * taps;
+    a.PWP = (p->out_w - 1) * p->stride_w + p->kw;
+    a.total_pix = (unsigned)total;
+    a.ntiles = (unsigned)((total + 255) / 256);
+    a.noc = (unsigned)(p->oc_pad / 128);
+    // most patch rows any tile needs: tiles start at every multiple of 256 modulo the frame size
+    int rows = 0;
+    const unsigned cyc = a.ntiles < (unsigned)hw ? a.ntiles : (unsigned)hw;
+    for (unsigned t = 0; t < cyc; t++) {
+        const long g0 = (long)t * 256, gl = (g0 + 256 < total ? g0 + 256 : total) - 1;
+        const long fA = g0 / hw, fB = gl / hw;
+        const int oyA0 = (int)((g0 - fA * hw) / p->out_w), oyB1 = (int)((gl - fB * hw) / p->out_w);
+        const int oyA1 = fA != fB ? p->out_h - 1 : oyB1;
+        const int n = (oyA1 - oyA0) * p->stride_h + p->kh + (fA != fB ? oyB1 * p->stride_h + p->kh : 0);
+        if (n > rows) rows = n;
+    }
+    // the last tile of the batch (cyc may not reach it)
+    {
+        const long g0 = (long)(a.ntiles - 1) * 256, gl = total - 1;
+        const long fA = g0 / hw, fB = gl / hw;
+        const int oyA0 = (int)((g0 - fA * hw) / p->out_w), oyB1 = (int)((gl - fB * hw) / p->out_w);
+        const int oyA1 = fA != fB ? p->out_h - 1 : oyB1;
+        const int n = (oyA1 - oyA0) * p->stride_h + p->kh + (fA != fB ? oyB1 * p->stride_h + p->kh : 0);
+        if (n > rows) rows = n;
+    }
+    const long units = (long)rows * a.PWP * 4;
+    a.ni = (int)((units + 511) / 512);
+    if (a.ni < 1 || a.ni > taps - 1) return false; // the prefetch of an epoch must end two steps before the epoch does
+    a.patch_bytes = a.ni * 8192;
+    g->lds = LUTB + 128 * 4 + 3 * (size_t)128 * BK + 4 * (size_t)a.patch_bytes;
+    if (g->lds > 160 * 1024) return false;
+    a.dhw = make_fastdiv((unsigned)hw);
+    a.dow = make_fastdiv((unsigned)p->out_w);
+    a.dpwp = make_fastdiv((unsigned)a.PWP);
+    a.out_bytes = (unsigned)persist_out_bytes(p);
+    a.in_bytes = (unsigned)in_extent_bytes(p);
+    a.kw_magic = (65536u + (unsigned)p->kw - 1u) / (unsigned)p->kw;
+    unsigned ngrp = (unsigned)(tune().persist_slots > 0 ? tune().persist_slots : device_cus()) / a.noc;
+    if (ngrp < 1) ngrp = 1;
+    if (ngrp > (a.ntiles + 1) / 2) ngrp = (a.ntiles + 1) / 2;
+    a.ngrp = ngrp;
+    g->grid = a.noc * ngrp;
+    return true;
+}
+template <bool HAS_LUT, bool HAS_ADD>
+static int launch_duo_t(const mhip_conv_i8_t *p, const duo_geom_t &g) {
+    static bool attr = false;
+    if (!attr && hipFuncSetAttribute((const void *)conv_i8_duo<HAS_LUT, HAS_ADD>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
+        return mhip_check(hipErrorUnknown, "conv_i8_duo LDS attribute");
+    attr = true;
+    hipLaunchKernelGGL((conv_i8_duo<HAS_LUT, HAS_ADD>), dim3(g.grid), dim3(1024), g.lds, mhip_stream_native(), *p, g.a);
+    return mhip_check(hipGetLastError(), "conv_i8_duo launch");
+}
+static int launch_duo(const mhip_conv_i8_t *p) {
+    duo_geom_t g;
+    if (!duo_geom(p, &g)) return -1;
+    if (p->add) return p->lut ? launch_duo_t<true, true>(p, g) : launch_duo_t<false, true>(p, g);
+    return p->lut ? launch_duo_t<true, false>(p, g) : launch_duo_t<false, false>(p, g);
+}
+
 static int launch_patch(const mhip_conv_i8_t *p, int k64, int th) {
     patch_geom_t g;
     if (!patch_geom(p, th, &g)) return -1;
@@ -2043,6 +2458,7 @@ static variant_t default_variant(const mhip_conv_i8_t *p, int nks) {
     v.w8 = 0;
     v.wres = 0;
     v.pws = 0;
+    v.duo = 0;
     // wide, shallow k x k layers: the patch-staged kernel wins wherever its double-buffered form fits (measured on the
     // 160x160 and 80x80 layers of yolov5s: 1.25-1.9x over the implicit-GEMM forms)
     patch_geom_t g;
@@ -2109,6 +2525,7 @@ static int launch_variant_t(const mhip_conv_i8_t *p, long total_pix, int k64, co
 }
 
 static int launch_variant(const mhip_conv_i8_t *p, long total_pix, int k64, const variant_t &v) {
+    if (v.duo) return launch_duo(p);
     if (v.pws) return launch_pws(p, k64);
     if (v.patch) return launch_patch(p, k64, v.patch);
     const int bn = p->oc_pad % 128 == 0 ? 128 : (p->oc_pad % 64 == 0 ? 64 : 32);
@@ -2199,6 +2616,8 @@ extern "C" int mhip_conv_i8_variants(const mhip_conv_i8_t *p, int *codes, int ma
         if (v.w8 && (p->oc_pad % 128 != 0 || nks < 3)) continue;
         pws_geom_t pg;
         if (v.pws && !pws_geom(p, &pg)) continue;
+        duo_geom_t dg;
+        if (v.duo && !duo_geom(p, &dg)) continue;
         if (v.wres) {
             const int bn = p->oc_pad % 128 == 0 ? 128 : (p->oc_pad % 64 == 0 ? 64 : 32);
             if (LUTB + 2 * (size_t)v.bpx * BK + (size_t)nks * bn * BK > 80 * 1024) continue;

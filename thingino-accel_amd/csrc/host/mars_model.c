@@ -1581,8 +1581,8 @@ mars_error_t mars_hip_autotune(mars_model_t *model, int reps) {
         if (op->pair_next || (i > 0 && m->ops[i - 1].pair_next)) continue; /* paired launches have one form */
         mhip_conv_i8_t p;
         conv_i8_params(m, op, &p);
-        int codes[16];
-        const int n = mhip_conv_i8_variants(&p, codes, 16);
+        int codes[32];
+        const int n = mhip_conv_i8_variants(&p, codes, 32);
         if (getenv("MARS_VERBOSE") && atoi(getenv("MARS_VERBOSE")) > 1)
             fprintf(stderr, "Mars: autotune layer %d: %dx%dx%d -> %dx%dx%d k%dx%d s%d pixstride %d choff %d lut %d safe %d\n", op->layer,
                     p.in_h, p.in_w, p.in_c, p.out_h, p.out_w, p.out_c, p.kh, p.kw, p.stride_w, p.out_pix_stride, p.out_ch_off,
