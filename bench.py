@@ -47,8 +47,11 @@ def load_dist_helpers():
     return mod
 
 
-def frames_for_rank(D, rank, world, per_gpu, nbytes):
+def frames_for_rank(D, rank, world, per_gpu, nbytes, f32=False):
     from conftest import lcg_frame
+    if f32:  # uniform [0, 1) floats from the same LCG
+        import cases
+        return [cases.f32(0x5EED0000 + f, nbytes // 4, 0.0, 1.0).view(np.uint8) for f in D.shard_frames(per_gpu, rank, world)]
     return [lcg_frame(0x5EED0000 + f, nbytes) for f in D.shard_frames(per_gpu, rank, world)]
 
 
@@ -156,6 +159,11 @@ def main():
                     help="threads of the frames-parallel CPU baseline (0 = every core this process may run on)")
     ap.add_argument("--hw", type=int, default=640)
     ap.add_argument("--width", type=int, default=8, help="channel multiple x16: 8 = yolov5s, 4 = yolov5n")
+    ap.add_argument("--dtype", choices=["int8", "f32"], default="int8",
+                    help="int8 (default): the headline workload.  f32: BASELINE config 5, the yolov5s_float32 twin (NCHW / OIHW "
+                         "float32) with its convolutions on the f32 matrix cores (mars_hip_set_tuning f32_mfma=2); graph only "
+                         "(float heads have no int8 decode), outputs checked against the CPU reference within 1e-4*max(1,|b|)")
+    ap.add_argument("--f32-mode", type=int, default=2, help="--dtype f32: 0 exact order, 1 default policy, 2 matrix cores everywhere")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--vary-scales", action="store_true",
                     help="check run, not the benchmark workload: the twin with per-convolution scales (every fused table "
@@ -200,7 +208,11 @@ def main():
     D = load_dist_helpers()
     import marsfile
     M.nna_init()
-    model_bytes = M.synth_model(width_x16=args.width, input_hw=args.hw, seed=1, vary_scales=args.vary_scales)
+    f32 = args.dtype == "f32"
+    if f32:
+        args.no_tail = True
+        M.set_tuning("f32_mfma", args.f32_mode)
+    model_bytes = M.synth_model(width_x16=args.width, input_hw=args.hw, seed=1, vary_scales=args.vary_scales, float32=f32)
     hdr, tensors, _ = marsfile.parse(model_bytes)
     in_bytes = marsfile.tensor_nbytes(tensors[hdr["inputs"][0]])
     out_ids = list(hdr["outputs"])
@@ -224,7 +236,7 @@ def main():
         dist.broadcast(t, src=0)  # the one collective of the path: weights over xGMI
         torch.cuda.synchronize()
 
-    frames = frames_for_rank(D, rank, world, args.batch, in_bytes)
+    frames = frames_for_rank(D, rank, world, args.batch, in_bytes, f32)
     iv = model.input_view(0)
     for f in range(args.batch):
         iv[f] = frames[f]
@@ -253,6 +265,7 @@ def main():
     # ---- timed region: exactly K steps; in the last `event_steps` of them every launch is bracketed by
     # HIP events on the library's stream (per-kernel durations for the roofline)
     conv_ms = conv_ops = all_ms = 0.0
+    ckind = 1 if f32 else 0  # the dominant kernel family: conv_f32_* or conv_i8_*
     per_kind = {}
     ev_steps = max(1, min(args.event_steps, args.steps))
     barrier()
@@ -265,7 +278,7 @@ def main():
             for op in model.ops():
                 per_kind[op["kind"]] = per_kind.get(op["kind"], 0.0) + op["ms"]
                 all_ms += op["ms"]
-                if op["kind"] == 0:
+                if op["kind"] == ckind:
                     conv_ms += op["ms"]
                     conv_ops += 2.0 * op["macs"] * args.batch
     barrier()
@@ -286,18 +299,43 @@ def main():
                 fh.write("%d %d %d %.4f %.4f %.3f %.1f %.0f\n" % (i, op["layer"], op["kind"], op["ms"], op["macs"] / 1e9,
                                                                  op["bytes"] / 1e6, tops, gbs))
     if rank == 0:
-        n_conv = sum(1 for op in model.ops() if op["kind"] == 0)
-        macs_per_img = sum(op["macs"] for op in model.ops() if op["kind"] == 0)
+        n_conv = sum(1 for op in model.ops() if op["kind"] == ckind)
+        macs_per_img = sum(op["macs"] for op in model.ops() if op["kind"] == ckind)
         bytes_per_img = sum(op["bytes"] for op in model.ops())
         achieved = conv_ops / (conv_ms * 1e-3) / 1e12 if conv_ms > 0 else 0.0
-        conv_bytes_per_img = sum(op["bytes"] for op in model.ops() if op["kind"] == 0)
-        traffic, traffic_src = pmc_traffic(args)
-        floor_ms = sum(max(op["bytes"] * args.batch / 8e12, 2.0 * op["macs"] * args.batch / 5e15)
-                       for op in model.ops() if op["kind"] == 0) * 1e3
-        peak = 5000.0  # dense int8 MFMA, TOP/s: 2x the ~2.5 PF bf16 dense peak (MI355X_MICROARCH.md, Matrix cores)
+        conv_bytes_per_img = sum(op["bytes"] for op in model.ops() if op["kind"] == ckind)
+        traffic, traffic_src = (None, None) if f32 else pmc_traffic(args)
+        mpeak = 157.3e12 if f32 else 5e15  # dense f32 MFMA (v_mfma_f32_16x16x4_f32) / dense int8 MFMA, op/s
+        floor_ms = sum(max(op["bytes"] * args.batch / 8e12, 2.0 * op["macs"] * args.batch / mpeak)
+                       for op in model.ops() if op["kind"] == ckind) * 1e3
+        peak = mpeak / 1e12  # dense int8 MFMA, TOP/s: 2x the ~2.5 PF bf16 dense peak (MI355X_MICROARCH.md, Matrix cores)
+        conv_s = conv_ms / ev_steps * 1e-3
+        hbm_gbs = conv_bytes_per_img * args.batch / conv_s / 1e9 if conv_ms > 0 else 0.0
+        # int8: the conv family's arithmetic intensity (2*MAC / algorithmic byte ~ 260 op/B) is below the machine's ridge
+        # (5000 TOP/s / 8 TB/s = 625 op/B), so its roof is HBM: achieved = algorithmic bytes of the conv launches / their
+        # summed durations; the matrix-roof view of the same launches is reported next to it.  f32: 4-byte activations but
+        # a 32x lower matrix peak (157.3 TF, v_mfma_f32_16x16x4_f32): ridge 20 flop/B against ~65 flop/B -> the roof is MFMA.
+        roof = {"bound": "mfma" if f32 else "hbm",
+                "kernel": ("conv_f32_mfma / conv_f32_kernel" if f32 else "conv_i8_*") + " (%d launches per step)" % n_conv,
+                "achieved": achieved if f32 else hbm_gbs, "peak": peak if f32 else 8000.0, "unit": "TFLOP/s" if f32 else "GB/s",
+                "frac": (achieved / peak) if f32 else hbm_gbs / 8000.0,
+                "traffic": traffic, "traffic_source": traffic_src,
+                "algorithmic_bytes": conv_bytes_per_img * args.batch,
+                "intensity_ops_per_byte": 2.0 * macs_per_img / conv_bytes_per_img if conv_bytes_per_img else None,
+                "mfma_view": {"achieved": achieved, "peak": peak, "unit": "TFLOP/s" if f32 else "TOP/s", "frac": achieved / peak},
+                "hbm_view": {"achieved": hbm_gbs, "peak": 8000.0, "unit": "GB/s", "frac": hbm_gbs / 8000.0},
+                # what the same launches would take with every layer on its own roof: sum over the conv launches of
+                # max(algorithmic bytes / 8 TB/s, 2*MAC / matrix peak); `frac_of_per_layer_floor` = that / measured
+                "per_layer_floor_ms": floor_ms,
+                "frac_of_per_layer_floor": (floor_ms / (conv_ms / ev_steps)) if conv_ms > 0 else 0.0,
+                "event_timed_steps": ev_steps,
+                "conv_ms_per_step": conv_ms / ev_steps,
+                "all_kernels_ms_per_step": all_ms / ev_steps,
+                "ms_per_step_by_kind": {str(k): v / ev_steps for k, v in sorted(per_kind.items())}}
         result = {
-            "metric": "images/sec %s_int8 %dx%d batch%d" % ("yolov5s" if args.width == 8 else "yolov5n" if args.width == 4 else
-                                                         "yolov5(width_x16=%d)" % args.width, args.hw, args.hw, args.batch),
+            "metric": "images/sec %s_%s %dx%d batch%d" % ("yolov5s" if args.width == 8 else "yolov5n" if args.width == 4 else
+                                                        "yolov5(width_x16=%d)" % args.width, "float32" if f32 else "int8",
+                                                        args.hw, args.hw, args.batch),
             "value": world * args.batch * args.steps / dt,
             "unit": "images/s",
             "n_gpus": world,
@@ -309,9 +347,12 @@ def main():
             # 128 per GPU): the same total as 4 GPUs x 256, i.e. strong scaling from there
             "scaling": "strong" if total_batch else "weak",
             "vs_baseline": None,
-            "dtype": "int8",
+            "dtype": "f32" if f32 else "int8",
             "data": "synthetic",
-            "config": {"workload": "synthetic yolov5s_int8.mars twin (mars_synth_model width_x16=%d, seed 1), %dx%d int8 "
+            "config": {"workload": ("synthetic yolov5s_float32.mars twin (mars_synth_model width_x16=%d, seed 1, float32), %dx%d f32 "
+                                    "NCHW frames, batch %d per GPU, graph only, f32_mfma mode %d" %
+                                    (args.width, args.hw, args.hw, args.batch, args.f32_mode)) if f32 else
+                                   "synthetic yolov5s_int8.mars twin (mars_synth_model width_x16=%d, seed 1), %dx%d int8 "
                                    "NHWC frames, batch %d per GPU, decode+NMS tail %s%s" %
                                    (args.width, args.hw, args.hw, args.batch, "off" if args.no_tail else "on",
                                     ", per-convolution scales (check run)" if args.vary_scales else ""),
@@ -320,25 +361,7 @@ def main():
                                            else "configs[1]-class: the metric's batch 256 per GPU" if args.batch == 256 else "custom"),
                        "ranks": world, "sharding": "frames", "collectives_in_forward": 0,
                        "autotuned_launch_variants": bool(args.autotune and not args.no_autotune), "conv_gmac_per_image": macs_per_img / 1e9, "algorithmic_mb_per_image": bytes_per_img / 1e6},
-            # The conv family's arithmetic intensity (2*MAC / algorithmic byte ~ 260 op/B) is below the machine's ridge
-            # (5000 TOP/s / 8 TB/s = 625 op/B), so its roof is HBM: achieved = algorithmic bytes of the conv launches /
-            # their summed durations.  The matrix-roof view of the same launches is reported next to it.
-            "roofline": {"bound": "hbm", "kernel": "conv_i8_* (%d launches per step)" % n_conv,
-                         "achieved": conv_bytes_per_img * args.batch / (conv_ms / ev_steps * 1e-3) / 1e9 if conv_ms > 0 else 0.0,
-                         "peak": 8000.0, "unit": "GB/s",
-                         "frac": (conv_bytes_per_img * args.batch / (conv_ms / ev_steps * 1e-3) / 1e9 / 8000.0) if conv_ms > 0 else 0.0,
-                         "traffic": traffic, "traffic_source": traffic_src,
-                         "algorithmic_bytes": conv_bytes_per_img * args.batch,
-                         "intensity_ops_per_byte": 2.0 * macs_per_img / conv_bytes_per_img if conv_bytes_per_img else None,
-                         "mfma_view": {"achieved": achieved, "peak": peak, "unit": "TOP/s", "frac": achieved / peak},
-                         # what the same launches would take with every layer on its own roof: sum over the conv launches
-                         # of max(algorithmic bytes / 8 TB/s, 2*MAC / 5 POP/s); `frac_of_per_layer_floor` = that / measured
-                         "per_layer_floor_ms": floor_ms,
-                         "frac_of_per_layer_floor": (floor_ms / (conv_ms / ev_steps)) if conv_ms > 0 else 0.0,
-                         "event_timed_steps": ev_steps,
-                         "conv_ms_per_step": conv_ms / ev_steps,
-                         "all_kernels_ms_per_step": all_ms / ev_steps,
-                         "ms_per_step_by_kind": {str(k): v / ev_steps for k, v in sorted(per_kind.items())}},
+            "roofline": roof,
         }
         if world == 1:
             # not the headline value: the same batch INCLUDING host->HBM input copies and HBM->host
@@ -368,10 +391,23 @@ def main():
             result["latency_batch1"] = lat
             m1.close()
         if world == 1 and not args.no_cpu_baseline:
-            base, ref_outs = cpu_baseline(model_bytes, frames, out_ids)
+            base, ref_outs = cpu_baseline(model_bytes, frames, out_ids, max_frames=1 if f32 else 16)
             model.download()
-            same = all(np.array_equal(ref_outs[f][i], model.output_view(i)[f])
-                       for f in range(len(ref_outs)) for i in range(len(out_ids)))
+            if f32:  # north_star: within 1e-4 on the float32 models
+                worst = 0.0
+                for f in range(len(ref_outs)):
+                    for i in range(len(out_ids)):
+                        a = model.output_view(i)[f].view(np.float32).astype(np.float64)
+                        b = ref_outs[f][i].view(np.float32).astype(np.float64)
+                        bad = ~((np.isnan(a) & np.isnan(b)) | (a == b))
+                        if bad.any():
+                            worst = max(worst, float(np.nanmax(np.abs(a - b)[bad] / np.maximum(1.0, np.abs(b)[bad]))))
+                base["gpu_matches_within_1e-4"] = bool(worst <= 1e-4)
+                base["worst_relative_error"] = worst
+                same = worst == 0.0
+            else:
+                same = all(np.array_equal(ref_outs[f][i], model.output_view(i)[f])
+                           for f in range(len(ref_outs)) for i in range(len(out_ids)))
             base["gpu_matches_bit_exact"] = bool(same)
             base["frames_compared"] = len(ref_outs)
             result["cpu_baseline"] = base

@@ -68,7 +68,10 @@ mars_error_t mars_hip_set_fusion(mars_model_t *model, int level);
 
 /* Launch-policy knob of the convolution kernels (process-wide): "persist" (0|1), "persist_stages"
  * (2|3), "persist_maxk", "persist_slots" (0 = what the device holds at once), "stages", "bpx", "variant"
- * (force one launch variant wherever a layer has it).
+ * (force one launch variant wherever a layer has it); "f32_mfma" (float32 convolutions: 0 = the reference's summation
+ * order everywhere, bit-identical; 1 = default: the f32 matrix cores -- fused rounding per tap, inside the 1e-4
+ * tolerance of the float32 models -- for every convolution from which no byte-wise MAXPOOL over float bytes is
+ * reachable; 2 = matrix cores everywhere).
  * The defaults are the measured optimum; tests use "persist_slots" to force the multi-tile walk
  * of the persistent kernel on small inputs.  Results never depend on these.  0 = ok, -1 = unknown key. */
 int mars_hip_set_tuning(const char *key, int value);

@@ -51,6 +51,8 @@ typedef struct {
     /* geometry (conv / pool / concat / upsample share these) */
     int in_h, in_w, in_c, out_h, out_w, out_c, kh, kw, sh, sw, pt, pl;
     int nchw, relu, is_mul, is_f32, leaky, safe;
+    int silu_f32;  /* conv_f32 with the float SIGMOID + MUL pair (ONNX SiLU) folded into its epilogue */
+    int f32_exact; /* conv_f32 whose result reaches a byte-wise MAXPOOL over float bytes: keeps the reference's summation order */
     int variant; /* conv_i8 launch variant pinned by mars_hip_autotune (0 = default policy) */
     int add_t; float add_s_conv, add_s_other, add_inv; /* conv_i8 with a residual Add folded in: other operand (tensor index + 1, 0 = none) */
     int nseg, seg_t[4], seg_c[4], seg_up;

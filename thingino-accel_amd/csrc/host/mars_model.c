@@ -623,6 +623,42 @@ static void fuse_silu(mars_model_ext_t *m) {
     free(writers);
 }
 
+/* float32 form of the same chain: conv_f32 -> SIGMOID (float, :742-749) -> MUL (float, :807-816).  The epilogue evaluates
+ * s = 1.0f / (1.0f + expf(-v)), out = v * s with the reference's roundings and this image's libm expf (expf_exact.h), so
+ * the fused result is the same float bit for bit; the two intermediates are never written (5 of the 7 float passes over
+ * the tensor disappear: the element-wise layers were 36 % of the float32 graph's time). */
+static void fuse_silu_f32(mars_model_ext_t *m) {
+    const int nt = (int)m->pub.header.num_tensors;
+    int *readers = (int *)calloc((size_t)nt + 1, sizeof(int));
+    int *writers = (int *)calloc((size_t)nt + 1, sizeof(int));
+    if (!readers || !writers) { free(readers); free(writers); return; }
+    for (int i = 0; i < m->n_ops; i++) {
+        for (int k = 0; k < m->ops[i].n_in; k++)
+            if (m->ops[i].t_in[k] >= 0) readers[m->ops[i].t_in[k]]++;
+        if (m->ops[i].t_out >= 0) writers[m->ops[i].t_out]++;
+    }
+    for (int i = 0; i + 2 < m->n_ops; i++) {
+        mars_op_t *c = &m->ops[i], *s = &m->ops[i + 1], *mu = &m->ops[i + 2];
+        if (c->kind != OP_CONV_F32 || s->kind != OP_SIGMOID_F32 || mu->kind != OP_BINARY_F32 || !mu->is_mul) continue;
+        const int q1 = c->t_out, q2 = s->t_out, q3 = mu->t_out;
+        if (s->t_in[0] != q1 || q1 == q2 || q2 == q3 || q1 == q3 || q3 == c->t_in[0]) continue;
+        if (!((mu->t_in[0] == q1 && mu->t_in[1] == q2) || (mu->t_in[0] == q2 && mu->t_in[1] == q1))) continue;
+        if (readers[q1] != 2 || readers[q2] != 1 || writers[q1] != 1 || writers[q2] != 1 || writers[q3] != 1) continue;
+        if (m->mt[q1].io_out || m->mt[q2].io_out || m->mt[q1].io_in || m->mt[q2].io_in || m->mt[q3].is_weight) continue;
+        const size_t n1 = (size_t)c->out_h * c->out_w * c->out_c;
+        if (s->n != n1 || mu->n != n1) continue; /* the chain must cover exactly the conv's result */
+        c->silu_f32 = 1;
+        c->t_out = q3;
+        touch(m, q3, n1 * 4);
+        m->mt[q1].needed = 0;
+        m->mt[q2].needed = 0;
+        memmove(&m->ops[i + 1], &m->ops[i + 3], (size_t)(m->n_ops - i - 3) * sizeof(mars_op_t));
+        m->n_ops -= 2;
+    }
+    free(readers);
+    free(writers);
+}
+
 /* ------------------------------------------------------------- zero-copy concat
  * A concat input that (a) has exactly one producer launch of a kind that can write a channel slice
  * (int8 NHWC conv, int8 add/mul, max-pool, upsample), (b) is read by nothing but that concat, and
@@ -950,6 +986,38 @@ static void fuse_pool_chains(mars_model_ext_t *m) {
     m->n_ops = w;
 }
 
+/* float32 graphs: which convolutions may take the f32 matrix cores (fused rounding per tap, inside the 1e-4 tolerance)?
+ * The reference's MAXPOOL runs int8 byte logic on whatever bytes it is given (mars_runtime.c:919-957), and so does the
+ * fused-ReLU clamp of a float convolution (:700-707): over float bytes both are DISCONTINUOUS functions of their input (a
+ * last-bit change can flip which byte wins / whether a mantissa byte is zeroed: measured, 1 value in 16 384 left the
+ * tolerance), so every convolution from which one of them can be reached keeps the reference's summation order (conv_f32_kernel, bit-identical); byte-copying
+ * layers (concat, upsample) and the float element-wise layers only pass small differences on. */
+static void f32_policy(mars_model_ext_t *m) {
+    const int nt = (int)m->pub.header.num_tensors;
+    unsigned char *hot = (unsigned char *)calloc((size_t)nt + 1, 1);
+    if (!hot) {
+        for (int i = 0; i < m->n_ops; i++) m->ops[i].f32_exact = 1;
+        return;
+    }
+    for (int i = m->n_ops - 1; i >= 0; i--) {
+        mars_op_t *o = &m->ops[i];
+        int reach = 0;
+        if (o->kind == OP_MAXPOOL && o->t_in[0] >= 0 && m->pub.tensors[o->t_in[0]].desc.dtype == MARS_DTYPE_FLOAT32) reach = 1;
+        if (o->kind == OP_RELU_BYTES && o->t_out >= 0) { /* the fused-ReLU byte clamp over float bytes (:700-707): in place */
+            hot[o->t_out] = 1;
+            continue;
+        }
+        if (o->t_out >= 0 && hot[o->t_out]) reach = 1;
+        for (int k = 0; k < o->chain_n; k++)
+            if (o->chain_out[k] >= 0 && hot[o->chain_out[k]]) reach = 1;
+        if (!reach) continue;
+        for (int k = 0; k < o->n_in; k++)
+            if (o->t_in[k] >= 0) hot[o->t_in[k]] = 1;
+        if (o->kind == OP_CONV_F32) o->f32_exact = 1;
+    }
+    free(hot);
+}
+
 /* ------------------------------------------------------------------- load */
 /* Ragged pixel rows of graph outputs (the 255-channel YOLO heads) are kept at a 16-byte-aligned pitch on the device:
  * the producing convolution then takes the aligned epilogue (16-byte stores straight from registers, every launch
@@ -1055,6 +1123,7 @@ static mars_error_t build_plan(mars_model_ext_t *m) {
     if (m->plan_err != MARS_OK) return (mars_error_t)m->plan_err;
     if (m->fusion >= 1) {
         fuse_silu(m);
+        fuse_silu_f32(m);
         fuse_add(m);
         if (!m->no_vconcat) virtual_concat(m);
         elide_concat(m);
@@ -1062,6 +1131,7 @@ static mars_error_t build_plan(mars_model_ext_t *m) {
         pair_convs(m);
         pad_output_rows(m);
     }
+    f32_policy(m);
     return (mars_error_t)m->plan_err;
 }
 
@@ -1357,6 +1427,11 @@ static int launch_op(mars_model_ext_t *m, mars_op_t *op) {
             p.in_h = op->in_h; p.in_w = op->in_w; p.in_c = op->in_c;
             p.out_h = op->out_h; p.out_w = op->out_w; p.out_c = op->out_c;
             p.kh = op->kh; p.kw = op->kw; p.stride_h = op->sh; p.stride_w = op->sw; p.pad_top = op->pt; p.pad_left = op->pl;
+            p.silu = op->silu_f32;
+            {
+                const int mode = mhip_conv_f32_mode(-1);
+                p.use_mfma = mode == 2 || (mode == 1 && !op->f32_exact);
+            }
             return mhip_conv_f32(&p);
         }
         case OP_RELU_BYTES:
@@ -1562,7 +1637,14 @@ mars_error_t mars_hip_set_fusion(mars_model_t *model, int level) {
     return e;
 }
 
-int mars_hip_set_tuning(const char *key, int value) { return mhip_conv_i8_tune(key, value); }
+int mars_hip_set_tuning(const char *key, int value) {
+    if (key && !strcmp(key, "f32_mfma")) { /* 0 exact everywhere, 1 matrix cores where provably safe (default), 2 everywhere */
+        if (value < 0 || value > 2) return -1;
+        mhip_conv_f32_mode(value);
+        return 0;
+    }
+    return mhip_conv_i8_tune(key, value);
+}
 
 /* Time every launch variant of every int8 convolution on the device, at the current batch, and pin the fastest
  * (all variants write the same bytes; the layer's real buffers are used, so the tensors stay valid). */

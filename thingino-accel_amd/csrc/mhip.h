@@ -110,8 +110,14 @@ typedef struct {
     int frames;
     int in_h, in_w, in_c, out_h, out_w, out_c;
     int kh, kw, stride_h, stride_w, pad_top, pad_left;
+    int silu;     /* fused conv -> SIGMOID -> MUL chain (float forms): out = v * (1 / (1 + expf(-v))), libm-exact expf */
+    int use_mfma; /* 0: reference summation order, bit-identical; 1: implicit GEMM on v_mfma_f32_16x16x4_f32 (fused
+                     rounding per tap: inside the 1e-4 tolerance of the float32 models, not bit-equal) */
 } mhip_conv_f32_t;
 int mhip_conv_f32(const mhip_conv_f32_t *p);
+/* policy knob: 0 never the matrix cores, 1 (default) wherever the host proves it safe, 2 everywhere.  set < 0 only
+ * reads; returns the mode in force (first call reads MARS_HIP_F32_MFMA) */
+int mhip_conv_f32_mode(int set);
 
 /* ---- element-wise (eltwise.hip).  n = elements per frame. */
 int mhip_lut_i8(const int8_t *in, size_t in_stride, int8_t *out, size_t out_stride, int frames,
