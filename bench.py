@@ -371,6 +371,26 @@ def main():
             for _ in range(2):
                 model.run()
             result["pcie_inclusive_images_per_s"] = 2 * args.batch / (time.perf_counter() - t1)
+            if not f32:
+                # the same through the double-buffered path (mars_hip_pipe_*: upload k+1 / graph k / tail k / download k-1
+                # overlap): frames in over PCIe every batch; back come the detections only, or the raw head tensors too.
+                # The staging buffers are filled once (a camera would DMA into them): the host-side fill is the caller's.
+                stacked = np.stack(frames)
+                for key, dl in (("pipelined_detections_images_per_s", False), ("pipelined_raw_outputs_images_per_s", True)):
+                    model.pipe_open(download_outputs=dl, detect=True, det_outputs=outputs, thresh=0.45)
+                    for _ in range(3):
+                        model.pipe_input_view(0)[:] = stacked
+                        model.pipe_submit()
+                    nb = 8
+                    t1 = time.perf_counter()
+                    for _ in range(nb):
+                        model.pipe_wait(copy=False)
+                        model.pipe_submit()
+                    dtp = time.perf_counter() - t1
+                    for _ in range(3):
+                        model.pipe_wait(copy=False)
+                    model.pipe_close()
+                    result[key] = nb * args.batch / dtp
         if world == 1:
             # the reference's real call pattern (mars_test.c:33-148): ONE frame per mars_run.  Latency of the graph alone
             # (input resident) and through mars_run() (H2D + graph + D2H), median of 20

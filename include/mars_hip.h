@@ -126,6 +126,34 @@ mars_error_t mars_hip_detect(mars_model_t *model, const int *output_indices, int
 mars_error_t mars_hip_detect_device(mars_model_t *model, const int *output_indices, int n_outputs,
                                     float nms_thresh);
 
+/* ------------------------------------------------------- pipelined host I/O */
+/* mars_run() pays host->HBM copy, graph and HBM->host copy one after the other.  With an open pipe up to three batches are
+ * in flight: batch k+1 uploads and batch k-1 downloads (on their own streams, from / into their own buffers) while batch k
+ * is computed.  Usage (batch size = mars_hip_set_batch, unchanged while the pipe is open):
+ *     mars_hip_pipe_open(model, &opts);
+ *     for every batch:  fill mars_hip_pipe_input(model, 0)  ->  mars_hip_pipe_submit(model)
+ *                       [from the third batch on]  mars_hip_pipe_wait(model, outs, &dets, &counts)  -> use results
+ *     mars_hip_pipe_wait() once more per batch still in flight; mars_hip_pipe_close(model).
+ * Results of a batch are bit for bit what mars_run() / mars_hip_detect() give for the same input. */
+typedef struct {
+    int download_outputs;   /* 1: the graph outputs come back (dense [batch][frame bytes] each, as mars_run leaves them) */
+    int detect;             /* 1: decode + NMS on the device, detections come back ([batch][MARS_YOLO_MAX_DET] + counts) */
+    int det_outputs[4];     /* detect: output indices forming the prediction list, as for mars_hip_detect */
+    int n_det_outputs;
+    float nms_thresh;
+} mars_hip_pipe_opts_t;
+mars_error_t mars_hip_pipe_open(mars_model_t *model, const mars_hip_pipe_opts_t *opts);
+/* pinned host buffer ([batch][frame bytes]) to fill for the NEXT submit; changes after every submit */
+void *mars_hip_pipe_input(mars_model_t *model, int input_index);
+/* queue upload + graph (+ tail) + download of the buffer just filled; returns at once.  At most three batches may be
+ * in flight: MARS_ERR_ALLOC_FAILED asks for a mars_hip_pipe_wait first */
+mars_error_t mars_hip_pipe_submit(mars_model_t *model);
+/* block until the OLDEST submitted batch is complete.  outputs (may be NULL): array of mars_get_num_outputs() pointers,
+ * set to that batch's host copies (download_outputs); dets / counts (may be NULL): its detections (detect).  The
+ * buffers stay valid until the third submit after this call. */
+mars_error_t mars_hip_pipe_wait(mars_model_t *model, const void **outputs, const mars_det_t **dets, const int **counts);
+void mars_hip_pipe_close(mars_model_t *model);
+
 /* --------------------------------------------------- synthetic .mars writer */
 /* Well-formed graphs (NHWC activations, OHWI int8 weights, int32 bias; or
  * NCHW/OIHW float32) with the YOLOv5 layer sequence and seeded weights, for

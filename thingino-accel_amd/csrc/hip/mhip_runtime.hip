@@ -12,13 +12,24 @@
 
 static hipStream_t g_stream = nullptr;
 static hipStream_t g_aux = nullptr;   // detection tail runs here, beside the next batch's graph
-static int g_use_aux = 0;
+static hipStream_t g_up = nullptr;    // pipelined I/O: host -> HBM copies of the NEXT batch (created on first use)
+static hipStream_t g_down = nullptr;  // pipelined I/O: HBM -> host copies of the PREVIOUS batch
+static int g_use_aux = 0;             // current stream of the launchers: 0 main, 1 aux, 2 upload, 3 download
 static int g_ready = 0;
 static int g_device = -1;
 static char g_err[256] = "";
 static void *g_zero_page = nullptr; // 256 zero bytes in HBM: DMA source for out-of-image conv taps
 
-extern "C" hipStream_t mhip_stream_native(void) { return g_use_aux ? g_aux : g_stream; }
+static hipStream_t stream_of(int which) {
+    if (which == 1) return g_aux;
+    if (which == 2 || which == 3) {
+        hipStream_t &st = which == 2 ? g_up : g_down;
+        if (!st && hipStreamCreateWithFlags(&st, hipStreamNonBlocking) != hipSuccess) st = nullptr;
+        return st ? st : g_stream;
+    }
+    return g_stream;
+}
+extern "C" hipStream_t mhip_stream_native(void) { return stream_of(g_use_aux); }
 
 extern "C" int mhip_check(hipError_t e, const char *what) {
     if (e == hipSuccess) return 0;
@@ -72,6 +83,9 @@ extern "C" void mhip_shutdown(void) {
     (void)hipStreamSynchronize(g_aux);
     (void)hipStreamDestroy(g_stream);
     (void)hipStreamDestroy(g_aux);
+    if (g_up) { (void)hipStreamSynchronize(g_up); (void)hipStreamDestroy(g_up); }
+    if (g_down) { (void)hipStreamSynchronize(g_down); (void)hipStreamDestroy(g_down); }
+    g_up = g_down = nullptr;
     g_aux = nullptr;
     g_use_aux = 0;
     if (g_zero_page) (void)hipFree(g_zero_page);
@@ -99,14 +113,18 @@ extern "C" void *mhip_stream(void) { return (void *)g_stream; }
 extern "C" int mhip_sync(void) {
     int rc = mhip_check(hipStreamSynchronize(g_stream), "hipStreamSynchronize");
     int rc2 = mhip_check(hipStreamSynchronize(g_aux), "hipStreamSynchronize aux");
+    if (g_up && mhip_check(hipStreamSynchronize(g_up), "hipStreamSynchronize upload") && !rc) rc = -1;
+    if (g_down && mhip_check(hipStreamSynchronize(g_down), "hipStreamSynchronize download") && !rc) rc = -1;
     return rc ? rc : rc2;
 }
 // every launcher enqueues on "the current stream": main by default, aux while selected
 extern "C" void mhip_select_aux(int on) { g_use_aux = on ? 1 : 0; }
-// make stream `aux ? aux : main` wait for an event recorded elsewhere
-extern "C" int mhip_stream_wait(int aux, void *ev) {
-    return mhip_check(hipStreamWaitEvent(aux ? g_aux : g_stream, (hipEvent_t)ev, 0), "hipStreamWaitEvent");
+extern "C" void mhip_select_stream(int which) { g_use_aux = which >= 0 && which <= 3 ? which : 0; }
+// make a stream (0 main, 1 aux, 2 upload, 3 download) wait for an event recorded elsewhere
+extern "C" int mhip_stream_wait(int which, void *ev) {
+    return mhip_check(hipStreamWaitEvent(stream_of(which), (hipEvent_t)ev, 0), "hipStreamWaitEvent");
 }
+extern "C" int mhip_event_sync(void *ev) { return mhip_check(hipEventSynchronize((hipEvent_t)ev), "hipEventSynchronize"); }
 
 extern "C" void *mhip_malloc(size_t bytes) {
     void *p = nullptr;

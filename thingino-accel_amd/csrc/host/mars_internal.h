@@ -31,6 +31,7 @@ enum {
 };
 
 #define NO_OFF ((size_t)-1)
+#define MARS_MAX_IO 4 /* graph inputs / outputs (header arrays of the .mars format) */
 
 typedef struct {
     size_t bytes;    /* numel * elemsize by shape */
@@ -102,7 +103,13 @@ typedef struct {
     int det_lut_n;
     void *ev_graph_done, *ev_tail_done; /* main->aux and aux->main hand-offs */
     int tail_pending;
+    void *pipe; /* double-buffered I/O state (mars_pipe.c), NULL when closed */
 } mars_model_ext_t;
+
+/* detection tail pieces shared with the pipelined I/O (mars_yolo.c) */
+mars_error_t mars_detect_prepare(mars_model_ext_t *m, const int *output_indices, int n_outputs);
+int mars_detect_launch(mars_model_ext_t *m, const int *output_indices, int n_outputs, float nms_thresh, void *dets_dev,
+                       int *counts_dev);
 
 /* shared host helpers (mars_model.c) */
 int32_t mars_trunc_x86(float x);

@@ -1089,6 +1089,7 @@ static void free_ops(mars_model_ext_t *m) {
 void mars_free(mars_model_t *model) {
     if (!model) return;
     mars_model_ext_t *m = (mars_model_ext_t *)model;
+    if (m->pipe) mars_hip_pipe_close(model);
     if (mhip_ready()) mhip_sync();
     free_device_state(m);
     free_ops(m);
@@ -1157,6 +1158,7 @@ static mars_error_t upload_params(mars_model_ext_t *m) {
 
 static mars_error_t alloc_batch(mars_model_ext_t *m, int n) {
     const uint32_t nt = m->pub.header.num_tensors;
+    if (m->pipe) mars_hip_pipe_close(&m->pub); /* its slots were sized for the old batch */
     if (mhip_sync()) return MARS_ERR_LAYER_FAILED;
     /* segmented (virtual concat) convolutions address their output with 32-bit buffer offsets: if this batch makes
      * an output tensor of one of them 2 GiB or more, plan again with materialised concats */

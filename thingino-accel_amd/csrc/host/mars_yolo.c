@@ -36,6 +36,59 @@ static int ensure_det_buffers(mars_model_ext_t *m, int frames) {
     return 0;
 }
 
+/* decode tables of the listed outputs (they depend only on the output scales): built and uploaded once.  Synchronises. */
+mars_error_t mars_detect_prepare(mars_model_ext_t *m, const int *output_indices, int n_outputs) {
+    mars_model_t *model = &m->pub;
+    if (!output_indices || n_outputs <= 0 || n_outputs > 4) return MARS_ERR_INVALID_TENSOR;
+    if (!m->det_lut_dev) m->det_lut_dev = (float *)mhip_malloc(4 * 768 * sizeof(float));
+    if (!m->det_lut_dev) return MARS_ERR_ALLOC_FAILED;
+    int lut_stale = m->det_lut_n != n_outputs;
+    for (int s = 0; s < n_outputs; s++) {
+        mars_runtime_tensor_t *t = mars_get_output(model, output_indices[s]);
+        if (!t || t->desc.dtype != MARS_DTYPE_INT8) return MARS_ERR_INVALID_TENSOR;
+        if (memcmp(&m->det_lut_scale[s], &t->desc.scale, sizeof(float)) != 0) lut_stale = 1;
+    }
+    if (!lut_stale) return MARS_OK;
+    float lut[4 * 768];
+    for (int s = 0; s < n_outputs; s++) {
+        float sc = mars_get_output(model, output_indices[s])->desc.scale;
+        build_decode_lut(sc, lut + s * 768);
+        m->det_lut_scale[s] = sc;
+    }
+    if (mhip_sync()) return MARS_ERR_LAYER_FAILED;
+    if (mhip_h2d_async(m->det_lut_dev, lut, (size_t)n_outputs * 768 * sizeof(float)) || mhip_sync())
+        return MARS_ERR_LAYER_FAILED; /* `lut` is on this stack frame */
+    m->det_lut_n = n_outputs;
+    return MARS_OK;
+}
+
+/* decode + NMS of the current batch on the CURRENT stream, from the output tensors' current device buffers into
+ * dets_dev [batch][1000] / counts_dev [2 * batch].  Tables must be prepared.  0 or a launch error. */
+int mars_detect_launch(mars_model_ext_t *m, const int *output_indices, int n_outputs, float nms_thresh, void *dets_dev,
+                       int *counts_dev) {
+    mars_model_t *model = &m->pub;
+    mhip_detect_t p;
+    memset(&p, 0, sizeof(p));
+    for (int s = 0; s < n_outputs; s++) {
+        if (output_indices[s] < 0 || (uint32_t)output_indices[s] >= model->header.num_outputs) return -1;
+        uint32_t ti = model->header.output_tensor_ids[output_indices[s]];
+        if (ti >= model->header.num_tensors || !m->mt[ti].dev) return -1;
+        p.pred[s] = (const int8_t *)m->mt[ti].dev;
+        p.stride[s] = m->mt[ti].stride;
+        p.pix_c[s] = m->mt[ti].pix_c; p.pix_stride[s] = m->mt[ti].pix_stride;
+        p.npred[s] = (int)(m->mt[ti].bytes / 85); /* rows of 85 int8: x,y,w,h,obj,80 classes */
+        p.lut[s] = m->det_lut_dev + s * 768;
+    }
+    p.nseg = n_outputs;
+    p.frames = m->batch;
+    p.nms_thresh = nms_thresh;
+    p.dets = dets_dev;
+    p.counts = counts_dev;
+    p.raw_counts = counts_dev + m->batch;
+    p.do_nms = 1;
+    return mhip_detect(&p);
+}
+
 mars_error_t mars_hip_detect_device(mars_model_t *model, const int *output_indices, int n_outputs, float nms_thresh) {
     if (!model || !output_indices || n_outputs <= 0 || n_outputs > 4) return MARS_ERR_INVALID_TENSOR;
     mars_model_ext_t *m = (mars_model_ext_t *)model;
@@ -44,40 +97,13 @@ mars_error_t mars_hip_detect_device(mars_model_t *model, const int *output_indic
         if (ensure_det_buffers(m, m->batch)) return MARS_ERR_ALLOC_FAILED;
         m->det_lut_n = 0;
     }
-    mhip_detect_t p;
-    memset(&p, 0, sizeof(p));
-    int lut_stale = m->det_lut_n != n_outputs;
     for (int s = 0; s < n_outputs; s++) {
-        mars_runtime_tensor_t *t = mars_get_output(model, output_indices[s]);
-        if (!t) return MARS_ERR_INVALID_TENSOR;
+        if (!mars_get_output(model, output_indices[s])) return MARS_ERR_INVALID_TENSOR;
         uint32_t ti = model->header.output_tensor_ids[output_indices[s]];
-        if (!m->mt[ti].dev || t->desc.dtype != MARS_DTYPE_INT8) return MARS_ERR_INVALID_TENSOR;
-        p.pred[s] = (const int8_t *)m->mt[ti].dev;
-        p.stride[s] = m->mt[ti].stride;
-        p.pix_c[s] = m->mt[ti].pix_c; p.pix_stride[s] = m->mt[ti].pix_stride;
-        p.npred[s] = (int)(m->mt[ti].bytes / 85); /* rows of 85 int8: x,y,w,h,obj,80 classes */
-        p.lut[s] = m->det_lut_dev + s * 768;
-        if (memcmp(&m->det_lut_scale[s], &t->desc.scale, sizeof(float)) != 0) lut_stale = 1;
+        if (!m->mt[ti].dev) return MARS_ERR_INVALID_TENSOR;
     }
-    if (lut_stale) { /* tables depend only on the output scales: built and uploaded once */
-        float lut[4 * 768];
-        for (int s = 0; s < n_outputs; s++) {
-            float sc = mars_get_output(model, output_indices[s])->desc.scale;
-            build_decode_lut(sc, lut + s * 768);
-            m->det_lut_scale[s] = sc;
-        }
-        if (mhip_sync()) return MARS_ERR_LAYER_FAILED;
-        if (mhip_h2d_async(m->det_lut_dev, lut, (size_t)n_outputs * 768 * sizeof(float)) || mhip_sync())
-            return MARS_ERR_LAYER_FAILED; /* `lut` is on this stack frame */
-        m->det_lut_n = n_outputs;
-    }
-    p.nseg = n_outputs;
-    p.frames = m->batch;
-    p.nms_thresh = nms_thresh;
-    p.dets = m->det_dev;
-    p.counts = m->det_counts_dev;
-    p.raw_counts = m->det_counts_dev + m->batch;
-    p.do_nms = 1;
+    mars_error_t e = mars_detect_prepare(m, output_indices, n_outputs);
+    if (e != MARS_OK) return e;
     /* The tail runs on the auxiliary stream: it starts when the graph launches enqueued so far
      * have finished, and the NEXT run's output-writing layers wait for it (mars_hip_run_device_async),
      * so decode/sort/NMS of batch k overlap the convolutions of batch k+1. */
@@ -87,7 +113,7 @@ mars_error_t mars_hip_detect_device(mars_model_t *model, const int *output_indic
     if (mhip_event_record(m->ev_graph_done)) return MARS_ERR_LAYER_FAILED;
     mhip_select_aux(1);
     int rc = mhip_stream_wait(1, m->ev_graph_done);
-    if (!rc) rc = mhip_detect(&p);
+    if (!rc) rc = mars_detect_launch(m, output_indices, n_outputs, nms_thresh, m->det_dev, m->det_counts_dev);
     if (!rc) rc = mhip_event_record(m->ev_tail_done);
     mhip_select_aux(0);
     if (rc) return MARS_ERR_LAYER_FAILED;

@@ -80,6 +80,11 @@ class SynthOpts(C.Structure):
                 ("nchw_int8", C.c_int), ("seed", C.c_uint), ("tiny", C.c_int), ("vary_scales", C.c_int)]
 
 
+class PipeOpts(C.Structure):
+    _fields_ = [("download_outputs", C.c_int), ("detect", C.c_int), ("det_outputs", C.c_int * 4), ("n_det_outputs", C.c_int),
+                ("nms_thresh", C.c_float)]
+
+
 assert C.sizeof(MarsHeader) == 76 and C.sizeof(MarsTensorDesc) == 124
 
 # every symbol the headers under include/ declare (checked by tests/test_abi.py)
@@ -105,7 +110,8 @@ EXPORTS = {
                    "mars_hip_set_profiling", "mars_hip_num_ops", "mars_hip_op_info", "mars_hip_stream",
                    "mars_hip_load_memory_ex", "mars_hip_param_arena", "mars_yolo_parse_output", "mars_yolo_nms",
                    "mars_hip_detect", "mars_hip_detect_device", "mars_synth_model", "mars_hip_set_tuning", "mars_hip_autotune", "mars_yolo_letterbox",
-                   "mars_hip_preprocess", "mars_hip_tensor_frame_bytes", "mars_hip_tensor_byte_size"],
+                   "mars_hip_preprocess", "mars_hip_tensor_frame_bytes", "mars_hip_tensor_byte_size", "mars_hip_pipe_open",
+                   "mars_hip_pipe_input", "mars_hip_pipe_submit", "mars_hip_pipe_wait", "mars_hip_pipe_close"],
 }
 
 _lib = None
@@ -152,6 +158,13 @@ def lib():
     L.mars_hip_tensor_frame_bytes.argtypes = [P(MarsModel), C.c_int]
     L.mars_hip_tensor_byte_size.restype = C.c_size_t
     L.mars_hip_tensor_byte_size.argtypes = [P(MarsTensorDesc)]
+    L.mars_hip_pipe_open.argtypes = [P(MarsModel), P(PipeOpts)]
+    L.mars_hip_pipe_input.restype = C.c_void_p
+    L.mars_hip_pipe_input.argtypes = [P(MarsModel), C.c_int]
+    L.mars_hip_pipe_submit.argtypes = [P(MarsModel)]
+    L.mars_hip_pipe_wait.argtypes = [P(MarsModel), P(C.c_void_p), P(C.c_void_p), P(C.c_void_p)]
+    L.mars_hip_pipe_close.argtypes = [P(MarsModel)]
+    L.mars_hip_pipe_close.restype = None
     for n in ("mars_hip_upload_inputs", "mars_hip_run_device", "mars_hip_run_device_async",
               "mars_hip_download_outputs", "mars_hip_get_batch", "mars_hip_num_ops"):
         getattr(L, n).argtypes = [P(MarsModel)]
@@ -372,6 +385,52 @@ class Model:
         rc = lib().mars_hip_detect_device(self.p, idx, len(outputs), thresh)
         if rc != MARS_OK:
             raise MarsError(rc, "mars_hip_detect_device")
+
+    # -- pipelined host I/O (mars_hip_pipe_*)
+    def pipe_open(self, download_outputs=True, detect=False, det_outputs=(0,), thresh=0.45):
+        o = PipeOpts(int(download_outputs), int(detect), (C.c_int * 4)(*(list(det_outputs) + [0] * (4 - len(det_outputs)))),
+                     len(det_outputs) if detect else 0, thresh)
+        rc = lib().mars_hip_pipe_open(self.p, C.byref(o))
+        if rc != MARS_OK:
+            raise MarsError(rc, "mars_hip_pipe_open")
+        self._pipe = (bool(download_outputs), bool(detect))
+
+    def pipe_input_view(self, i=0):
+        """uint8 view [batch, frame_bytes] of the staging buffer the NEXT pipe_submit() uploads"""
+        ptr = lib().mars_hip_pipe_input(self.p, i)
+        n = lib().mars_hip_tensor_frame_bytes(self.p, self.header.input_tensor_ids[i]) * self.batch
+        return np.ctypeslib.as_array(C.cast(ptr, C.POINTER(C.c_uint8)), shape=(n,)).reshape(self.batch, -1)
+
+    def pipe_submit(self):
+        rc = lib().mars_hip_pipe_submit(self.p)
+        if rc != MARS_OK:
+            raise MarsError(rc, "mars_hip_pipe_submit")
+
+    def pipe_wait(self, copy=True):
+        """-> (outputs: list of uint8 [batch, frame_bytes] or None, dets: list of record arrays per frame or None)"""
+        nout = self.header.num_outputs
+        outs = (C.c_void_p * max(nout, 1))()
+        dets, counts = C.c_void_p(), C.c_void_p()
+        rc = lib().mars_hip_pipe_wait(self.p, outs, C.byref(dets), C.byref(counts))
+        if rc != MARS_OK:
+            raise MarsError(rc, "mars_hip_pipe_wait")
+        want_out, want_det = self._pipe
+        ro = rd = None
+        if want_out:
+            ro = []
+            for i in range(nout):
+                n = lib().mars_hip_tensor_frame_bytes(self.p, self.header.output_tensor_ids[i]) * self.batch
+                a = np.ctypeslib.as_array(C.cast(outs[i], C.POINTER(C.c_uint8)), shape=(n,)).reshape(self.batch, -1)
+                ro.append(a.copy() if copy else a)
+        if want_det:
+            d = np.ctypeslib.as_array(C.cast(dets.value, C.POINTER(C.c_uint8)),
+                                      shape=(self.batch * MAX_DET * DET_DTYPE.itemsize,)).view(DET_DTYPE).reshape(self.batch, MAX_DET)
+            c = np.ctypeslib.as_array(C.cast(counts.value, C.POINTER(C.c_int32)), shape=(self.batch,))
+            rd = [d[f, :c[f]].copy() for f in range(self.batch)] if copy else (d, c)
+        return ro, rd
+
+    def pipe_close(self):
+        lib().mars_hip_pipe_close(self.p)
 
     def close(self):
         if self.p:
