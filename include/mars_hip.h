@@ -71,7 +71,8 @@ mars_error_t mars_hip_set_fusion(mars_model_t *model, int level);
  * (force one launch variant wherever a layer has it); "f32_mfma" (float32 convolutions: 0 = the reference's summation
  * order everywhere, bit-identical; 1 = default: the f32 matrix cores -- fused rounding per tap, inside the 1e-4
  * tolerance of the float32 models -- for every convolution from which no byte-wise MAXPOOL over float bytes is
- * reachable; 2 = matrix cores everywhere).
+ * reachable; 2 = matrix cores everywhere); "graph_max_batch" (default 8: at batches up to this the plan is captured into a
+ * HIP graph after its first run and replayed with one call -- single frames are launch-bound; 0 = never).
  * The defaults are the measured optimum; tests use "persist_slots" to force the multi-tile walk
  * of the persistent kernel on small inputs.  Results never depend on these.  0 = ok, -1 = unknown key. */
 int mars_hip_set_tuning(const char *key, int value);

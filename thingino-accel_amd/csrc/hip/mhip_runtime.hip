@@ -171,6 +171,26 @@ extern "C" int mhip_d2h_2d_async(void *dst, size_t dpitch, const void *src, size
     return mhip_check(hipMemcpy2DAsync(dst, dpitch, src, spitch, row_bytes, rows, hipMemcpyDeviceToHost, mhip_stream_native()), "D2H 2D");
 }
 
+// ---- HIP graphs: a launch-bound plan (single frames: ~60 launches of a few microseconds each) is captured once from the
+// main stream and replayed with one call.  Relaxed capture mode: the launchers' occupancy queries are not stream work.
+extern "C" int mhip_graph_begin(void) {
+    return mhip_check(hipStreamBeginCapture(g_stream, hipStreamCaptureModeRelaxed), "hipStreamBeginCapture");
+}
+extern "C" void *mhip_graph_end(int ok) { // ends the capture; ok == 0 (a launch failed): discard
+    hipGraph_t graph = nullptr;
+    if (hipStreamEndCapture(g_stream, &graph) != hipSuccess || !graph) return nullptr;
+    hipGraphExec_t exec = nullptr;
+    if (ok && hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0) != hipSuccess) exec = nullptr;
+    (void)hipGraphDestroy(graph);
+    return (void *)exec;
+}
+extern "C" int mhip_graph_launch(void *exec) {
+    return mhip_check(hipGraphLaunch((hipGraphExec_t)exec, g_stream), "hipGraphLaunch");
+}
+extern "C" void mhip_graph_destroy(void *exec) {
+    if (exec) (void)hipGraphExecDestroy((hipGraphExec_t)exec);
+}
+
 extern "C" void *mhip_event_create(void) {
     hipEvent_t ev;
     if (hipEventCreate(&ev) != hipSuccess) return nullptr;

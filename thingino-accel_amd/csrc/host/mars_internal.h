@@ -103,6 +103,9 @@ typedef struct {
     int det_lut_n;
     void *ev_graph_done, *ev_tail_done; /* main->aux and aux->main hand-offs */
     int tail_pending;
+    void *graph_exec;   /* captured HIP graph of the plan at the current batch (small batches), or NULL */
+    unsigned graph_gen; /* tuning generation it was captured under */
+    int ran_plain;      /* the plan has run launch by launch at this batch: every launcher's one-time set-up is done */
     void *pipe; /* double-buffered I/O state (mars_pipe.c), NULL when closed */
 } mars_model_ext_t;
 

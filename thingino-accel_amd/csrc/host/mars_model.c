@@ -37,6 +37,20 @@ static int verbose(void) {
 }
 #define VLOG(...) do { if (verbose()) fprintf(stderr, "Mars: " __VA_ARGS__); } while (0)
 
+/* single frames / small batches are launch-bound (60 launches of a few microseconds): their plan is captured into a HIP
+ * graph after the first plain run and replayed.  g_graph_max_batch: largest batch that takes this path (0 = off);
+ * g_tune_gen: bumped by every tuning call, so that graphs captured under older launch policies are dropped. */
+static int g_graph_max_batch = 8;
+static unsigned g_tune_gen = 1;
+static void drop_graph(mars_model_ext_t *m) {
+    if (m->graph_exec) {
+        mhip_sync();
+        mhip_graph_destroy(m->graph_exec);
+    }
+    m->graph_exec = NULL;
+    m->ran_plain = 0;
+}
+
 /* ------------------------------------------------------------------ errors */
 static const char *const k_err[] = {
     "OK", "Invalid magic number", "Version mismatch", "Memory allocation failed",
@@ -1058,6 +1072,7 @@ static void pad_output_rows(mars_model_ext_t *m) {
 }
 
 static void free_device_state(mars_model_ext_t *m) {
+    drop_graph(m);
     if (m->act_dev) mhip_free(m->act_dev);
     if (m->scratch_dev) mhip_free(m->scratch_dev);
     m->act_dev = m->scratch_dev = NULL;
@@ -1077,6 +1092,7 @@ static void free_device_state(mars_model_ext_t *m) {
 }
 
 static void free_ops(mars_model_ext_t *m) {
+    drop_graph(m);
     for (int i = 0; i < m->n_ops; i++) {
         if (m->ops[i].ev0) mhip_event_destroy(m->ops[i].ev0);
         if (m->ops[i].ev1) mhip_event_destroy(m->ops[i].ev1);
@@ -1493,10 +1509,43 @@ static int launch_op(mars_model_ext_t *m, mars_op_t *op) {
     }
 }
 
+static mars_error_t enqueue_plan(mars_model_t *model);
+
 mars_error_t mars_hip_run_device_async(mars_model_t *model) {
     if (!model) return MARS_ERR_INVALID_FILE;
     mars_model_ext_t *m = (mars_model_ext_t *)model;
     if (!m->act_dev || !m->arena_dev) return MARS_ERR_NNA_INIT_FAILED;
+    /* graph path: small batch, no per-launch events, no cross-stream hand-off pending, buffers not being swapped */
+    int graphable = g_graph_max_batch > 0 && m->batch <= g_graph_max_batch && !m->profiling && !m->tail_pending && !m->pipe;
+    for (int i = 0; i < m->n_ops && graphable; i++)
+        if (m->ops[i].kind == OP_FAIL) graphable = 0;
+    if (!graphable) return enqueue_plan(model);
+    if (m->graph_exec && m->graph_gen != g_tune_gen) drop_graph(m);
+    if (!m->graph_exec) {
+        if (!m->ran_plain) { /* first run at this batch: launch by launch (one-time set-up of every launcher happens here) */
+            mars_error_t e = enqueue_plan(model);
+            if (e == MARS_OK) m->ran_plain = 1;
+            return e;
+        }
+        if (mhip_graph_begin() == 0) {
+            mars_error_t e = enqueue_plan(model);
+            m->graph_exec = mhip_graph_end(e == MARS_OK);
+            m->graph_gen = g_tune_gen;
+            if (e != MARS_OK) { m->graph_exec = NULL; return e; }
+        }
+        VLOG("plan of %d launches at batch %d %s\n", m->n_ops, m->batch, m->graph_exec ? "captured into a HIP graph" : "could not be captured");
+        if (!m->graph_exec) { /* capture refused: stay on the plain path for this plan */
+            g_graph_max_batch = 0;
+            return enqueue_plan(model);
+        }
+    }
+    if (mhip_graph_launch(m->graph_exec)) return MARS_ERR_LAYER_FAILED;
+    for (uint32_t i = 0; i < model->header.num_layers; i++) model->layers[i].is_executed = true;
+    return MARS_OK;
+}
+
+static mars_error_t enqueue_plan(mars_model_t *model) {
+    mars_model_ext_t *m = (mars_model_ext_t *)model;
     for (uint32_t i = 0; i < model->header.num_layers; i++) model->layers[i].is_executed = false;
     void *prof_last = NULL;
     for (int i = 0; i < m->n_ops; i++) {
@@ -1640,6 +1689,12 @@ mars_error_t mars_hip_set_fusion(mars_model_t *model, int level) {
 }
 
 int mars_hip_set_tuning(const char *key, int value) {
+    g_tune_gen++; /* captured graphs froze the launch policy they were recorded under */
+    if (key && !strcmp(key, "graph_max_batch")) { /* largest batch whose plan is replayed as a HIP graph (0 = never) */
+        if (value < 0) return -1;
+        g_graph_max_batch = value;
+        return 0;
+    }
     if (key && !strcmp(key, "f32_mfma")) { /* 0 exact everywhere, 1 matrix cores where provably safe (default), 2 everywhere */
         if (value < 0 || value > 2) return -1;
         mhip_conv_f32_mode(value);
@@ -1654,6 +1709,7 @@ mars_error_t mars_hip_autotune(mars_model_t *model, int reps) {
     if (!model) return MARS_ERR_INVALID_FILE;
     mars_model_ext_t *m = (mars_model_ext_t *)model;
     if (!m->act_dev || !m->arena_dev) return MARS_ERR_NNA_INIT_FAILED;
+    drop_graph(m);
     if (reps <= 0) reps = 3;
     void *e0 = mhip_event_create(), *e1 = mhip_event_create();
     if (!e0 || !e1) return MARS_ERR_ALLOC_FAILED;

@@ -46,6 +46,11 @@ void mhip_event_destroy(void *ev);
 int mhip_event_record(void *ev);
 float mhip_event_elapsed_ms(void *start, void *stop); /* waits for stop */
 const char *mhip_last_error(void);
+/* capture the launches enqueued on the main stream between begin and end into an executable graph (NULL on failure) */
+int mhip_graph_begin(void);
+void *mhip_graph_end(int ok);
+int mhip_graph_launch(void *exec);
+void mhip_graph_destroy(void *exec);
 
 /* ---- int8 convolution (conv_i8.hip) */
 typedef struct {
