@@ -876,3 +876,34 @@ def test_pipelined_io_matches_mars_run(gpu, orc):
     for i in range(3):
         assert np.array_equal(m.output_view(i), want[2][0][i])
     m.close()
+
+
+def test_multi_gpu_recipe_from_c(gpu, orc, tmp_path):
+    """tests/c/multi_gpu.c: one process per GPU from plain C -- fork before any GPU call,
+    ncclUniqueId over a pipe, rank 0 loads the file, the others descriptors only, ONE ncclBroadcast of the parameter
+    arena, frames sharded by rank.  Run with one rank here (an RCCL group of one: what a one-GPU box can host); every
+    frame's checksum must equal the oracle's for that frame."""
+    import subprocess
+    root = os.path.join(HERE, "..")
+    libdir = os.path.join(root, "thingino-accel_amd", "lib")
+    exe = tmp_path / "multi_gpu"
+    subprocess.run(["gcc", "-O1", "-Wall", "-D__HIP_PLATFORM_AMD__", "-I" + os.path.join(root, "include"), "-I/opt/rocm/include",
+                    os.path.join(HERE, "c", "multi_gpu.c"), "-o", str(exe), "-L" + libdir, "-lnna_mars", "-L/opt/rocm/lib", "-lrccl",
+                    "-lamdhip64", "-Wl,-rpath," + libdir, "-Wl,-rpath,/opt/rocm/lib"], check=True)
+    d = gpu.synth_model(width_x16=4, input_hw=64, seed=41)
+    path = tmp_path / "twin.mars"
+    path.write_bytes(d)
+    out = subprocess.run([str(exe), str(path), "1", "3"], capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, (out.returncode, out.stdout[-500:], out.stderr[-1500:])
+    hdr, tensors, _ = marsfile.parse(d)
+    nb = marsfile.tensor_nbytes(tensors[hdr["inputs"][0]])
+    lines = [l.split() for l in out.stdout.splitlines() if l.startswith("frame")]
+    assert [int(l[1]) for l in lines] == [0, 1, 2]
+    for l in lines:
+        g, rc = run_oracle(orc, d, lcg_frame(0x5EED0000 + int(l[1]), nb))
+        assert rc == 0
+        h = 0xCBF29CE484222325
+        for b in g.tensor(hdr["outputs"][0]).tobytes():
+            h = ((h ^ b) * 0x100000001B3) & 0xFFFFFFFFFFFFFFFF
+        assert l[4] == "%016x" % h, l
+        g.close()
