@@ -1348,8 +1348,31 @@ __global__ __launch_bounds__(1024) void conv_i8_duo(const mhip_conv_i8_t p, cons
     uint8_t *slut = (uint8_t *)dynlds; // LDS byte address 0 (requant_pack LUT0)
     lds_base_must_be_zero(dynlds);
     int *sbias = (int *)(dynlds + LUTB);
-    int8_t *wring = dynlds + LUTB + BN * 4;
+    int *pslots = (int *)(dynlds + LUTB + BN * 4); // 16 waves x 8 ints: descriptor of the patch epoch a wave prefetches
+    int8_t *wring = dynlds + LUTB + BN * 4 + 512;
     int8_t *patches = wring + STG * BN * BK;
+    // Scalar registers are what this kernel runs out of (106 of 106 in use made the compiler park uniform values in
+    // vector registers and spill those: every reload then dragged an s_waitcnt vmcnt(0) into the K loop).  Everything
+    // that is NOT needed in every step -- tile set-up, patch prefetch, epilogue -- therefore re-reads its parameters from
+    // the kernel-argument segment through a pointer the optimiser cannot see through, instead of keeping them live.
+    // ... and per-lane values derived from the lane id are recomputed there from an opaque copy of it: loop-invariant
+    // code motion otherwise hoists that arithmetic out of the epoch loop and keeps (spills) its results across it
+    auto lane_ = [&]() __attribute__((always_inline)) {
+        int l = (int)(threadIdx.x & 63u);
+        asm volatile("" : "+v"(l));
+        return l;
+    };
+    typedef const __attribute__((address_space(4))) char *kaptr_t;
+    auto P_ = [&]() __attribute__((always_inline)) {
+        kaptr_t k = (kaptr_t)__builtin_amdgcn_kernarg_segment_ptr();
+        asm volatile("" : "+s"(k));
+        return (const __attribute__((address_space(4))) mhip_conv_i8_t *)k;
+    };
+    auto G_ = [&]() __attribute__((always_inline)) {
+        kaptr_t k = (kaptr_t)__builtin_amdgcn_kernarg_segment_ptr();
+        asm volatile("" : "+s"(k));
+        return (const __attribute__((address_space(4))) duo_args_t *)(k + ((sizeof(mhip_conv_i8_t) + 7) & ~(size_t)7));
+    };
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -1381,45 +1404,63 @@ __global__ __launch_bounds__(1024) void conv_i8_duo(const mhip_conv_i8_t p, cons
     }
     if (tid < BN) sbias[tid] = p.bias ? p.bias[oc0 + tid] : 0;
 
-    const int C = p.in_c, hw = p.out_h * p.out_w;
+    if (G_()->nks != g.nks || P_()->in_c != p.in_c) __builtin_trap(); // the kernel-argument offsets assumed above
+    const int C = p.in_c;
     const int frow = lane & 15, fchunk = lane >> 4;
-    const int chan = wn * 64 + (lane >> 4) * (4 * WOC);
-    const int pstride = p.out_pix_stride ? p.out_pix_stride : p.out_c;
-    const int lo = p.relu ? 0 : -128;
     const uint8_t *lut128 = slut + 128;
-    const __amdgpu_buffer_rsrc_t orsrc = __builtin_amdgcn_make_buffer_rsrc(p.out, 0, (int)g.out_bytes, 0x00020000);
-    const __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc((void *)p.in, 0, (int)g.in_bytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t wrs = __builtin_amdgcn_make_buffer_rsrc((void *)p.w, 0, p.oc_pad * g.k64, 0x00020000);
 
-    // the row segments of a tile (uniform): flat pixels [tile*P, tile*P + P) touch one frame (segment A only) or two
-    struct seg_t { unsigned fA, fB; int oyA0, iyA0, nA, nB; };
-    auto segments = [&](unsigned tile) {
+    // the row segments of a tile (uniform): flat pixels [tile*P, tile*P + P) touch one frame (segment A only) or two.
+    // 3x3, stride 1, pad 1 (host-checked): segment rows = output rows + 2, first input row = first output row - 1.
+    struct seg_t { unsigned fA, fB; int oyA0, nA, nB; };
+    auto segments = [&](unsigned tile) __attribute__((always_inline)) {
+        const auto *G = G_();
+        const auto *Pp = P_();
         seg_t s;
-        const unsigned g0 = tile * P, gl = (g0 + P < g.total_pix ? g0 + P : g.total_pix) - 1u;
-        s.fA = fdiv(g0, g.dhw);
-        s.fB = fdiv(gl, g.dhw);
-        s.oyA0 = (int)fdiv(g0 - s.fA * (unsigned)hw, g.dow);
-        const int oyB1 = (int)fdiv(gl - s.fB * (unsigned)hw, g.dow);
+        const unsigned hw = (unsigned)(Pp->out_h * Pp->out_w), tp = G->total_pix;
+        const unsigned g0 = tile * P, gl = (g0 + P < tp ? g0 + P : tp) - 1u;
+        const fastdiv_t dhw = {G->dhw.m, G->dhw.s1, G->dhw.s2}, dow = {G->dow.m, G->dow.s1, G->dow.s2};
+        s.fA = fdiv(g0, dhw);
+        s.fB = fdiv(gl, dhw);
+        s.oyA0 = (int)fdiv(g0 - s.fA * hw, dow);
+        const int oyB1 = (int)fdiv(gl - s.fB * hw, dow);
         const bool two = s.fA != s.fB;
-        const int oyA1 = two ? p.out_h - 1 : oyB1;
-        s.iyA0 = s.oyA0 * p.stride_h - p.pad_top;
-        s.nA = (oyA1 - s.oyA0) * p.stride_h + p.kh;
-        s.nB = two ? oyB1 * p.stride_h + p.kh : 0;
+        const int oyA1 = two ? Pp->out_h - 1 : oyB1;
+        s.nA = oyA1 - s.oyA0 + 3;
+        s.nB = two ? oyB1 + 3 : 0;
         return s;
+    };
+    // descriptor of a patch epoch in this wave's LDS slot: {fA * in_stride, fB * in_stride, first input row of A, rows of A,
+    // rows of B, chunk * 64}.  Written once per epoch (scalar arithmetic), read back into VECTOR registers by every piece.
+    int *const myslot = pslots + wv * 8;
+    auto put_epoch = [&](unsigned tile, int chunk64) __attribute__((always_inline)) {
+        const seg_t s = segments(tile);
+        const unsigned istr = (unsigned)P_()->in_stride;
+        if (lane == 0) {
+            *(v4i *)myslot = (v4i){(int)(s.fA * istr), (int)(s.fB * istr), s.oyA0 - 1, s.nA};
+            *(v4i *)(myslot + 4) = (v4i){s.nB, chunk64, 0, 0};
+        }
     };
     // One DMA instruction of a patch chunk: instruction n of team wave tw fills 16-byte units (n*8 + tw)*64 + lane of the
     // buffer (unit = position * 4 + 16-byte piece of the 64-channel chunk, swizzled as in conv_i8_patch for C = 64).
-    // This lane's unit of instruction n is position pos0 + n*128, piece cc: both fixed for the whole run.
-    const unsigned lane_sw = (unsigned)lane ^ (((unsigned)lane >> 3) & 2u);
-    const unsigned pos0 = (unsigned)tw * 16u + (lane_sw >> 2), ccoff = (lane_sw & 3u) * 16u;
-    auto issue_patch = [&](const seg_t &s, unsigned fA_off, unsigned fB_off, int chunk64, int n, int8_t *dst) {
-        const unsigned pos = pos0 + (unsigned)n * 128u;
-        const unsigned prow = fdiv(pos, g.dpwp), px = pos - prow * (unsigned)g.PWP;
-        const bool inA = (int)prow < s.nA;
-        const int iy = inA ? s.iyA0 + (int)prow : (int)prow - s.nA - p.pad_top;
-        const int ix = (int)px - p.pad_left;
-        const bool ok = (inA || (int)prow - s.nA < s.nB) && (unsigned)iy < (unsigned)p.in_h && (unsigned)ix < (unsigned)p.in_w;
-        const unsigned off = (inA ? fA_off : fB_off) + (unsigned)((iy * p.in_w + ix) * C + chunk64) + ccoff;
+    // This lane's unit of instruction n is position pos0 + n*128, piece ccoff / 16: both fixed for the whole run.
+    auto issue_patch = [&](int n, int8_t *dst) __attribute__((always_inline)) {
+        const auto *G = G_();
+        const auto *Pp = P_();
+        const v4i d0 = *(const v4i *)myslot, d1 = *(const v4i *)(myslot + 4);
+        const unsigned ln = (unsigned)lane_();
+        const unsigned lane_sw = ln ^ ((ln >> 3) & 2u);
+        const unsigned pos = (unsigned)tw * 16u + (lane_sw >> 2) + (unsigned)n * 128u, ccoff = (lane_sw & 3u) * 16u;
+        const fastdiv_t dpwp = {G->dpwp.m, G->dpwp.s1, G->dpwp.s2};
+        const unsigned prow = fdiv(pos, dpwp), px = pos - prow * (unsigned)G->PWP;
+        const int nA = d0[3], nB = d1[0];
+        const bool inA = (int)prow < nA;
+        const int iy = inA ? d0[2] + (int)prow : (int)prow - nA - 1;
+        const int ix = (int)px - 1;
+        const int in_w = Pp->in_w;
+        const bool ok = (inA || (int)prow - nA < nB) && (unsigned)iy < (unsigned)Pp->in_h && (unsigned)ix < (unsigned)in_w;
+        const unsigned off = (unsigned)(inA ? d0[0] : d0[1]) + (unsigned)((iy * in_w + ix) * Pp->in_c + d1[1]) + ccoff;
+        const __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc((void *)Pp->in, 0, (int)G->in_bytes, 0x00020000);
         blds16(xrs, ok ? (int)off : -1, 0, dst + (n * 8 + tw) * 1024);
     };
     // weights of one K step (chunk, tap): bytes [tap * C + chunk * 64, + 64) of every row; each of the 16 waves fetches
@@ -1430,30 +1471,43 @@ __global__ __launch_bounds__(1024) void conv_i8_duo(const mhip_conv_i8_t p, cons
     // ---- per-team tile state
     int ubase[WPX];
     v4i acc[WOC][WPX];
-    auto out_off = [&](unsigned tile, int u) { // output byte offset of this lane's pixel of subtile u, or -1
-        const unsigned gp = tile * P + (unsigned)((wm * WPX + u) * 16 + frow);
-        const bool valid = gp < g.total_pix;
+    auto out_off = [&](unsigned tile, int u) __attribute__((always_inline)) { // output byte offset of this lane's pixel of subtile u, or -1
+        const auto *G = G_();
+        const auto *Pp = P_();
+        const int ln = lane_();
+        const unsigned gp = tile * P + (unsigned)((wm * WPX + u) * 16 + (ln & 15));
+        const bool valid = gp < G->total_pix;
         const unsigned gq = valid ? gp : 0u;
-        const unsigned f = fdiv(gq, g.dhw), rem = gq - f * (unsigned)hw;
-        const unsigned off = f * (unsigned)p.out_stride + rem * (unsigned)pstride + (unsigned)(p.out_ch_off + oc0 + chan);
-        return valid && oc0 + chan < p.out_c ? (int)off : -1;
+        const unsigned hw = (unsigned)(Pp->out_h * Pp->out_w);
+        const fastdiv_t dhw = {G->dhw.m, G->dhw.s1, G->dhw.s2};
+        const unsigned f = fdiv(gq, dhw), rem = gq - f * hw;
+        const int out_c = Pp->out_c, pstride = Pp->out_pix_stride ? Pp->out_pix_stride : out_c;
+        const int ch = oc0 + wn * 64 + (ln >> 4) * (4 * WOC);
+        const unsigned off = f * (unsigned)Pp->out_stride + rem * (unsigned)pstride + (unsigned)(Pp->out_ch_off + ch);
+        return valid && ch < out_c ? (int)off : -1;
     };
-    auto setup_tile = [&](unsigned tile) {
+    auto setup_tile = [&](unsigned tile) __attribute__((always_inline)) {
         const seg_t s = segments(tile);
+        const auto *G = G_();
+        const auto *Pp = P_();
+        const unsigned hw = (unsigned)(Pp->out_h * Pp->out_w);
+        const int out_w = Pp->out_w, pwp = G->PWP;
+        const fastdiv_t dhw = {G->dhw.m, G->dhw.s1, G->dhw.s2}, dow = {G->dow.m, G->dow.s1, G->dow.s2};
+        const int ln = lane_(), fchunk = ln >> 4;
 #pragma unroll
         for (int u = 0; u < WPX; u++) {
-            const unsigned gp = tile * P + (unsigned)((wm * WPX + u) * 16 + frow);
-            const bool valid = gp < g.total_pix;
+            const unsigned gp = tile * P + (unsigned)((wm * WPX + u) * 16 + (ln & 15));
+            const bool valid = gp < G->total_pix;
             const unsigned gq = valid ? gp : 0u;
-            const unsigned f = fdiv(gq, g.dhw), rem = gq - f * (unsigned)hw;
-            const int oy = (int)fdiv(rem, g.dow), ox = (int)rem - oy * p.out_w;
-            const int prow = f == s.fA ? (oy - s.oyA0) * p.stride_h : s.nA + oy * p.stride_h;
-            ubase[u] = valid ? (prow * g.PWP + ox * p.stride_w) * 4 + fchunk : fchunk;
+            const unsigned f = fdiv(gq, dhw), rem = gq - f * hw;
+            const int oy = (int)fdiv(rem, dow), ox = (int)rem - oy * out_w;
+            const int prow = f == s.fA ? oy - s.oyA0 : s.nA + oy;
+            ubase[u] = valid ? (prow * pwp + ox) * 4 + fchunk : fchunk;
         }
         // accumulators start at the bias (lane holds channels wn*64 + q*16 + (lane>>4)*4 .. +3 of every pixel subtile)
 #pragma unroll
         for (int q = 0; q < WOC; q++) {
-            const v4i b = *(const v4i *)(sbias + wn * 64 + q * 16 + (lane >> 4) * 4);
+            const v4i b = *(const v4i *)(sbias + wn * 64 + q * 16 + (ln >> 4) * 4);
 #pragma unroll
             for (int u = 0; u < WPX; u++) acc[q][u] = b;
         }
@@ -1463,18 +1517,14 @@ __global__ __launch_bounds__(1024) void conv_i8_duo(const mhip_conv_i8_t p, cons
     __syncthreads(); // LUT / bias visible
     unsigned mytile = t0 + (unsigned)team;
     if (nmine > 0) {
-        const seg_t s = segments(mytile);
-        for (int n = 0; n < g.ni; n++)
-            issue_patch(s, s.fA * (unsigned)p.in_stride, s.fB * (unsigned)p.in_stride, startc * 64, n, mypatch);
+        put_epoch(mytile, startc * 64);
+        for (int n = 0; n < g.ni; n++) issue_patch(n, mypatch);
     }
     if (lane < 32) blds16(wrs, wvoff, 0, wring + wv * 512);                              // step 0: chunk 0, tap 0
     if (G > 1 && lane < 32) blds16(wrs, wvoff + C, 0, wring + BN * BK + wv * 512);       // step 1: chunk 0, tap 1
 
     bool working = false, pvalid = false, have = false;
     int lc = 0, ebuf = 0, tdone = 0; // lc: chunks of the current tile done so far (in this team's order)
-    seg_t pseg = {};                 // next patch epoch (being prefetched): segments, frame offsets, chunk * 64
-    unsigned pfA = 0, pfB = 0;
-    int pck = 0;
     int8_t *pdst = mypatch;
     const int8_t *pb = mypatch;
     const int rowoff1 = g.PWP * 4, rowoff2 = g.PWP * 8; // 16-byte units per patch row (ky = 1, 2)
@@ -1507,12 +1557,7 @@ __global__ __launch_bounds__(1024) void conv_i8_duo(const mhip_conv_i8_t p, cons
                 // the epoch to prefetch: the next chunk of this tile, or the first chunk of this team's next tile
                 const unsigned ptile = lc + 1 == nchunk ? mytile + 2 : mytile;
                 pvalid = ptile < t1;
-                if (pvalid) {
-                    pseg = segments(ptile);
-                    pfA = pseg.fA * (unsigned)p.in_stride;
-                    pfB = pseg.fB * (unsigned)p.in_stride;
-                    pck = (kc + 1 == nchunk ? 0 : kc + 1) * 64;
-                }
+                if (pvalid) put_epoch(ptile, kn64);
             }
         }
         if (working) { // fragment reads of this wave's 16 MFMAs
@@ -1548,12 +1593,17 @@ __global__ __launch_bounds__(1024) void conv_i8_duo(const mhip_conv_i8_t p, cons
             asm volatile("" : "+s"(n)); // opaque: otherwise the per-piece lane arithmetic of all nine steps is hoisted out of
                                         // the epoch loop and its results are kept (and spilled) across it
             if (n < g.ni) {
-                issue_patch(pseg, pfA, pfB, pck, n, pdst);
+                issue_patch(n, pdst);
                 vx += 1;
             }
         }
         if ((KT == TAPS - 1 || KT == 3) && KT == kend) { // a patch epoch of this team ends
             if (++lc == nchunk) { // ... and with it the tile: requantise, LUT, store
+                const auto *Pp = P_();
+                const float cs = Pp->cs;
+                const int lo = Pp->relu ? 0 : -128;
+                const bool fast = HAS_LUT && Pp->lut2 != nullptr;
+                const __amdgpu_buffer_rsrc_t orsrc = __builtin_amdgcn_make_buffer_rsrc((void *)Pp->out, 0, (int)G_()->out_bytes, 0x00020000);
 #pragma unroll
                 for (int u = 0; u < WPX; u++) {
                     uint32_t pk[WOC];
@@ -1562,8 +1612,8 @@ __global__ __launch_bounds__(1024) void conv_i8_duo(const mhip_conv_i8_t p, cons
                     for (int q = 0; q < WOC; q++)
 #pragma unroll
                         for (int r = 0; r < 4; r++) a[q * 4 + r] = acc[q][u][r];
-                    if (HAS_LUT && p.lut2 != nullptr) requant_pack<WOC * 4, HAS_LUT, true, true, false, true>(a, p.cs, lo, lut128, pk);
-                    else requant_pack<WOC * 4, HAS_LUT, true, true>(a, p.cs, lo, lut128, pk);
+                    if (fast) requant_pack<WOC * 4, HAS_LUT, true, true, false, true>(a, cs, lo, lut128, pk);
+                    else requant_pack<WOC * 4, HAS_LUT, true, true>(a, cs, lo, lut128, pk);
                     __builtin_amdgcn_raw_buffer_store_b128((v4i){(int)pk[0], (int)pk[1], (int)pk[2], (int)pk[3]}, orsrc, out_off(mytile, u), 0, 0);
                 }
                 vx += WPX;
@@ -2336,7 +2386,7 @@ static int device_cus() {
 static bool duo_geom(const mhip_conv_i8_t *p, duo_geom_t *g) {
     const bool direct = !p->out_nchw && ((p->out_c | p->out_pix_stride | p->out_ch_off) & 15) == 0;
     const int C = p->in_c, hw = p->out_h * p->out_w, taps = p->kh * p->kw;
-    if (!direct || !p->safe || (C != 64 && C != 128 && C != 256) || p->stride_w != 1 || p->stride_h != 1 || p->kh != 3 || p->kw != 3 || p->row_pad != p->kw * C || p->oc_pad % 128 != 0 || p->nseg > 1 || hw < 256 || p->add || persist_out_bytes(p) > 0x7fffffffL ||
+    if (!direct || !p->safe || (C != 64 && C != 128 && C != 256) || p->stride_w != 1 || p->stride_h != 1 || p->kh != 3 || p->kw != 3 || p->pad_top != 1 || p->pad_left != 1 || p->row_pad != p->kw * C || p->oc_pad % 128 != 0 || p->nseg > 1 || hw < 256 || p->add || persist_out_bytes(p) > 0x7fffffffL ||
         in_extent_bytes(p) > 0x7fffffffL)
         return false;
     const long total = (long)p->frames * hw;
@@ -2378,7 +2428,7 @@ static bool duo_geom(const mhip_conv_i8_t *p, duo_geom_t *g) {
     a.ni = (int)((units + 511) / 512);
     if (a.ni < 1 || a.ni > taps - 1) return false; // the prefetch of an epoch must end two steps before the epoch does
     a.patch_bytes = a.ni * 8192;
-    g->lds = LUTB + 128 * 4 + 3 * (size_t)128 * BK + 4 * (size_t)a.patch_bytes;
+    g->lds = LUTB + 128 * 4 + 512 + 3 * (size_t)128 * BK + 4 * (size_t)a.patch_bytes;
     if (g->lds > 160 * 1024) return false;
     a.dhw = make_fastdiv((unsigned)hw);
     a.dow = make_fastdiv((unsigned)p->out_w);
