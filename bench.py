@@ -90,12 +90,16 @@ def cpu_baseline(model_bytes, frames, out_ids, budget_s=14.0, max_frames=16):
                 sample="%d frames of the same workload through %s, %.1f s of CPU time" % (n, how, spent)), outs
 
 
-def cpu_baseline_parallel(model_bytes, frames, out_ids, nthreads, ref_outs):
+def cpu_baseline_parallel(model_bytes, frames, out_ids, nthreads, ref_outs, f32=False):
     """the same reference code, frames-parallel: one frame per thread, every host core this process may use (ctypes
     releases the GIL; every thread owns its model instance).  One frame per thread, so ~one single-frame time."""
     import threading
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
-    n = nthreads or len(os.sched_getaffinity(0))
+    # every core this process may use, but no more threads than keep the leg near one single-frame time: beyond ~64 the
+    # reference's scalar loops share memory bandwidth (256 threads: 8x one core on the int8 twin), and a float32 frame is
+    # 35 s alone (256 at once: 260 s)
+    cap = 16 if f32 else 64
+    n = nthreads or min(len(os.sched_getaffinity(0)), cap)
     n = max(1, min(n, len(frames)))
     kind = "port"
     try:
@@ -125,7 +129,7 @@ def cpu_baseline_parallel(model_bytes, frames, out_ids, nthreads, ref_outs):
     same = all(np.array_equal(runners[f].tensor(ti), ref_outs[f][i]) for f in range(min(n, len(ref_outs))) for i, ti in enumerate(out_ids))
     for r in runners:
         r.close()
-    return dict(value=n / dt, unit="images/s", cores=n, kind=kind, matches_single_core_run=bool(same),
+    return dict(value=n / dt, unit="images/s", cores=n, host_cores=len(os.sched_getaffinity(0)), kind=kind, matches_single_core_run=bool(same),
                 sample="%d frames at once, one per thread, %.1f s wall" % (n, dt))
 
 
@@ -164,6 +168,9 @@ def main():
                          "float32) with its convolutions on the f32 matrix cores (mars_hip_set_tuning f32_mfma=2); graph only "
                          "(float heads have no int8 decode), outputs checked against the CPU reference within 1e-4*max(1,|b|)")
     ap.add_argument("--f32-mode", type=int, default=2, help="--dtype f32: 0 exact order, 1 default policy, 2 matrix cores everywhere")
+    ap.add_argument("--timed-only", action="store_true",
+                    help="skip the legs after the timed region (mars_run / pipelined I/O / batch-1 latency / CPU baselines): "
+                         "what profiling passes want")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--vary-scales", action="store_true",
                     help="check run, not the benchmark workload: the twin with per-convolution scales (every fused table "
@@ -363,7 +370,7 @@ def main():
                        "autotuned_launch_variants": bool(args.autotune and not args.no_autotune), "conv_gmac_per_image": macs_per_img / 1e9, "algorithmic_mb_per_image": bytes_per_img / 1e6},
             "roofline": roof,
         }
-        if world == 1:
+        if world == 1 and not args.timed_only:
             # not the headline value: the same batch INCLUDING host->HBM input copies and HBM->host
             # output copies through the reference API's mars_run() (pinned staging, one stream)
             M.lib().mars_hip_sync()
@@ -391,7 +398,7 @@ def main():
                         model.pipe_wait(copy=False)
                     model.pipe_close()
                     result[key] = nb * args.batch / dtp
-        if world == 1:
+        if world == 1 and not args.timed_only:
             # the reference's real call pattern (mars_test.c:33-148): ONE frame per mars_run.  Latency of the graph alone
             # (input resident) and through mars_run() (H2D + graph + D2H), median of 20
             m1 = M.Model(model_bytes, batch=1)
@@ -410,7 +417,7 @@ def main():
             lat["launches"] = len(m1.ops())
             result["latency_batch1"] = lat
             m1.close()
-        if world == 1 and not args.no_cpu_baseline:
+        if world == 1 and not args.no_cpu_baseline and not args.timed_only:
             base, ref_outs = cpu_baseline(model_bytes, frames, out_ids, max_frames=1 if f32 else 16)
             model.download()
             if f32:  # north_star: within 1e-4 on the float32 models
@@ -432,7 +439,7 @@ def main():
             base["frames_compared"] = len(ref_outs)
             result["cpu_baseline"] = base
             # the fair node-level figure -- frames are independent, one frame per thread on every core
-            result["cpu_baseline_all_cores"] = cpu_baseline_parallel(model_bytes, frames, out_ids, args.cpu_threads, ref_outs)
+            result["cpu_baseline_all_cores"] = cpu_baseline_parallel(model_bytes, frames, out_ids, args.cpu_threads, ref_outs, f32)
     model.close()
     if dist is not None:
         dist.barrier()

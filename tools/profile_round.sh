@@ -1,20 +1,30 @@
 #!/bin/bash
-# One profiling pass of bench.py on the GPU box (run through gpurun from the repo root):
+# One profiling round of bench.py on the GPU box (run through gpurun from the repo root):
 #   tools/profile_round.sh TAG      -> gpurun_out/TAG_*  (copy what should be judged into profiles/)
 # rocprofv3 gets the interpreter directly after `--`; PMC passes are separate and carry no trace flags.
 set -e
-TAG=${1:-r01}
+TAG=${1:-r02}
 OUT=$PWD/gpurun_out
 mkdir -p $OUT
 W=2; K=4
-# the default launch policy (bench.py's default; --autotune would add ~4 launches of every variant of every layer)
-BENCH="bench.py --no-cpu-baseline --steps $K --warmup $W"
+# the default launch policy (bench.py's default); only the timed region, no I/O / CPU legs
+BENCH="bench.py --timed-only --steps $K --warmup $W"
 export TMPDIR=/tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/${TAG}_trace -o t -- python3 $BENCH > $OUT/${TAG}_bench_line_under_rocprof.json 2> $OUT/${TAG}_trace.err
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/${TAG}_pmc_fetch -o f -- python3 $BENCH > /dev/null 2> $OUT/${TAG}_pmc_fetch.err
 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/${TAG}_pmc_write -o w -- python3 $BENCH > /dev/null 2> $OUT/${TAG}_pmc_write.err
-python3 tools/pmc_summary.py --fetch $OUT/${TAG}_pmc_fetch --write $OUT/${TAG}_pmc_write --executions $((W + K + 2)) \
+python3 tools/pmc_summary.py --fetch $OUT/${TAG}_pmc_fetch --write $OUT/${TAG}_pmc_write --executions $((W + K)) \
     --note "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes) of: python3 $BENCH" --out $OUT/${TAG}_pmc_traffic.json > $OUT/${TAG}_pmc_traffic.txt
+# matrix-pipe occupancy per kernel symbol: MFMA-busy cycles against the cycles the CUs were busy
+rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_MFMA \
+    --output-format csv -d $OUT/${TAG}_pmc_mfma -o m -- python3 $BENCH > /dev/null 2> $OUT/${TAG}_pmc_mfma.err
+python3 tools/mfma_busy.py $OUT/${TAG}_pmc_mfma $OUT/${TAG}_trace $((W + K)) > $OUT/${TAG}_mfma_busy.json
 find $OUT/${TAG}_trace -name '*kernel_stats.csv' -exec cp {} $OUT/${TAG}_bench_kernel_stats.csv \;
-rm -rf $OUT/${TAG}_pmc_fetch $OUT/${TAG}_pmc_write
+rm -rf $OUT/${TAG}_pmc_fetch $OUT/${TAG}_pmc_write $OUT/${TAG}_pmc_mfma
 find $OUT/${TAG}_trace -name '*kernel_trace.csv' -delete
+# un-profiled lines: per-launch table, the 320x320 workloads, the float32 workload (config 5), the default line
+python3 bench.py --timed-only --ops $OUT/${TAG}_ops.txt > $OUT/${TAG}_bench_ops.json 2> $OUT/${TAG}_ops.err
+python3 bench.py --timed-only --hw 320 > $OUT/${TAG}_bench_320_yolov5s.json 2>> $OUT/${TAG}_ops.err
+python3 bench.py --timed-only --hw 320 --width 4 > $OUT/${TAG}_bench_320_yolov5n.json 2>> $OUT/${TAG}_ops.err
+python3 bench.py --dtype f32 --steps 10 --warmup 3 > $OUT/${TAG}_f32_bench.json 2>> $OUT/${TAG}_ops.err
+python3 bench.py > $OUT/${TAG}_bench_default.json 2>> $OUT/${TAG}_ops.err
