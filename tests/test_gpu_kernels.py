@@ -163,13 +163,15 @@ def test_conv_i8_tile_walk_resident_weights(gpu, orc, slots, variant):
         gpu.set_tuning("persist_slots", 0)
 
 
-@pytest.mark.parametrize("variant", [12, 13])
+@pytest.mark.parametrize("variant", [12, 13, 18, 19])
 def test_conv_i8_wide_one_tile_forms(gpu, orc, variant):
-    """variant 12 (two K slices per ring stage) and 13 (256 x 128 tile on an 8-wave workgroup): deep K loops, 128 /
-    256 output channels, pixel counts that are not multiples of the tile, aligned and ragged (255) rows"""
+    """variant 12 (two K slices per ring stage), 13 (256 x 128 tile on an 8-wave workgroup), 18 / 19 (128-byte K steps:
+    whole-line DMA requests, 128-byte LDS rows, 4 / 8 waves; layers with fewer than 128 input channels fall back to the
+    default there): deep K loops, 128 / 256 output channels, pixel counts that are not multiples of the tile, aligned
+    and ragged (255) rows"""
     shapes = [  # in_h, in_w, in_c, out_c, k, s
         (40, 40, 128, 128, 3, 1), (23, 17, 256, 256, 3, 1), (33, 31, 128, 256, 1, 1), (20, 20, 512, 255, 1, 1),
-        (19, 21, 64, 128, 3, 2), (16, 16, 1024, 128, 1, 1)]
+        (19, 21, 64, 128, 3, 2), (16, 16, 1024, 128, 1, 1), (21, 19, 128, 128, 3, 2), (9, 11, 256, 128, 5, 1)]
     try:
         gpu.set_tuning("variant", variant)
         for i, (h, w, ic, oc, k, s) in enumerate(shapes):

@@ -598,6 +598,125 @@ __global__ __launch_bounds__(NW * 64) void conv_i8_mfma(const mhip_conv_i8_t p, 
 }
 
 // ---------------------------------------------------------------------------------
+// 128-byte K steps (in_c >= 128, a power of two): the deep-K kernels above are bound by L2 -> LDS DMA throughput, and
+// that path delivers ~21-27 B/clk/CU when 4 lanes fetch a 64-byte piece of a row but ~40 when 8 lanes fetch a whole
+// 128-byte line (tools/probes/probe_dmarate.hip).  Here a ring stage holds 128 bytes of K per row: one DMA instruction
+// = 8 rows x 128 bytes (one request per cache line), two MFMA K-halves per stage, one barrier per 128 bytes of K.
+// LDS rows are 128 bytes; 16-byte slot s of row r holds K chunk s ^ ((r >> 1) & 7) (source-side swizzle as before: the
+// DMA writes lane-linearly), which gives the 16 lanes of every ds_read_b128 group 16 distinct bank groups:
+// bank group = (r & 1) * 8 + slot, and rows of equal parity in a group carry 8 distinct values of chunk ^ (r >> 1).
+// Tap decoding is scalar as in the buffer-addressed form (a 128-byte step lies inside one tap).
+__device__ __forceinline__ int lds_off128(int row, int chunk8) { return row * 128 + ((chunk8 ^ ((row >> 1) & 7)) << 4); }
+template <int BPX, int BN, int NW>
+__global__ __launch_bounds__(NW * 64) void conv_i8_r128(const mhip_conv_i8_t p, const long total_pix, const int k128,
+                                                         const unsigned noc, const unsigned nblk, const int lg_inc,
+                                                         const unsigned kw_magic, const fastdiv_t dhw, const fastdiv_t dow,
+                                                         const unsigned in_bytes) {
+    constexpr int STAGE = (BPX + BN) * 128;
+    constexpr int NWN = BN == 128 ? 2 : 1;
+    constexpr int NWM = NW / NWN;
+    constexpr int WPX = BPX / NWM / 16;
+    constexpr int WOC = BN / NWN / 16;
+    constexpr int XI = BPX / 8 / NW;  // X-tile DMA instructions per wave and stage (8 rows each)
+    constexpr int WI = BN / 8 / NW;   // W-tile ...
+    static_assert(XI >= 1 && WI >= 1 && BPX % (8 * NW) == 0 && BN % (8 * NW) == 0, "whole 8-row pieces per wave");
+    extern __shared__ __attribute__((aligned(16))) int8_t dynlds[];
+    uint8_t *slut = (uint8_t *)dynlds; // LDS byte address 0 (requant_pack LUT0)
+    lds_base_must_be_zero(dynlds);
+    long *rowoff = (long *)(dynlds + LUTB);
+    int8_t *lds = dynlds + BPX * 8 + LUTB;
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const unsigned id = xcd_remap(blockIdx.x, nblk);
+    const long pix0 = (long)(id / noc) * BPX;
+    const int oc0 = (int)(id % noc) * BN;
+    const int hw = p.out_h * p.out_w;
+    const int wm = wv % NWM, wn = wv / NWM;
+    const int pxw = wm * (WPX * 16), ocw = wn * (WOC * 16);
+    v4i acc[WOC][WPX];
+    init_acc<WPX, WOC>(p, acc, oc0 + ocw);
+    if (p.lut2) { if (tid < 128) ((uint32_t *)slut)[tid] = ((const uint32_t *)p.lut2)[tid]; }
+    else if (p.lut && tid < 64) ((uint32_t *)slut)[tid] = ((const uint32_t *)p.lut)[tid];
+    fill_rowoff<BPX>(p, rowoff, [=](int row) { long q = pix0 + row; return q < total_pix ? q : -1L; }, (unsigned)hw, dhw);
+
+    // DMA assignment: instruction j of this wave covers tile rows (wv * XI + j) * 8 .. + 7; lane i -> row i / 8, slot i % 8
+    const int lrow = lane >> 3, lslot = lane & 7;
+    int xvoff[XI];
+    unsigned tapmask[XI];
+#pragma unroll
+    for (int j = 0; j < XI; j++) {
+        const int trow = (wv * XI + j) * 8 + lrow;
+        const long pix = pix0 + trow;
+        const bool valid = pix < total_pix;
+        const unsigned f = valid ? fdiv((unsigned)pix, dhw) : 0u;
+        const unsigned rem = valid ? (unsigned)pix - f * (unsigned)hw : 0u;
+        const int oy = (int)fdiv(rem, dow), ox = (int)(rem - (unsigned)oy * (unsigned)p.out_w);
+        const int iy0 = oy * p.stride_h - p.pad_top, ix0 = ox * p.stride_w - p.pad_left;
+        const int chunk = lslot ^ ((trow >> 1) & 7);
+        xvoff[j] = (int)(f * (unsigned)p.in_stride) + (iy0 * p.in_w + ix0) * p.in_c + chunk * 16; // may be negative: only used with in-image taps
+        const int kx_lo = ix0 < 0 ? -ix0 : 0, kx_hi = p.in_w - ix0 < p.kw ? p.in_w - ix0 : p.kw;
+        const unsigned colbits = kx_hi > kx_lo ? ((kx_hi >= 32 ? ~0u : (1u << kx_hi) - 1u) & ~((1u << kx_lo) - 1u)) : 0u;
+        unsigned m = 0;
+        for (int r = 0; r < p.kh; r++) {
+            const int iy = iy0 + r;
+            if (iy >= 0 && iy < p.in_h) m |= colbits << (r * p.kw);
+        }
+        tapmask[j] = valid ? m : 0u;
+    }
+    int wvoff[WI];
+#pragma unroll
+    for (int j = 0; j < WI; j++) {
+        const int trow = (wv * WI + j) * 8 + lrow;
+        wvoff[j] = (oc0 + trow) * k128 + (lslot ^ ((trow >> 1) & 7)) * 16;
+    }
+    const __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc((void *)p.in, 0, (int)in_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t wrs = __builtin_amdgcn_make_buffer_rsrc((void *)p.w, 0, p.oc_pad * k128, 0x00020000);
+    const int taps = p.kh * p.kw;
+    const int nst = k128 / 128;
+    auto issue = [&](int st, int buf) {
+        int8_t *sb = lds + buf * STAGE;
+        const int utap = (st * 128) >> lg_inc, urc = (st * 128) & ((1 << lg_inc) - 1); // uniform: a 128-byte step lies inside one tap
+        const int uky = (int)(((unsigned)utap * kw_magic) >> 16), ukx = utap - uky * p.kw;
+        const int ukoff = (uky * p.in_w + ukx) * p.in_c + urc;
+        const bool uvalid = utap < taps;
+#pragma unroll
+        for (int j = 0; j < XI; j++) {
+            const bool ok = uvalid & (((tapmask[j] >> utap) & 1u) != 0u);
+            blds16(xrs, ok ? xvoff[j] + ukoff : -1, 0, sb + (wv * XI + j) * 1024);
+        }
+#pragma unroll
+        for (int j = 0; j < WI; j++) blds16(wrs, wvoff[j], st * 128, sb + BPX * 128 + (wv * WI + j) * 1024);
+    };
+
+    issue(0, 0);
+    const int frow = lane & 15, fchunk = lane >> 4;
+    for (int st = 0; st < nst; st++) {
+        wait_vmcnt<0>(); // stage st has landed (nothing else is in flight: the next stage is issued below)
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        const int8_t *xs = lds + (st & 1) * STAGE, *ws = xs + BPX * 128;
+        v4i xb[2][WPX], wa[2][WOC];
+#pragma unroll
+        for (int h = 0; h < 2; h++) {
+#pragma unroll
+            for (int t = 0; t < WPX; t++) xb[h][t] = *(const v4i *)(xs + lds_off128(pxw + t * 16 + frow, h * 4 + fchunk));
+#pragma unroll
+            for (int q = 0; q < WOC; q++) wa[h][q] = *(const v4i *)(ws + lds_off128(ocw + q * 16 + frow, h * 4 + fchunk));
+        }
+        if (st + 1 < nst) issue(st + 1, (st + 1) & 1); // the other buffer: every wave is past its reads of stage st - 1
+#pragma unroll
+        for (int h = 0; h < 2; h++)
+#pragma unroll
+            for (int q = 0; q < WOC; q++)
+#pragma unroll
+                for (int t = 0; t < WPX; t++) acc[q][t] = __builtin_amdgcn_mfma_i32_16x16x64_i8(wa[h][q], xb[h][t], acc[q][t], 0, 0, 0);
+    }
+    __syncthreads(); // every wave is done reading the ring: reuse it for the output tile
+    epilogue<BPX, BN, WPX, WOC, true>(p, acc, lds, slut, rowoff, oc0, pxw, ocw, hw);
+}
+
+// ---------------------------------------------------------------------------------
 // persistent form of the main kernel (the default for NHWC outputs with 16-byte aligned rows):
 // a workgroup owns ONE channel tile and walks a contiguous run of pixel tiles.  The K stages of
 // all its tiles form one stream through the LDS ring, so the loads of tile i+1 are in flight
@@ -2222,11 +2341,13 @@ static int launch_persist_t(const mhip_conv_i8_t *p, long total_pix, int k64, in
 //   code = 14 / 15: tile walker with the weights of its channel tile resident in LDS, 128 / 256 pixels
 //   code = 16: input patch staged once, weights streamed (8 waves, 16 x 16 pixels x 128 channels)
 //   code = 17: two-team strip kernel (16 waves: two 256-pixel x 128-channel tiles half a tile apart, shared weight ring)
-#define NVARIANTS 17
+//   code = 18 / 19: 128-byte K steps (whole-line DMA requests), 128 x 128 tile on 4 waves / 256 x 128 tile on 8 waves
+#define NVARIANTS 19
 struct variant_t {
-    int persist, bpx, stages, patch, ks2, w8, wres, pws, duo;
+    int persist, bpx, stages, patch, ks2, w8, wres, pws, duo, r128;
 };
 static int variant_code(const variant_t &v) {
+    if (v.r128) return v.r128 == 2 ? 19 : 18;
     if (v.duo) return 17;
     if (v.pws) return 16;
     if (v.wres) return v.bpx == 256 ? 15 : 14;
@@ -2236,14 +2357,15 @@ static int variant_code(const variant_t &v) {
     return 1 + (v.persist ? 1 : 0) + (v.bpx == 256 ? 2 : 0) + (v.stages == 3 ? 4 : 0);
 }
 static variant_t variant_of(int code) {
-    if (code == 17) return variant_t{0, 0, 0, 0, 0, 0, 0, 0, 1};
-    if (code == 16) return variant_t{0, 0, 0, 0, 0, 0, 0, 1, 0};
-    if (code == 14 || code == 15) return variant_t{1, code == 15 ? 256 : 128, 2, 0, 0, 0, 1, 0, 0};
-    if (code == 13) return variant_t{0, 256, 3, 0, 0, 1, 0, 0, 0};
-    if (code == 12) return variant_t{0, 128, 2, 0, 1, 0, 0, 0, 0};
-    if (code >= 9) return variant_t{0, 0, 0, code == 10 ? 16 : (code == 9 ? 8 : 4), 0, 0, 0, 0, 0};
+    if (code == 18 || code == 19) return variant_t{0, 0, 0, 0, 0, 0, 0, 0, 0, code - 17};
+    if (code == 17) return variant_t{0, 0, 0, 0, 0, 0, 0, 0, 1, 0};
+    if (code == 16) return variant_t{0, 0, 0, 0, 0, 0, 0, 1, 0, 0};
+    if (code == 14 || code == 15) return variant_t{1, code == 15 ? 256 : 128, 2, 0, 0, 0, 1, 0, 0, 0};
+    if (code == 13) return variant_t{0, 256, 3, 0, 0, 1, 0, 0, 0, 0};
+    if (code == 12) return variant_t{0, 128, 2, 0, 1, 0, 0, 0, 0, 0};
+    if (code >= 9) return variant_t{0, 0, 0, code == 10 ? 16 : (code == 9 ? 8 : 4), 0, 0, 0, 0, 0, 0};
     const int c = code - 1;
-    return variant_t{c & 1, (c & 2) ? 256 : 128, (c & 4) ? 3 : 2, 0, 0, 0, 0, 0, 0};
+    return variant_t{c & 1, (c & 2) ? 256 : 128, (c & 4) ? 3 : 2, 0, 0, 0, 0, 0, 0, 0};
 }
 
 // ---- patch-staged kernel: geometry, eligibility, launch
@@ -2365,6 +2487,35 @@ static int launch_pws(const mhip_conv_i8_t *p, int k64) {
     pws_geom_t g;
     if (!pws_geom(p, &g)) return -1;
     return p->lut ? launch_pws_t<true>(p, k64, g) : launch_pws_t<false>(p, k64, g);
+}
+
+// ---- 128-byte K steps (conv_i8_r128): eligibility, launch
+static bool r128_ok(const mhip_conv_i8_t *p) {
+    const int C = p->in_c;
+    return C >= 128 && (C & (C - 1)) == 0 && p->oc_pad % 128 == 0 && p->kh * p->kw <= 32 && (long)p->kh * p->kw * (p->kw - 1) < 65536 &&
+           p->row_pad == p->kw * C && p->nseg <= 1 && in_extent_bytes(p) <= 0x7fffffffL && (long)p->oc_pad * p->kh * p->row_pad <= 0x7fffffffL;
+}
+template <int BPX, int BN, int NW>
+static int launch_r128_t(const mhip_conv_i8_t *p, long total_pix) {
+    const int k128 = p->kh * p->row_pad; // taps * C: a multiple of 128
+    const unsigned npt = (unsigned)((total_pix + BPX - 1) / BPX), noc = (unsigned)(p->oc_pad / BN);
+    size_t ring = 2 * (size_t)(BPX + BN) * 128, tile = (size_t)BPX * (BN + OPAD);
+    const size_t lds = BPX * 8 + LUTB + (ring > tile ? ring : tile);
+    static bool attr = false;
+    if (!attr && hipFuncSetAttribute((const void *)conv_i8_r128<BPX, BN, NW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+        return mhip_check(hipErrorUnknown, "conv_i8_r128 LDS attribute");
+    attr = true;
+    int lg = 0;
+    while ((1 << lg) < p->in_c) lg++;
+    const unsigned magic = ((65536u + (unsigned)p->kw - 1u) / (unsigned)p->kw);
+    hipLaunchKernelGGL((conv_i8_r128<BPX, BN, NW>), dim3(npt * noc), dim3(NW * 64), lds, mhip_stream_native(), *p, total_pix, k128, noc,
+                       npt * noc, lg, magic, make_fastdiv((unsigned)(p->out_h * p->out_w)), make_fastdiv((unsigned)p->out_w),
+                       (unsigned)in_extent_bytes(p));
+    return mhip_check(hipGetLastError(), "conv_i8_r128 launch");
+}
+static int launch_r128(const mhip_conv_i8_t *p, long total_pix, int form) {
+    if (!r128_ok(p)) return -1;
+    return form == 2 ? launch_r128_t<256, 128, 8>(p, total_pix) : launch_r128_t<128, 128, 4>(p, total_pix);
 }
 
 // ---- two-team strip kernel (conv_i8_duo): geometry, eligibility, launch
@@ -2509,6 +2660,7 @@ static variant_t default_variant(const mhip_conv_i8_t *p, int nks) {
     v.wres = 0;
     v.pws = 0;
     v.duo = 0;
+    v.r128 = 0;
     // wide, shallow k x k layers: the patch-staged kernel wins wherever its double-buffered form fits (measured on the
     // 160x160 and 80x80 layers of yolov5s: 1.25-1.9x over the implicit-GEMM forms)
     patch_geom_t g;
@@ -2575,6 +2727,7 @@ static int launch_variant_t(const mhip_conv_i8_t *p, long total_pix, int k64, co
 }
 
 static int launch_variant(const mhip_conv_i8_t *p, long total_pix, int k64, const variant_t &v) {
+    if (v.r128) return launch_r128(p, total_pix, v.r128);
     if (v.duo) return launch_duo(p);
     if (v.pws) return launch_pws(p, k64);
     if (v.patch) return launch_patch(p, k64, v.patch);
@@ -2668,6 +2821,7 @@ extern "C" int mhip_conv_i8_variants(const mhip_conv_i8_t *p, int *codes, int ma
         if (v.pws && !pws_geom(p, &pg)) continue;
         duo_geom_t dg;
         if (v.duo && !duo_geom(p, &dg)) continue;
+        if (v.r128 && !r128_ok(p)) continue;
         if (v.wres) {
             const int bn = p->oc_pad % 128 == 0 ? 128 : (p->oc_pad % 64 == 0 ? 64 : 32);
             if (LUTB + 2 * (size_t)v.bpx * BK + (size_t)nks * bn * BK > 80 * 1024) continue;
