@@ -72,7 +72,9 @@ mars_error_t mars_hip_set_fusion(mars_model_t *model, int level);
  * order everywhere, bit-identical; 1 = default: the f32 matrix cores -- fused rounding per tap, inside the 1e-4
  * tolerance of the float32 models -- for every convolution from which no byte-wise MAXPOOL over float bytes is
  * reachable; 2 = matrix cores everywhere); "graph_max_batch" (default 8: at batches up to this the plan is captured into a
- * HIP graph after its first run and replayed with one call -- single frames are launch-bound; 0 = never).
+ * HIP graph after its first run and replayed with one call -- single frames are launch-bound; 0 = never);
+ * "dual_stream_min_batch" (default 64: a batch of at least this many frames is enqueued as two halves on two streams,
+ * frames being independent, so that the gaps of one half's kernels are filled by the other's; 0 = never).
  * The defaults are the measured optimum; tests use "persist_slots" to force the multi-tile walk
  * of the persistent kernel on small inputs.  Results never depend on these.  0 = ok, -1 = unknown key. */
 int mars_hip_set_tuning(const char *key, int value);

@@ -907,3 +907,58 @@ def test_multi_gpu_recipe_from_c(gpu, orc, tmp_path):
             h = ((h ^ b) * 0x100000001B3) & 0xFFFFFFFFFFFFFFFF
         assert l[4] == "%016x" % h, l
         g.close()
+
+
+@pytest.mark.parametrize("B", [2, 5])
+def test_two_half_batches_on_two_streams(gpu, orc, B):
+    """"dual_stream_min_batch": a batch enqueued as two halves on two streams (frames [0, ceil(B/2)) and the rest; the
+    default from 64 frames up, forced here at 2 and at an odd 5) writes the bytes of the one-stream run -- graph outputs,
+    the detection tail that follows on the auxiliary stream without a host sync, and the pipelined I/O path -- and
+    frame 0 still equals the oracle"""
+    d = gpu.synth_model(width_x16=4, input_hw=96, seed=77, vary_scales=True)
+    hdr, tensors, _ = marsfile.parse(d)
+    nb = marsfile.tensor_nbytes(tensors[hdr["inputs"][0]])
+    xs = [lcg_frame(0xD0A1 * 16 + f, nb) for f in range(B)]
+    res = {}
+    try:
+        for dual in (0, 2):
+            gpu.set_tuning("graph_max_batch", 0)
+            gpu.set_tuning("dual_stream_min_batch", dual)
+            m = gpu.Model(d, batch=B)
+            for f in range(B):
+                m.input_view(0)[f] = xs[f]
+            m.run()
+            outs = [m.output_view(i).copy() for i in range(3)]
+            for _ in range(3):  # graph k+1 behind tail k, by events only
+                m.run_device(sync=False)
+                m.detect_device(outputs=(0, 1, 2), thresh=0.45)
+            assert gpu.lib().mars_hip_sync() == 0
+            dets = m.detect(outputs=(0, 1, 2), thresh=0.45)
+            m.pipe_open(download_outputs=True, detect=True, det_outputs=(0, 1, 2), thresh=0.45)
+            piped = []
+            for k in range(3):
+                iv = m.pipe_input_view(0)
+                for f in range(B):
+                    iv[f] = xs[(f + k) % B]
+                m.pipe_submit()
+            for k in range(3):
+                po, pd = m.pipe_wait()
+                piped.append(([o.copy() for o in po], [x.tobytes() for x in pd]))
+            m.pipe_close()
+            m.close()
+            res[dual] = (outs, [x.tobytes() for x in dets], piped)
+    finally:
+        gpu.set_tuning("dual_stream_min_batch", 64)
+        gpu.set_tuning("graph_max_batch", 8)
+    a, b = res[0], res[2]
+    for i in range(3):
+        assert np.array_equal(a[0][i], b[0][i]), i
+    assert a[1] == b[1]
+    for k in range(3):
+        for i in range(3):
+            assert np.array_equal(a[2][k][0][i], b[2][k][0][i]), (k, i)
+        assert a[2][k][1] == b[2][k][1]
+    g, rc = run_oracle(orc, d, xs[0])
+    assert rc == 0
+    for oi, ti in enumerate(hdr["outputs"]):
+        assert np.array_equal(b[0][oi][0], g.tensor(ti))

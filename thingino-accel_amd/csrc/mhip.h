@@ -26,7 +26,7 @@ int mhip_device_info(int *cu_count, int *lds_bytes, int *gfx_version, size_t *hb
 void *mhip_stream(void);
 int mhip_sync(void);                    /* both streams */
 void mhip_select_aux(int on);          /* launchers enqueue on the auxiliary stream while on */
-void mhip_select_stream(int which);    /* ... or on: 0 main, 1 auxiliary, 2 upload, 3 download (pipelined I/O) */
+void mhip_select_stream(int which);    /* ... or on: 0 main, 1 auxiliary, 2 upload, 3 download (pipelined I/O), 4 second compute */
 int mhip_stream_wait(int which, void *ev); /* that stream waits for an event */
 int mhip_event_sync(void *ev);         /* host waits for an event */
 void *mhip_malloc(size_t bytes);         /* HBM */
