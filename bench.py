@@ -172,6 +172,8 @@ def main():
                     help="skip the legs after the timed region (mars_run / pipelined I/O / batch-1 latency / CPU baselines): "
                          "what profiling passes want")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--tune", action="append", default=[], metavar="KEY=INT",
+                    help="mars_hip_set_tuning(KEY, INT) before the model is loaded (experiments; results never depend on it)")
     ap.add_argument("--vary-scales", action="store_true",
                     help="check run, not the benchmark workload: the twin with per-convolution scales (every fused table "
                          "differs); the CPU-baseline leg then compares its frames bit for bit as usual")
@@ -216,6 +218,9 @@ def main():
     import marsfile
     M.nna_init()
     f32 = args.dtype == "f32"
+    for kv in args.tune:
+        k, v = kv.split("=")
+        M.set_tuning(k, int(v))
     if f32:
         args.no_tail = True
         M.set_tuning("f32_mfma", args.f32_mode)

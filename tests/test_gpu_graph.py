@@ -962,3 +962,48 @@ def test_two_half_batches_on_two_streams(gpu, orc, B):
     assert rc == 0
     for oi, ti in enumerate(hdr["outputs"]):
         assert np.array_equal(b[0][oi][0], g.tensor(ti))
+
+
+@pytest.mark.parametrize("direct", [1, 0])
+def test_rgb_stem_both_forms(gpu, orc, direct):
+    """the RGB stem with its fused SiLU table, three frames per run (frame boundaries; the first and the last bytes of
+    the tensor, which the operand-direct form gathers byte by byte): images that are all edge tiles, ragged tile
+    overhangs on every side, interior tiles, strides 1 and 2, kernels 3 / 5 / 6 -- in the operand-direct form
+    (conv_i8_rgb, the default) and in the patch-staged form it replaced, against the oracle"""
+    shapes = [  # h, w, out_c, k, s
+        (37, 53, 32, 6, 2), (70, 41, 16, 3, 1), (9, 5, 32, 3, 1), (33, 6, 48, 6, 2), (130, 131, 32, 6, 2), (96, 160, 64, 6, 2),
+        (64, 64, 32, 5, 2), (16, 16, 32, 6, 2)]
+    rng = np.random.default_rng(5)
+    try:
+        gpu.set_tuning("rgb_direct", direct)
+        for (h, w, oc, k, s) in shapes:
+            oh, ow = (h + s - 1) // s, (w + s - 1) // s
+            G = marsfile.Graph()
+            x = G.tensor([1, h, w, 3], scale=0.02)
+            a = G.tensor([1, oh, ow, oc], scale=0.05)
+            sg = G.tensor([1, oh, ow, oc], scale=1.0 / 256)
+            o = G.tensor([1, oh, ow, oc], scale=0.04)
+            wt = G.tensor([oc, k, k, 3], scale=0.004, data=rng.integers(-127, 128, (oc, k, k, 3), dtype=np.int8))
+            b = G.tensor([oc], dtype=marsfile.I32, scale=1.0, data=rng.integers(-2000, 2000, oc, dtype=np.int32))
+            G.conv(x, a, wt, b, (k, k), (s, s))
+            G.layer(marsfile.SIGMOID, [a], [sg])
+            G.layer(marsfile.MUL, [a, sg], [o])
+            d = G.serialise([x], [o])
+            hdr, tensors, _ = marsfile.parse(d)
+            B = 3
+            m = gpu.Model(d, batch=B)
+            xs = [lcg_frame(0x57E3 * 64 + 8 * h + f, h * w * 3) for f in range(B)]
+            for f in range(B):
+                m.input_view(0)[f] = xs[f]
+            m.run()
+            for f in range(B):
+                g, rc = run_oracle(orc, d, xs[f])
+                assert rc == 0
+                want = g.tensor(hdr["outputs"][0])
+                got = m.output_view(0)[f]
+                bad = np.flatnonzero(got != want)
+                assert bad.size == 0, ((h, w, oc, k, s), f, bad.size, [(int(i) // oc // ow, int(i) // oc % ow, int(i) % oc) for i in bad[:12]])
+                assert len(np.unique(want)) > 16
+            m.close()
+    finally:
+        gpu.set_tuning("rgb_direct", 1)

@@ -1906,7 +1906,7 @@ __global__ __launch_bounds__(NTHREADS) void conv_i8_generic(const mhip_conv_i8_t
 #define SC_TH 16
 #define SC_TW 16
 #define SC_BP (SC_TH * SC_TW)
-template <int WOC>
+template <int WOC, bool HOT = false>
 __global__ __launch_bounds__(NTHREADS) void conv_i8_smallc(const mhip_conv_i8_t p, const int k64, const int tiles_x,
                                                            const int tiles_y, const unsigned ntiles_all, const int PH,
                                                            const int PW, const int PWp, const fastdiv_t dhw,
@@ -1955,7 +1955,7 @@ __global__ __launch_bounds__(NTHREADS) void conv_i8_smallc(const mhip_conv_i8_t 
     v4i pre[2];
     int shf[2]; // fast path: column shift of the loaded pixels (PRE_ZERO: nothing of this unit is inside the image)
     constexpr int PRE_ZERO = 8, PRE_DONE = -100;
-    const bool fast3 = p.in_c == 3 && p.in_w >= 4;
+    const bool fast3 = HOT || (p.in_c == 3 && p.in_w >= 4);
     // Workgroup ids go round-robin over the 8 XCDs (the grid is a multiple of 8, so a workgroup's XCD is blockIdx.x & 7
     // for its whole run): XCD x is given the x-th eighth of the tile list and walks it in order, so the workgroups
     // that share patch halos and 128-byte input lines run side by side under ONE L2 (measured: the kernel fetched
@@ -2041,7 +2041,7 @@ __global__ __launch_bounds__(NTHREADS) void conv_i8_smallc(const mhip_conv_i8_t 
     const int nks = k64 / BK;
     // MFMA operand addresses of this lane: B = pixel (row wv*WPX+u, column lane&15), K chunk c = lane>>4 -> kernel row
     // 2*ks + (c>>1), pixel slots (c&1)*4..+3 of that row; A = weight row s*16 + (lane&15), chunk c (swizzled)
-    const bool even_sw = ((p.stride_w | PWp) & 1) == 0;
+    const bool even_sw = HOT || ((p.stride_w | PWp) & 1) == 0;
     int xoff[WPX];
 #pragma unroll
     for (int u = 0; u < WPX; u++)
@@ -2108,8 +2108,287 @@ __global__ __launch_bounds__(NTHREADS) void conv_i8_smallc(const mhip_conv_i8_t 
                            },
                            (unsigned)hw, dhw); // rewritten only after the next loop-top barrier
         __syncthreads();              // rowoff (and the committed next patch) visible to every wave
-        epilogue<SC_BP, BN, WPX, WOC, true>(p, acc, tile, slut, rowoff, 0, wv * (WPX * 16), 0, hw);
+        if (HOT) { // host: NHWC rows stored straight from registers, half-step table, range fix-up dead, no fused Add
+            __builtin_assume(p.lut2 != nullptr);
+            __builtin_assume(p.add == nullptr);
+            epilogue_t<SC_BP, BN, WPX, WOC, true, true, true, true>(p, acc, tile, slut, rowoff, 0, wv * (WPX * 16), 0, hw);
+        } else {
+            epilogue<SC_BP, BN, WPX, WOC, true>(p, acc, tile, slut, rowoff, 0, wv * (WPX * 16), 0, hw);
+        }
     }
+}
+
+// ---------------------------------------------------------------------------------
+// RGB stem, operand-direct form (in_c == 3, interleaved NHWC, stride 2 x even, kw <= 9: the hot case of the small-channel
+// kernel).  In NHWC the kw*3 bytes a kernel row takes from the image are CONTIGUOUS: the MFMA B operand of output pixel
+// (oy, ox), kernel row ky is just the 32 bytes at in[oy*2 - pt + ky][(ox*sw - pl)*3 ...] (bytes past kw*3 meet zero
+// weights).  So nothing is staged: a wave owns 4 rows x 32 columns of a 16 x 32 output tile and loads its operands
+// with buffer_load_dwordx4 -- per-lane offset fixed for the whole run, the tile in the scalar offset -- while it
+// requantises the previous tile, takes the weights lane-linearly from LDS and stores every pixel's channels straight
+// from registers.  No patch in LDS, no widening, no barrier, no row-offset table, and waves never wait for each other.
+//  * One load serves several MFMAs: a K step covers kernel rows (2ks, 2ks+1), lanes 32-63 holding the odd row, and with
+//    stride_h == 2 output row u reads image rows 2u + 2ks + {0,1}: the operand depends on u + ks only.  4 rows x 3
+//    K steps need 6 row-pair loads per column class, not 12.
+//  * Alignment decides the load rate (probed: a dwordx4 load runs at 64 B/clk when every lane's address is a multiple
+//    of 4, at a quarter of that otherwise).  Pixels are 3 bytes, so with an even stride the 16 pixels of one MFMA are
+//    the EVEN or the ODD columns of the tile (two column classes e): inside a class the byte address advances 6*sw per
+//    pixel, a multiple of 4, and the class's residue d_e = (3*(sw*e - pl)) mod 4 is absorbed by loading from d_e bytes
+//    earlier and using a copy of the weights shifted up by d_e bytes (18 + 3 <= 32: it fits the kernel row's K slot).
+//    Tile origins advance 96*sw bytes and rows in_w*3: when in_w % 4 == 0 every load is aligned (otherwise still correct).
+//  * Stores: a lane holds 8 channels of an even and of an odd column; v_permlane16_swap trades the halves between lane
+//    rows g and g^1, so every lane stores 16 contiguous bytes and one instruction writes 1 KB of consecutive pixels
+//    (8-byte stores of every other pixel doubled the L2 write requests: measured).
+//  * The wave's 4 rows go in two phases (rows 0-1: MFMAs, requantise, store; rows 2-3 likewise) so that 32 accumulator
+//    registers suffice and the next tile's loads are issued before the second phase's requantisation.
+// Three fetch paths, chosen per wave and tile by scalar tests: INTERIOR (every tap inside the image); EDGE (rows outside
+// the image get an out-of-range offset = zeros; bytes of columns outside the image are masked before the MFMAs -- they
+// hold the neighbouring row's pixels); and the wave tiles whose 16-byte loads would start before / end after the tensor
+// (two per batch) gather their operands byte by byte.
+#define RGB_TW 32
+#define RGB_TH 16
+template <int WOC, int KS, bool LUT2>
+__device__ __forceinline__ void conv_i8_rgb_body(
+    const mhip_conv_i8_t &p, const int k64, const int tiles_x, const int tiles_y, const unsigned ntiles_all, const fastdiv_t dtx,
+    const fastdiv_t dty, const unsigned in_bytes, const unsigned out_bytes) {
+    constexpr int TR = RGB_TH / 4;  // output rows per wave
+    constexpr int NJ = TR + KS - 1; // row pairs of the wave's window
+    extern __shared__ __attribute__((aligned(16))) int8_t dyn[];
+    uint8_t *slut = (uint8_t *)dyn;          // the half-step table at LDS byte address 0 (requant_pack FAST)
+    v4i *wl = (v4i *)(dyn + LUTB);           // [2 classes][KS][WOC][64 lanes]: A operands, lane-linear
+    v4i *bl = wl + 2 * KS * WOC * 64;        // [WOC][4]: bias = C operand of the first K step
+    lds_base_must_be_zero(dyn);
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6); // scalar: tile offsets stay in SGPRs (a buffer's scalar offset
+                                                             // computed from a vector value costs a waterfall loop per access)
+    if (LUT2 && tid < 128) ((uint32_t *)slut)[tid] = ((const uint32_t *)p.lut2)[tid];
+    const int dsh0 = (3 * (4 * p.stride_w - p.pad_left)) & 3, dsh1 = (3 * (5 * p.stride_w - p.pad_left)) & 3; // d_e (sw even)
+    // weights: packed rows are [kh][8 taps x 4 bytes]; lane (m, g)'s A operand of (class e, K step ks, channel subtile s)
+    // is bytes (g&1)*16 .. +15 of kernel row 2*ks + (g>>1), taps at 3 bytes each, moved up by d_e bytes
+    for (int i = tid; i < 2 * KS * WOC * 64 * 4; i += NTHREADS) {
+        const int d = i & 3, l = (i >> 2) & 63, j = i >> 8, s2 = j % WOC, ks = (j / WOC) % KS, e = j / (WOC * KS);
+        const int8_t *wrow = p.w + (size_t)(s2 * 16 + (l & 15)) * k64 + (2 * ks + (l >> 5)) * 32;
+        uint32_t word = 0;
+        for (int b = 0; b < 4; b++) {
+            const int kb = ((l >> 4) & 1) * 16 + d * 4 + b - (e ? dsh1 : dsh0);
+            if (kb >= 0 && kb < 3 * p.kw) word |= (uint32_t)(uint8_t)wrow[(kb / 3) * 4 + kb % 3] << (8 * b);
+        }
+        ((uint32_t *)wl)[i] = word;
+    }
+    if (tid < WOC * 16) ((int *)bl)[tid] = p.bias ? p.bias[tid] : 0;
+
+    const int n = lane & 15, g = lane >> 4, half = g & 1, kr = g >> 1;
+    const int rowb = p.in_w * 3;
+    const __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc((void *)p.in, 0, (int)in_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t ors = __builtin_amdgcn_make_buffer_rsrc((void *)p.out, 0, (int)out_bytes, 0x00020000);
+    const int pixs = p.out_pix_stride ? p.out_pix_stride : p.out_c;
+    // per-lane offset inside a wave tile's input window (never negative: a negative lane offset is out of range for the
+    // buffer, whatever the scalar offset adds); what a column class adds goes into the scalar offset
+    const int vin = kr * rowb + 2 * n * p.stride_w * 3 + half * 16;
+    const int cls0 = -dsh0, cls1 = p.stride_w * 3 - dsh1;
+    // per-lane offset inside an output row of the tile.  WOC == 2: after the lane swap this lane stores 16 channels of
+    // column 2n + (g&1); WOC == 4: 16 channels of column 2n + e, once per class
+    const int vout = (WOC == 2 ? (2 * n + (g & 1)) * pixs + (g >> 1) * 16 : 2 * n * pixs + g * 16) + p.out_ch_off;
+    const int vch = WOC == 2 ? (g >> 1) * 16 : g * 16; // first channel this lane stores
+
+    // tile order as in conv_i8_smallc: XCD x walks the x-th eighth of the tile list
+    const unsigned xcd = blockIdx.x & 7u;
+    const unsigned xstart = (unsigned)(((unsigned long long)ntiles_all * xcd) >> 3);
+    const unsigned ntiles = ((unsigned)(((unsigned long long)ntiles_all * (xcd + 1u)) >> 3) - xstart) * 8u + xcd;
+    auto tile_xy = [&](unsigned t, int &tx, int &ty, unsigned &f) {
+        const unsigned j = xstart + (t >> 3), q = fdiv(j, dtx);
+        tx = (int)(j - q * (unsigned)tiles_x);
+        f = fdiv(q, dty);
+        ty = (int)(q - f * (unsigned)tiles_y);
+    };
+
+    v4i xb[2][NJ];                                      // [class][row pair j]: image rows iy0 + 2j + kr
+    bool masked = false;                                // wave-uniform: EDGE operands wait for their column mask
+    // row pairs [J0, J1) of tile t's window
+    auto fetch = [&](unsigned t, auto J0c, auto J1c) {
+        constexpr int J0 = decltype(J0c)::value, J1 = decltype(J1c)::value;
+        int tx, ty;
+        unsigned f;
+        tile_xy(t, tx, ty, f);
+        const int iy0 = (ty * RGB_TH + wv * TR) * 2 - p.pad_top, ix0 = tx * RGB_TW * p.stride_w - p.pad_left;
+        const long fbase = (long)f * (long)p.in_stride;
+        const int iy_last = iy0 + 2 * NJ - 1; // last image row of the window
+        const int iy_lastv = iy_last < p.in_h - 1 ? iy_last : p.in_h - 1;
+        // last byte + 1 any lane with a row inside the image touches / first byte of the window's first such row
+        const long reach_hi = fbase + (long)iy_lastv * rowb + (long)(ix0 + (RGB_TW - 1) * p.stride_w) * 3 + 32;
+        const long reach_lo = fbase + (long)(iy0 > 0 ? iy0 : 0) * rowb + (long)ix0 * 3 - 3;
+        const bool inside = reach_hi <= (long)in_bytes && reach_lo >= 0;
+        const bool interior = iy0 >= 0 && iy_last < p.in_h && ix0 >= 0 && ix0 + (RGB_TW - 1) * p.stride_w + p.kw <= p.in_w;
+        masked = !interior && inside;
+        if (interior && inside) { // scalar tile offset + fixed lane offset
+            const unsigned sbase = (unsigned)(fbase + (long)iy0 * rowb + (long)ix0 * 3);
+#pragma unroll
+            for (int j = J0; j < J1; j++)
+#pragma unroll
+                for (int e = 0; e < 2; e++)
+                    xb[e][j] = __builtin_amdgcn_raw_buffer_load_b128(xrs, vin, (int)(sbase + (unsigned)(2 * j * rowb + (e ? cls1 : cls0))), 0);
+            return;
+        }
+        if (inside) {
+            const int sb = (int)(fbase + (long)iy0 * rowb + (long)ix0 * 3); // may be negative: goes into the lane offset
+#pragma unroll
+            for (int j = J0; j < J1; j++) {
+                const bool rv = (unsigned)(iy0 + 2 * j + kr) < (unsigned)p.in_h;
+                const int off = vin + sb + 2 * j * rowb;
+#pragma unroll
+                for (int e = 0; e < 2; e++)
+                    xb[e][j] = __builtin_amdgcn_raw_buffer_load_b128(xrs, rv ? off + (e ? cls1 : cls0) : -1, 0, 0);
+            }
+            return;
+        }
+        // a 16-byte load of this window would start before / end after the tensor: byte by byte (two wave tiles per batch)
+#pragma unroll
+        for (int e = 0; e < 2; e++)
+#pragma unroll
+            for (int j = J0; j < J1; j++) {
+                const int iy = iy0 + 2 * j + kr;
+                const bool rv = iy >= 0 && iy < p.in_h;
+                const long rowoff = fbase + (long)iy * rowb;
+                const int b0 = (ix0 + (2 * n + e) * p.stride_w) * 3 + half * 16 - (e ? dsh1 : dsh0);
+                v4i v;
+#pragma unroll 1
+                for (int d = 0; d < 4; d++) {
+                    uint32_t word = 0;
+#pragma unroll 1
+                    for (int b = 0; b < 4; b++) {
+                        const int rb = b0 + d * 4 + b;
+                        const bool ok = rv && rb >= 0 && rb < rowb;
+                        const uint32_t byte = (uint32_t)__builtin_amdgcn_raw_buffer_load_b8(xrs, ok ? (int)(rowoff + rb) : -1, 0, 0);
+                        word |= (byte & 0xFFu) << (8 * b);
+                    }
+                    v[d] = (int)word;
+                }
+                xb[e][j] = v;
+            }
+    };
+
+    // rows u0, u0 + 1 of the wave's tile: MFMAs over every K step, class and channel subtile
+    auto rows_mfma = [&](int u0, v4i (&acc)[WOC][2][2]) {
+#pragma unroll
+        for (int ks = 0; ks < KS; ks++)
+#pragma unroll
+            for (int s2 = 0; s2 < WOC; s2++)
+#pragma unroll
+                for (int e = 0; e < 2; e++) {
+                    const v4i wa = wl[((e * KS + ks) * WOC + s2) * 64 + lane];
+                    if (ks == 0) {
+                        const v4i b4 = bl[s2 * 4 + g];
+#pragma unroll
+                        for (int u = 0; u < 2; u++) acc[s2][u][e] = __builtin_amdgcn_mfma_i32_16x16x64_i8(wa, xb[e][u0 + u + ks], b4, 0, 0, 0);
+                    } else {
+#pragma unroll
+                        for (int u = 0; u < 2; u++)
+                            acc[s2][u][e] = __builtin_amdgcn_mfma_i32_16x16x64_i8(wa, xb[e][u0 + u + ks], acc[s2][u][e], 0, 0, 0);
+                    }
+                }
+    };
+    // ... requantised, packed and stored
+    auto rows_store = [&](int u0, v4i (&acc)[WOC][2][2], int oy0, int ox0, unsigned obase) {
+        const bool chok = vch < p.out_c;
+#pragma unroll
+        for (int u = 0; u < 2; u++) {
+            uint32_t pk[2][WOC];
+#pragma unroll
+            for (int e = 0; e < 2; e++) {
+                int a[WOC * 4];
+#pragma unroll
+                for (int s2 = 0; s2 < WOC; s2++)
+#pragma unroll
+                    for (int r = 0; r < 4; r++) a[s2 * 4 + r] = acc[s2][u][e][r];
+                if (LUT2) requant_pack<WOC * 4, true, true, true, false, true>(a, p.cs, -128, slut + 128, pk[e]);
+                else requant_pack<WOC * 4, false, true, true>(a, p.cs, p.relu ? 0 : -128, slut + 128, pk[e]);
+            }
+            const int oy = oy0 + u0 + u;
+            const int soff = (int)(obase + (unsigned)(oy * p.out_w) * (unsigned)pixs);
+            const bool rok = chok && oy < p.out_h; // stores always issue: the same vmcnt in every wave
+            if (WOC == 2) {
+                // lane rows g, g^1 trade halves: even g ends with channels 8g..8g+15 of column 2n, odd g with channels
+                // 8(g-1)..8(g-1)+15 of column 2n+1
+                const auto w0 = __builtin_amdgcn_permlane16_swap(pk[0][0], pk[1][0], false, false);
+                const auto w1 = __builtin_amdgcn_permlane16_swap(pk[0][1], pk[1][1], false, false);
+                const int voff = (rok && ox0 + 2 * n + (g & 1) < p.out_w) ? vout : -1;
+                __builtin_amdgcn_raw_buffer_store_b128((v4i){(int)w0[0], (int)w1[0], (int)w0[1], (int)w1[1]}, ors, voff, soff, 0);
+            } else {
+#pragma unroll
+                for (int e = 0; e < 2; e++) {
+                    const int voff = (rok && ox0 + 2 * n + e < p.out_w) ? vout + e * pixs : -1;
+                    __builtin_amdgcn_raw_buffer_store_b128((v4i){(int)pk[e][0], (int)pk[e][1], (int)pk[e][WOC > 2 ? 2 : 0], (int)pk[e][WOC > 3 ? 3 : 0]}, ors, voff, soff, 0);
+                }
+            }
+        }
+    };
+
+    // The window's first NA row pairs (all that rows 0-1 need) are requested while the PREVIOUS tile's second phase
+    // requantises, the rest at the top of the tile's own first phase: 32 + 16 operand registers are never live together
+    // with 32 accumulators and the requantisation's temporaries (112 registers: 4 waves per SIMD and room for a wave of
+    // the detection tail beside them).
+    constexpr int NA = (1 + KS < NJ) ? 1 + KS : NJ;
+    using jz = std::integral_constant<int, 0>;
+    using ja = std::integral_constant<int, NA>;
+    using jn = std::integral_constant<int, NJ>;
+    auto mask_pairs = [&](int ox0, auto J0c, auto J1c) { // EDGE: columns outside the image delivered the neighbouring row's bytes
+        constexpr int J0 = decltype(J0c)::value, J1 = decltype(J1c)::value;
+        const int ix0 = ox0 * p.stride_w - p.pad_left;
+#pragma unroll
+        for (int e = 0; e < 2; e++) {
+            // this lane's 16 bytes start at byte b0 of its image row: bytes [nlo, nhi) are inside the row
+            const int b0 = (ix0 + (2 * n + e) * p.stride_w) * 3 + half * 16 - (e ? dsh1 : dsh0);
+            int nlo = -b0, nhi = rowb - b0;
+            nlo = nlo < 0 ? 0 : (nlo > 16 ? 16 : nlo);
+            nhi = nhi < 0 ? 0 : (nhi > 16 ? 16 : nhi);
+            v4i keep;
+#pragma unroll
+            for (int d = 0; d < 4; d++) {
+                const int a = nlo - 4 * d, b = nhi - 4 * d; // bytes [a, b) of dword d
+                const uint32_t below_b = b >= 4 ? 0xFFFFFFFFu : (b <= 0 ? 0u : (1u << (8 * b)) - 1u);
+                const uint32_t below_a = a >= 4 ? 0xFFFFFFFFu : (a <= 0 ? 0u : (1u << (8 * a)) - 1u);
+                keep[d] = (int)(below_b & ~below_a);
+            }
+#pragma unroll
+            for (int j = J0; j < J1; j++) xb[e][j] &= keep;
+        }
+    };
+
+    __syncthreads(); // table, weights, bias in LDS
+    unsigned t = blockIdx.x;
+    if (t < ntiles) fetch(t, jz{}, ja{});
+    for (; t < ntiles; t += gridDim.x) {
+        if (NA < NJ) fetch(t, ja{}, jn{}); // sets `masked` to the same value again
+        int tx, ty;
+        unsigned f;
+        tile_xy(t, tx, ty, f);
+        const int oy0 = ty * RGB_TH + wv * TR, ox0 = tx * RGB_TW;
+        const unsigned obase = f * (unsigned)p.out_stride + (unsigned)ox0 * (unsigned)pixs;
+        const bool edge = masked;
+        if (edge) mask_pairs(ox0, jz{}, ja{});
+        v4i acc[WOC][2][2];
+        rows_mfma(0, acc);
+        rows_store(0, acc, oy0, ox0, obase);
+        if (edge && NA < NJ) mask_pairs(ox0, ja{}, jn{});
+        rows_mfma(2, acc);
+        const unsigned tn = t + gridDim.x;
+        if (tn < ntiles) fetch(tn, jz{}, ja{}); // the next tile's operands travel during the second phase's requantisation
+        rows_store(2, acc, oy0, ox0, obase);
+    }
+}
+
+// the hot instantiation (32 channels, fused table) fits 4 waves per SIMD without spilling; the others are left to the
+// allocator (3 waves)
+template <int WOC, int KS, bool LUT2>
+__global__ __launch_bounds__(NTHREADS) __attribute__((amdgpu_waves_per_eu(4, 4))) void conv_i8_rgb4(
+    const mhip_conv_i8_t p, const int k64, const int tiles_x, const int tiles_y, const unsigned ntiles_all, const fastdiv_t dtx,
+    const fastdiv_t dty, const unsigned in_bytes, const unsigned out_bytes) {
+    conv_i8_rgb_body<WOC, KS, LUT2>(p, k64, tiles_x, tiles_y, ntiles_all, dtx, dty, in_bytes, out_bytes);
+}
+template <int WOC, int KS, bool LUT2>
+__global__ __launch_bounds__(NTHREADS) void conv_i8_rgb(const mhip_conv_i8_t p, const int k64, const int tiles_x, const int tiles_y,
+                                                        const unsigned ntiles_all, const fastdiv_t dtx, const fastdiv_t dty,
+                                                        const unsigned in_bytes, const unsigned out_bytes) {
+    conv_i8_rgb_body<WOC, KS, LUT2>(p, k64, tiles_x, tiles_y, ntiles_all, dtx, dty, in_bytes, out_bytes);
 }
 
 // packed weight / bias row that carries output channel `oc` (see epilogue_t): channels are permuted inside
@@ -2165,6 +2444,7 @@ struct tune_t {
     int bpx;            // MARS_HIP_BPX           0: auto, else pixels per workgroup (128 | 256)
     int variant;        // MARS_HIP_VARIANT       0: policy, else this launch variant wherever the layer allows it (tests)
     int bufmode;        // MARS_HIP_BUFMODE       1: buffer-addressed K loop where eligible
+    int rgb_direct;     // MARS_HIP_RGB_DIRECT    1: the RGB stem runs in its operand-direct form (conv_i8_rgb) where eligible
     int wres;           // MARS_HIP_WRES          bit 0 / 1: the default policy may keep the weights resident in LDS (tile
                         //                        walker) for single / paired launches
 };
@@ -2184,6 +2464,7 @@ static const tune_t &tune() {
         g_tune.variant = env_int("MARS_HIP_VARIANT", 0);
         g_tune.bufmode = env_int("MARS_HIP_BUFMODE", 1);
         g_tune.wres = env_int("MARS_HIP_WRES", 3);
+        g_tune.rgb_direct = env_int("MARS_HIP_RGB_DIRECT", 1);
         g_tune.init = 1;
     }
     return g_tune;
@@ -2191,7 +2472,7 @@ static const tune_t &tune() {
 extern "C" int mhip_conv_i8_tune(const char *key, int value) {
     (void)tune();
     struct { const char *k; int *v; } tab[] = {{"persist", &g_tune.persist}, {"persist_stages", &g_tune.persist_stages},
-                                               {"persist_maxk", &g_tune.persist_maxk}, {"persist_slots", &g_tune.persist_slots}, {"wres", &g_tune.wres},
+                                               {"persist_maxk", &g_tune.persist_maxk}, {"persist_slots", &g_tune.persist_slots}, {"wres", &g_tune.wres}, {"rgb_direct", &g_tune.rgb_direct},
                                                {"stages", &g_tune.stages}, {"bpx", &g_tune.bpx}, {"variant", &g_tune.variant}, {"bufmode", &g_tune.bufmode}};
     for (auto &e : tab)
         if (key && !strcmp(key, e.k)) {
@@ -2201,6 +2482,8 @@ extern "C" int mhip_conv_i8_tune(const char *key, int value) {
     return -1;
 }
 
+static long persist_out_bytes(const mhip_conv_i8_t *p);
+static long in_extent_bytes(const mhip_conv_i8_t *p);
 template <int WOC>
 static int launch_smallc(const mhip_conv_i8_t *p, int k64) {
     const int tiles_x = (p->out_w + SC_TW - 1) / SC_TW, tiles_y = (p->out_h + SC_TH - 1) / SC_TH;
@@ -2217,7 +2500,34 @@ static int launch_smallc(const mhip_conv_i8_t *p, int k64) {
     if (lds > 64 * 1024) return -1;
     if (ntiles >= 0x0fffffffL) return -1; // tile ids reach 8 x the longest per-XCD range
     long grid = ntiles < 256L * 8 ? (ntiles + 7) / 8 * 8 : 256L * 8; // a multiple of 8: a workgroup stays on its XCD's ids
-    hipLaunchKernelGGL((conv_i8_smallc<WOC>), dim3((unsigned)grid), dim3(NTHREADS), lds, mhip_stream_native(), *p, k64,
+    const bool hot = direct && p->in_c == 3 && p->in_w >= 4 && ((p->stride_w | PWp) & 1) == 0 && p->lut2 && p->safe && !p->add;
+    const bool rgb_ok = direct && p->in_c == 3 && p->safe && !p->add && (p->lut2 || !p->lut);
+    // operand-direct form: 32-bit offsets, stride 2 x even, 16 stored channels per lane, the class shift inside the K slot
+    const long in_ext = in_extent_bytes(p), out_ext = persist_out_bytes(p);
+    const int ksteps = (p->kh + 1) / 2;
+    if (rgb_ok && tune().rgb_direct && p->kw <= 9 && (p->stride_w & 1) == 0 && p->stride_h == 2 && p->out_c % 16 == 0 && ksteps >= 1 &&
+        ksteps <= 4 && k64 == ksteps * 64 && in_ext >= 16 && in_ext < 0x7fffffffL && out_ext < 0x7fffffffL) {
+        const int rtx = (p->out_w + RGB_TW - 1) / RGB_TW, rty = (p->out_h + RGB_TH - 1) / RGB_TH;
+        const long rtiles = (long)rtx * rty * p->frames;
+        if (rtiles >= 0x0fffffffL) return -1;
+        const long rgrid = rtiles < 256L * 8 ? (rtiles + 7) / 8 * 8 : 256L * 8;
+        const fastdiv_t dtx = make_fastdiv((unsigned)rtx), dty = make_fastdiv((unsigned)rty);
+        const size_t rgb_lds = LUTB + 2 * (size_t)ksteps * WOC * 1024 + WOC * 64;
+#define RGB(K)                                                                                                                   \
+    hipLaunchKernelGGL((p->lut2 ? (WOC == 2 ? conv_i8_rgb4<WOC, K, true> : conv_i8_rgb<WOC, K, true>) : conv_i8_rgb<WOC, K, false>), \
+                       dim3((unsigned)rgrid), dim3(NTHREADS), rgb_lds, mhip_stream_native(), *p, k64, rtx, rty, (unsigned)rtiles, dtx, \
+                       dty, (unsigned)in_ext, (unsigned)out_ext)
+        switch (ksteps) {
+            case 1: RGB(1); break;
+            case 2: RGB(2); break;
+            case 3: RGB(3); break;
+            default: RGB(4); break;
+        }
+#undef RGB
+        return mhip_check(hipGetLastError(), "conv_i8_rgb launch");
+    }
+    auto kern = hot ? conv_i8_smallc<WOC, true> : conv_i8_smallc<WOC, false>;
+    hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(NTHREADS), lds, mhip_stream_native(), *p, k64,
                        tiles_x, tiles_y, (unsigned)ntiles, PH, PW, PWp, make_fastdiv((unsigned)(p->out_h * p->out_w)),
                        make_fastdiv((unsigned)tiles_x), make_fastdiv((unsigned)tiles_y), make_fastdiv((unsigned)gpr), (int)tile_bytes);
     return mhip_check(hipGetLastError(), "conv_i8_smallc launch");

@@ -14,7 +14,8 @@ static hipStream_t g_stream = nullptr;
 static hipStream_t g_aux = nullptr;   // detection tail runs here, beside the next batch's graph
 static hipStream_t g_up = nullptr;    // pipelined I/O: host -> HBM copies of the NEXT batch (created on first use)
 static hipStream_t g_down = nullptr;  // pipelined I/O: HBM -> host copies of the PREVIOUS batch
-static hipStream_t g_second = nullptr; // second compute stream: the other half of a large batch runs here (mars_model.c)
+static hipStream_t g_seconds[3] = {nullptr, nullptr, nullptr};
+ // second compute stream: the other half of a large batch runs here (mars_model.c)
 static int g_use_aux = 0;             // current stream of the launchers: 0 main, 1 aux, 2 upload, 3 download, 4 second compute
 static int g_ready = 0;
 static int g_device = -1;
@@ -28,13 +29,14 @@ static hipStream_t stream_of(int which) {
         if (!st && hipStreamCreateWithFlags(&st, hipStreamNonBlocking) != hipSuccess) st = nullptr;
         return st ? st : g_stream;
     }
-    if (which == 4) { // same priority as the main stream: the two halves of a batch are peers
-        if (!g_second) {
+    if (which >= 4 && which <= 6) { // same priority as the main stream: the parts of a batch are peers
+        hipStream_t &st = g_seconds[which - 4];
+        if (!st) {
             int lo = 0, hi = 0;
             if (hipDeviceGetStreamPriorityRange(&lo, &hi) != hipSuccess) lo = hi = 0;
-            if (hipStreamCreateWithPriority(&g_second, hipStreamNonBlocking, hi) != hipSuccess) g_second = nullptr;
+            if (hipStreamCreateWithPriority(&st, hipStreamNonBlocking, hi) != hipSuccess) st = nullptr;
         }
-        return g_second ? g_second : g_stream;
+        return st ? st : g_stream;
     }
     return g_stream;
 }
@@ -94,8 +96,11 @@ extern "C" void mhip_shutdown(void) {
     (void)hipStreamDestroy(g_aux);
     if (g_up) { (void)hipStreamSynchronize(g_up); (void)hipStreamDestroy(g_up); }
     if (g_down) { (void)hipStreamSynchronize(g_down); (void)hipStreamDestroy(g_down); }
-    if (g_second) { (void)hipStreamSynchronize(g_second); (void)hipStreamDestroy(g_second); }
-    g_up = g_down = g_second = nullptr;
+    for (int k = 0; k < 3; k++) {
+        if (g_seconds[k]) { (void)hipStreamSynchronize(g_seconds[k]); (void)hipStreamDestroy(g_seconds[k]); }
+        g_seconds[k] = nullptr;
+    }
+    g_up = g_down = nullptr;
     g_aux = nullptr;
     g_use_aux = 0;
     if (g_zero_page) (void)hipFree(g_zero_page);
@@ -125,12 +130,13 @@ extern "C" int mhip_sync(void) {
     int rc2 = mhip_check(hipStreamSynchronize(g_aux), "hipStreamSynchronize aux");
     if (g_up && mhip_check(hipStreamSynchronize(g_up), "hipStreamSynchronize upload") && !rc) rc = -1;
     if (g_down && mhip_check(hipStreamSynchronize(g_down), "hipStreamSynchronize download") && !rc) rc = -1;
-    if (g_second && mhip_check(hipStreamSynchronize(g_second), "hipStreamSynchronize second") && !rc) rc = -1;
+    for (int k = 0; k < 3; k++)
+        if (g_seconds[k] && mhip_check(hipStreamSynchronize(g_seconds[k]), "hipStreamSynchronize second") && !rc) rc = -1;
     return rc ? rc : rc2;
 }
 // every launcher enqueues on "the current stream": main by default, aux while selected
 extern "C" void mhip_select_aux(int on) { g_use_aux = on ? 1 : 0; }
-extern "C" void mhip_select_stream(int which) { g_use_aux = which >= 0 && which <= 4 ? which : 0; }
+extern "C" void mhip_select_stream(int which) { g_use_aux = which >= 0 && which <= 6 ? which : 0; }
 // make a stream (0 main, 1 aux, 2 upload, 3 download) wait for an event recorded elsewhere
 extern "C" int mhip_stream_wait(int which, void *ev) {
     return mhip_check(hipStreamWaitEvent(stream_of(which), (hipEvent_t)ev, 0), "hipStreamWaitEvent");

@@ -47,6 +47,7 @@ static unsigned g_tune_gen = 1;
  * in every convolution kernel, profiles/r02_mfma_busy.json) and the tail of every launch.  Measured on the yolov5s twin,
  * batch 256: 4.76 -> 4.58 ms per batch. */
 static int g_dual_min_batch = 64;
+static int g_dual_ways = 2; /* parts (= streams) such a batch is cut into: 2..4 */
 static void drop_graph(mars_model_ext_t *m) {
     if (m->graph_exec) {
         mhip_sync();
@@ -1119,7 +1120,8 @@ void mars_free(mars_model_t *model) {
     if (m->ev_graph_done) mhip_event_destroy(m->ev_graph_done);
     if (m->ev_tail_done) mhip_event_destroy(m->ev_tail_done);
     if (m->ev_fork) mhip_event_destroy(m->ev_fork);
-    if (m->ev_join) mhip_event_destroy(m->ev_join);
+    for (int k = 0; k < 3; k++)
+        if (m->ev_join[k]) mhip_event_destroy(m->ev_join[k]);
     free(m->arena_host);
     free(m->mt);
     free(m->pub.weights);
@@ -1623,32 +1625,38 @@ static mars_error_t enqueue_plan(mars_model_t *model) {
                !(g_graph_max_batch > 0 && B <= g_graph_max_batch);
     if (dual) {
         if (!m->ev_fork) m->ev_fork = mhip_event_create();
-        if (!m->ev_join) m->ev_join = mhip_event_create();
-        if (!m->ev_fork || !m->ev_join) dual = 0;
+        for (int k = 0; k < 3; k++) {
+            if (!m->ev_join[k]) m->ev_join[k] = mhip_event_create();
+            if (!m->ev_join[k]) dual = 0;
+        }
+        if (!m->ev_fork) dual = 0;
     }
     mars_error_t e;
     if (!dual) {
         m->frame0 = 0; m->run_frames = B;
         e = enqueue_range(m, 0, m->tail_pending);
     } else {
-        /* everything the main stream was given before this run (uploads, an earlier run) comes first for both halves */
+        /* everything the main stream was given before this run (uploads, an earlier run) comes first for every part */
+        const int ways = g_dual_ways < B ? g_dual_ways : B;
         mhip_select_stream(0);
         int rc = mhip_event_record(m->ev_fork);
-        if (!rc) rc = mhip_stream_wait(4, m->ev_fork);
+        for (int k = 1; k < ways && !rc; k++) rc = mhip_stream_wait(3 + k, m->ev_fork);
         if (rc) return MARS_ERR_LAYER_FAILED;
-        const int n0 = (B + 1) / 2;
-        m->frame0 = 0; m->run_frames = n0;
-        e = enqueue_range(m, 0, m->tail_pending);
-        if (e == MARS_OK) {
-            m->frame0 = n0; m->run_frames = B - n0;
-            e = enqueue_range(m, 4, m->tail_pending);
+        e = MARS_OK;
+        int f0 = 0;
+        for (int k = 0; k < ways && e == MARS_OK; k++) {
+            const int n = (B - f0 + (ways - k) - 1) / (ways - k);
+            m->frame0 = f0; m->run_frames = n;
+            e = enqueue_range(m, k ? 3 + k : 0, m->tail_pending);
+            f0 += n;
         }
         /* join even after a failure: nothing may be left running behind the main stream's back */
-        mhip_select_stream(4);
-        rc = mhip_event_record(m->ev_join);
-        mhip_select_stream(0);
-        if (!rc) rc = mhip_stream_wait(0, m->ev_join);
-        if (rc && e == MARS_OK) e = MARS_ERR_LAYER_FAILED;
+        for (int k = 1; k < ways; k++) {
+            mhip_select_stream(3 + k);
+            rc = mhip_event_record(m->ev_join[k - 1]);
+            if (!rc) rc = mhip_stream_wait(0, m->ev_join[k - 1]);
+            if (rc && e == MARS_OK) e = MARS_ERR_LAYER_FAILED;
+        }
     }
     mhip_select_stream(0);
     m->frame0 = 0; m->run_frames = B;
@@ -1750,6 +1758,11 @@ int mars_hip_set_tuning(const char *key, int value) {
     if (key && !strcmp(key, "dual_stream_min_batch")) { /* smallest batch that runs as two halves on two streams (0 = never) */
         if (value < 0) return -1;
         g_dual_min_batch = value;
+        return 0;
+    }
+    if (key && !strcmp(key, "dual_stream_ways")) {
+        if (value < 2 || value > 4) return -1;
+        g_dual_ways = value;
         return 0;
     }
     if (key && !strcmp(key, "f32_mfma")) { /* 0 exact everywhere, 1 matrix cores where provably safe (default), 2 everywhere */
