@@ -27,7 +27,8 @@
 //                    SEG: input = never-materialised concat of up to 4 tensors -> 1x1 layers
 //   conv_i8_patch    input patch of a tile staged once in LDS, weights resident, taps fed from LDS
 //                                                                           -> k x k layers on wide maps
-//   conv_i8_smallc   in_c <= 4 (RGB stem): patch with pixels widened to 4 bytes, weights resident
+//   conv_i8_rgb      in_c == 3, stride 2 (the RGB stem): MFMA operands loaded straight from the image, no staging
+//   conv_i8_smallc   in_c <= 4 otherwise: patch with pixels widened to 4 bytes, weights resident
 //   conv_i8_generic  any other in_c: register-staged byte gather (fallback)
 // Launch variants / policy / autotune hooks: bottom of this file.  Design notes: DESIGN.md section 5.
 #include <hip/hip_runtime.h>
@@ -2266,25 +2267,31 @@ __device__ __forceinline__ void conv_i8_rgb_body(
             }
     };
 
-    // rows u0, u0 + 1 of the wave's tile: MFMAs over every K step, class and channel subtile
+    // rows u0, u0 + 1 of the wave's tile: MFMAs over every K step, class and channel subtile.  The A operands come from LDS
+    // one group ahead of their MFMAs and no further (left alone the scheduler hoists all twelve reads: 48 registers)
     auto rows_mfma = [&](int u0, v4i (&acc)[WOC][2][2]) {
+        constexpr int NG = KS * WOC * 2;
+        v4i wa = wl[lane]; // group 0 = (e 0, ks 0, s 0)
 #pragma unroll
-        for (int ks = 0; ks < KS; ks++)
+        for (int gi = 0; gi < NG; gi++) {
+            const int ks = gi / (WOC * 2), s2 = (gi / 2) % WOC, e = gi & 1;
+            v4i wn = wa;
+            if (gi + 1 < NG) {
+                const int ks1 = (gi + 1) / (WOC * 2), s1 = ((gi + 1) / 2) % WOC, e1 = (gi + 1) & 1;
+                wn = wl[((e1 * KS + ks1) * WOC + s1) * 64 + lane];
+            }
+            if (ks == 0) {
+                const v4i b4 = bl[s2 * 4 + g];
 #pragma unroll
-            for (int s2 = 0; s2 < WOC; s2++)
+                for (int u = 0; u < 2; u++) acc[s2][u][e] = __builtin_amdgcn_mfma_i32_16x16x64_i8(wa, xb[e][u0 + u + ks], b4, 0, 0, 0);
+            } else {
 #pragma unroll
-                for (int e = 0; e < 2; e++) {
-                    const v4i wa = wl[((e * KS + ks) * WOC + s2) * 64 + lane];
-                    if (ks == 0) {
-                        const v4i b4 = bl[s2 * 4 + g];
-#pragma unroll
-                        for (int u = 0; u < 2; u++) acc[s2][u][e] = __builtin_amdgcn_mfma_i32_16x16x64_i8(wa, xb[e][u0 + u + ks], b4, 0, 0, 0);
-                    } else {
-#pragma unroll
-                        for (int u = 0; u < 2; u++)
-                            acc[s2][u][e] = __builtin_amdgcn_mfma_i32_16x16x64_i8(wa, xb[e][u0 + u + ks], acc[s2][u][e], 0, 0, 0);
-                    }
-                }
+                for (int u = 0; u < 2; u++)
+                    acc[s2][u][e] = __builtin_amdgcn_mfma_i32_16x16x64_i8(wa, xb[e][u0 + u + ks], acc[s2][u][e], 0, 0, 0);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            wa = wn;
+        }
     };
     // ... requantised, packed and stored
     auto rows_store = [&](int u0, v4i (&acc)[WOC][2][2], int oy0, int ox0, unsigned obase) {
@@ -2301,6 +2308,7 @@ __device__ __forceinline__ void conv_i8_rgb_body(
                     for (int r = 0; r < 4; r++) a[s2 * 4 + r] = acc[s2][u][e][r];
                 if (LUT2) requant_pack<WOC * 4, true, true, true, false, true>(a, p.cs, -128, slut + 128, pk[e]);
                 else requant_pack<WOC * 4, false, true, true>(a, p.cs, p.relu ? 0 : -128, slut + 128, pk[e]);
+                __builtin_amdgcn_sched_barrier(0); // one class at a time: interleaved, the temporaries of all four cost a wave per SIMD
             }
             const int oy = oy0 + u0 + u;
             const int soff = (int)(obase + (unsigned)(oy * p.out_w) * (unsigned)pixs);
@@ -2323,9 +2331,8 @@ __device__ __forceinline__ void conv_i8_rgb_body(
     };
 
     // The window's first NA row pairs (all that rows 0-1 need) are requested while the PREVIOUS tile's second phase
-    // requantises, the rest at the top of the tile's own first phase: 32 + 16 operand registers are never live together
-    // with 32 accumulators and the requantisation's temporaries (112 registers: 4 waves per SIMD and room for a wave of
-    // the detection tail beside them).
+    // requantises, the rest after the tile's own first-phase MFMAs (they travel during its requantisation): at most 32
+    // operand registers are live together with the 32 accumulators and the requantisation's temporaries.
     constexpr int NA = (1 + KS < NJ) ? 1 + KS : NJ;
     using jz = std::integral_constant<int, 0>;
     using ja = std::integral_constant<int, NA>;
@@ -2357,7 +2364,6 @@ __device__ __forceinline__ void conv_i8_rgb_body(
     unsigned t = blockIdx.x;
     if (t < ntiles) fetch(t, jz{}, ja{});
     for (; t < ntiles; t += gridDim.x) {
-        if (NA < NJ) fetch(t, ja{}, jn{}); // sets `masked` to the same value again
         int tx, ty;
         unsigned f;
         tile_xy(t, tx, ty, f);
@@ -2367,6 +2373,7 @@ __device__ __forceinline__ void conv_i8_rgb_body(
         if (edge) mask_pairs(ox0, jz{}, ja{});
         v4i acc[WOC][2][2];
         rows_mfma(0, acc);
+        if (NA < NJ) fetch(t, ja{}, jn{}); // (sets `masked` to the same value again)
         rows_store(0, acc, oy0, ox0, obase);
         if (edge && NA < NJ) mask_pairs(ox0, ja{}, jn{});
         rows_mfma(2, acc);
