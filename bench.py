@@ -218,9 +218,13 @@ def main():
     import marsfile
     M.nna_init()
     f32 = args.dtype == "f32"
+    dual_min = 64  # the library's default for "dual_stream_min_batch"
     for kv in args.tune:
         k, v = kv.split("=")
         M.set_tuning(k, int(v))
+        if k == "dual_stream_min_batch":
+            dual_min = int(v)
+    dual_on = dual_min > 0
     if f32:
         args.no_tail = True
         M.set_tuning("f32_mfma", args.f32_mode)
@@ -341,6 +345,10 @@ def main():
                 "per_layer_floor_ms": floor_ms,
                 "frac_of_per_layer_floor": (floor_ms / (conv_ms / ev_steps)) if conv_ms > 0 else 0.0,
                 "event_timed_steps": ev_steps,
+                # kernel durations: HIP events on the library's stream, every launch over the FULL batch on ONE stream.
+                # The timed steps themselves run the batch as two halves on two streams (config.execution), whose launches
+                # overlap: ms_per_step may be smaller than the sum of kernel durations
+                "timing": "hip events, one stream, full-batch launches",
                 "conv_ms_per_step": conv_ms / ev_steps,
                 "all_kernels_ms_per_step": all_ms / ev_steps,
                 "ms_per_step_by_kind": {str(k): v / ev_steps for k, v in sorted(per_kind.items())}}
@@ -371,6 +379,8 @@ def main():
                        "frames_per_gpu": args.batch, "frames_total": args.batch * world,
                        "baseline_config": ("configs[3]: 1024 frames frame-sharded over 8 GPUs" if world == 8 and args.batch * world == 1024
                                            else "configs[1]-class: the metric's batch 256 per GPU" if args.batch == 256 else "custom"),
+                       "execution": ("two half-batches on two streams (dual_stream_min_batch)" if dual_on and args.batch >= dual_min
+                                     else "one stream"),
                        "ranks": world, "sharding": "frames", "collectives_in_forward": 0,
                        "autotuned_launch_variants": bool(args.autotune and not args.no_autotune), "conv_gmac_per_image": macs_per_img / 1e9, "algorithmic_mb_per_image": bytes_per_img / 1e6},
             "roofline": roof,

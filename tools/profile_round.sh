@@ -8,7 +8,12 @@ OUT=$PWD/gpurun_out
 mkdir -p $OUT
 W=2; K=4
 # the default launch policy (bench.py's default); only the timed region, no I/O / CPU legs
-BENCH="bench.py --timed-only --steps $K --warmup $W"
+# The per-kernel passes run every launch over the full batch on ONE stream (--tune dual_stream_min_batch=0), which is
+# also how bench.py times the kernels for its roofline object: per-launch averages then mean one launch = one layer of
+# 256 frames.  (The default run cuts the batch into two halves on two streams whose launches overlap; its trace is kept
+# too, as TAG_two_streams_kernel_stats.csv.)
+BENCH="bench.py --timed-only --steps $K --warmup $W --tune dual_stream_min_batch=0"
+BENCH2="bench.py --timed-only --steps $K --warmup $W"
 export TMPDIR=/tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/${TAG}_trace -o t -- python3 $BENCH > $OUT/${TAG}_bench_line_under_rocprof.json 2> $OUT/${TAG}_trace.err
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/${TAG}_pmc_fetch -o f -- python3 $BENCH > /dev/null 2> $OUT/${TAG}_pmc_fetch.err
@@ -20,6 +25,9 @@ rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES SQ_BUSY_CYCLES SQ_WAV
     --output-format csv -d $OUT/${TAG}_pmc_mfma -o m -- python3 $BENCH > /dev/null 2> $OUT/${TAG}_pmc_mfma.err
 python3 tools/mfma_busy.py $OUT/${TAG}_pmc_mfma $OUT/${TAG}_trace $((W + K)) > $OUT/${TAG}_mfma_busy.json
 find $OUT/${TAG}_trace -name '*kernel_stats.csv' -exec cp {} $OUT/${TAG}_bench_kernel_stats.csv \;
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/${TAG}_trace2 -o t -- python3 $BENCH2 > $OUT/${TAG}_two_streams_line_under_rocprof.json 2> $OUT/${TAG}_trace2.err
+find $OUT/${TAG}_trace2 -name '*kernel_stats.csv' -exec cp {} $OUT/${TAG}_two_streams_kernel_stats.csv \;
+find $OUT/${TAG}_trace2 -name '*kernel_trace.csv' -delete
 rm -rf $OUT/${TAG}_pmc_fetch $OUT/${TAG}_pmc_write $OUT/${TAG}_pmc_mfma
 find $OUT/${TAG}_trace -name '*kernel_trace.csv' -delete
 # un-profiled lines: per-launch table, the 320x320 workloads, the float32 workload (config 5), the default line
