@@ -393,6 +393,21 @@ def main():
             for _ in range(2):
                 model.run()
             result["pcie_inclusive_images_per_s"] = 2 * args.batch / (time.perf_counter() - t1)
+            if not args.no_tail:
+                # context for `value`: the same steps without the decode + NMS tail.  The twin's random heads put ~19 000
+                # predictions per frame above the threshold, so every frame hits the reference's cap of 1000 candidates
+                # and keeps ~780 boxes: the worst case for the sort and the NMS (a trained detector yields tens).
+                dets = model.detect(outputs=outputs, thresh=0.45)
+                result["config"]["kept_boxes_per_frame"] = float(np.mean([len(x) for x in dets]))
+                M.lib().mars_hip_sync()
+                for _ in range(3):
+                    model.run_device(sync=False)
+                M.lib().mars_hip_sync()
+                t1 = time.perf_counter()
+                for _ in range(10):
+                    model.run_device(sync=False)
+                M.lib().mars_hip_sync()
+                result["graph_only_images_per_s"] = 10 * args.batch / (time.perf_counter() - t1)
             if not f32:
                 # the same through the double-buffered path (mars_hip_pipe_*: upload k+1 / graph k / tail k / download k-1
                 # overlap): frames in over PCIe every batch; back come the detections only, or the raw head tensors too.

@@ -88,10 +88,12 @@ extern "C" int mhip_init(int device_hint) {
     return 0;
 }
 
+extern "C" void mhip_tail_release(void); // yolo_tail.hip: the sort's permutation buffer
 extern "C" void mhip_shutdown(void) {
     if (!g_ready) return;
     (void)hipStreamSynchronize(g_stream);
     (void)hipStreamSynchronize(g_aux);
+    mhip_tail_release();
     (void)hipStreamDestroy(g_stream);
     (void)hipStreamDestroy(g_aux);
     if (g_up) { (void)hipStreamSynchronize(g_up); (void)hipStreamDestroy(g_up); }
