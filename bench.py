@@ -202,6 +202,11 @@ def main():
     # BENCH_FORCE_DIST=1: take the multi-process path (process group, descriptor-only load is skipped on rank 0, arena
     # broadcast, barriers, max over ranks) with however many ranks there are -- a one-GPU rehearsal of the N>1 code
     multi = world > 1 or os.environ.get("BENCH_FORCE_DIST") == "1"
+    # stdout carries exactly ONE line, the JSON: whatever libraries write to file descriptor 1 while the job runs (RCCL
+    # prints a version banner there) goes to stderr instead; the descriptor is restored just before the line is printed
+    sys.stdout.flush()
+    saved_stdout = os.dup(1)
+    os.dup2(2, 1)
     if multi:
         import torch
         import torch.distributed as dist
@@ -474,8 +479,11 @@ def main():
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
+    sys.stdout.flush()
+    os.dup2(saved_stdout, 1)
+    os.close(saved_stdout)
     if rank == 0:
-        print(json.dumps(result))
+        print(json.dumps(result), flush=True)
 
 
 if __name__ == "__main__":

@@ -18,6 +18,7 @@ def run_bench(*extra, env=None):
     assert out.returncode == 0, out.stderr[-2000:]
     lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1  # exactly one JSON line
+    assert out.stdout.strip() == lines[0]  # ... and nothing else on stdout (library banners go to stderr)
     return json.loads(lines[0])
 
 
@@ -44,6 +45,7 @@ def test_bench_line_has_the_contract_fields():
     lat = d["latency_batch1"]
     assert lat["graph_resident_ms"] > 0 and lat["mars_run_ms"] >= lat["graph_resident_ms"] * 0.5 and lat["launches"] > 0
     assert d["config"]["frames_total"] == 4 and d["config"]["ranks"] == 1
+    assert d["graph_only_images_per_s"] > 0 and d["config"]["kept_boxes_per_frame"] >= 0
 
 
 def test_bench_flags():
