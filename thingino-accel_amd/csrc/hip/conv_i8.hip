@@ -2451,6 +2451,7 @@ struct tune_t {
     int bpx;            // MARS_HIP_BPX           0: auto, else pixels per workgroup (128 | 256)
     int variant;        // MARS_HIP_VARIANT       0: policy, else this launch variant wherever the layer allows it (tests)
     int bufmode;        // MARS_HIP_BUFMODE       1: buffer-addressed K loop where eligible
+    int small_batch;    // MARS_HIP_SMALL_BATCH   1: launches with few workgroups take the small-tile policy (default_variant)
     int rgb_direct;     // MARS_HIP_RGB_DIRECT    1: the RGB stem runs in its operand-direct form (conv_i8_rgb) where eligible
     int wres;           // MARS_HIP_WRES          bit 0 / 1: the default policy may keep the weights resident in LDS (tile
                         //                        walker) for single / paired launches
@@ -2472,6 +2473,7 @@ static const tune_t &tune() {
         g_tune.bufmode = env_int("MARS_HIP_BUFMODE", 1);
         g_tune.wres = env_int("MARS_HIP_WRES", 3);
         g_tune.rgb_direct = env_int("MARS_HIP_RGB_DIRECT", 1);
+        g_tune.small_batch = env_int("MARS_HIP_SMALL_BATCH", 1);
         g_tune.init = 1;
     }
     return g_tune;
@@ -2479,7 +2481,7 @@ static const tune_t &tune() {
 extern "C" int mhip_conv_i8_tune(const char *key, int value) {
     (void)tune();
     struct { const char *k; int *v; } tab[] = {{"persist", &g_tune.persist}, {"persist_stages", &g_tune.persist_stages},
-                                               {"persist_maxk", &g_tune.persist_maxk}, {"persist_slots", &g_tune.persist_slots}, {"wres", &g_tune.wres}, {"rgb_direct", &g_tune.rgb_direct},
+                                               {"persist_maxk", &g_tune.persist_maxk}, {"persist_slots", &g_tune.persist_slots}, {"wres", &g_tune.wres}, {"rgb_direct", &g_tune.rgb_direct}, {"small_batch", &g_tune.small_batch},
                                                {"stages", &g_tune.stages}, {"bpx", &g_tune.bpx}, {"variant", &g_tune.variant}, {"bufmode", &g_tune.bufmode}};
     for (auto &e : tab)
         if (key && !strcmp(key, e.k)) {
@@ -2981,6 +2983,28 @@ static variant_t default_variant(const mhip_conv_i8_t *p, int nks) {
     // wide, shallow k x k layers: the patch-staged kernel wins wherever its double-buffered form fits (measured on the
     // 160x160 and 80x80 layers of yolov5s: 1.25-1.9x over the implicit-GEMM forms)
     patch_geom_t g;
+    // Few frames: a launch whose large-batch tiling yields fewer workgroups than the device has CUs is bound by the
+    // latency of ONE workgroup's K walk, not by bytes per MAC.  Smaller tiles put more CUs to work and shorten every
+    // step: 4-row patches, the 128 x 128 tile with 128-byte K steps for deep K loops (half the barriers per MAC, four
+    // waves), the plain two-stage tile walker without the up-front weight fetch for 1 x 1 layers.  These are the
+    // autotuner's choices at batch 1 (yolov5s twin, 640 x 640: 0.62 -> 0.53 ms per frame).
+    const long wg_large = ((long)p->frames * p->out_h * p->out_w + 255) / 256 * ((p->oc_pad + 127) / 128);
+    const bool few = wg_large < 256 && tune().persist && !tune().bpx && !tune().stages && tune().small_batch;
+    if (few) {
+        if (patch_geom(p, 4, &g)) {
+            v.persist = 0; v.bpx = 0; v.stages = 0; v.patch = 4;
+            return v;
+        }
+        if (nks >= 8 && r128_ok(p)) {
+            v.persist = 0; v.bpx = 0; v.stages = 0; v.r128 = 1;
+            return v;
+        }
+        v.bpx = 128;
+        v.persist = nks <= tune().persist_maxk && persist_eligible(p);
+        if (((p->out_c | p->out_pix_stride | p->out_ch_off) & 15) != 0 && p->nseg <= 1) v.persist = 0;
+        v.stages = v.persist ? 2 : 3;
+        return v;
+    }
     if (tune().persist && !tune().bpx && !tune().stages) {
         // 16 output rows per workgroup wherever that patch fits at all (single-buffered included: the taller patch
         // re-reads fewer halo rows, measured 5-40 % over 8 rows on the 160x160 / 80x80 layers), else 8 rows
