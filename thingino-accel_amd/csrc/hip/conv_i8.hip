@@ -2144,7 +2144,7 @@ __global__ __launch_bounds__(NTHREADS) void conv_i8_smallc(const mhip_conv_i8_t 
 // Three fetch paths, chosen per wave and tile by scalar tests: INTERIOR (every tap inside the image); EDGE (rows outside
 // the image get an out-of-range offset = zeros; bytes of columns outside the image are masked before the MFMAs -- they
 // hold the neighbouring row's pixels); and the wave tiles whose 16-byte loads would start before / end after the tensor
-// (two per batch) gather their operands byte by byte.
+// (two per batch) load from the nearest offset inside it and shift the bytes into place.
 #define RGB_TW 32
 #define RGB_TH 16
 template <int WOC, int KS, bool LUT2>
@@ -2165,15 +2165,19 @@ __device__ __forceinline__ void conv_i8_rgb_body(
     const int dsh0 = (3 * (4 * p.stride_w - p.pad_left)) & 3, dsh1 = (3 * (5 * p.stride_w - p.pad_left)) & 3; // d_e (sw even)
     // weights: packed rows are [kh][8 taps x 4 bytes]; lane (m, g)'s A operand of (class e, K step ks, channel subtile s)
     // is bytes (g&1)*16 .. +15 of kernel row 2*ks + (g>>1), taps at 3 bytes each, moved up by d_e bytes
-    for (int i = tid; i < 2 * KS * WOC * 64 * 4; i += NTHREADS) {
-        const int d = i & 3, l = (i >> 2) & 63, j = i >> 8, s2 = j % WOC, ks = (j / WOC) % KS, e = j / (WOC * KS);
-        const int8_t *wrow = p.w + (size_t)(s2 * 16 + (l & 15)) * k64 + (2 * ks + (l >> 5)) * 32;
-        uint32_t word = 0;
-        for (int b = 0; b < 4; b++) {
-            const int kb = ((l >> 4) & 1) * 16 + d * 4 + b - (e ? dsh1 : dsh0);
-            if (kb >= 0 && kb < 3 * p.kw) word |= (uint32_t)(uint8_t)wrow[(kb / 3) * 4 + kb % 3] << (8 * b);
+    if (p.w_rgb) { // laid out by the host at load time (mhip_conv_i8_rgb_pack): a plain copy
+        for (int i = tid; i < 2 * KS * WOC * 64; i += NTHREADS) wl[i] = ((const v4i *)p.w_rgb)[i];
+    } else {
+        for (int i = tid; i < 2 * KS * WOC * 64 * 4; i += NTHREADS) {
+            const int d = i & 3, l = (i >> 2) & 63, j = i >> 8, s2 = j % WOC, ks = (j / WOC) % KS, e = j / (WOC * KS);
+            const int8_t *wrow = p.w + (size_t)(s2 * 16 + (l & 15)) * k64 + (2 * ks + (l >> 5)) * 32;
+            uint32_t word = 0;
+            for (int b = 0; b < 4; b++) {
+                const int kb = ((l >> 4) & 1) * 16 + d * 4 + b - (e ? dsh1 : dsh0);
+                if (kb >= 0 && kb < 3 * p.kw) word |= (uint32_t)(uint8_t)wrow[(kb / 3) * 4 + kb % 3] << (8 * b);
+            }
+            ((uint32_t *)wl)[i] = word;
         }
-        ((uint32_t *)wl)[i] = word;
     }
     if (tid < WOC * 16) ((int *)bl)[tid] = p.bias ? p.bias[tid] : 0;
 
@@ -2219,7 +2223,7 @@ __device__ __forceinline__ void conv_i8_rgb_body(
         const long reach_lo = fbase + (long)(iy0 > 0 ? iy0 : 0) * rowb + (long)ix0 * 3 - 3;
         const bool inside = reach_hi <= (long)in_bytes && reach_lo >= 0;
         const bool interior = iy0 >= 0 && iy_last < p.in_h && ix0 >= 0 && ix0 + (RGB_TW - 1) * p.stride_w + p.kw <= p.in_w;
-        masked = !interior && inside;
+        masked = !interior;
         if (interior && inside) { // scalar tile offset + fixed lane offset
             const unsigned sbase = (unsigned)(fbase + (long)iy0 * rowb + (long)ix0 * 3);
 #pragma unroll
@@ -2241,30 +2245,29 @@ __device__ __forceinline__ void conv_i8_rgb_body(
             }
             return;
         }
-        // a 16-byte load of this window would start before / end after the tensor: byte by byte (two wave tiles per batch)
+        // a 16-byte load of this window would start before / end after the tensor (two wave tiles per batch): load from
+        // the nearest offset that keeps all 16 bytes inside and shift the bytes into place (zeros move in; whatever lies
+        // outside the lane's image row is masked like on every edge tile)
+        masked = true;
+        const long sb = fbase + (long)iy0 * rowb + (long)ix0 * 3;
 #pragma unroll
-        for (int e = 0; e < 2; e++)
+        for (int j = J0; j < J1; j++) {
+            const bool rv = (unsigned)(iy0 + 2 * j + kr) < (unsigned)p.in_h;
 #pragma unroll
-            for (int j = J0; j < J1; j++) {
-                const int iy = iy0 + 2 * j + kr;
-                const bool rv = iy >= 0 && iy < p.in_h;
-                const long rowoff = fbase + (long)iy * rowb;
-                const int b0 = (ix0 + (2 * n + e) * p.stride_w) * 3 + half * 16 - (e ? dsh1 : dsh0);
-                v4i v;
-#pragma unroll 1
-                for (int d = 0; d < 4; d++) {
-                    uint32_t word = 0;
-#pragma unroll 1
-                    for (int b = 0; b < 4; b++) {
-                        const int rb = b0 + d * 4 + b;
-                        const bool ok = rv && rb >= 0 && rb < rowb;
-                        const uint32_t byte = (uint32_t)__builtin_amdgcn_raw_buffer_load_b8(xrs, ok ? (int)(rowoff + rb) : -1, 0, 0);
-                        word |= (byte & 0xFFu) << (8 * b);
-                    }
-                    v[d] = (int)word;
-                }
-                xb[e][j] = v;
+            for (int e = 0; e < 2; e++) {
+                const long off = sb + vin + 2 * j * rowb + (e ? cls1 : cls0);
+                long lo = off < 0 ? 0 : off;
+                lo = lo > (long)in_bytes - 16 ? (long)in_bytes - 16 : lo;
+                const int d = (int)(off - lo); // wanted byte b = loaded byte b + d
+                const v4i v = __builtin_amdgcn_raw_buffer_load_b128(xrs, rv ? (int)lo : -1, 0, 0);
+                unsigned __int128 w = ((unsigned __int128)(uint32_t)v[3] << 96) | ((unsigned __int128)(uint32_t)v[2] << 64) |
+                                      ((unsigned __int128)(uint32_t)v[1] << 32) | (unsigned __int128)(uint32_t)v[0];
+                if (d >= 16 || d <= -16) w = 0;
+                else if (d > 0) w >>= 8 * d;
+                else if (d < 0) w <<= -8 * d;
+                xb[e][j] = (v4i){(int)(uint32_t)w, (int)(uint32_t)(w >> 32), (int)(uint32_t)(w >> 64), (int)(uint32_t)(w >> 96)};
             }
+        }
     };
 
     // rows u0, u0 + 1 of the wave's tile: MFMAs over every K step, class and channel subtile.  The A operands come from LDS
@@ -2396,6 +2399,27 @@ __global__ __launch_bounds__(NTHREADS) void conv_i8_rgb(const mhip_conv_i8_t p, 
                                                         const unsigned ntiles_all, const fastdiv_t dtx, const fastdiv_t dty,
                                                         const unsigned in_bytes, const unsigned out_bytes) {
     conv_i8_rgb_body<WOC, KS, LUT2>(p, k64, tiles_x, tiles_y, ntiles_all, dtx, dty, in_bytes, out_bytes);
+}
+
+// host twin of the loop above: the kernel's LDS weight image [2 classes][KS][WOC][64 lanes][16 bytes]
+extern "C" size_t mhip_conv_i8_rgb_pack(int in_c, int kh, int kw, int stride_h, int stride_w, int pad_left, int oc_pad, int k64,
+                                        const int8_t *packed, int8_t *out) {
+    const int KS = (kh + 1) / 2, WOC = oc_pad / 16;
+    if (in_c != 3 || kw > 9 || (stride_w & 1) || stride_h != 2 || KS < 1 || KS > 4 || k64 != KS * 64 || (WOC != 2 && WOC != 4)) return 0;
+    const size_t bytes = (size_t)2 * KS * WOC * 64 * 16;
+    if (!out) return bytes;
+    const int dsh0 = (3 * (4 * stride_w - pad_left)) & 3, dsh1 = (3 * (5 * stride_w - pad_left)) & 3;
+    for (size_t i = 0; i < bytes / 4; i++) {
+        const int d = (int)(i & 3), l = (int)((i >> 2) & 63), j = (int)(i >> 8), s2 = j % WOC, ks = (j / WOC) % KS, e = j / (WOC * KS);
+        const int8_t *wrow = packed + (size_t)(s2 * 16 + (l & 15)) * k64 + (2 * ks + (l >> 5)) * 32;
+        uint32_t word = 0;
+        for (int b = 0; b < 4; b++) {
+            const int kb = ((l >> 4) & 1) * 16 + d * 4 + b - (e ? dsh1 : dsh0);
+            if (kb >= 0 && kb < 3 * kw) word |= (uint32_t)(uint8_t)wrow[(kb / 3) * 4 + kb % 3] << (8 * b);
+        }
+        memcpy(out + i * 4, &word, 4);
+    }
+    return bytes;
 }
 
 // packed weight / bias row that carries output channel `oc` (see epilogue_t): channels are permuted inside

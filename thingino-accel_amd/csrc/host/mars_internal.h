@@ -66,6 +66,7 @@ typedef struct {
     float cs, f0, f1, f2;
     size_t n;                 /* elements per frame for element-wise ops */
     size_t w_off, b_off, lut_off, s_off; /* offsets into the parameter arena */
+    size_t w2_off;   /* the RGB stem's weights as conv_i8_rgb keeps them in LDS (mhip_conv_i8_rgb_pack), or NO_OFF */
     size_t lut2_off; /* 512-entry half-step form of the fused LUT (4-instruction requantisation), or NO_OFF */
     size_t w_blob_off[2];     /* operands that live in the blob mirror */
     double macs, bytes;       /* algorithmic work per frame */

@@ -207,7 +207,7 @@ static mars_op_t *new_op(mars_model_ext_t *m, int kind, int layer) {
     op->kind = kind;
     op->layer = layer;
     op->t_in[0] = op->t_in[1] = op->t_in[2] = op->t_in[3] = op->t_out = -1;
-    op->w_off = op->b_off = op->lut_off = op->lut2_off = op->s_off = NO_OFF;
+    op->w_off = op->b_off = op->lut_off = op->lut2_off = op->s_off = op->w2_off = NO_OFF;
     op->w_blob_off[0] = op->w_blob_off[1] = NO_OFF;
     op->prof_kind = 4;
     return op;
@@ -348,6 +348,16 @@ static void plan_conv(mars_model_ext_t *m, int li) {
         mars_pack_conv_i8(tmp, wcount, op->nchw, out_c, in_c, kh, kw, c_eff, op->row_pad, op->oc_pad,
                           (int8_t *)m->arena_host + op->w_off);
         free(tmp);
+    }
+    if (!op->nchw) { /* RGB stem: its matrix-core operands pre-laid for conv_i8_rgb (12 KB for 32 channels, 6 x 6) */
+        const size_t n2 = mhip_conv_i8_rgb_pack(in_c, kh, kw, sh, sw, pl, op->oc_pad, (int)k64, NULL, NULL);
+        if (n2) {
+            op->w2_off = arena_reserve(m, n2);
+            if (op->w2_off == NO_OFF) return;
+            if (!m->deferred)
+                mhip_conv_i8_rgb_pack(in_c, kh, kw, sh, sw, pl, op->oc_pad, (int)k64, (const int8_t *)m->arena_host + op->w_off,
+                                      (int8_t *)m->arena_host + op->w2_off);
+        }
     }
     if (tb >= 0) { /* raw bytes reinterpreted as int32, whatever the tensor says it is (:645,656) */
         op->b_off = arena_reserve(m, (size_t)op->oc_pad * 4);
@@ -1404,6 +1414,7 @@ static void conv_i8_params(const mars_model_ext_t *m, const mars_op_t *op, mhip_
     p->bias = op->b_off != NO_OFF ? (const int32_t *)(A + op->b_off) : NULL;
     p->lut = op->lut_off != NO_OFF ? A + op->lut_off : NULL;
     p->lut2 = op->lut_off != NO_OFF && op->lut2_off != NO_OFF ? A + op->lut2_off : NULL;
+    p->w_rgb = op->w2_off != NO_OFF ? (const int8_t *)(A + op->w2_off) : NULL;
     p->frames = m->run_frames;
     p->in_h = op->in_h; p->in_w = op->in_w;
     p->out_h = op->out_h; p->out_w = op->out_w; p->out_c = op->store_c ? op->store_c : op->out_c;

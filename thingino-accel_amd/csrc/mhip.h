@@ -61,6 +61,8 @@ typedef struct {
     const uint8_t *lut;  /* 256-entry post-requant map (index q+128) or NULL */
     const uint8_t *lut2; /* optional 512-entry half-step form of `lut` (index trunc(2*acc*cs)+256, lower clamp folded in);
                             only valid when mhip_conv_i8_lut2_ok(cs): enables the 4-instruction requantisation */
+    const int8_t *w_rgb;        /* optional: the RGB stem's A operands in the layout conv_i8_rgb keeps in LDS
+                                 * (mhip_conv_i8_rgb_pack); NULL = the kernel re-lays p.w itself, once per workgroup */
     int frames;
     int in_h, in_w, in_c;       /* input as NHWC */
     int out_h, out_w, out_c;
@@ -92,6 +94,10 @@ typedef struct {
 /* row of the packed weights / bias that holds output channel oc (channels are permuted so that a lane's
  * results are consecutive channels) */
 int mhip_conv_i8_oc_row(int oc, int oc_pad);
+/* Bytes of, and (out != NULL) the content of, conv_i8_rgb's LDS weight image for this geometry; 0 = not an RGB-stem shape
+ * that kernel takes.  `packed` = the layer's packed weights [oc_pad][k64] (mars_pack_conv_i8, 4-byte taps). */
+size_t mhip_conv_i8_rgb_pack(int in_c, int kh, int kw, int stride_h, int stride_w, int pad_left, int oc_pad, int k64,
+                             const int8_t *packed, int8_t *out);
 /* is the float->int conversion of acc*cs provably in range for every int32 accumulator? */
 int mhip_conv_i8_is_safe(float cs);
 /* may the half-step LUT be used for this combined scale?  (no int32 accumulator may requantise to +-0x3EFFFFFF) */
