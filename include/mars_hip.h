@@ -73,6 +73,9 @@ mars_error_t mars_hip_set_fusion(mars_model_t *model, int level);
  * tolerance of the float32 models -- for every convolution from which no byte-wise MAXPOOL over float bytes is
  * reachable; 2 = matrix cores everywhere); "graph_max_batch" (default 8: at batches up to this the plan is captured into a
  * HIP graph after its first run and replayed with one call -- single frames are launch-bound; 0 = never);
+ * "small_batch" (default 1: a launch whose large-batch tiling yields fewer workgroups than the device has CUs takes
+ * smaller tiles -- what single frames want; 0 = the large-batch policy everywhere); "rgb_direct" (default 1: the RGB stem
+ * loads its matrix-core operands straight from the image; 0 = the patch-staged form);
  * "dual_stream_min_batch" (default 64: a batch of at least this many frames is enqueued as two halves on two streams,
  * frames being independent, so that the gaps of one half's kernels are filled by the other's; 0 = never).
  * The defaults are the measured optimum; tests use "persist_slots" to force the multi-tile walk
