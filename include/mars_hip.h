@@ -62,7 +62,9 @@ mars_error_t mars_hip_write_tensor(mars_model_t *model, int tensor_index, int fr
 
 /* Fusion level: 0 = one kernel per reference layer, every tensor materialised
  * (per-layer parity); 1 (default) = conv epilogue fusion of the
- * conv->sigmoid->mul chain and ReLU, copies elided where bit-identical.
+ * conv->sigmoid->mul chain and ReLU, copies elided where bit-identical;
+ * 2 = 1 + the C3 bottleneck's 1x1 evaluated inside the following 3x3's
+ * launch (fewer launches: single-frame latency; no gain at large batches).
  * Must be set before mars_hip_set_batch / first run; re-plans. */
 mars_error_t mars_hip_set_fusion(mars_model_t *model, int level);
 

@@ -1007,3 +1007,31 @@ def test_rgb_stem_both_forms(gpu, orc, direct):
             m.close()
     finally:
         gpu.set_tuning("rgb_direct", 1)
+
+
+@pytest.mark.parametrize("width,hw,B", [(8, 256, 2), (4, 256, 1), (8, 128, 3)])
+def test_fused_bottleneck_level2(gpu, orc, width, hw, B):
+    """fusion level 2: the C3 bottleneck's 1x1 + SiLU evaluated on the staged patch of the following 3x3 (halo pixels
+    included, zeros outside the image as the 3x3's SAME padding wants; the 1x1's output tensor is never written):
+    fewer launches, the same bytes -- twins with per-convolution scales, 32- and 64-channel bottlenecks, maps that
+    are not multiples of the tile, against the oracle and against level 1"""
+    d = gpu.synth_model(width_x16=width, input_hw=hw, seed=41 + hw, vary_scales=True)
+    hdr, tensors, _ = marsfile.parse(d)
+    nb = marsfile.tensor_nbytes(tensors[hdr["inputs"][0]])
+    xs = [lcg_frame(0xB0771E * 16 + f, nb) for f in range(B)]
+    outs, nops = {}, {}
+    for level in (1, 2):
+        m = gpu.Model(d, batch=B, fusion=level)
+        for f in range(B):
+            m.input_view(0)[f] = xs[f]
+        m.run()
+        outs[level] = [m.output_view(i).copy() for i in range(3)]
+        nops[level] = len(m.ops())
+        m.close()
+    assert nops[2] < nops[1]
+    for i in range(3):
+        assert np.array_equal(outs[1][i], outs[2][i]), i
+    g, rc = run_oracle(orc, d, xs[B - 1])
+    assert rc == 0
+    for oi, ti in enumerate(hdr["outputs"]):
+        assert np.array_equal(outs[2][oi][B - 1], g.tensor(ti))

@@ -139,6 +139,35 @@ __device__ __forceinline__ void lut4_fast(int q0, int q1, int q2, int q3, int &v
                  : "v"(q0), "v"(q1), "v"(q2), "v"(q3)
                  : "memory");
 }
+// the same half-step requantisation against a SECOND table at LDS bytes 512..1023 (the 1x1 stage of the fused bottleneck)
+template <int NV>
+__device__ __forceinline__ void requant_pack_pre(const int (&a)[NV], float cs, uint32_t (&pk)[NV / 4]) {
+    const float cs2 = cs * 2.0f;
+    const int klo = -256, khi = 255;
+    int q[NV], v[NV];
+#pragma unroll
+    for (int i = 0; i < NV; i++) {
+        const int k = (int)((float)a[i] * cs2);
+        asm("v_med3_i32 %0, %1, %2, %3" : "=v"(q[i]) : "v"(k), "v"(klo), "v"(khi));
+    }
+#pragma unroll
+    for (int g = 0; g < NV / 4; g++)
+        asm volatile("ds_read_i8 %0, %4 offset:768\n\tds_read_i8 %1, %5 offset:768\n\t"
+                     "ds_read_i8 %2, %6 offset:768\n\tds_read_i8 %3, %7 offset:768"
+                     : "=&v"(v[4 * g]), "=&v"(v[4 * g + 1]), "=&v"(v[4 * g + 2]), "=&v"(v[4 * g + 3])
+                     : "v"(q[4 * g]), "v"(q[4 * g + 1]), "v"(q[4 * g + 2]), "v"(q[4 * g + 3])
+                     : "memory");
+    if (NV == 16)
+        asm volatile("s_waitcnt lgkmcnt(0)"
+                     : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]), "+v"(v[3]), "+v"(v[4]), "+v"(v[5]), "+v"(v[6]), "+v"(v[7]),
+                       "+v"(v[8 % NV]), "+v"(v[9 % NV]), "+v"(v[10 % NV]), "+v"(v[11 % NV]), "+v"(v[12 % NV]), "+v"(v[13 % NV]),
+                       "+v"(v[14 % NV]), "+v"(v[15 % NV]));
+    else
+        asm volatile("s_waitcnt lgkmcnt(0)"
+                     : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]), "+v"(v[3]), "+v"(v[4]), "+v"(v[5]), "+v"(v[6]), "+v"(v[7]));
+#pragma unroll
+    for (int g = 0; g < NV / 4; g++) pk[g] = pack4(v[4 * g], v[4 * g + 1], v[4 * g + 2], v[4 * g + 3]);
+}
 template <int NV, bool HAS_LUT, bool SAFE, bool LUT0, bool ADD = false, bool FAST = false>
 __device__ __forceinline__ void requant_pack(const int (&a)[NV], float cs, int lo, const uint8_t *lut128, uint32_t (&pk)[NV / 4],
                                              const uint32_t *xw = nullptr, const add_args_t *ga = nullptr) {
@@ -1054,7 +1083,11 @@ __global__ __launch_bounds__(NTHREADS) void conv_i8_persist(const mhip_conv_i8_t
 //   16-byte bank groups for any tap (derivation: DESIGN.md section 5).
 #define PT_TW 16
 #define PT_NIMAX 10
-template <int TH, int BN, bool HAS_LUT>
+// PRE (fused C3 bottleneck, stride 1, in_c 32 / 64): t = SiLU(conv1x1(x)) is evaluated on the staged patch of x -- halo
+// included, zero where the pixel lies outside the image (the k x k convolution's SAME padding applies to t) -- into a
+// second patch buffer, and the K loop reads that one: t never goes to HBM.  The 1x1's weights ([in_c][64], K padded
+// with zeros) and its half-step table (LDS bytes 512..1023) stay resident like the main weights.
+template <int TH, int BN, bool HAS_LUT, bool PRE = false>
 __global__ __launch_bounds__(NTHREADS) void conv_i8_patch(const mhip_conv_i8_t p, const int k64, const int tiles_x,
                                                           const int tiles_y, const unsigned ntiles_all, const int PH,
                                                           const int PW, const int PWP, const int PWH, const int ni,
@@ -1068,10 +1101,13 @@ __global__ __launch_bounds__(NTHREADS) void conv_i8_patch(const mhip_conv_i8_t p
     uint8_t *slut = (uint8_t *)dynlds; // LDS byte address 0 (requant_pack LUT0)
     lds_base_must_be_zero(dynlds);
     const int nks = k64 / BK;
-    int *dutab = (int *)(dynlds + LUTB);                   // [nks][4] unit offsets of the K chunks
-    int8_t *wl = dynlds + LUTB + ((nks * 16 + 255) & ~255); // [nks][BN][64], swizzled like the ring tiles
+    constexpr int LB = LUTB + (PRE ? 512 : 0);             // PRE: the 1x1's table behind the main one
+    int *dutab = (int *)(dynlds + LB);                     // [nks][4] unit offsets of the K chunks
+    int8_t *wl = dynlds + LB + ((nks * 16 + 255) & ~255);   // [nks][BN][64], swizzled like the ring tiles
     const int patch_bytes = ni * 4096;                     // whole DMA instructions (4 waves x 1 KB)
-    int8_t *patch0 = wl + nks * BN * BK;
+    int8_t *w1l = wl + nks * BN * BK;                      // PRE: [in_c][64] weights of the 1x1
+    int8_t *patch0 = w1l + (PRE ? p.in_c * BK : 0);
+    int8_t *tpatch = patch0 + (dbl ? 2 : 1) * patch_bytes; // PRE: the patch of t
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -1087,6 +1123,7 @@ __global__ __launch_bounds__(NTHREADS) void conv_i8_patch(const mhip_conv_i8_t p
         if (p.lut2) { if (tid < 128) ((uint32_t *)slut)[tid] = ((const uint32_t *)p.lut2)[tid]; }
         else if (tid < 64) ((uint32_t *)slut)[tid] = ((const uint32_t *)p.lut)[tid];
     }
+    if (PRE && tid >= 128) ((uint32_t *)slut)[tid] = ((const uint32_t *)p.pre_lut2)[tid - 128]; // LDS 512..1023
     // K chunk table: chunk (ks, f) -> kernel row ky, column kx, channel chunk
     const int rowbytes = p.kw * C, kbytes = p.kh * rowbytes;
     for (int i = tid; i < nks * 4; i += NTHREADS) {
@@ -1106,6 +1143,8 @@ __global__ __launch_bounds__(NTHREADS) void conv_i8_patch(const mhip_conv_i8_t p
             const int ks = i / (BN / 16), g = i - ks * (BN / 16);
             glds16(p.w + (size_t)(oc0 + g * 16 + (lane >> 2)) * k64 + ks * BK + schunk * 16, wl + (ks * BN + g * 16) * BK);
         }
+        if (PRE)
+            for (int g = wv; g < C / 16; g += 4) glds16(p.pre_w + (size_t)(g * 16 + (lane >> 2)) * BK + schunk * 16, w1l + g * 16 * BK);
     }
     // this lane's units of the patch DMA: instruction n of wave wv fills physical units (n*4+wv)*64 + lane
     int uoff[PT_NIMAX], upos[PT_NIMAX]; // byte offset from the tile's first input pixel; (py << 16) | px, or -1
@@ -1188,6 +1227,60 @@ __global__ __launch_bounds__(NTHREADS) void conv_i8_patch(const mhip_conv_i8_t p
         int tx, ty;
         unsigned f;
         tile_xy(t, tx, ty, f);
+        if (PRE) {
+            // stage 1: t = SiLU(requant(W1 x + b1)) for every pixel of the patch, 16 flat pixels per MFMA column block;
+            // lane (i, g) ends with the 4 * WOC1 consecutive channels g * 4 * WOC1 .. of pixel i (row order of the packer)
+            constexpr int W1MAX = 4;
+            const int WOC1 = C >> 4;
+            const int P = PH * PWP, nsub = (P + 15) >> 4;
+            const int iy0 = ty * TH * s - p.pad_top, ix0 = tx * PT_TW * s - p.pad_left;
+            for (int sub = wv; sub < nsub; sub += 4) {
+                int pp = sub * 16 + frow;
+                const bool live = pp < P;
+                pp = live ? pp : P - 1;
+                const unsigned Ur = (unsigned)(pp * cpp + (fchunk & (cpp - 1))); // in_c 32: chunks 2, 3 meet zero weights
+                const v4i xb1 = *(const v4i *)(patch + ((Ur ^ ((Ur >> 3) & M)) << 4));
+                const unsigned py = fdiv((unsigned)pp, dpwp), px = (unsigned)pp - py * (unsigned)PWP;
+                const bool inimg = live && (int)py < PH && (int)px < PW && (unsigned)(iy0 + (int)py) < (unsigned)p.in_h &&
+                                   (unsigned)(ix0 + (int)px) < (unsigned)p.in_w;
+                uint32_t pk1[W1MAX];
+                if (WOC1 == 4) {
+                    int a1[16];
+#pragma unroll
+                    for (int q = 0; q < 4; q++) {
+                        const v4i wa = *(const v4i *)(w1l + lds_off(q * 16 + frow, fchunk));
+                        const v4i b1 = *(const v4i *)(p.pre_bias + q * 16 + (lane >> 4) * 4);
+                        const v4i r = __builtin_amdgcn_mfma_i32_16x16x64_i8(wa, xb1, b1, 0, 0, 0);
+#pragma unroll
+                        for (int e = 0; e < 4; e++) a1[q * 4 + e] = r[e];
+                    }
+                    uint32_t pk4[4];
+                    requant_pack_pre<16>(a1, p.pre_cs, pk4);
+#pragma unroll
+                    for (int e = 0; e < 4; e++) pk1[e] = inimg ? pk4[e] : 0u;
+                    const unsigned Uw = (unsigned)(pp * cpp + (lane >> 4));
+                    if (live) *(v4i *)(tpatch + ((Uw ^ ((Uw >> 3) & M)) << 4)) = (v4i){(int)pk1[0], (int)pk1[1], (int)pk1[2], (int)pk1[3]};
+                } else {
+                    int a1[8];
+#pragma unroll
+                    for (int q = 0; q < 2; q++) {
+                        const v4i wa = *(const v4i *)(w1l + lds_off(q * 16 + frow, fchunk));
+                        const v4i b1 = *(const v4i *)(p.pre_bias + q * 16 + (lane >> 4) * 4);
+                        const v4i r = __builtin_amdgcn_mfma_i32_16x16x64_i8(wa, xb1, b1, 0, 0, 0);
+#pragma unroll
+                        for (int e = 0; e < 4; e++) a1[q * 4 + e] = r[e];
+                    }
+                    uint32_t pk2[2];
+                    requant_pack_pre<8>(a1, p.pre_cs, pk2);
+                    const int g4 = lane >> 4; // channels g4 * 8 .. + 7: unit g4 >> 1, byte (g4 & 1) * 8
+                    const unsigned Uw = (unsigned)(pp * cpp + (g4 >> 1));
+                    if (live)
+                        *(uint2 *)(tpatch + ((Uw ^ ((Uw >> 3) & M)) << 4) + (g4 & 1) * 8) = make_uint2(inimg ? pk2[0] : 0u, inimg ? pk2[1] : 0u);
+                }
+            }
+            __syncthreads(); // t complete: the K loop below reads it in place of x
+            patch = tpatch;
+        }
         // output offsets of this lane's pixels; with a fused residual Add the other operand (same layout) is fetched
         // now, ahead of the K loop, so its latency never shows
         int voffs[WPX];
@@ -2737,7 +2830,10 @@ static bool patch_geom(const mhip_conv_i8_t *p, int th, patch_geom_t *g) {
     g->ni = (int)((units + 255) / 256);
     if (g->ni > PT_NIMAX) return false;
     // two workgroups per CU in any case (80 KB each): double-buffered patch if that fits, else one buffer
-    const size_t fixed = LUTB + (((size_t)g->nks * 16 + 255) & ~(size_t)255) + (size_t)g->nks * g->bn * BK;
+    const bool pre = p->pre_w != nullptr; // + the 1x1's table, its weights and the patch of its output
+    if (pre && (s != 1 || (C != 32 && C != 64) || !p->pre_bias || !p->pre_lut2 || !p->lut2)) return false;
+    const size_t fixed = LUTB + (pre ? 512 + (size_t)C * BK + (size_t)g->ni * 4096 : 0) +
+                         (((size_t)g->nks * 16 + 255) & ~(size_t)255) + (size_t)g->nks * g->bn * BK;
     g->dbl = fixed + 2 * (size_t)g->ni * 4096 <= 80 * 1024;
     g->lds = fixed + (g->dbl ? 2 : 1) * (size_t)g->ni * 4096;
     if (g->lds > 80 * 1024) return false;
@@ -2745,8 +2841,9 @@ static bool patch_geom(const mhip_conv_i8_t *p, int th, patch_geom_t *g) {
     return true;
 }
 
-template <int TH, int BN, bool HAS_LUT>
+template <int TH, int BN, bool HAS_LUT, bool PRE = false>
 static int launch_patch_t(const mhip_conv_i8_t *p, int k64, const patch_geom_t &g) {
+    auto kern = conv_i8_patch<TH, BN, HAS_LUT, PRE>;
     // workgroups the device holds at once at THIS layer's LDS size (small patches fit 3-4 per CU), cached per size
     static int cus = 0;
     static size_t slots_lds[4];
@@ -2754,7 +2851,7 @@ static int launch_patch_t(const mhip_conv_i8_t *p, int k64, const patch_geom_t &
     if (!cus) {
         int dev = 0;
         hipDeviceProp_t prop;
-        if (hipFuncSetAttribute((const void *)conv_i8_patch<TH, BN, HAS_LUT>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024) != hipSuccess ||
+        if (hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024) != hipSuccess ||
             hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess)
             return mhip_check(hipErrorUnknown, "conv_i8_patch occupancy query");
         cus = prop.multiProcessorCount;
@@ -2764,7 +2861,7 @@ static int launch_patch_t(const mhip_conv_i8_t *p, int k64, const patch_geom_t &
         if (slots_lds[i] == g.lds) slots = slots_n[i];
     if (!slots) {
         int occ = 0;
-        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, conv_i8_patch<TH, BN, HAS_LUT>, NTHREADS, g.lds) != hipSuccess)
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, kern, NTHREADS, g.lds) != hipSuccess)
             return mhip_check(hipErrorUnknown, "conv_i8_patch occupancy query");
         slots = (occ > 0 ? occ : 1) * cus;
         if (nslots < 4) { slots_lds[nslots] = g.lds; slots_n[nslots++] = slots; }
@@ -2776,7 +2873,7 @@ static int launch_patch_t(const mhip_conv_i8_t *p, int k64, const patch_geom_t &
     if (gx > ntiles) gx = ntiles;
     const int xmap = gx >= 8 && ntiles < 0x0fffffffu; // ids reach 8 x the longest range
     if (xmap) gx &= ~7u;
-    hipLaunchKernelGGL((conv_i8_patch<TH, BN, HAS_LUT>), dim3(gx, noc), dim3(NTHREADS), g.lds, mhip_stream_native(), *p, k64,
+    hipLaunchKernelGGL(kern, dim3(gx, noc), dim3(NTHREADS), g.lds, mhip_stream_native(), *p, k64,
                        g.tiles_x, g.tiles_y, ntiles, g.PH, g.PW, g.PWP, g.PWH, g.ni, (const int8_t *)mhip_zero_page(),
                        make_fastdiv((unsigned)g.tiles_x), make_fastdiv((unsigned)g.tiles_y), make_fastdiv((unsigned)g.PWP),
                        (unsigned)persist_out_bytes(p), g.dbl, xmap);
@@ -2956,11 +3053,25 @@ static int launch_duo(const mhip_conv_i8_t *p) {
 static int launch_patch(const mhip_conv_i8_t *p, int k64, int th) {
     patch_geom_t g;
     if (!patch_geom(p, th, &g)) return -1;
-#define PATCH(T, B) (p->lut ? launch_patch_t<T, B, true>(p, k64, g) : launch_patch_t<T, B, false>(p, k64, g))
+#define PATCH(T, B)                                                                       \
+    (p->pre_w ? launch_patch_t<T, B, true, true>(p, k64, g)                               \
+              : (p->lut ? launch_patch_t<T, B, true>(p, k64, g) : launch_patch_t<T, B, false>(p, k64, g)))
     if (th == 16) return g.bn == 64 ? PATCH(16, 64) : PATCH(16, 32);
     if (th == 8) return g.bn == 64 ? PATCH(8, 64) : PATCH(8, 32);
     return g.bn == 64 ? PATCH(4, 64) : PATCH(4, 32);
 #undef PATCH
+}
+
+// fused bottleneck (pre_* fields): only the patch-staged kernel evaluates it; some tile height must fit
+static int pre_tile_rows(const mhip_conv_i8_t *p) {
+    patch_geom_t g;
+    for (int th : {16, 8, 4})
+        if (patch_geom(p, th, &g) && (th == 4 || g.dbl)) return th;
+    return 0;
+}
+extern "C" int mhip_conv_i8_pre_ok(const mhip_conv_i8_t *p) {
+    if (!p || !p->pre_w || p->nseg > 1 || p->out_nchw) return 0;
+    return pre_tile_rows(p) != 0;
 }
 
 // a convolution whose input is a virtual concatenation: 1x1, stride 1, unpadded, segments tile [0, in_c) in steps of 32
@@ -3161,6 +3272,18 @@ extern "C" int mhip_conv_i8_variants(const mhip_conv_i8_t *p, int *codes, int ma
     if (!p || (p->in_c % 16) != 0 || mhip_conv_i8_small_c(p->in_c, p->kw, p->out_c)) return 0;
     const int k64 = (p->kh * p->row_pad + BK - 1) / BK * BK, nks = k64 / BK;
     int n = 0;
+    if (p->pre_w) { // fused bottleneck: the patch-staged kernel at 16 / 8 / 4 tile rows
+        patch_geom_t g;
+        const int first = pre_tile_rows(p);
+        for (int th : {first, 16, 8, 4})
+            if (th && n < max && patch_geom(p, th, &g)) {
+                const int code = th == 16 ? 10 : (th == 8 ? 9 : 11);
+                bool seen = false;
+                for (int i = 0; i < n; i++) seen |= codes[i] == code;
+                if (!seen) codes[n++] = code;
+            }
+        return n;
+    }
     if (p->nseg > 1) { // the tile walker only: plain, or with resident weights where they fit
         const int bn = p->oc_pad % 128 == 0 ? 128 : (p->oc_pad % 64 == 0 ? 64 : 32);
         const variant_t dv = default_variant(p, nks);
@@ -3228,6 +3351,20 @@ extern "C" int mhip_conv_i8(const mhip_conv_i8_t *p) {
         if (p->stride_h >= 1 && p->stride_w >= 1 && (long)PH * ((PW + 3) / 4) <= 2 * NTHREADS && total_pix <= 0x7fffffffL)
             return oc_pad == 32 ? launch_smallc<2>(p, k64) : launch_smallc<4>(p, k64);
         return -1;
+    }
+    if (p->pre_w) { // fused bottleneck: the patch-staged kernel at the tallest tile that fits (4 rows for few workgroups)
+        if (!mhip_zero_page() || !mhip_conv_i8_pre_ok(p)) return -1;
+        int th = pre_tile_rows(p);
+        const int code = p->variant ? p->variant : tune().variant;
+        patch_geom_t g;
+        if (code >= 9 && code <= 11) { // forced (autotuner / tests): that height if it fits
+            const int want = code == 10 ? 16 : (code == 9 ? 8 : 4);
+            if (patch_geom(p, want, &g)) th = want;
+        } else if (tune().small_batch && patch_geom(p, 4, &g) &&
+                   ((long)p->frames * p->out_h * p->out_w + 255) / 256 * ((p->oc_pad + 127) / 128) < 256) {
+            th = 4;
+        }
+        return launch_patch(p, k64, th);
     }
     if ((p->in_c % 16) == 0) {
         if (!mhip_zero_page()) return -1;

@@ -66,6 +66,9 @@ typedef struct {
     float cs, f0, f1, f2;
     size_t n;                 /* elements per frame for element-wise ops */
     size_t w_off, b_off, lut_off, s_off; /* offsets into the parameter arena */
+    int pre;         /* fused bottleneck: a 1x1 + SiLU evaluated on the staged patch before this convolution (fuse_bottleneck) */
+    size_t pre_w_off, pre_b_off, pre_lut2_off;
+    float pre_cs;
     size_t w2_off;   /* the RGB stem's weights as conv_i8_rgb keeps them in LDS (mhip_conv_i8_rgb_pack), or NO_OFF */
     size_t lut2_off; /* 512-entry half-step form of the fused LUT (4-instruction requantisation), or NO_OFF */
     size_t w_blob_off[2];     /* operands that live in the blob mirror */

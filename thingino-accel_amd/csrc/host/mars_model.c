@@ -821,6 +821,63 @@ static void fuse_add(mars_model_ext_t *m) {
     free(writers);
 }
 
+/* Fused C3 bottleneck: conv1x1 + SiLU (A) whose only reader is the k x k convolution B right behind it (B usually
+ * carries the folded residual Add of A's input) -> B evaluates A on its staged input patch (conv_i8_patch<PRE>); A's
+ * output tensor is never written.  Same bytes: B sees, at every in-image pixel of its window, exactly the int8 value A
+ * would have stored there, and zeros outside the image as its SAME padding prescribes.  Only where the device code can
+ * take it (mhip_conv_i8_pre_ok: stride 1, 32 / 64 channels, patch fits); everything else keeps the two launches.
+ * Fusion level 2 only: measured on the yolov5s twin it removes 4 launches (batch 1: 0.494 -> 0.485 ms) but returns
+ * nothing at batch 256 -- these 32 / 64-channel layers are bound by the requantisation's vector instructions, not by
+ * the bytes the fusion saves, and the halo makes the fused kernel requantise 1.3x the pixels. */
+static void conv_i8_params(const mars_model_ext_t *m, const mars_op_t *op, mhip_conv_i8_t *p);
+static void fuse_bottleneck(mars_model_ext_t *m) {
+    const int nt = (int)m->pub.header.num_tensors;
+    int *readers = (int *)calloc((size_t)nt + 1, sizeof(int));
+    if (!readers) return;
+    for (int i = 0; i < m->n_ops; i++)
+        for (int k = 0; k < m->ops[i].n_in; k++)
+            if (m->ops[i].t_in[k] >= 0) readers[m->ops[i].t_in[k]]++;
+    for (int i = 0; i + 1 < m->n_ops; i++) {
+        mars_op_t *a = &m->ops[i], *b = &m->ops[i + 1];
+        if (a->kind != OP_CONV_I8 || b->kind != OP_CONV_I8 || a->pre || b->pre) continue;
+        const int T = a->t_out;
+        if (T < 0 || b->t_in[0] != T || readers[T] != 1 || m->mt[T].io_in || m->mt[T].io_out || m->mt[T].is_weight) continue;
+        if (a->kh != 1 || a->kw != 1 || a->sh != 1 || a->sw != 1 || a->nchw || b->nchw || !a->safe || !b->safe || a->nseg || b->nseg ||
+            a->add_t || a->n_in != 1 || a->out_pix_stride || a->relu || a->lut2_off == NO_OFF || b->lut2_off == NO_OFF ||
+            a->in_c != a->out_c || a->out_c != b->in_c || (a->in_c != 32 && a->in_c != 64) || b->sh != 1 || b->sw != 1 ||
+            a->in_h != b->in_h || a->in_w != b->in_w || a->b_off == NO_OFF || a->pair_next || b->pair_next ||
+            (i > 0 && m->ops[i - 1].pair_next))
+            continue;
+        const int X = a->t_in[0];
+        if (X < 0 || X == b->t_out || m->mt[X].is_weight) continue;
+        /* the device side decides on geometry: describe B with A folded in (pointers only need to be non-null here) */
+        mars_op_t trial = *b;
+        trial.pre = 1;
+        trial.t_in[0] = X;
+        mhip_conv_i8_t p;
+        memset(&p, 0, sizeof(p));
+        p.frames = 1; p.in_c = trial.in_c; p.in_h = trial.in_h; p.in_w = trial.in_w; p.out_h = trial.out_h; p.out_w = trial.out_w;
+        p.out_c = trial.store_c ? trial.store_c : trial.out_c; p.kh = trial.kh; p.kw = trial.kw; p.stride_h = trial.sh; p.stride_w = trial.sw;
+        p.pad_top = trial.pt; p.pad_left = trial.pl; p.row_pad = trial.row_pad; p.oc_pad = trial.oc_pad; p.safe = trial.safe;
+        p.out_pix_stride = trial.out_pix_stride; p.out_ch_off = trial.out_ch_off;
+        p.pre_w = (const int8_t *)m; p.pre_bias = (const int32_t *)m; p.pre_lut2 = (const uint8_t *)m; p.lut2 = (const uint8_t *)m;
+        p.lut = (const uint8_t *)m;
+        if (!mhip_conv_i8_pre_ok(&p)) continue;
+        b->pre = 1;
+        b->pre_w_off = a->w_off; b->pre_b_off = a->b_off; b->pre_lut2_off = a->lut2_off; b->pre_cs = a->cs;
+        b->t_in[0] = X;
+        b->macs += a->macs;
+        m->mt[T].needed = 0;
+        readers[T] = 0;
+        a->kind = -1;
+    }
+    int w = 0;
+    for (int i = 0; i < m->n_ops; i++)
+        if (m->ops[i].kind != -1) m->ops[w++] = m->ops[i];
+    m->n_ops = w;
+    free(readers);
+}
+
 /* Virtual concat: when every reader of a Concat output is a plain 1x1 convolution, the concat tensor is never
  * written -- the convolution's K loop takes each run of channels straight from the tensor that owns it
  * (conv_i8_persist<SEG>).  The slice copies disappear and every producer keeps writing dense rows.  Same bytes
@@ -1165,6 +1222,7 @@ static mars_error_t build_plan(mars_model_ext_t *m) {
         elide_concat(m);
         fuse_pool_chains(m);
         pair_convs(m);
+        if (m->fusion >= 2) fuse_bottleneck(m); /* opt-in (level 2); after pairing: a paired launch stays a pair */
         pad_output_rows(m);
     }
     f32_policy(m);
@@ -1415,6 +1473,12 @@ static void conv_i8_params(const mars_model_ext_t *m, const mars_op_t *op, mhip_
     p->lut = op->lut_off != NO_OFF ? A + op->lut_off : NULL;
     p->lut2 = op->lut_off != NO_OFF && op->lut2_off != NO_OFF ? A + op->lut2_off : NULL;
     p->w_rgb = op->w2_off != NO_OFF ? (const int8_t *)(A + op->w2_off) : NULL;
+    if (op->pre) {
+        p->pre_w = (const int8_t *)(A + op->pre_w_off);
+        p->pre_bias = (const int32_t *)(A + op->pre_b_off);
+        p->pre_lut2 = A + op->pre_lut2_off;
+        p->pre_cs = op->pre_cs;
+    }
     p->frames = m->run_frames;
     p->in_h = op->in_h; p->in_w = op->in_w;
     p->out_h = op->out_h; p->out_w = op->out_w; p->out_c = op->store_c ? op->store_c : op->out_c;

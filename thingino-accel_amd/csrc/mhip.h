@@ -61,6 +61,13 @@ typedef struct {
     const uint8_t *lut;  /* 256-entry post-requant map (index q+128) or NULL */
     const uint8_t *lut2; /* optional 512-entry half-step form of `lut` (index trunc(2*acc*cs)+256, lower clamp folded in);
                             only valid when mhip_conv_i8_lut2_ok(cs): enables the 4-instruction requantisation */
+    /* optional: a 1x1 stride-1 convolution with a fused SiLU table (in_c -> in_c channels) evaluated on the staged input
+     * patch BEFORE this k x k convolution reads it (C3 bottleneck: cv2(cv1(x)), patch-staged kernel only):
+     * packed weights [in_c][64], bias rows, half-step table, combined scale */
+    const int8_t *pre_w;
+    const int32_t *pre_bias;
+    const uint8_t *pre_lut2;
+    float pre_cs;
     const int8_t *w_rgb;        /* optional: the RGB stem's A operands in the layout conv_i8_rgb keeps in LDS
                                  * (mhip_conv_i8_rgb_pack); NULL = the kernel re-lays p.w itself, once per workgroup */
     int frames;
@@ -96,6 +103,8 @@ typedef struct {
 int mhip_conv_i8_oc_row(int oc, int oc_pad);
 /* Bytes of, and (out != NULL) the content of, conv_i8_rgb's LDS weight image for this geometry; 0 = not an RGB-stem shape
  * that kernel takes.  `packed` = the layer's packed weights [oc_pad][k64] (mars_pack_conv_i8, 4-byte taps). */
+/* can the convolution described by *p take a preceding 1x1 (pre_* fields) in its launch?  (geometry only) */
+int mhip_conv_i8_pre_ok(const mhip_conv_i8_t *p);
 size_t mhip_conv_i8_rgb_pack(int in_c, int kh, int kw, int stride_h, int stride_w, int pad_left, int oc_pad, int k64,
                              const int8_t *packed, int8_t *out);
 /* is the float->int conversion of acc*cs provably in range for every int32 accumulator? */
