@@ -163,17 +163,19 @@ def test_conv_i8_tile_walk_resident_weights(gpu, orc, slots, variant):
         gpu.set_tuning("persist_slots", 0)
 
 
-@pytest.mark.parametrize("variant", [12, 13, 18, 19])
-def test_conv_i8_wide_one_tile_forms(gpu, orc, variant):
+@pytest.mark.parametrize("variant,slots", [(12, 0), (13, 0), (18, 0), (19, 0), (20, 0), (20, 2), (20, 3)])
+def test_conv_i8_wide_one_tile_forms(gpu, orc, variant, slots):
     """variant 12 (two K slices per ring stage), 13 (256 x 128 tile on an 8-wave workgroup), 18 / 19 (128-byte K steps:
     whole-line DMA requests, 128-byte LDS rows, 4 / 8 waves; layers with fewer than 128 input channels fall back to the
-    default there): deep K loops, 128 / 256 output channels, pixel counts that are not multiples of the tile, aligned
-    and ragged (255) rows"""
+    default there), 20 (the same steps as one persistent 8-wave workgroup per CU with a three-stage ring that runs
+    across tile boundaries; `slots` forces few workgroups so that each walks several tiles): deep K loops, 128 / 256
+    output channels, pixel counts that are not multiples of the tile, aligned and ragged (255) rows"""
     shapes = [  # in_h, in_w, in_c, out_c, k, s
         (40, 40, 128, 128, 3, 1), (23, 17, 256, 256, 3, 1), (33, 31, 128, 256, 1, 1), (20, 20, 512, 255, 1, 1),
         (19, 21, 64, 128, 3, 2), (16, 16, 1024, 128, 1, 1), (21, 19, 128, 128, 3, 2), (9, 11, 256, 128, 5, 1)]
     try:
         gpu.set_tuning("variant", variant)
+        gpu.set_tuning("persist_slots", slots)
         for i, (h, w, ic, oc, k, s) in enumerate(shapes):
             oh, ow = (h + s - 1) // s, (w + s - 1) // s
             ph = max((oh - 1) * s + k - h, 0) // 2
@@ -183,8 +185,27 @@ def test_conv_i8_wide_one_tile_forms(gpu, orc, variant):
             b = cases.conv_i8_call(orc.conv2d_int8, case, 7)
             assert np.array_equal(a, b), (case[0], int((a != b).sum()))
             assert len(np.unique(a)) > 32
+        if variant == 20:  # a whole graph, several frames: fused SiLU tables, folded Adds fall back, tile walks over frames
+            import marsfile
+            from conftest import lcg_frame
+            d = gpu.synth_model(width_x16=8, input_hw=256, seed=29, vary_scales=True)
+            hdr, tensors, _ = marsfile.parse(d)
+            nb = marsfile.tensor_nbytes(tensors[hdr["inputs"][0]])
+            m = gpu.Model(d, batch=3)
+            xs = [lcg_frame(0xAE0000 + f, nb) for f in range(3)]
+            for f in range(3):
+                m.input_view(0)[f] = xs[f]
+            m.run()
+            for f in range(3):
+                g = orc.Graph(d)
+                g.set_input(0, xs[f].tobytes())
+                assert g.run() == 0
+                for oi, ti in enumerate(hdr["outputs"]):
+                    assert np.array_equal(m.output_view(oi)[f], g.tensor(ti)), (f, oi)
+            m.close()
     finally:
         gpu.set_tuning("variant", 0)
+        gpu.set_tuning("persist_slots", 0)
 
 
 def test_conv_i8_patch_staged_streamed_weights(gpu, orc):

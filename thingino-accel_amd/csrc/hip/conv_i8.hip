@@ -1068,6 +1068,205 @@ __global__ __launch_bounds__(NTHREADS) void conv_i8_persist(const mhip_conv_i8_t
 }
 
 // ---------------------------------------------------------------------------------
+// conv_i8_r128p (launch variant 20): the 128-byte-K-step tile as ONE persistent 8-wave workgroup per CU with a THREE-stage
+// ring (3 x (256 + 128) x 128 B = 144 KB of LDS) that runs across tile boundaries.  The argument (DESIGN.md section 5,
+// "Deep-K"): the L2 -> LDS DMA delivers ~27 B/clk/CU in 64-byte row pieces and ~40 in whole 128-byte lines, but only with
+// enough bytes in flight (latency x bandwidth ~ 96 KB per CU); conv_i8_r128 has the lines but one stage in flight, the
+// 8-wave 64-byte tile has 96 KB in flight but the pieces.  Here two 48 KB stages are in flight behind the one being
+// multiplied, and the K stream of tile i+1 is already arriving while tile i is requantised (stores go out as raw buffer
+// stores, always the same number per wave, so vmcnt is counted across them as in conv_i8_persist).
+template <bool HAS_LUT>
+__global__ __launch_bounds__(512) void conv_i8_r128p(const mhip_conv_i8_t p, const unsigned total_pix, const int k128,
+                                                      const unsigned noc, const unsigned npt, const unsigned ngrp, const int lg_inc,
+                                                      const unsigned kw_magic, const fastdiv_t dhw, const fastdiv_t dow,
+                                                      const unsigned in_bytes, const unsigned out_bytes) {
+    constexpr int BPX = 256, BN = 128, NW = 8, STG = 3;
+    constexpr int STAGE = (BPX + BN) * 128;
+    constexpr int NWN = 2, NWM = NW / NWN;
+    constexpr int WPX = BPX / NWM / 16; // 4
+    constexpr int WOC = BN / NWN / 16;  // 4
+    constexpr int XI = BPX / 8 / NW;    // 4 DMA instructions of 8 rows x 128 B for the pixel tile
+    constexpr int WI = BN / 8 / NW;     // 2 for the weight tile
+    constexpr int L = XI + WI;          // per wave and stage
+    constexpr int NST = WPX;            // buffer stores per wave and tile
+    extern __shared__ __attribute__((aligned(16))) int8_t dynlds[];
+    uint8_t *slut = (uint8_t *)dynlds; // LDS byte address 0 (requant_pack LUT0)
+    int8_t *lds = dynlds + LUTB;
+    lds_base_must_be_zero(dynlds);
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const unsigned id = xcd_remap(blockIdx.x, noc * ngrp);
+    const unsigned grp = id / noc, ot = id - grp * noc;
+    const int oc0 = (int)ot * BN;
+    const unsigned t0 = (unsigned)(((unsigned long long)grp * npt) / ngrp);
+    const unsigned t1 = (unsigned)(((unsigned long long)(grp + 1) * npt) / ngrp);
+    if (t0 >= t1) return;
+    const unsigned hw = (unsigned)(p.out_h * p.out_w);
+    const int wm = wv % NWM, wn = wv / NWM;
+    const int pxw = wm * (WPX * 16), ocw = wn * (WOC * 16);
+
+    v4i bias[WOC];
+#pragma unroll
+    for (int q = 0; q < WOC; q++)
+        bias[q] = p.bias ? *(const v4i *)(p.bias + oc0 + ocw + q * 16 + (lane >> 4) * 4) : (v4i){0, 0, 0, 0};
+    if (HAS_LUT) {
+        if (p.lut2) { if (tid < 128) ((uint32_t *)slut)[tid] = ((const uint32_t *)p.lut2)[tid]; }
+        else if (tid < 64) ((uint32_t *)slut)[tid] = ((const uint32_t *)p.lut)[tid];
+        __syncthreads();
+    }
+    const __amdgpu_buffer_rsrc_t orsrc = __builtin_amdgcn_make_buffer_rsrc(p.out, 0, (int)out_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc((void *)p.in, 0, (int)in_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t wrs = __builtin_amdgcn_make_buffer_rsrc((void *)p.w, 0, p.oc_pad * k128, 0x00020000);
+
+    // DMA assignment: instruction j of this wave covers tile rows (wv * XI + j) * 8 .. + 7; lane i -> row i / 8, slot i % 8
+    const int lrow = lane >> 3, lslot = lane & 7;
+    int xvoff[XI];
+    unsigned tapmask[XI];
+    auto setup_rows = [&](unsigned tile) {
+#pragma unroll
+        for (int j = 0; j < XI; j++) {
+            const int trow = (wv * XI + j) * 8 + lrow;
+            const unsigned pix = tile * BPX + (unsigned)trow;
+            const bool valid = pix < total_pix;
+            const unsigned f = valid ? fdiv(pix, dhw) : 0u;
+            const unsigned rem = valid ? pix - f * hw : 0u;
+            const int oy = (int)fdiv(rem, dow), ox = (int)(rem - (unsigned)oy * (unsigned)p.out_w);
+            const int iy0 = oy * p.stride_h - p.pad_top, ix0 = ox * p.stride_w - p.pad_left;
+            const int chunk = lslot ^ ((trow >> 1) & 7);
+            xvoff[j] = (int)(f * (unsigned)p.in_stride) + (iy0 * p.in_w + ix0) * p.in_c + chunk * 16; // only used with in-image taps
+            const int kx_lo = ix0 < 0 ? -ix0 : 0, kx_hi = p.in_w - ix0 < p.kw ? p.in_w - ix0 : p.kw;
+            const unsigned colbits = kx_hi > kx_lo ? ((kx_hi >= 32 ? ~0u : (1u << kx_hi) - 1u) & ~((1u << kx_lo) - 1u)) : 0u;
+            unsigned m = 0;
+            for (int r = 0; r < p.kh; r++) {
+                const int iy = iy0 + r;
+                if (iy >= 0 && iy < p.in_h) m |= colbits << (r * p.kw);
+            }
+            tapmask[j] = valid ? m : 0u;
+        }
+    };
+    int wvoff[WI];
+#pragma unroll
+    for (int j = 0; j < WI; j++) {
+        const int trow = (wv * WI + j) * 8 + lrow;
+        wvoff[j] = (oc0 + trow) * k128 + (lslot ^ ((trow >> 1) & 7)) * 16;
+    }
+    const int taps = p.kh * p.kw;
+    const int nst = k128 / 128;
+    auto issue = [&](int st, int buf) {
+        int8_t *sb = lds + buf * STAGE;
+        const int utap = (st * 128) >> lg_inc, urc = (st * 128) & ((1 << lg_inc) - 1); // uniform: a 128-byte step lies inside one tap
+        const int uky = (int)(((unsigned)utap * kw_magic) >> 16), ukx = utap - uky * p.kw;
+        const int ukoff = (uky * p.in_w + ukx) * p.in_c + urc;
+        const bool uvalid = utap < taps;
+#pragma unroll
+        for (int j = 0; j < XI; j++) {
+            const bool ok = uvalid & (((tapmask[j] >> utap) & 1u) != 0u);
+            blds16(xrs, ok ? xvoff[j] + ukoff : -1, 0, sb + (wv * XI + j) * 1024);
+        }
+#pragma unroll
+        for (int j = 0; j < WI; j++) blds16(wrs, wvoff[j], st * 128, sb + BPX * 128 + (wv * WI + j) * 1024);
+    };
+
+    // issue cursor over the (tile, stage) stream; younger[i] = vector-memory instructions this wave has issued after the
+    // i-th oldest stage still in the ring
+    unsigned itile = t0;
+    int ist = 0;
+    int younger[STG - 1];
+    setup_rows(t0);
+    int nbuf = 0;
+#pragma unroll
+    for (int s2 = 0; s2 < STG - 1; s2++) {
+        int n = 0;
+        if (itile < t1) {
+            issue(ist, nbuf);
+            n = L;
+            if (++ist == nst) {
+                ist = 0;
+                if (++itile < t1) setup_rows(itile);
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < s2; i++) younger[i] += n;
+        younger[s2] = 0;
+        nbuf++;
+    }
+    nbuf = STG - 1;
+
+    const int frow = lane & 15, fchunk = lane >> 4;
+    const int chan = ocw + (lane >> 4) * (4 * WOC);
+    const int pstride = p.out_pix_stride ? p.out_pix_stride : p.out_c;
+    const int lo = p.relu ? 0 : -128;
+    const uint8_t *lut128 = slut + 128;
+    int buf = 0;
+    for (unsigned tile = t0; tile < t1; tile++) {
+        v4i acc[WOC][WPX];
+        for (int st = 0; st < nst; st++) {
+            wait_vmcnt_at_most<(STG - 2) * L, NST>(younger[0]);
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
+            const int8_t *xs = lds + buf * STAGE, *ws = xs + BPX * 128;
+            v4i xb[2][WPX], wa[2][WOC];
+#pragma unroll
+            for (int h = 0; h < 2; h++) {
+#pragma unroll
+                for (int t = 0; t < WPX; t++) xb[h][t] = *(const v4i *)(xs + lds_off128(pxw + t * 16 + frow, h * 4 + fchunk));
+#pragma unroll
+                for (int q = 0; q < WOC; q++) wa[h][q] = *(const v4i *)(ws + lds_off128(ocw + q * 16 + frow, h * 4 + fchunk));
+            }
+            int n = 0;
+            if (itile < t1) { // into the buffer multiplied one step ago: every wave is past the barrier above, hence past its reads
+                issue(ist, nbuf);
+                n = L;
+                if (++ist == nst) {
+                    ist = 0;
+                    if (++itile < t1) setup_rows(itile);
+                }
+            }
+#pragma unroll
+            for (int i = 0; i + 1 < STG - 1; i++) younger[i] = younger[i + 1] + n;
+            younger[STG - 2] = 0;
+            if (st == 0) {
+#pragma unroll
+                for (int q = 0; q < WOC; q++)
+#pragma unroll
+                    for (int t = 0; t < WPX; t++) acc[q][t] = __builtin_amdgcn_mfma_i32_16x16x64_i8(wa[0][q], xb[0][t], bias[q], 0, 0, 0);
+            } else {
+#pragma unroll
+                for (int q = 0; q < WOC; q++)
+#pragma unroll
+                    for (int t = 0; t < WPX; t++) acc[q][t] = __builtin_amdgcn_mfma_i32_16x16x64_i8(wa[0][q], xb[0][t], acc[q][t], 0, 0, 0);
+            }
+#pragma unroll
+            for (int q = 0; q < WOC; q++)
+#pragma unroll
+                for (int t = 0; t < WPX; t++) acc[q][t] = __builtin_amdgcn_mfma_i32_16x16x64_i8(wa[1][q], xb[1][t], acc[q][t], 0, 0, 0);
+            buf = buf + 1 == STG ? 0 : buf + 1;
+            nbuf = nbuf + 1 == STG ? 0 : nbuf + 1;
+        }
+        // epilogue: requantise, optional LUT, one 16-byte buffer store per pixel subtile
+#pragma unroll
+        for (int t = 0; t < WPX; t++) {
+            const unsigned pix = tile * BPX + pxw + t * 16 + (lane & 15);
+            const unsigned f = fdiv(pix, dhw), rem = pix - f * hw;
+            const unsigned off = f * (unsigned)p.out_stride + rem * (unsigned)pstride + (unsigned)(p.out_ch_off + oc0 + chan);
+            const bool ok = pix < total_pix && oc0 + chan + WOC * 4 <= p.out_c;
+            uint32_t pk[WOC];
+            int a[WOC * 4];
+#pragma unroll
+            for (int q = 0; q < WOC; q++)
+#pragma unroll
+                for (int r = 0; r < 4; r++) a[q * 4 + r] = acc[q][t][r];
+            if (HAS_LUT && p.lut2) requant_pack<WOC * 4, HAS_LUT, true, true, false, true>(a, p.cs, lo, lut128, pk);
+            else requant_pack<WOC * 4, HAS_LUT, true, true>(a, p.cs, lo, lut128, pk);
+            __builtin_amdgcn_raw_buffer_store_b128((v4i){(int)pk[0], (int)pk[1], (int)pk[2], (int)pk[3]}, orsrc, ok ? (int)off : -1, 0, 0);
+        }
+#pragma unroll
+        for (int i = 0; i < STG - 1; i++) younger[i] += NST;
+    }
+}
+
+// ---------------------------------------------------------------------------------
 // patch-staged kernel: k x k convolutions on wide feature maps with few channels (the 160x160 / 80x80 layers of
 // yolov5: in_c 32..128).  The implicit-GEMM kernels above fetch every input pixel once per kernel tap through the
 // 64 B/clk L1 path, which is what bounds these layers (few output channels per fetched byte).  Here a workgroup
@@ -2778,12 +2977,12 @@ static int launch_persist_t(const mhip_conv_i8_t *p, long total_pix, int k64, in
 //   code = 16: input patch staged once, weights streamed (8 waves, 16 x 16 pixels x 128 channels)
 //   code = 17: two-team strip kernel (16 waves: two 256-pixel x 128-channel tiles half a tile apart, shared weight ring)
 //   code = 18 / 19: 128-byte K steps (whole-line DMA requests), 128 x 128 tile on 4 waves / 256 x 128 tile on 8 waves
-#define NVARIANTS 19
+#define NVARIANTS 20
 struct variant_t {
     int persist, bpx, stages, patch, ks2, w8, wres, pws, duo, r128;
 };
 static int variant_code(const variant_t &v) {
-    if (v.r128) return v.r128 == 2 ? 19 : 18;
+    if (v.r128) return 17 + v.r128;
     if (v.duo) return 17;
     if (v.pws) return 16;
     if (v.wres) return v.bpx == 256 ? 15 : 14;
@@ -2793,7 +2992,7 @@ static int variant_code(const variant_t &v) {
     return 1 + (v.persist ? 1 : 0) + (v.bpx == 256 ? 2 : 0) + (v.stages == 3 ? 4 : 0);
 }
 static variant_t variant_of(int code) {
-    if (code == 18 || code == 19) return variant_t{0, 0, 0, 0, 0, 0, 0, 0, 0, code - 17};
+    if (code >= 18 && code <= 20) return variant_t{0, 0, 0, 0, 0, 0, 0, 0, 0, code - 17};
     if (code == 17) return variant_t{0, 0, 0, 0, 0, 0, 0, 0, 1, 0};
     if (code == 16) return variant_t{0, 0, 0, 0, 0, 0, 0, 1, 0, 0};
     if (code == 14 || code == 15) return variant_t{1, code == 15 ? 256 : 128, 2, 0, 0, 0, 1, 0, 0, 0};
@@ -2935,6 +3134,36 @@ static bool r128_ok(const mhip_conv_i8_t *p) {
     return C >= 128 && (C & (C - 1)) == 0 && p->oc_pad % 128 == 0 && p->kh * p->kw <= 32 && (long)p->kh * p->kw * (p->kw - 1) < 65536 &&
            p->row_pad == p->kw * C && p->nseg <= 1 && in_extent_bytes(p) <= 0x7fffffffL && (long)p->oc_pad * p->kh * p->row_pad <= 0x7fffffffL;
 }
+// conv_i8_r128p: one persistent workgroup per CU (144 KB of LDS), aligned rows only (raw buffer stores)
+static bool r128p_ok(const mhip_conv_i8_t *p) {
+    return r128_ok(p) && p->safe && !p->add && !p->out_nchw && ((p->out_c | p->out_pix_stride | p->out_ch_off) & 15) == 0 &&
+           persist_out_bytes(p) <= 0x7fffffffL;
+}
+template <bool HAS_LUT>
+static int launch_r128p_t(const mhip_conv_i8_t *p, long total_pix) {
+    const int k128 = p->kh * p->row_pad;
+    const unsigned npt = (unsigned)((total_pix + 255) / 256), noc = (unsigned)(p->oc_pad / 128);
+    const size_t lds = LUTB + 3 * (size_t)(256 + 128) * 128;
+    static int cus = 0;
+    if (!cus) {
+        int dev = 0;
+        hipDeviceProp_t prop;
+        if (hipFuncSetAttribute((const void *)conv_i8_r128p<HAS_LUT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess ||
+            hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess)
+            return mhip_check(hipErrorUnknown, "conv_i8_r128p LDS attribute");
+        cus = prop.multiProcessorCount;
+    }
+    unsigned ngrp = (unsigned)(tune().persist_slots > 0 ? tune().persist_slots : cus) / noc;
+    if (ngrp < 1) ngrp = 1;
+    if (ngrp > npt) ngrp = npt;
+    int lg = 0;
+    while ((1 << lg) < p->in_c) lg++;
+    const unsigned magic = ((65536u + (unsigned)p->kw - 1u) / (unsigned)p->kw);
+    hipLaunchKernelGGL((conv_i8_r128p<HAS_LUT>), dim3(noc * ngrp), dim3(512), lds, mhip_stream_native(), *p, (unsigned)total_pix, k128,
+                       noc, npt, ngrp, lg, magic, make_fastdiv((unsigned)(p->out_h * p->out_w)), make_fastdiv((unsigned)p->out_w),
+                       (unsigned)in_extent_bytes(p), (unsigned)persist_out_bytes(p));
+    return mhip_check(hipGetLastError(), "conv_i8_r128p launch");
+}
 template <int BPX, int BN, int NW>
 static int launch_r128_t(const mhip_conv_i8_t *p, long total_pix) {
     const int k128 = p->kh * p->row_pad; // taps * C: a multiple of 128
@@ -2955,6 +3184,10 @@ static int launch_r128_t(const mhip_conv_i8_t *p, long total_pix) {
 }
 static int launch_r128(const mhip_conv_i8_t *p, long total_pix, int form) {
     if (!r128_ok(p)) return -1;
+    if (form == 3) {
+        if (!r128p_ok(p)) return -1;
+        return p->lut ? launch_r128p_t<true>(p, total_pix) : launch_r128p_t<false>(p, total_pix);
+    }
     return form == 2 ? launch_r128_t<256, 128, 8>(p, total_pix) : launch_r128_t<128, 128, 4>(p, total_pix);
 }
 
@@ -3309,7 +3542,7 @@ extern "C" int mhip_conv_i8_variants(const mhip_conv_i8_t *p, int *codes, int ma
         if (v.pws && !pws_geom(p, &pg)) continue;
         duo_geom_t dg;
         if (v.duo && !duo_geom(p, &dg)) continue;
-        if (v.r128 && !r128_ok(p)) continue;
+        if (v.r128 && !(v.r128 == 3 ? r128p_ok(p) : r128_ok(p))) continue;
         if (v.wres) {
             const int bn = p->oc_pad % 128 == 0 ? 128 : (p->oc_pad % 64 == 0 ? 64 : 32);
             if (LUTB + 2 * (size_t)v.bpx * BK + (size_t)nks * bn * BK > 80 * 1024) continue;
