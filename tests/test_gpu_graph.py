@@ -970,14 +970,15 @@ def test_rgb_stem_both_forms(gpu, orc, direct):
     the tensor, which the operand-direct form gathers byte by byte): images that are all edge tiles, ragged tile
     overhangs on every side, interior tiles, strides 1 and 2, kernels 3 / 5 / 6 -- in the operand-direct form
     (conv_i8_rgb, the default) and in the patch-staged form it replaced, against the oracle"""
-    shapes = [  # h, w, out_c, k, s
+    shapes = [  # h, w, out_c, k, s (or (stride_h, stride_w))
         (37, 53, 32, 6, 2), (70, 41, 16, 3, 1), (9, 5, 32, 3, 1), (33, 6, 48, 6, 2), (130, 131, 32, 6, 2), (96, 160, 64, 6, 2),
-        (64, 64, 32, 5, 2), (16, 16, 32, 6, 2)]
+        (64, 64, 32, 5, 2), (16, 16, 32, 6, 2), (4, 128, 32, 7, (2, 4)), (61, 203, 16, 9, (2, 4)), (50, 50, 32, 4, (4, 2))]
     rng = np.random.default_rng(5)
     try:
         gpu.set_tuning("rgb_direct", direct)
         for (h, w, oc, k, s) in shapes:
-            oh, ow = (h + s - 1) // s, (w + s - 1) // s
+            sh, sw = s if isinstance(s, tuple) else (s, s)
+            oh, ow = (h + sh - 1) // sh, (w + sw - 1) // sw
             G = marsfile.Graph()
             x = G.tensor([1, h, w, 3], scale=0.02)
             a = G.tensor([1, oh, ow, oc], scale=0.05)
@@ -985,7 +986,7 @@ def test_rgb_stem_both_forms(gpu, orc, direct):
             o = G.tensor([1, oh, ow, oc], scale=0.04)
             wt = G.tensor([oc, k, k, 3], scale=0.004, data=rng.integers(-127, 128, (oc, k, k, 3), dtype=np.int8))
             b = G.tensor([oc], dtype=marsfile.I32, scale=1.0, data=rng.integers(-2000, 2000, oc, dtype=np.int32))
-            G.conv(x, a, wt, b, (k, k), (s, s))
+            G.conv(x, a, wt, b, (k, k), (sh, sw))
             G.layer(marsfile.SIGMOID, [a], [sg])
             G.layer(marsfile.MUL, [a, sg], [o])
             d = G.serialise([x], [o])

@@ -58,7 +58,8 @@ def test_conv_i8_stem_edges(gpu, orc):
     workgroup, strides 1 and 2"""
     shapes = [  # in_h, in_w, in_c, out_c, k, s
         (37, 53, 3, 32, 6, 2), (70, 41, 3, 16, 3, 1), (9, 3, 3, 32, 3, 1), (33, 6, 3, 48, 6, 2), (18, 50, 1, 32, 5, 2),
-        (11, 13, 4, 64, 3, 1), (21, 35, 2, 16, 6, 2), (130, 131, 3, 32, 6, 2)]
+        (11, 13, 4, 64, 3, 1), (21, 35, 2, 16, 6, 2), (130, 131, 3, 32, 6, 2),
+        (16, 128, 3, 32, 7, 4), (40, 90, 2, 48, 8, 3)]  # patches wider than the staged kernel holds: the gather kernel on the same packing
     for i, (h, w, ic, oc, k, s) in enumerate(shapes):
         oh, ow = (h + s - 1) // s, (w + s - 1) // s
         ph = max((oh - 1) * s + k - h, 0) // 2

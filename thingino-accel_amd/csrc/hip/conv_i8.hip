@@ -2083,6 +2083,7 @@ __global__ __launch_bounds__(1024) void conv_i8_duo(const mhip_conv_i8_t p, cons
 
 // ---------------------------------------------------------------------------------
 // generic kernel: any in_c (the 3-channel stem); register-staged byte gather
+__device__ __forceinline__ bool mhip_small_c_dev(int in_c, int kw, int out_c) { return in_c <= 4 && kw <= 8 && out_c <= 64; }
 template <int BN>
 __global__ __launch_bounds__(NTHREADS) void conv_i8_generic(const mhip_conv_i8_t p, const long total_pix, const int k64,
                                                             const fastdiv_t dhw) {
@@ -2118,7 +2119,9 @@ __global__ __launch_bounds__(NTHREADS) void conv_i8_generic(const mhip_conv_i8_t
     }
     int ky = 0, rc = cc * 16; // kernel row, byte inside the padded kernel row
     while (rc >= p.row_pad) { rc -= p.row_pad; ky++; }
-    const int row_bytes = p.kw * p.in_c;
+    // K layout of a kernel row: kw taps of `ceff` bytes.  Small-channel layers are packed with every tap widened to 4 bytes
+    // (mhip_conv_i8_pack_geom); this kernel serves those of them that neither conv_i8_rgb nor conv_i8_smallc takes
+    const int ceff = mhip_small_c_dev(p.in_c, p.kw, p.out_c) ? 4 : p.in_c;
     const int nks = k64 / BK;
     constexpr int WLOADS = (BN * 4 + NTHREADS - 1) / NTHREADS;
     v4i xreg[2], wreg[WLOADS];
@@ -2135,9 +2138,10 @@ __global__ __launch_bounds__(NTHREADS) void conv_i8_generic(const mhip_conv_i8_t
                 for (int e = 0; e < 16; e++) {
                     const int rr = rc + e;
                     int8_t val = 0;
-                    if (rr < row_bytes) {
-                        const int ix = ix0[j] + rr / p.in_c;
-                        if (ix >= 0 && ix < p.in_w) val = rowp[rr];
+                    const int tap = rr / ceff, ch = rr - tap * ceff;
+                    if (tap < p.kw && ch < p.in_c) {
+                        const int ix = ix0[j] + tap;
+                        if (ix >= 0 && ix < p.in_w) val = rowp[tap * p.in_c + ch];
                     }
                     b[e] = val;
                 }
@@ -2809,23 +2813,10 @@ extern "C" int mhip_conv_i8_tune(const char *key, int value) {
 
 static long persist_out_bytes(const mhip_conv_i8_t *p);
 static long in_extent_bytes(const mhip_conv_i8_t *p);
+// operand-direct RGB stem (conv_i8_rgb): -2 = not a shape it takes
 template <int WOC>
-static int launch_smallc(const mhip_conv_i8_t *p, int k64) {
-    const int tiles_x = (p->out_w + SC_TW - 1) / SC_TW, tiles_y = (p->out_h + SC_TH - 1) / SC_TH;
-    const long ntiles = (long)tiles_x * tiles_y * p->frames;
-    const int PH = (SC_TH - 1) * p->stride_h + p->kh, PW = (SC_TW - 1) * p->stride_w + p->kw;
-    const int PWp = (PW + 8 + 3) & ~3;
-    const int gpr = (PW + 3) / 4;
-    if ((long)PH * gpr > 2 * NTHREADS || ntiles > 0x7fffffffL) return -1;
-    constexpr int BN = WOC * 16;
+static int try_rgb(const mhip_conv_i8_t *p, int k64) {
     const bool direct = !p->out_nchw && ((p->out_c | p->out_pix_stride | p->out_ch_off) & 15) == 0; // as epilogue()
-    const size_t tile_bytes = direct ? 0 : (size_t)SC_BP * (BN + OPAD);
-    const size_t lds = (size_t)BN * k64 + 2 * ((((size_t)PH + 1) * PWp * 4 + 15) & ~(size_t)15) + tile_bytes + LUTB +
-                       (size_t)SC_BP * 8 + (size_t)BN * 4;
-    if (lds > 64 * 1024) return -1;
-    if (ntiles >= 0x0fffffffL) return -1; // tile ids reach 8 x the longest per-XCD range
-    long grid = ntiles < 256L * 8 ? (ntiles + 7) / 8 * 8 : 256L * 8; // a multiple of 8: a workgroup stays on its XCD's ids
-    const bool hot = direct && p->in_c == 3 && p->in_w >= 4 && ((p->stride_w | PWp) & 1) == 0 && p->lut2 && p->safe && !p->add;
     const bool rgb_ok = direct && p->in_c == 3 && p->safe && !p->add && (p->lut2 || !p->lut);
     // operand-direct form: 32-bit offsets, stride 2 x even, 16 stored channels per lane, the class shift inside the K slot
     const long in_ext = in_extent_bytes(p), out_ext = persist_out_bytes(p);
@@ -2851,6 +2842,26 @@ static int launch_smallc(const mhip_conv_i8_t *p, int k64) {
 #undef RGB
         return mhip_check(hipGetLastError(), "conv_i8_rgb launch");
     }
+    return -2;
+}
+
+template <int WOC>
+static int launch_smallc(const mhip_conv_i8_t *p, int k64) {
+    const int tiles_x = (p->out_w + SC_TW - 1) / SC_TW, tiles_y = (p->out_h + SC_TH - 1) / SC_TH;
+    const long ntiles = (long)tiles_x * tiles_y * p->frames;
+    const int PH = (SC_TH - 1) * p->stride_h + p->kh, PW = (SC_TW - 1) * p->stride_w + p->kw;
+    const int PWp = (PW + 8 + 3) & ~3;
+    const int gpr = (PW + 3) / 4;
+    if ((long)PH * gpr > 2 * NTHREADS || ntiles > 0x7fffffffL) return -1;
+    constexpr int BN = WOC * 16;
+    const bool direct = !p->out_nchw && ((p->out_c | p->out_pix_stride | p->out_ch_off) & 15) == 0; // as epilogue()
+    const size_t tile_bytes = direct ? 0 : (size_t)SC_BP * (BN + OPAD);
+    const size_t lds = (size_t)BN * k64 + 2 * ((((size_t)PH + 1) * PWp * 4 + 15) & ~(size_t)15) + tile_bytes + LUTB +
+                       (size_t)SC_BP * 8 + (size_t)BN * 4;
+    if (lds > 64 * 1024) return -1;
+    if (ntiles >= 0x0fffffffL) return -1; // tile ids reach 8 x the longest per-XCD range
+    long grid = ntiles < 256L * 8 ? (ntiles + 7) / 8 * 8 : 256L * 8; // a multiple of 8: a workgroup stays on its XCD's ids
+    const bool hot = direct && p->in_c == 3 && p->in_w >= 4 && ((p->stride_w | PWp) & 1) == 0 && p->lut2 && p->safe && !p->add;
     auto kern = hot ? conv_i8_smallc<WOC, true> : conv_i8_smallc<WOC, false>;
     hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(NTHREADS), lds, mhip_stream_native(), *p, k64,
                        tiles_x, tiles_y, (unsigned)ntiles, PH, PW, PWp, make_fastdiv((unsigned)(p->out_h * p->out_w)),
@@ -3581,9 +3592,24 @@ extern "C" int mhip_conv_i8(const mhip_conv_i8_t *p) {
     if (total_pix <= 0 || total_pix > 0x7fffffffL || (total_pix + BP - 1) / BP * (oc_pad / 32) > 0x7fffffffL) return -1;
     if (mhip_conv_i8_small_c(p->in_c, p->kw, p->out_c)) {
         const int PH = (SC_TH - 1) * p->stride_h + p->kh, PW = (SC_TW - 1) * p->stride_w + p->kw;
-        if (p->stride_h >= 1 && p->stride_w >= 1 && (long)PH * ((PW + 3) / 4) <= 2 * NTHREADS && total_pix <= 0x7fffffffL)
-            return oc_pad == 32 ? launch_smallc<2>(p, k64) : launch_smallc<4>(p, k64);
-        return -1;
+        if (p->stride_h >= 1 && p->stride_w >= 1 && total_pix <= 0x7fffffffL) {
+            const int rc = oc_pad == 32 ? try_rgb<2>(p, k64) : try_rgb<4>(p, k64);
+            if (rc != -2) return rc;
+        }
+        {
+            const int PWp = (PW + 8 + 3) & ~3;
+            const bool direct = !p->out_nchw && ((p->out_c | p->out_pix_stride | p->out_ch_off) & 15) == 0;
+            const size_t lds = (size_t)oc_pad * k64 + 2 * ((((size_t)PH + 1) * PWp * 4 + 15) & ~(size_t)15) +
+                               (direct ? 0 : (size_t)SC_BP * (oc_pad + OPAD)) + LUTB + (size_t)SC_BP * 8 + (size_t)oc_pad * 4;
+            const long ntiles = (long)((p->out_w + SC_TW - 1) / SC_TW) * ((p->out_h + SC_TH - 1) / SC_TH) * p->frames;
+            if (p->stride_h >= 1 && p->stride_w >= 1 && (long)PH * ((PW + 3) / 4) <= 2 * NTHREADS && total_pix <= 0x7fffffffL &&
+                lds <= 64 * 1024 && ntiles < 0x0fffffffL)
+                return oc_pad == 32 ? launch_smallc<2>(p, k64) : launch_smallc<4>(p, k64);
+        }
+        // a patch larger than the small-channel kernel stages (large strides / kernels): the gather kernel reads the same packing
+        if (p->add || p->nseg > 1) return -1;
+        if (oc_pad % 64 == 0) return launch_generic<64>(p, total_pix, k64);
+        return launch_generic<32>(p, total_pix, k64);
     }
     if (p->pre_w) { // fused bottleneck: the patch-staged kernel at the tallest tile that fits (4 rows for few workgroups)
         if (!mhip_zero_page() || !mhip_conv_i8_pre_ok(p)) return -1;
