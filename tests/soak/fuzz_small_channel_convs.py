@@ -1,11 +1,11 @@
 """Soak test (GPU box, through gpurun): small-channel convolutions of random geometry -- 1..4 input channels, kernels 1..9,
 strides 1..4, with and without the fused SiLU table, several frames -- GPU vs the oracle.
-  python tools/fuzz_small_channel_convs.py SEED N"""
+  python tests/soak/fuzz_small_channel_convs.py SEED N"""
 import os, sys
 import numpy as np
-sys.path.insert(0, os.path.join(os.path.dirname(__file__), "..", "tests"))
-sys.path.insert(0, os.path.join(os.path.dirname(__file__), "..", "thingino-accel_amd"))
-sys.path.insert(0, os.path.join(os.path.dirname(__file__), "..", "oracle"))
+sys.path.insert(0, os.path.join(os.path.dirname(__file__), ".."))
+sys.path.insert(0, os.path.join(os.path.dirname(__file__), "..", "..", "thingino-accel_amd"))
+sys.path.insert(0, os.path.join(os.path.dirname(__file__), "..", "..", "oracle"))
 import marsfile, marsrt as gpu, orcbind as orc
 from conftest import lcg_frame
 gpu.nna_init()

@@ -1,11 +1,11 @@
 """Soak test (GPU box, through gpurun): YOLOv5 twins with per-convolution scales over seeds / widths / input sizes / batches
 (1..67: the two-stream execution included) / fusion levels 1 and 2; graph outputs and detections vs the oracle.
-  python tools/fuzz_twins.py SEED N"""
+  python tests/soak/fuzz_twins.py SEED N"""
 import os, sys, time
 import numpy as np
-sys.path.insert(0, os.path.join(os.path.dirname(__file__), "..", "tests"))
-sys.path.insert(0, os.path.join(os.path.dirname(__file__), "..", "thingino-accel_amd"))
-sys.path.insert(0, os.path.join(os.path.dirname(__file__), "..", "oracle"))
+sys.path.insert(0, os.path.join(os.path.dirname(__file__), ".."))
+sys.path.insert(0, os.path.join(os.path.dirname(__file__), "..", "..", "thingino-accel_amd"))
+sys.path.insert(0, os.path.join(os.path.dirname(__file__), "..", "..", "oracle"))
 import marsfile, marsrt as gpu, orcbind as orc
 from conftest import lcg_frame
 gpu.nna_init()
