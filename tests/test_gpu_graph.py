@@ -1036,3 +1036,31 @@ def test_fused_bottleneck_level2(gpu, orc, width, hw, B):
     assert rc == 0
     for oi, ti in enumerate(hdr["outputs"]):
         assert np.array_equal(outs[2][oi][B - 1], g.tensor(ti))
+
+
+def test_concat_of_96_channels_is_materialised(gpu, orc):
+    """a 1x1 convolution over a concat whose channel total is not a power of two (64 + 32): the never-materialised
+    concat form (tile walker, K position by shifts) does not take it, so the plan must keep the copy -- found by
+    tests/soak/fuzz_graphs.py, which had the fused plans fail to launch"""
+    rng = np.random.default_rng(96)
+    hw = 20
+    G = marsfile.Graph()
+    x = G.tensor([1, hw, hw, 32], scale=0.03)
+    a = _silu_conv(G, rng, x, 32, 64, hw, 1, 0.05, 1.0 / 256, 0.04)
+    cat = G.tensor([1, hw, hw, 96], scale=0.04)
+    G.concat([a, x], cat)
+    o = _silu_conv(G, rng, cat, 96, 64, hw, 1, 0.06, 1.0 / 256, 0.05)
+    d = G.serialise([x], [o])
+    hdr, tensors, _ = marsfile.parse(d)
+    B = 2
+    xs = [lcg_frame(0x960000 + f, hw * hw * 32) for f in range(B)]
+    for level in (0, 1, 2):
+        m = gpu.Model(d, batch=B, fusion=level)
+        for f in range(B):
+            m.input_view(0)[f] = xs[f]
+        m.run()
+        for f in range(B):
+            g, rc = run_oracle(orc, d, xs[f])
+            assert rc == 0
+            assert np.array_equal(m.output_view(0)[f], g.tensor(hdr["outputs"][0])), (level, f)
+        m.close()

@@ -900,7 +900,8 @@ static void virtual_concat(mars_model_ext_t *m) {
                 if (o->t_in[k] == T) {
                     if (o->kind != OP_CONV_I8 || k != 0 || o->n_in != 1 || o->nchw || o->kh != 1 || o->kw != 1 || o->sh != 1 ||
                         o->sw != 1 || o->pt || o->pl || !o->safe || o->nseg || (o->out_c & 15) || o->in_h != o->out_h ||
-                        o->in_w != o->out_w)
+                        o->in_w != o->out_w || (o->in_c & (o->in_c - 1)) != 0 || o->add_t) /* the tile walker: K position by
+                                                                                            * shifts, no folded Add */
                         bad = 1;
                     if (first_reader < 0) first_reader = i;
                     last_reader = i;
