@@ -16,68 +16,84 @@ bad = 0
 
 
 def build():
+    """tensors are kept as (id, d1, d2, d3) = their shape[1..3].  NHWC graphs: (H, W, C).  NCHW-tagged graphs: (C, H, W) --
+    convolutions take their dims by the tag, while pools / concats / upsampling index shape[1..3] as H, W, C whatever the
+    tag says (the reference's behaviour), so there a pool halves "C" and "H" and a concat joins along "W" """
     G = marsfile.Graph()
+    nchw = bool(rng.integers(0, 4) == 0)
+    fmt = marsfile.NCHW if nchw else marsfile.NHWC
     h, w = int(rng.integers(6, 40)), int(rng.integers(6, 40))
-    c = int(rng.choice([3, 16, 32, 64]))
-    x = G.tensor([1, h, w, c], scale=float(rng.choice([0.02, 0.04])))
-    avail = [(x, h, w, c)]
-    desc = []
+    c = int(rng.choice([3, 5, 8, 16, 24, 32, 40, 64]))
+    dims = (c, h, w) if nchw else (h, w, c)
+    x = G.tensor([1, *dims], fmt=fmt, scale=float(rng.choice([0.02, 0.04])))
+    avail = [(x, *dims)]
+    desc = [("nchw" if nchw else "nhwc", dims)]
     for _ in range(int(rng.integers(3, 11))):
-        t, th, tw, tc = avail[int(rng.integers(0, len(avail)))]
+        t, d1, d2, d3 = avail[int(rng.integers(0, len(avail)))]
         op = str(rng.choice(["conv", "conv", "conv", "pool", "act", "bin", "concat", "up"]))
         if op == "conv":
-            k = int(rng.choice([1, 3, 5])) if tc > 4 else int(rng.choice([3, 6]))
-            s = int(rng.choice([1, 1, 2]))
-            oc = int(rng.choice([16, 24, 32, 64, 128]))
-            oh, ow = (th + s - 1) // s, (tw + s - 1) // s
-            wt = G.tensor([oc, k, k, tc], fmt=marsfile.OHWI, scale=0.003 / (k * k * tc) ** 0.5 * 8,
-                          data=rng.integers(-127, 128, (oc, k, k, tc), dtype=np.int8))
-            b = G.tensor([oc], dtype=marsfile.I32, fmt=marsfile.D1, scale=1.0, data=rng.integers(-3000, 3000, oc, dtype=np.int32))
-            a = G.tensor([1, oh, ow, oc], scale=float(rng.choice([0.04, 0.06])))
+            tc, th, tw = (d1, d2, d3) if nchw else (d3, d1, d2)
+            if th * tw > 4000 or tc > 300:
+                continue
+            k = int(rng.choice([1, 3, 5, 7])) if tc > 4 else int(rng.choice([3, 6]))
+            if tc >= 64 and k == 7: k = 3
+            s = int(rng.choice([1, 1, 2, 3]))
+            oc = int(rng.choice([7, 16, 24, 32, 64, 81, 128]))
+            pad = int(rng.choice([marsfile.PAD_SAME, marsfile.PAD_SAME, marsfile.PAD_SAME, marsfile.PAD_VALID]))
+            oh, ow = (th + s - 1) // s, (tw + s - 1) // s  # the output tensor's shape; VALID still fills it (unpadded window)
+            wshape = (oc, tc, k, k) if nchw else (oc, k, k, tc)
+            wt = G.tensor(list(wshape), fmt=marsfile.OIHW if nchw else marsfile.OHWI, scale=0.003 / (k * k * tc) ** 0.5 * 8,
+                          data=rng.integers(-127, 128, wshape, dtype=np.int8))
+            b = G.tensor([oc], dtype=marsfile.I32, fmt=marsfile.D1, scale=1.0, data=rng.integers(-3000, 3000, oc, dtype=np.int32)) \
+                if rng.integers(0, 5) else marsfile.NONE
+            od = (oc, oh, ow) if nchw else (oh, ow, oc)
+            a = G.tensor([1, *od], fmt=fmt, scale=float(rng.choice([0.04, 0.06])))
             silu = bool(rng.integers(0, 2))
-            G.conv(t, a, wt, b, (k, k), (s, s), act=0 if silu else int(rng.integers(0, 2)))
+            G.conv(t, a, wt, b, (k, k), (s, s), pad=pad, act=0 if silu else int(rng.integers(0, 2)))
             out = a
             if silu:
-                sg = G.tensor([1, oh, ow, oc], scale=1.0 / 256)
-                o = G.tensor([1, oh, ow, oc], scale=float(rng.choice([0.03, 0.05])))
+                sg = G.tensor([1, *od], fmt=fmt, scale=1.0 / 256)
+                o = G.tensor([1, *od], fmt=fmt, scale=float(rng.choice([0.03, 0.05])))
                 G.layer(marsfile.SIGMOID, [a], [sg])
                 G.layer(marsfile.MUL, [a, sg], [o])
                 out = o
-            avail.append((out, oh, ow, oc)); desc.append(("conv", k, s, tc, oc, silu))
+            avail.append((out, *od)); desc.append(("conv", k, s, tc, oc, silu, pad))
         elif op == "pool":
             k = int(rng.choice([2, 3, 5])); s = int(rng.choice([1, 2]))
-            oh, ow = (th + s - 1) // s, (tw + s - 1) // s
-            o = G.tensor([1, oh, ow, tc], scale=G.tensors[t]["scale"])
+            od = ((d1 + s - 1) // s, (d2 + s - 1) // s, d3)
+            o = G.tensor([1, *od], fmt=fmt, scale=G.tensors[t]["scale"])
             G.pool(t, o, (k, k), (s, s))
-            avail.append((o, oh, ow, tc)); desc.append(("pool", k, s))
+            avail.append((o, *od)); desc.append(("pool", k, s))
         elif op == "act":
             kind = int(rng.choice([marsfile.RELU, marsfile.RELU6, marsfile.LEAKY, marsfile.SIGMOID]))
-            o = G.tensor([1, th, tw, tc], scale=float(rng.choice([0.01, 0.03])))
+            o = G.tensor([1, d1, d2, d3], fmt=fmt, scale=float(rng.choice([0.01, 0.03])))
             G.layer(kind, [t], [o])
-            avail.append((o, th, tw, tc)); desc.append(("act", kind))
+            avail.append((o, d1, d2, d3)); desc.append(("act", kind))
         elif op == "bin":
-            same = [q for q in avail if q[1:] == (th, tw, tc) and q[0] != t]
+            same = [q for q in avail if q[1:] == (d1, d2, d3) and q[0] != t]
             if not same:
                 continue
             u = same[int(rng.integers(0, len(same)))][0]
-            o = G.tensor([1, th, tw, tc], scale=float(rng.choice([0.03, 0.06])))
+            o = G.tensor([1, d1, d2, d3], fmt=fmt, scale=float(rng.choice([0.03, 0.06])))
             G.layer(int(rng.choice([marsfile.ADD, marsfile.MUL])), [t, u], [o])
-            avail.append((o, th, tw, tc)); desc.append(("bin",))
+            avail.append((o, d1, d2, d3)); desc.append(("bin",))
         elif op == "concat":
-            same = [q for q in avail if q[1] == th and q[2] == tw and q[0] != t and q[3] % 16 == 0]
-            if not same or tc % 16:
+            same = [q for q in avail if q[1] == d1 and q[2] == d2 and q[0] != t]
+            if not same:
                 continue
-            parts = [t] + [q[0] for q in same[:int(rng.integers(1, 3))]]
-            cs = tc + sum(q[3] for q in same[:len(parts) - 1])
-            o = G.tensor([1, th, tw, cs], scale=G.tensors[t]["scale"])
+            extra = same[:int(rng.integers(1, 3))]
+            parts = [t] + [q[0] for q in extra]
+            cs = d3 + sum(q[3] for q in extra)
+            o = G.tensor([1, d1, d2, cs], fmt=fmt, scale=G.tensors[t]["scale"])
             G.concat(parts, o)
-            avail.append((o, th, tw, cs)); desc.append(("concat", len(parts)))
+            avail.append((o, d1, d2, cs)); desc.append(("concat", [d3] + [q[3] for q in extra]))
         else:
-            if th * tw > 600:
+            if d1 * d2 > 600:
                 continue
-            o = G.tensor([1, th * 2, tw * 2, tc], scale=G.tensors[t]["scale"])
-            G.upsample(t, o, 2, 2)
-            avail.append((o, th * 2, tw * 2, tc)); desc.append(("up",))
+            f = int(rng.choice([2, 2, 3]))
+            o = G.tensor([1, d1 * f, d2 * f, d3], fmt=fmt, scale=G.tensors[t]["scale"])
+            G.upsample(t, o, f if rng.integers(0, 2) else 0, f if rng.integers(0, 2) else 0)
+            avail.append((o, d1 * f, d2 * f, d3)); desc.append(("up", f))
     outs = [q[0] for q in avail[1:]][-3:]
     if not outs:
         return None
