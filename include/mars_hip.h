@@ -81,6 +81,8 @@ mars_error_t mars_hip_set_fusion(mars_model_t *model, int level);
  * "dual_stream_min_batch" (default 64: a batch of at least this many frames is enqueued as two halves on two streams,
  * frames being independent, so that the gaps of one half's kernels are filled by the other's; 0 = never);
  * "dual_stream_ways" (2..4 parts, default 2: more parts measured slower).
+ * "run_chunk" (default 128: mars_run on a batch of at least twice this many frames goes through in chunks of this size --
+ * copy-in of chunk k+1, graph of chunk k and copy-out of chunk k-1 overlap; 0 = one piece).
  * The defaults are the measured optimum; tests use "persist_slots" to force the multi-tile walk
  * of the persistent kernel on small inputs.  Results never depend on these.  0 = ok, -1 = unknown key. */
 int mars_hip_set_tuning(const char *key, int value);

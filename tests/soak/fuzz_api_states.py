@@ -53,7 +53,7 @@ for step in range(STEPS):
     elif op == "tune":
         k, v = [("graph_max_batch", int(rng.choice([0, 8, 100]))), ("dual_stream_min_batch", int(rng.choice([0, 2, 64]))),
                 ("small_batch", int(rng.choice([0, 1]))), ("persist_slots", int(rng.choice([0, 3, 7]))),
-                ("rgb_direct", int(rng.choice([0, 1])))][int(rng.integers(0, 5))]
+                ("rgb_direct", int(rng.choice([0, 1]))), ("run_chunk", int(rng.choice([0, 1, 2, 128])))][int(rng.integers(0, 6))]
         gpu.set_tuning(k, v); op = "tune %s=%d" % (k, v)
     elif op == "prof":
         m.set_profiling(int(rng.choice([0, 1, 2])))
@@ -98,6 +98,6 @@ for step in range(STEPS):
         m.pipe_close()
     print("step", step, op, "batch", B, flush=True)
 m.close()
-for k, v in (("graph_max_batch", 8), ("dual_stream_min_batch", 64), ("small_batch", 1), ("persist_slots", 0), ("rgb_direct", 1)):
+for k, v in (("graph_max_batch", 8), ("dual_stream_min_batch", 64), ("small_batch", 1), ("persist_slots", 0), ("rgb_direct", 1), ("run_chunk", 128)):
     gpu.set_tuning(k, v)
 print("api state fuzz done:", STEPS, "steps,", bad, "mismatches")

@@ -1064,3 +1064,38 @@ def test_concat_of_96_channels_is_materialised(gpu, orc):
             assert rc == 0
             assert np.array_equal(m.output_view(0)[f], g.tensor(hdr["outputs"][0])), (level, f)
         m.close()
+
+
+def test_mars_run_in_overlapped_chunks(gpu, orc):
+    """"run_chunk": mars_run at a large batch copies chunk k+1 in while chunk k runs and chunk k-1 is copied out (three
+    streams, one synchronisation at the end); forced here at 2 frames per chunk on a batch of 5 (chunks of 2, 2, 1) and
+    of 9 (8 chunks at most): every frame equals the one-piece run and the oracle, the detection tail that was left
+    pending before the call is respected, and the model keeps working afterwards"""
+    d = gpu.synth_model(width_x16=4, input_hw=96, seed=61, vary_scales=True)
+    hdr, tensors, _ = marsfile.parse(d)
+    nb = marsfile.tensor_nbytes(tensors[hdr["inputs"][0]])
+    try:
+        for B in (5, 9):
+            xs = [lcg_frame(0xC4C4 * 16 + f, nb) for f in range(B)]
+            res = {}
+            for chunk in (0, 2):
+                gpu.set_tuning("run_chunk", chunk)
+                m = gpu.Model(d, batch=B)
+                for f in range(B):
+                    m.input_view(0)[f] = xs[f]
+                m.run()
+                m.detect_device(outputs=(0, 1, 2), thresh=0.45)  # tail pending on the auxiliary stream
+                for i in range(3):
+                    m.output_view(i)[:] = 0
+                m.run()
+                res[chunk] = [m.output_view(i).copy() for i in range(3)]
+                m.close()
+            for i in range(3):
+                assert np.array_equal(res[0][i], res[2][i]), (B, i)
+            for f in (0, B - 1):
+                g, rc = run_oracle(orc, d, xs[f])
+                assert rc == 0
+                for oi, ti in enumerate(hdr["outputs"]):
+                    assert np.array_equal(res[2][oi][f], g.tensor(ti)), (B, f, oi)
+    finally:
+        gpu.set_tuning("run_chunk", 128)

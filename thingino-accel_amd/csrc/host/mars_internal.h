@@ -109,6 +109,7 @@ typedef struct {
     int tail_pending;
     int frame0, run_frames; /* frame range the launches being enqueued cover (a large batch runs as two halves on two streams) */
     void *ev_fork, *ev_join[3];
+    void *ev_chunk[2][8]; /* mars_run at large batches: [0] chunk uploaded, [1] chunk computed */
     void *graph_exec;   /* captured HIP graph of the plan at the current batch (small batches), or NULL */
     unsigned graph_gen; /* tuning generation it was captured under */
     int ran_plain;      /* the plan has run launch by launch at this batch: every launcher's one-time set-up is done */
