@@ -1819,7 +1819,7 @@ mars_error_t mars_hip_download_outputs(mars_model_t *model) {
  * synchronous call; the link is busy in both directions nearly all of the time instead of a third of it. */
 static int g_run_chunk = 128; /* frames per chunk; batches below twice this go as one piece (tuning key "run_chunk", 0 = never).
                                * Measured, yolov5s twin: batch 256 12.2k -> 14.6k img/s, batch 512 12.3k -> 17.4k; smaller chunks lose
-                               * again (the upload / compute / download streams share hardware queues with the library's others) */
+                               * again (each chunk's hand-off between the three streams costs about a millisecond) */
 static mars_error_t run_chunked(mars_model_ext_t *m) {
     mars_model_t *model = &m->pub;
     const int B = m->batch;
