@@ -394,10 +394,11 @@ def main():
             # not the headline value: the same batch INCLUDING host->HBM input copies and HBM->host
             # output copies through the reference API's mars_run() (pinned staging, one stream)
             M.lib().mars_hip_sync()
+            model.run()  # first call: creates the copy streams / events of the chunked path
             t1 = time.perf_counter()
-            for _ in range(2):
+            for _ in range(3):
                 model.run()
-            result["pcie_inclusive_images_per_s"] = 2 * args.batch / (time.perf_counter() - t1)
+            result["pcie_inclusive_images_per_s"] = 3 * args.batch / (time.perf_counter() - t1)
             if not args.no_tail:
                 # context for `value`: the same steps without the decode + NMS tail.  The twin's random heads put ~19 000
                 # predictions per frame above the threshold, so every frame hits the reference's cap of 1000 candidates
