@@ -1614,7 +1614,10 @@ mars_error_t mars_hip_run_device_async(mars_model_t *model) {
     for (int i = 0; i < m->n_ops && graphable; i++)
         if (m->ops[i].kind == OP_FAIL) graphable = 0;
     if (!graphable) return enqueue_plan(model);
-    if (m->graph_exec && m->graph_gen != g_tune_gen) drop_graph(m);
+    if (m->graph_exec && m->graph_gen != g_tune_gen) {
+        drop_graph(m);
+        m->ran_plain = 0; /* a new launch policy may want workspaces: their first use must not fall inside a capture */
+    }
     if (!m->graph_exec) {
         if (!m->ran_plain) { /* first run at this batch: launch by launch (one-time set-up of every launcher happens here) */
             mars_error_t e = enqueue_plan(model);
