@@ -16,10 +16,16 @@ total = 128 per GPU (`--weak` keeps 256 per GPU there too; `--total-batch T` ask
 Prints ONE JSON line (rank 0).  `roofline` is for the dominant kernel (conv_i8_kernel, the
 implicit-GEMM MFMA convolution): algorithmic bytes (and, as `mfma_view`, int8 ops) of all its launches / their summed
 duration, measured with HIP events on the library's stream inside the timed region.
-`cpu_baseline` is the reference's own C code (oracle/_ref, -O3 -funroll-loops as in its
-Makefile:21) on one host core over a bounded sample (1 frame of the same workload); the GPU
-result for that frame is compared with it bit for bit.
+`roofline.frac_wall` puts the same algorithmic bytes over `ms_per_step` (the execution mode of `value`: two
+half-batches on two streams).  `cpu_baseline` is the reference's own C code (oracle/_ref, -O3 -funroll-loops as in
+its Makefile:21) on one host core over a bounded sample (as many frames of the same workload as fit in ~14 s, at most
+16); the GPU's head tensors AND its detections (kept boxes, order, classes: the reference's parse_output + nms on
+the reference's head tensors) for those frames are compared with it bit for bit (`map_delta`).
+`sustained_images_per_s` = >= 3 s of back-to-back steps after the timed region, with the shader clock the chip held.
+`--io pipelined` (any N): every rank also feeds its frames from pinned host memory through mars_hip_pipe_* and reports
+the I/O-inclusive rate (MAX over ranks), the first thing an 8-GPU run is bound by.
 """
+import hashlib
 import argparse
 import importlib.util
 import json
@@ -133,20 +139,44 @@ def cpu_baseline_parallel(model_bytes, frames, out_ids, nthreads, ref_outs, f32=
                 sample="%d frames at once, one per thread, %.1f s wall" % (n, dt))
 
 
+def kernel_source_sha16():
+    """sha256 (first 16 hex digits) over the device sources: ties a committed PMC profile to the kernels it profiled"""
+    h = hashlib.sha256()
+    d = os.path.join(ROOT, "thingino-accel_amd", "csrc", "hip")
+    for f in sorted(os.listdir(d)):
+        if f.endswith((".hip", ".hpp", ".h")):
+            with open(os.path.join(d, f), "rb") as fh:
+                h.update(f.encode() + b"\0" + fh.read())
+    return h.hexdigest()[:16]
+
+
 def pmc_traffic(args):
     """HBM bytes one step's conv launches move, from the committed rocprofv3 PMC passes (FETCH_SIZE doubled per
     MI355X_MICROARCH.md, WRITE_SIZE; tools/pmc_summary.py) -- counters cannot be collected from inside this
-    process, so the number is the profiled one of the same workload, or None when no matching profile exists."""
+    process, so the number is the profiled one of the same workload AND the same kernel sources (the profile records
+    their hash), or None when no matching profile exists."""
     path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "pmc_traffic.json")
     try:
         with open(path) as fh:
             d = json.load(fh)
         if d["config"] != {"width": args.width, "hw": args.hw, "batch": args.batch}:
-            return None, None
+            return None, "profiles/pmc_traffic.json is for another workload"
+        if d.get("kernel_source_sha16") != kernel_source_sha16():
+            return None, "profiles/pmc_traffic.json was taken with other kernel sources (%s, now %s)" % (
+                d.get("kernel_source_sha16"), kernel_source_sha16())
         c = d["conv_i8"]
-        return c["read_bytes_per_step"] + c["write_bytes_per_step"], "profiles/pmc_traffic.json (per step, all conv_i8 launches)"
+        return c["read_bytes_per_step"] + c["write_bytes_per_step"], "profiles/pmc_traffic.json (per step, all conv_i8 launches; kernel sources %s)" % d["kernel_source_sha16"]
     except (OSError, KeyError, ValueError):
         return None, None
+
+
+def reference_detections(ref_outs, scales, thresh=0.45):
+    """the reference's own tail (mars_yolo_test.c:80-130, oracle/_ref) on the reference's head tensors of one frame"""
+    import refbind
+    import orcbind
+    pred = np.concatenate([o.view(np.int8).ravel() for o in ref_outs])
+    tail = refbind if refbind.available() else orcbind
+    return tail.nms(tail.parse_output(pred, len(pred) // 85, np.float32(scales[0])), thresh)
 
 
 def main():
@@ -178,6 +208,11 @@ def main():
                     help="check run, not the benchmark workload: the twin with per-convolution scales (every fused table "
                          "differs); the CPU-baseline leg then compares its frames bit for bit as usual")
     ap.add_argument("--no-tail", action="store_true", help="graph only, skip decode+NMS")
+    ap.add_argument("--io", choices=["resident", "pipelined"], default="resident",
+                    help="pipelined: after the timed (resident) region every rank also runs its batches through mars_hip_pipe_* "
+                         "(pinned host frames in, detections out) and the line carries `pipelined_io` (MAX over ranks); at N=1 "
+                         "the default run measures this anyway")
+    ap.add_argument("--sustain-s", type=float, default=3.0, help="seconds of back-to-back steps of the sustained leg (0 = skip)")
     ap.add_argument("--ops", type=str, default="", help="write a per-launch table (last timed step) to this file")
     ap.add_argument("--autotune", action="store_true",
                     help="time the launch variants of every convolution once before the warmup and pin the fastest "
@@ -238,6 +273,7 @@ def main():
     in_bytes = marsfile.tensor_nbytes(tensors[hdr["inputs"][0]])
     out_ids = list(hdr["outputs"])
 
+    rccl_info = None
     if multi and rank != 0:
         # descriptors only; the packed parameters arrive by RCCL broadcast from rank 0
         model = M.Model(D.strip_weights(model_bytes), batch=args.batch, flags=1)
@@ -254,8 +290,14 @@ def main():
             print("bench: %d ranks in the RCCL group, parameter arena %d bytes broadcast from rank 0" % (dist.get_world_size(), nbytes),
                   file=sys.stderr)
         t = torch.as_tensor(D.DeviceBuffer(ptr, nbytes), device="cuda")
+        torch.cuda.synchronize()
+        dist.barrier()
+        tb = time.perf_counter()
         dist.broadcast(t, src=0)  # the one collective of the path: weights over xGMI
         torch.cuda.synchronize()
+        tb = time.perf_counter() - tb
+        rccl_info = {"ranks_in_group": dist.get_world_size(), "backend": dist.get_backend(), "param_arena_bytes": int(nbytes),
+                     "broadcast_ms": D.max_over_ranks(dist, tb, device="cuda") * 1e3}
 
     frames = frames_for_rank(D, rank, world, args.batch, in_bytes, f32)
     iv = model.input_view(0)
@@ -308,6 +350,58 @@ def main():
     if dist is not None:
         dt = D.max_over_ranks(dist, dt, device="cuda")
 
+    # ---- sustained leg (every rank): the timed region above is a burst of K steps after an idle device; a camera pipeline
+    # runs for hours.  Back-to-back steps for >= --sustain-s seconds, the shader clock sampled while they run
+    # (mars_hip_clock_mhz: one probe wave on its own stream): the chip lowers its clock under a sustained int8 MFMA load.
+    sustained = None
+    if args.sustain_s > 0 and not args.timed_only:
+        nsteps = max(args.steps, int(args.sustain_s / max(dt / args.steps, 1e-4)) + 1)
+        clocks = []
+        barrier()
+        t1 = time.perf_counter()
+        for k in range(nsteps):
+            step()
+            if k % max(1, nsteps // 8) == nsteps // 16:  # ~8 samples spread over the leg (each blocks the host ~0.3 ms)
+                c = float(M.lib().mars_hip_clock_mhz(200))
+                if c > 0:
+                    clocks.append(c)
+        barrier()
+        dts = time.perf_counter() - t1
+        if dist is not None:
+            dts = D.max_over_ranks(dist, dts, device="cuda")
+        sustained = {"images_per_s": world * args.batch * nsteps / dts, "steps": nsteps, "seconds": dts,
+                     "ms_per_step": dts / nsteps * 1e3,
+                     "shader_clock_mhz": {"median": float(np.median(clocks)) if clocks else None,
+                                          "min": min(clocks) if clocks else None, "max": max(clocks) if clocks else None,
+                                          "samples": len(clocks), "how": "s_memtime / s_memrealtime of a probe wave beside the running graph"}}
+
+    # ---- I/O-inclusive leg (every rank; default at N=1, --io pipelined at any N): frames come from pinned host memory
+    # every batch (mars_hip_pipe_*: upload k+1 / graph k / tail k / download k-1 on their own streams), detections (or the
+    # raw head tensors too) go back.  The staging buffers are filled once (a camera would DMA into them).
+    pipe_rates = {}
+    want_pipe = not f32 and not args.no_tail and not args.timed_only and (world == 1 or args.io == "pipelined")
+    if want_pipe:
+        stacked = np.stack(frames)
+        modes = (("detections", False), ("raw_outputs", True)) if world == 1 else (("detections", False),)
+        for key, dl in modes:
+            model.pipe_open(download_outputs=dl, detect=True, det_outputs=outputs, thresh=0.45)
+            for _ in range(3):
+                model.pipe_input_view(0)[:] = stacked
+                model.pipe_submit()
+            nb = 8
+            barrier()
+            t1 = time.perf_counter()
+            for _ in range(nb):
+                model.pipe_wait(copy=False)
+                model.pipe_submit()
+            for _ in range(3):
+                model.pipe_wait(copy=False)
+            dtp = time.perf_counter() - t1
+            if dist is not None:
+                dtp = D.max_over_ranks(dist, dtp, device="cuda")
+            model.pipe_close()
+            pipe_rates[key] = world * (nb + 3) * args.batch / dtp
+
     result = None
     if rank == 0 and args.ops:
         import ctypes as C
@@ -354,6 +448,10 @@ def main():
                 # The timed steps themselves run the batch as two halves on two streams (config.execution), whose launches
                 # overlap: ms_per_step may be smaller than the sum of kernel durations
                 "timing": "hip events, one stream, full-batch launches",
+                # the same algorithmic bytes over the step time of `value` (its execution mode: config.execution), so that
+                # kernel time <= step time holds on this line: frac_wall <= what the per-kernel view can show
+                "wall_achieved": conv_bytes_per_img * args.batch / (dt / args.steps) / 1e9 if not f32 else 2.0 * macs_per_img * args.batch / (dt / args.steps) / 1e12,
+                "frac_wall": (conv_bytes_per_img * args.batch / (dt / args.steps) / 1e9 / 8000.0) if not f32 else (2.0 * macs_per_img * args.batch / (dt / args.steps) / mpeak),
                 "conv_ms_per_step": conv_ms / ev_steps,
                 "all_kernels_ms_per_step": all_ms / ev_steps,
                 "ms_per_step_by_kind": {str(k): v / ev_steps for k, v in sorted(per_kind.items())}}
@@ -390,6 +488,17 @@ def main():
                        "autotuned_launch_variants": bool(args.autotune and not args.no_autotune), "conv_gmac_per_image": macs_per_img / 1e9, "algorithmic_mb_per_image": bytes_per_img / 1e6},
             "roofline": roof,
         }
+        if sustained is not None:
+            result["sustained_images_per_s"] = sustained["images_per_s"]
+            result["sustained"] = sustained
+        if pipe_rates:
+            result["pipelined_io"] = {"images_per_s": pipe_rates.get("detections"), "returns": "detections (4 KB per frame)",
+                                      "ranks": world, "timing": "barrier, 11 batches per rank, MAX over ranks"}
+            if world == 1:
+                result["pipelined_detections_images_per_s"] = pipe_rates.get("detections")
+                result["pipelined_raw_outputs_images_per_s"] = pipe_rates.get("raw_outputs")
+        if multi:
+            result["config"]["rccl"] = rccl_info
         if world == 1 and not args.timed_only:
             # not the headline value: the same batch INCLUDING host->HBM input copies and HBM->host
             # output copies through the reference API's mars_run() (pinned staging, one stream)
@@ -414,26 +523,6 @@ def main():
                     model.run_device(sync=False)
                 M.lib().mars_hip_sync()
                 result["graph_only_images_per_s"] = 10 * args.batch / (time.perf_counter() - t1)
-            if not f32:
-                # the same through the double-buffered path (mars_hip_pipe_*: upload k+1 / graph k / tail k / download k-1
-                # overlap): frames in over PCIe every batch; back come the detections only, or the raw head tensors too.
-                # The staging buffers are filled once (a camera would DMA into them): the host-side fill is the caller's.
-                stacked = np.stack(frames)
-                for key, dl in (("pipelined_detections_images_per_s", False), ("pipelined_raw_outputs_images_per_s", True)):
-                    model.pipe_open(download_outputs=dl, detect=True, det_outputs=outputs, thresh=0.45)
-                    for _ in range(3):
-                        model.pipe_input_view(0)[:] = stacked
-                        model.pipe_submit()
-                    nb = 8
-                    t1 = time.perf_counter()
-                    for _ in range(nb):
-                        model.pipe_wait(copy=False)
-                        model.pipe_submit()
-                    dtp = time.perf_counter() - t1
-                    for _ in range(3):
-                        model.pipe_wait(copy=False)
-                    model.pipe_close()
-                    result[key] = nb * args.batch / dtp
         if world == 1 and not args.timed_only:
             # the reference's real call pattern (mars_test.c:33-148): ONE frame per mars_run.  Latency of the graph alone
             # (input resident) and through mars_run() (H2D + graph + D2H), median of 20
@@ -441,7 +530,13 @@ def main():
             m1.input_view(0)[0] = frames[0]
             m1.upload()
             lat = {}
-            for name, fn in (("graph_resident_ms", m1.run_device), ("mars_run_ms", m1.run)):
+            def run_and_detect():  # the demo's loop (mars_yolo_test.c:132-214): run, then decode + NMS of the result
+                m1.run()
+                m1.detect(outputs=outputs, thresh=0.45)
+            legs = [("graph_resident_ms", m1.run_device), ("mars_run_ms", m1.run)]
+            if not args.no_tail:
+                legs.append(("mars_run_plus_detect_ms", run_and_detect))
+            for name, fn in legs:
                 for _ in range(3):
                     fn()
                 ts = []
@@ -462,9 +557,12 @@ def main():
                     for i in range(len(out_ids)):
                         a = model.output_view(i)[f].view(np.float32).astype(np.float64)
                         b = ref_outs[f][i].view(np.float32).astype(np.float64)
+                        if (np.isnan(a) != np.isnan(b)).any() or (np.isinf(a) != np.isinf(b)).any():
+                            worst = float("inf")  # a NaN / inf on one side only is a failure, not a value np.nanmax may drop
                         bad = ~((np.isnan(a) & np.isnan(b)) | (a == b))
-                        if bad.any():
-                            worst = max(worst, float(np.nanmax(np.abs(a - b)[bad] / np.maximum(1.0, np.abs(b)[bad]))))
+                        if bad.any() and worst != float("inf"):
+                            err = np.abs(a - b)[bad] / np.maximum(1.0, np.abs(b)[bad])
+                            worst = float("inf") if np.isnan(err).any() else max(worst, float(err.max()))
                 base["gpu_matches_within_1e-4"] = bool(worst <= 1e-4)
                 base["worst_relative_error"] = worst
                 same = worst == 0.0
@@ -473,6 +571,22 @@ def main():
                            for f in range(len(ref_outs)) for i in range(len(out_ids)))
             base["gpu_matches_bit_exact"] = bool(same)
             base["frames_compared"] = len(ref_outs)
+            if not f32 and not args.no_tail:
+                # BASELINE's "mAP delta vs CPU ref": no labelled data exists for this path, so it degenerates to exact
+                # agreement of the kept boxes -- count, order, coordinates, confidences, classes -- between the GPU tail
+                # on the GPU's heads and the reference's parse_output + nms on the reference's heads
+                gdets = model.detect(outputs=outputs, thresh=0.45)
+                scales = [float(tensors[ti]["scale"]) for ti in out_ids]
+                nbox, dsame = 0, True
+                for f in range(len(ref_outs)):
+                    want = reference_detections(ref_outs[f], scales)
+                    nbox += len(want)
+                    dsame = dsame and gdets[f].tobytes() == want.tobytes()
+                base["detections_match_bit_exact"] = bool(dsame)
+                base["detections_compared"] = int(nbox)
+                result["map_delta"] = 0.0 if (dsame and same) else None
+                result["map_delta_evidence"] = ("%d kept boxes of %d frames (index order, boxes, confidences, classes) and the int8 head "
+                                                "tensors bit-identical to the reference's CPU run" % (nbox, len(ref_outs))) if (dsame and same) else "MISMATCH"
             result["cpu_baseline"] = base
             # the fair node-level figure -- frames are independent, one frame per thread on every core
             result["cpu_baseline_all_cores"] = cpu_baseline_parallel(model_bytes, frames, out_ids, args.cpu_threads, ref_outs, f32)

@@ -45,6 +45,10 @@ mars_error_t mars_hip_run_device(mars_model_t *model);       /* enqueue all laye
 mars_error_t mars_hip_run_device_async(mars_model_t *model); /* enqueue only */
 mars_error_t mars_hip_download_outputs(mars_model_t *model); /* HBM -> pinned host, waits */
 mars_error_t mars_hip_sync(void);
+/* Shader clock of the device right now, in MHz: a one-wave probe on a stream of its own samples the shader-cycle and the
+ * 100 MHz reference counters around a ~micros us pause, beside whatever the library's other streams are running (the
+ * benchmark's sustained leg reports it: the chip lowers its clock under load).  < 0: no device. */
+float mars_hip_clock_mhz(int micros);
 
 /* Device address / per-frame stride of any tensor (weights: stride 0). */
 void *mars_hip_tensor_device(mars_model_t *model, int tensor_index, size_t *frame_stride);
@@ -161,7 +165,9 @@ void *mars_hip_pipe_input(mars_model_t *model, int input_index);
 mars_error_t mars_hip_pipe_submit(mars_model_t *model);
 /* block until the OLDEST submitted batch is complete.  outputs (may be NULL): array of mars_get_num_outputs() pointers,
  * set to that batch's host copies (download_outputs); dets / counts (may be NULL): its detections (detect).  The
- * buffers stay valid until the third submit after this call. */
+ * buffers stay valid until the SECOND mars_hip_pipe_submit after this call returns (four buffer sets, three batches in
+ * flight): in the steady-state loop "wait k; submit k+3; use results of k" the results are safe while k+3 is queued and
+ * are overwritten by the submit after that. */
 mars_error_t mars_hip_pipe_wait(mars_model_t *model, const void **outputs, const mars_det_t **dets, const int **counts);
 void mars_hip_pipe_close(mars_model_t *model);
 

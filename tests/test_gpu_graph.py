@@ -824,6 +824,47 @@ def test_c_program_links_and_runs(gpu, orc, tmp_path):
     assert lines[3] == "nna" and int(lines[4]) == want.size and lines[5] == "%016x" % h
 
 
+def test_pipe_results_survive_the_next_submit(gpu, orc):
+    """include/mars_hip.h: what mars_hip_pipe_wait() hands out stays valid until the SECOND submit after the call (four buffer
+    sets, three batches in flight).  The steady-state loop -- wait k, submit k+3, only then read the results of k through
+    the views (copy=False) -- must see batch k's bytes, not those of a later batch (with three buffer sets the submit right
+    after the wait queued its copies into exactly these buffers)."""
+    d = gpu.synth_model(width_x16=4, input_hw=96, seed=33)
+    hdr, tensors, _ = marsfile.parse(d)
+    nb = marsfile.tensor_nbytes(tensors[hdr["inputs"][0]])
+    B, NB = 2, 9
+    xs = [[lcg_frame(0xB10000 + 16 * k + f, nb) for f in range(B)] for k in range(NB)]
+    m = gpu.Model(d, batch=B)
+    want = []
+    for k in range(NB):
+        for f in range(B):
+            m.input_view(0)[f] = xs[k][f]
+        m.run()
+        dets = m.detect(outputs=(0, 1, 2), thresh=0.45)
+        want.append(([m.output_view(i).copy() for i in range(3)], dets))
+    m.pipe_open(download_outputs=True, detect=True, det_outputs=(0, 1, 2), thresh=0.45)
+
+    def submit(k):
+        iv = m.pipe_input_view(0)
+        for f in range(B):
+            iv[f] = xs[k][f]
+        m.pipe_submit()
+
+    for k in range(3):
+        submit(k)
+    for k in range(NB):
+        outs, (dv, cv) = m.pipe_wait(copy=False)   # views into the pipe's pinned result buffers
+        if k + 3 < NB:
+            submit(k + 3)                          # the next batch is queued (and may complete) before the results are read
+            gpu.lib().mars_hip_sync()              # worst case: everything queued so far has finished
+        for i in range(3):
+            assert np.array_equal(outs[i], want[k][0][i]), (k, i)
+        for f in range(B):
+            assert dv[f, :cv[f]].tobytes() == want[k][1][f].tobytes(), (k, f)
+    m.pipe_close()
+    m.close()
+
+
 def test_pipelined_io_matches_mars_run(gpu, orc):
     """mars_hip_pipe_*: five batches through the double-buffered path (upload k+1 / graph k / tail k / download k-1 on
     their own streams and buffers) == the same batches through mars_run() + mars_hip_detect(), bit for bit: raw outputs
@@ -1036,6 +1077,31 @@ def test_fused_bottleneck_level2(gpu, orc, width, hw, B):
     assert rc == 0
     for oi, ti in enumerate(hdr["outputs"]):
         assert np.array_equal(outs[2][oi][B - 1], g.tensor(ti))
+
+
+def test_fused_bottleneck_refused_at_a_batch_falls_back(gpu, orc, monkeypatch):
+    """a fused bottleneck is accepted at load time on geometry alone; whether the fused launch fits 32-bit offsets depends on
+    the batch.  alloc_batch re-checks every fused launch at the real batch and plans again without the fusion when one
+    does not fit (the 1x1 has left the plan: there would be no fallback at launch time).  MARS_HIP_BOTTLENECK_LIMIT makes
+    a small batch count as too large."""
+    d = gpu.synth_model(width_x16=8, input_hw=128, seed=77, vary_scales=True)
+    hdr, tensors, _ = marsfile.parse(d)
+    nb = marsfile.tensor_nbytes(tensors[hdr["inputs"][0]])
+    xs = [lcg_frame(0xB0771F * 16 + f, nb) for f in range(3)]
+    m = gpu.Model(d, batch=1, fusion=2)
+    fused_ops = len(m.ops())
+    monkeypatch.setenv("MARS_HIP_BOTTLENECK_LIMIT", "2")
+    m.set_batch(3)  # "too large": the plan is rebuilt with the 1x1 launches back in
+    assert len(m.ops()) > fused_ops
+    for f in range(3):
+        m.input_view(0)[f] = xs[f]
+    m.run()
+    for f in (0, 2):
+        g, rc = run_oracle(orc, d, xs[f])
+        assert rc == 0
+        for oi, ti in enumerate(hdr["outputs"]):
+            assert np.array_equal(m.output_view(oi)[f], g.tensor(ti)), (f, oi)
+    m.close()
 
 
 def test_concat_of_96_channels_is_materialised(gpu, orc):

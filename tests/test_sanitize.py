@@ -54,6 +54,11 @@ def test_crafted_files_from_advice(fuzz_bin, tmp_path):
         # oc_pad = (out_c + 31) & ~31 wrapped negative; the arena's capacity doubling never reached it
         "huge_outc.mars": _conv_file([1, 4, 4, 16], [1, 1, 1, 0x7fffffff], [16, 1, 1, 16], 1, 1),
         "nchw_wrap.mars": _conv_file([1, 0x7ffffff1, 1, 1], [1, 16, 1, 1], [16, 1, 1, 1], 1, 1, in_fmt=0, out_fmt=0),
+        # NDHWC32 (tag 1) / NMHWSOIB2 (tag 3) descriptors whose channel counts sit next to INT_MAX: the
+        # "+ 31" of tensor_byte_size overflowed a signed int (UBSan), and the wrapped sizes asked for gigabytes of staging
+        "ndhwc32_wrap.mars": _conv_file([1, 0x7ffffff0, 2, 2], [1, 16, 2, 2], [16, 1, 1, 16], 1, 1, in_fmt=1, out_fmt=1),
+        "nmhwsoib2_wrap.mars": _conv_file([0x7fffffe1, 0x7ffffff5, 3, 3], [1, 16, 1, 1], [16, 1, 1, 16], 1, 1, in_fmt=3, out_fmt=3),
+        "ndhwc32_out_wrap.mars": _conv_file([1, 16, 4, 4], [1, 0x7fffffff, 4, 4], [16, 1, 1, 16], 1, 1, in_fmt=7, out_fmt=1),
     }
     paths = []
     for name, data in cases.items():

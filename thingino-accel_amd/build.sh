@@ -19,7 +19,11 @@ HIPFLAGS="--offload-arch=gfx950 -O3 -ffp-contract=off -mllvm -amdgpu-mfma-vgpr-f
 pids=()
 for f in "$SRC"/hip/*.hip; do
   o="$OBJ/$(basename "$f" .hip).hip.o"
-  if [ ! -f "$o" ] || [ "$f" -nt "$o" ] || [ "$SRC/mhip.h" -nt "$o" ]; then
+  stale=0
+  for h in "$SRC"/mhip.h "$SRC"/expf_exact.h "$SRC"/hip/*.hpp; do  # every header a kernel file may include
+    [ -f "$h" ] && [ "$h" -nt "$o" ] && stale=1
+  done
+  if [ ! -f "$o" ] || [ "$f" -nt "$o" ] || [ $stale = 1 ]; then
     $HIPCC $HIPFLAGS -c "$f" -o "$o" & pids+=($!)
   fi
 done

@@ -227,3 +227,29 @@ extern "C" float mhip_event_elapsed_ms(void *start, void *stop) {
     if (hipEventElapsedTime(&ms, (hipEvent_t)start, (hipEvent_t)stop) != hipSuccess) return -1.f;
     return ms;
 }
+
+// ---- shader clock under load (bench.py's sustained leg): one wave reads the shader-cycle counter (s_memtime) and the
+// constant 100 MHz counter (s_memrealtime) at both ends of a ~`micros` us sleep, on a stream of its own, beside whatever
+// the other streams are running: clock = d(memtime) / d(memrealtime) x 100 MHz (MI355X_MICROARCH.md, DVFS give-back 6).
+// The stamps go to a buffer of their own; nothing else reads them.
+__global__ void clock_probe_kernel(unsigned long long *out, int rounds) {
+    const unsigned long long c0 = __builtin_amdgcn_s_memtime(), r0 = __builtin_amdgcn_s_memrealtime();
+    for (int i = 0; i < rounds; i++) __builtin_amdgcn_s_sleep(127); // 127 x 64 cycles each
+    const unsigned long long c1 = __builtin_amdgcn_s_memtime(), r1 = __builtin_amdgcn_s_memrealtime();
+    if (threadIdx.x == 0) {
+        out[0] = c1 - c0;
+        out[1] = r1 - r0;
+    }
+}
+extern "C" float mhip_clock_probe_mhz(int micros) {
+    if (!g_ready) return -1.f;
+    static hipStream_t st = nullptr;
+    static unsigned long long *dev = nullptr;
+    if (!st && hipStreamCreateWithFlags(&st, hipStreamNonBlocking) != hipSuccess) return -1.f;
+    if (!dev && hipMalloc((void **)&dev, 16) != hipSuccess) return -1.f;
+    int rounds = micros > 0 ? micros / 4 + 1 : 64; // ~4 us per round at 2 GHz
+    hipLaunchKernelGGL(clock_probe_kernel, dim3(1), dim3(64), 0, st, dev, rounds);
+    unsigned long long h[2] = {0, 0};
+    if (hipMemcpyAsync(h, dev, 16, hipMemcpyDeviceToHost, st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess) return -1.f;
+    return h[1] ? (float)((double)h[0] / (double)h[1] * 100.0) : -1.f;
+}

@@ -111,11 +111,11 @@ size_t mars_hip_tensor_byte_size(const mars_tensor_t *t) {
     }
     if (t->format == MARS_FORMAT_NDHWC32 && t->ndims >= 4) {
         const uint32_t n = (uint32_t)t->shape[0], h = (uint32_t)t->shape[2], w = (uint32_t)t->shape[3];
-        const uint32_t d = (uint32_t)((t->shape[1] + 31) / 32);
+        const uint32_t d = (uint32_t)((int32_t)((uint32_t)t->shape[1] + 31u) / 32); /* the reference's int sum, wrapped without UB */
         return (size_t)(int32_t)(n * d * h * w * 32u) * es; /* int product, then * size_t (:101) */
     }
     if (t->format == MARS_FORMAT_NMHWSOIB2 && t->ndims >= 4) {
-        const uint32_t no = (uint32_t)((t->shape[0] + 31) / 32), mi = (uint32_t)((t->shape[1] + 31) / 32);
+        const uint32_t no = (uint32_t)((int32_t)((uint32_t)t->shape[0] + 31u) / 32), mi = (uint32_t)((int32_t)((uint32_t)t->shape[1] + 31u) / 32);
         return (size_t)(int32_t)(no * mi * (uint32_t)t->shape[2] * (uint32_t)t->shape[3] * 1024u);
     }
     size_t numel = 1;
@@ -1226,7 +1226,7 @@ static mars_error_t build_plan(mars_model_ext_t *m) {
         elide_concat(m);
         fuse_pool_chains(m);
         pair_convs(m);
-        if (m->fusion >= 2) fuse_bottleneck(m); /* opt-in (level 2); after pairing: a paired launch stays a pair */
+        if (m->fusion >= 2 && !m->no_bottleneck) fuse_bottleneck(m); /* opt-in (level 2); after pairing: a paired launch stays a pair */
         pad_output_rows(m);
     }
     f32_policy(m);
@@ -1274,6 +1274,33 @@ static mars_error_t alloc_batch(mars_model_ext_t *m, int n) {
                 break;
             }
         }
+    /* fused bottlenecks were accepted on geometry alone (one frame, no strides): the launcher's limits also depend on the
+     * batch (32-bit output offsets, tile count).  The 1x1 has left the plan, so a launch that fails would have no
+     * fallback: check every fused launch against THIS batch and plan again without the fusion if one does not fit */
+    if (m->fusion >= 2 && !m->no_bottleneck)
+        for (int i = 0; i < m->n_ops; i++) {
+            const mars_op_t *op = &m->ops[i];
+            if (op->kind != OP_CONV_I8 || !op->pre || op->t_out < 0) continue;
+            const mtensor_t *t = &m->mt[op->t_out];
+            mhip_conv_i8_t p;
+            memset(&p, 0, sizeof(p));
+            p.frames = n; p.in_c = op->in_c; p.in_h = op->in_h; p.in_w = op->in_w; p.out_h = op->out_h; p.out_w = op->out_w;
+            p.out_c = op->store_c ? op->store_c : op->out_c; p.kh = op->kh; p.kw = op->kw; p.stride_h = op->sh; p.stride_w = op->sw;
+            p.pad_top = op->pt; p.pad_left = op->pl; p.row_pad = op->row_pad; p.oc_pad = op->oc_pad; p.safe = op->safe;
+            p.out_pix_stride = op->out_pix_stride; p.out_ch_off = op->out_ch_off;
+            p.out_stride = ALIGN_UP(t->extent > t->bytes ? t->extent : t->bytes, 256);
+            p.in_stride = op->t_in[0] >= 0 ? ALIGN_UP(m->mt[op->t_in[0]].extent > m->mt[op->t_in[0]].bytes ? m->mt[op->t_in[0]].extent : m->mt[op->t_in[0]].bytes, 256) : 0;
+            p.pre_w = (const int8_t *)m; p.pre_bias = (const int32_t *)m; p.pre_lut2 = (const uint8_t *)m; p.lut2 = (const uint8_t *)m;
+            p.lut = (const uint8_t *)m;
+            const char *lim = getenv("MARS_HIP_BOTTLENECK_LIMIT"); /* tests: exercise the fallback with a small batch */
+            if (!mhip_conv_i8_pre_ok(&p) || (lim && (size_t)n > (size_t)strtoull(lim, NULL, 0))) {
+                m->no_bottleneck = 1;
+                mars_error_t e = build_plan(m);
+                if (e == MARS_OK) e = upload_params(m);
+                if (e != MARS_OK) return e;
+                break;
+            }
+        }
     free_device_state(m);
     size_t per_frame = 0;
     for (uint32_t i = 0; i < nt; i++) {
@@ -1305,7 +1332,10 @@ static mars_error_t alloc_batch(mars_model_ext_t *m, int n) {
              * buffer size; a batch (extension) = n densely packed frames */
             const size_t hb = t->bytes * (size_t)n, ref = reference_buffer_size(m);
             size_t cap = hb > ref ? hb : ref;
-            if (ref > ((size_t)1 << 32)) cap = hb; /* wrapped int products of a hostile descriptor: not honoured */
+            /* what the reference can ever report is bounded by its 8 MiB arena; anything larger comes from wrapped int
+             * products of a hostile descriptor (NDHWC32 / NMHWSOIB2 shapes near INT_MAX) and is not honoured: a single-frame
+             * load must not pin and clear gigabytes per I/O tensor */
+            if (ref > ((size_t)8 << 20)) cap = hb;
             t->host = (uint8_t *)mhip_host_alloc(cap ? cap : 64);
             if (!t->host) return MARS_ERR_ALLOC_FAILED;
             memset(t->host, 0, cap);
@@ -1609,8 +1639,9 @@ mars_error_t mars_hip_run_device_async(mars_model_t *model) {
     if (!model) return MARS_ERR_INVALID_FILE;
     mars_model_ext_t *m = (mars_model_ext_t *)model;
     if (!m->act_dev || !m->arena_dev) return MARS_ERR_NNA_INIT_FAILED;
-    /* graph path: small batch, no per-launch events, no cross-stream hand-off pending, buffers not being swapped */
-    int graphable = g_graph_max_batch > 0 && m->batch <= g_graph_max_batch && !m->profiling && !m->tail_pending && !m->pipe;
+    /* graph path: small batch, no per-launch events, buffers not being swapped.  A detection tail still running on the
+     * auxiliary stream (mars_hip_detect_device) does not rule it out: the whole graph is ordered behind it (below) */
+    int graphable = g_graph_max_batch > 0 && m->batch <= g_graph_max_batch && !m->profiling && !m->pipe;
     for (int i = 0; i < m->n_ops && graphable; i++)
         if (m->ops[i].kind == OP_FAIL) graphable = 0;
     if (!graphable) return enqueue_plan(model);
@@ -1624,6 +1655,11 @@ mars_error_t mars_hip_run_device_async(mars_model_t *model) {
             if (e == MARS_OK) m->ran_plain = 1;
             return e;
         }
+        if (m->tail_pending) { /* the hand-off to a running tail is an outside event: it must not end up inside the capture */
+            mhip_select_stream(0);
+            if (mhip_stream_wait(0, m->ev_tail_done)) return MARS_ERR_LAYER_FAILED;
+            m->tail_pending = 0;
+        }
         if (mhip_graph_begin() == 0) {
             mars_error_t e = enqueue_plan(model);
             m->graph_exec = mhip_graph_end(e == MARS_OK);
@@ -1635,6 +1671,11 @@ mars_error_t mars_hip_run_device_async(mars_model_t *model) {
             g_graph_max_batch = 0;
             return enqueue_plan(model);
         }
+    }
+    if (m->tail_pending) { /* the previous run's tail still reads the graph outputs: the replay (all of it) comes after */
+        mhip_select_stream(0);
+        if (mhip_stream_wait(0, m->ev_tail_done)) return MARS_ERR_LAYER_FAILED;
+        m->tail_pending = 0;
     }
     if (mhip_graph_launch(m->graph_exec)) return MARS_ERR_LAYER_FAILED;
     for (uint32_t i = 0; i < model->header.num_layers; i++) model->layers[i].is_executed = true;
@@ -1893,6 +1934,8 @@ mars_error_t mars_run(mars_model_t *model) {
 }
 
 mars_error_t mars_hip_sync(void) { return mhip_sync() ? MARS_ERR_LAYER_FAILED : MARS_OK; }
+
+float mars_hip_clock_mhz(int micros) { return mhip_clock_probe_mhz(micros); }
 
 /* --------------------------------------------------------------- extensions */
 mars_error_t mars_hip_set_batch(mars_model_t *model, int n) {

@@ -5,7 +5,8 @@
  * mars_get_output()->vaddr (reference src/mars/mars_test.c:73-120).  Through mars_run() a batch pays host->HBM copy,
  * graph and HBM->host copy one after the other on one stream (measured: 12 k images/s against 51 k with resident
  * inputs).  A camera pipeline does not need that order: while batch k is computed, batch k+1 can travel to the device
- * and the results of batch k-1 back.  mars_hip_pipe_* gives the caller exactly that with three slots:
+ * and the results of batch k-1 back.  mars_hip_pipe_* gives the caller exactly that with three batches in flight over
+ * four buffer sets (the fourth keeps a collected result readable while the next batch is being queued):
  *
  *     upload stream    H2D(k+1)                 |  graph inputs / outputs of a slot are separate HBM buffers, so the
  *     main stream      graph(k)                 |  three stages never touch the same bytes; events order the hand-offs
@@ -21,8 +22,12 @@
 
 #include "mars_internal.h"
 
-#define PIPE_SLOTS 3 /* with two, batch k+1 could only be queued once batch k-1 had fully come back: its upload then started
-                        a millisecond into graph k and graph k+1 waited for it (34 k instead of 45 k images/s measured) */
+#define PIPE_DEPTH 3 /* batches in flight.  With two, batch k+1 could only be queued once batch k-1 had fully come back: its
+                        upload then started a millisecond into graph k and graph k+1 waited for it (34 k instead of 45 k
+                        images/s measured) */
+#define PIPE_SLOTS 4 /* buffer sets: one more than the depth, so that the slot whose results mars_hip_pipe_wait() has just
+                        handed out is NOT the one the next submit refills (with three sets it was: the steady-state loop
+                        "wait k, submit k+3" queued copies into the buffers the caller was still reading) */
 
 typedef struct {
     uint8_t *in_host[MARS_MAX_IO], *in_dev[MARS_MAX_IO];
@@ -175,7 +180,7 @@ mars_error_t mars_hip_pipe_submit(mars_model_t *model) {
     mars_model_ext_t *m = (mars_model_ext_t *)model;
     mars_pipe_t *pp = (mars_pipe_t *)m->pipe;
     if (!pp || m->batch != pp->batch) return MARS_ERR_INVALID_FILE; /* the batch was re-planned: open the pipe again */
-    if (pp->inflight >= PIPE_SLOTS) return MARS_ERR_ALLOC_FAILED;    /* collect a result first (mars_hip_pipe_wait) */
+    if (pp->inflight >= PIPE_DEPTH) return MARS_ERR_ALLOC_FAILED;    /* collect a result first (mars_hip_pipe_wait) */
     pipe_slot_t *sl = &pp->slot[pp->head];
     const size_t B = (size_t)m->batch;
     int rc = 0;

@@ -128,6 +128,7 @@ mars_error_t mars_hip_detect(mars_model_t *model, const int *output_indices, int
     if (e != MARS_OK) return e;
     mars_model_ext_t *m = (mars_model_ext_t *)model;
     if (mhip_sync()) return MARS_ERR_LAYER_FAILED; /* both streams: the tail ran on the auxiliary one */
+    m->tail_pending = 0; /* ... and is complete: the next run needs no hand-off (and may replay its captured graph) */
     if (mhip_d2h_async(dets, m->det_dev, (size_t)m->batch * MARS_YOLO_MAX_DET * sizeof(mars_det_t)) ||
         mhip_d2h_async(counts, m->det_counts_dev, (size_t)m->batch * sizeof(int)) || mhip_sync())
         return MARS_ERR_LAYER_FAILED;

@@ -111,7 +111,7 @@ EXPORTS = {
                    "mars_hip_load_memory_ex", "mars_hip_param_arena", "mars_yolo_parse_output", "mars_yolo_nms",
                    "mars_hip_detect", "mars_hip_detect_device", "mars_synth_model", "mars_hip_set_tuning", "mars_hip_autotune", "mars_yolo_letterbox",
                    "mars_hip_preprocess", "mars_hip_tensor_frame_bytes", "mars_hip_tensor_byte_size", "mars_hip_pipe_open",
-                   "mars_hip_pipe_input", "mars_hip_pipe_submit", "mars_hip_pipe_wait", "mars_hip_pipe_close"],
+                   "mars_hip_pipe_input", "mars_hip_pipe_submit", "mars_hip_pipe_wait", "mars_hip_pipe_close", "mars_hip_clock_mhz"],
 }
 
 _lib = None
@@ -165,6 +165,8 @@ def lib():
     L.mars_hip_pipe_wait.argtypes = [P(MarsModel), P(C.c_void_p), P(C.c_void_p), P(C.c_void_p)]
     L.mars_hip_pipe_close.argtypes = [P(MarsModel)]
     L.mars_hip_pipe_close.restype = None
+    L.mars_hip_clock_mhz.argtypes = [C.c_int]
+    L.mars_hip_clock_mhz.restype = C.c_float
     for n in ("mars_hip_upload_inputs", "mars_hip_run_device", "mars_hip_run_device_async",
               "mars_hip_download_outputs", "mars_hip_get_batch", "mars_hip_num_ops"):
         getattr(L, n).argtypes = [P(MarsModel)]
@@ -407,7 +409,9 @@ class Model:
             raise MarsError(rc, "mars_hip_pipe_submit")
 
     def pipe_wait(self, copy=True):
-        """-> (outputs: list of uint8 [batch, frame_bytes] or None, dets: list of record arrays per frame or None)"""
+        """-> (outputs: list of uint8 [batch, frame_bytes] or None, dets: list of record arrays per frame or None).
+        copy=False returns views into the pipe's pinned result buffers: valid until the SECOND pipe_submit() after this
+        call (include/mars_hip.h, mars_hip_pipe_wait)."""
         nout = self.header.num_outputs
         outs = (C.c_void_p * max(nout, 1))()
         dets, counts = C.c_void_p(), C.c_void_p()

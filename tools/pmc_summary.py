@@ -50,7 +50,12 @@ def main():
                      "read_bytes_per_step": 2.0 * rd.get(k, 0) * 1024 / a.executions,
                      "write_bytes_per_step": wr.get(k, 0) * 1024 / a.executions})
     conv = [r for r in rows if r["kernel"].startswith("conv_i8")]
-    out = {"note": a.note, "config": {"width": a.width, "hw": a.hw, "batch": a.batch}, "executions": a.executions, "fetch_size_doubled": True, "kernels": rows,
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("bench", os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    out = {"note": a.note, "kernel_source_sha16": bench.kernel_source_sha16(),
+           "config": {"width": a.width, "hw": a.hw, "batch": a.batch}, "executions": a.executions, "fetch_size_doubled": True, "kernels": rows,
            "conv_i8": {"launches_per_step": sum(r["launches_per_step"] for r in conv),
                        "read_bytes_per_step": sum(r["read_bytes_per_step"] for r in conv),
                        "write_bytes_per_step": sum(r["write_bytes_per_step"] for r in conv)},
