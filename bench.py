@@ -508,6 +508,17 @@ def main():
             for _ in range(3):
                 model.run()
             result["pcie_inclusive_images_per_s"] = 3 * args.batch / (time.perf_counter() - t1)
+            if not args.no_tail and not f32:
+                # the same call for a caller that wants detections, not head tensors: the graph outputs stay in HBM
+                # (mars_hip_set_output_mode), mars_hip_detect brings back 24 KB per frame at most
+                M.lib().mars_hip_set_output_mode(model.p, 1)
+                model.run()
+                t1 = time.perf_counter()
+                for _ in range(3):
+                    model.run()
+                    model.detect(outputs=outputs, thresh=0.45)
+                result["pcie_inclusive_detections_only_images_per_s"] = 3 * args.batch / (time.perf_counter() - t1)
+                M.lib().mars_hip_set_output_mode(model.p, 0)
             if not args.no_tail:
                 # context for `value`: the same steps without the decode + NMS tail.  The twin's random heads put ~19 000
                 # predictions per frame above the threshold, so every frame hits the reference's cap of 1000 candidates

@@ -45,6 +45,14 @@ mars_error_t mars_hip_run_device(mars_model_t *model);       /* enqueue all laye
 mars_error_t mars_hip_run_device_async(mars_model_t *model); /* enqueue only */
 mars_error_t mars_hip_download_outputs(mars_model_t *model); /* HBM -> pinned host, waits */
 mars_error_t mars_hip_sync(void);
+/* What mars_run() brings back.  MARS_HIP_OUTPUT_HEADS (default): the reference's behaviour, every graph output is copied to
+ * mars_get_output()->vaddr (for the 640x640 detectors 2.1 MB per frame: at large batches that copy is what bounds
+ * mars_run).  MARS_HIP_OUTPUT_ON_DEVICE: the outputs stay in HBM -- for callers that only want the detections
+ * (mars_hip_detect reads the device tensors) or fetch single tensors themselves (mars_hip_read_tensor /
+ * mars_hip_download_outputs); vaddr then keeps whatever an earlier download left there. */
+#define MARS_HIP_OUTPUT_HEADS 0
+#define MARS_HIP_OUTPUT_ON_DEVICE 1
+mars_error_t mars_hip_set_output_mode(mars_model_t *model, int mode);
 /* Shader clock of the device right now, in MHz: a one-wave probe on a stream of its own samples the shader-cycle and the
  * 100 MHz reference counters around a ~micros us pause, beside whatever the library's other streams are running (the
  * benchmark's sustained leg reports it: the chip lowers its clock under load).  < 0: no device. */

@@ -283,6 +283,50 @@ def test_config4_yolov5s_twin_640_batch256(gpu, orc):
     m.close()
 
 
+def test_config3_yolov5n_twin_640_batch256(gpu, orc):
+    """BASELINE config 3 at its own size: a yolov5n-class int8 graph (the twin at width 4 -- the shipped yolov5n_int8.mars
+    is the older compiler's NCHW-tagged file and runs at batch 1 in test_shipped_models_all_tensors), 640x640, 256 frames
+    on one GPU, decode + NMS tail on.  Frames 0 and 255 against the CPU oracle bit for bit (all three heads and the kept
+    boxes: order, coordinates, confidences, classes), a frame in the middle against the same frame run alone, and the
+    pipelined path's detections for frame 255 against the synchronous ones."""
+    d = gpu.synth_model(width_x16=4, input_hw=640, seed=1)
+    hdr, tensors, _ = marsfile.parse(d)
+    nb = marsfile.tensor_nbytes(tensors[hdr["inputs"][0]])
+    B = 256
+    m = gpu.Model(d, batch=B)
+    iv = m.input_view(0)
+    for f in range(B):
+        iv[f] = lcg_frame(0x5EED0000 + f, nb)
+    m.run()
+    dets = m.detect(outputs=(0, 1, 2), thresh=0.45)
+    outs = [m.output_view(i).copy() for i in range(3)]
+    for f in (0, 255):
+        g, rc = run_oracle(orc, d, lcg_frame(0x5EED0000 + f, nb))
+        assert rc == 0
+        parts = []
+        for i, ti in enumerate(hdr["outputs"]):
+            want = g.tensor(ti)
+            assert np.array_equal(want, outs[i][f]), "frame %d head %d: %d bytes differ" % (f, i, int((want != outs[i][f]).sum()))
+            parts.append(orc.parse_output(want.view(np.int8), len(want) // 85, np.float32(tensors[ti]["scale"])))
+        want_d = orc.nms(np.concatenate(parts)[:1000], 0.45)
+        assert dets[f].tobytes() == want_d.tobytes(), "detections of frame %d" % f
+        g.close()
+    # the double-buffered path at this batch: same detections
+    m.pipe_open(download_outputs=False, detect=True, det_outputs=(0, 1, 2), thresh=0.45)
+    m.pipe_input_view(0)[:] = iv
+    m.pipe_submit()
+    _, pd = m.pipe_wait()
+    for f in (0, 131, 255):
+        assert pd[f].tobytes() == dets[f].tobytes(), "pipelined detections of frame %d" % f
+    m.pipe_close()
+    m.set_batch(1)
+    m.input_view(0)[0] = lcg_frame(0x5EED0000 + 131, nb)
+    m.run()
+    for i in range(3):
+        assert np.array_equal(m.output_view(i)[0], outs[i][131]), "frame 131 of the batch != the frame alone"
+    m.close()
+
+
 def test_config2_tiny160_batch64(gpu, orc):
     """BASELINE config 2: the shipped tiny_160_int8.mars at batch 64.  Frame 0 carries the reference's test pattern
     (mars_test.c:82-84) and must give the golden digest; every other frame is its own LCG frame, checked against the
@@ -1163,5 +1207,37 @@ def test_mars_run_in_overlapped_chunks(gpu, orc):
                 assert rc == 0
                 for oi, ti in enumerate(hdr["outputs"]):
                     assert np.array_equal(res[2][oi][f], g.tensor(ti)), (B, f, oi)
+        # output mode "on device": mars_run copies nothing back (vaddr keeps what it held); the detections and explicit
+        # downloads still see the new results -- in one piece and in chunks
+        B = 5
+        xs = [lcg_frame(0xC4C5 * 16 + f, nb) for f in range(B)]
+        for chunk in (0, 2):
+            gpu.set_tuning("run_chunk", chunk)
+            m = gpu.Model(d, batch=B)
+            for f in range(B):
+                m.input_view(0)[f] = xs[f]
+            m.run()
+            want = [m.output_view(i).copy() for i in range(3)]
+            want_d = m.detect(outputs=(0, 1, 2), thresh=0.45)
+            assert gpu.lib().mars_hip_set_output_mode(m.p, 1) == 0
+            assert gpu.lib().mars_hip_set_output_mode(m.p, 7) != 0
+            for i in range(3):
+                m.output_view(i)[:] = 0x5A
+            for f in range(B):
+                m.input_view(0)[f] = xs[B - 1 - f]          # other frames than before
+            m.run()
+            for i in range(3):
+                assert (m.output_view(i) == 0x5A).all(), (chunk, i)   # nothing was copied back
+            got_d = m.detect(outputs=(0, 1, 2), thresh=0.45)
+            for f in range(B):
+                assert got_d[f].tobytes() == want_d[B - 1 - f].tobytes(), (chunk, f)
+            m.download()
+            for i in range(3):
+                assert np.array_equal(m.output_view(i), want[i][::-1]), (chunk, i)
+            assert gpu.lib().mars_hip_set_output_mode(m.p, 0) == 0
+            m.run()
+            for i in range(3):
+                assert np.array_equal(m.output_view(i), want[i][::-1]), (chunk, i)
+            m.close()
     finally:
         gpu.set_tuning("run_chunk", 128)

@@ -164,13 +164,14 @@ def test_conv_i8_tile_walk_resident_weights(gpu, orc, slots, variant):
         gpu.set_tuning("persist_slots", 0)
 
 
-@pytest.mark.parametrize("variant,slots", [(12, 0), (13, 0), (18, 0), (19, 0), (20, 0), (20, 2), (20, 3)])
+@pytest.mark.parametrize("variant,slots", [(12, 0), (13, 0), (18, 0), (19, 0)])
 def test_conv_i8_wide_one_tile_forms(gpu, orc, variant, slots):
     """variant 12 (two K slices per ring stage), 13 (256 x 128 tile on an 8-wave workgroup), 18 / 19 (128-byte K steps:
     whole-line DMA requests, 128-byte LDS rows, 4 / 8 waves; layers with fewer than 128 input channels fall back to the
-    default there), 20 (the same steps as one persistent 8-wave workgroup per CU with a three-stage ring that runs
-    across tile boundaries; `slots` forces few workgroups so that each walks several tiles): deep K loops, 128 / 256
-    output channels, pixel counts that are not multiples of the tile, aligned and ragged (255) rows"""
+    default there): deep K loops, 128 / 256 output channels, pixel counts that are not multiples of the tile, aligned and
+    ragged (255) rows.  (Variants 16, 17 and 20 -- patch-staged input with streamed weights, the two-team strip kernel, the
+    persistent 128-byte-step tile -- were measured in round 2, never chosen by the policy or the tuner on a BASELINE
+    workload, and removed in round 3: DESIGN.md section 5.)"""
     shapes = [  # in_h, in_w, in_c, out_c, k, s
         (40, 40, 128, 128, 3, 1), (23, 17, 256, 256, 3, 1), (33, 31, 128, 256, 1, 1), (20, 20, 512, 255, 1, 1),
         (19, 21, 64, 128, 3, 2), (16, 16, 1024, 128, 1, 1), (21, 19, 128, 128, 3, 2), (9, 11, 256, 128, 5, 1)]
@@ -186,78 +187,26 @@ def test_conv_i8_wide_one_tile_forms(gpu, orc, variant, slots):
             b = cases.conv_i8_call(orc.conv2d_int8, case, 7)
             assert np.array_equal(a, b), (case[0], int((a != b).sum()))
             assert len(np.unique(a)) > 32
-        if variant == 20:  # a whole graph, several frames: fused SiLU tables, folded Adds fall back, tile walks over frames
-            import marsfile
-            from conftest import lcg_frame
-            d = gpu.synth_model(width_x16=8, input_hw=256, seed=29, vary_scales=True)
-            hdr, tensors, _ = marsfile.parse(d)
-            nb = marsfile.tensor_nbytes(tensors[hdr["inputs"][0]])
-            m = gpu.Model(d, batch=3)
-            xs = [lcg_frame(0xAE0000 + f, nb) for f in range(3)]
-            for f in range(3):
-                m.input_view(0)[f] = xs[f]
-            m.run()
-            for f in range(3):
-                g = orc.Graph(d)
-                g.set_input(0, xs[f].tobytes())
-                assert g.run() == 0
-                for oi, ti in enumerate(hdr["outputs"]):
-                    assert np.array_equal(m.output_view(oi)[f], g.tensor(ti)), (f, oi)
-            m.close()
     finally:
         gpu.set_tuning("variant", 0)
         gpu.set_tuning("persist_slots", 0)
 
 
-def test_conv_i8_patch_staged_streamed_weights(gpu, orc):
-    """variant 16: input patch staged once in LDS, weights streamed through a ring (8 waves, 16x16 pixels x 128
-    channels): 64 / 128 input channels, 128 / 256 output channels, 3x3 and 5x5, stride 1 and 2, sizes that are and are
-    not multiples of the tile, several frames in a graph with a folded residual Add"""
-    shapes = [  # in_h, in_w, in_c, out_c, k, s
-        (48, 48, 128, 128, 3, 1), (32, 48, 128, 256, 3, 1), (31, 30, 64, 128, 3, 1), (31, 31, 64, 128, 3, 2),
-        (16, 16, 64, 128, 5, 1), (47, 32, 128, 128, 3, 1), (40, 40, 128, 128, 3, 1)]  # the last one: not eligible (69 % fill)
-    try:
-        gpu.set_tuning("variant", 16)
-        for i, (h, w, ic, oc, k, s) in enumerate(shapes):
-            oh, ow = (h + s - 1) // s, (w + s - 1) // s
-            ph = max((oh - 1) * s + k - h, 0) // 2
-            pw = max((ow - 1) * s + k - w, 0) // 2
-            case = ("pws%d" % i, 1, h, w, ic, oc, k, k, s, s, ph, pw, oh, ow, 0.03, 0.003 / (k * k * ic) ** 0.5 * 8, 0.05, True)
-            a = cases.conv_i8_call(gpu.conv2d_int8, case, 11)
-            b = cases.conv_i8_call(orc.conv2d_int8, case, 11)
-            assert np.array_equal(a, b), (case[0], int((a != b).sum()))
-            assert len(np.unique(a)) > 32
-        import marsfile
-        from conftest import lcg_frame
-        d = gpu.synth_model(width_x16=8, input_hw=256, seed=23, vary_scales=True)  # 32x32x128 bottlenecks with folded Adds
-        hdr, tensors, _ = marsfile.parse(d)
-        nb = marsfile.tensor_nbytes(tensors[hdr["inputs"][0]])
-        m = gpu.Model(d, batch=2)
-        xs = [lcg_frame(0xAD0000 + f, nb) for f in range(2)]
-        for f in range(2):
-            m.input_view(0)[f] = xs[f]
-        m.run()
-        for f in range(2):
-            g = orc.Graph(d)
-            g.set_input(0, xs[f].tobytes())
-            assert g.run() == 0
-            for oi, ti in enumerate(hdr["outputs"]):
-                assert np.array_equal(m.output_view(oi)[f], g.tensor(ti))
-        m.close()
-    finally:
-        gpu.set_tuning("variant", 0)
-
-
-@pytest.mark.parametrize("variant", [9, 10, 11])
-def test_conv_i8_patch_staged(gpu, orc, variant):
+@pytest.mark.parametrize("variant,ring", [(9, 0), (10, 0), (11, 0), (10, 1), (9, 3), (11, 4), (10, 4)])
+def test_conv_i8_patch_staged(gpu, orc, variant, ring):
     """the patch-staged kernel (input patch of a tile staged once in LDS, weights resident, taps fed from LDS):
     3x3 / 5x5 / 3x1 kernels, stride 1 and 2 (de-interleaved patch columns), in_c 32 / 64, partial tiles at the
-    right and bottom edges, SAME padding on every side, several tiles per workgroup"""
+    right and bottom edges, SAME padding on every side, several tiles per workgroup.  `ring` forces the depth of the patch
+    ring (1 = one buffer, no prefetch; 3 / 4 = two / three patches in flight behind the one being computed, with an LDS
+    budget that holds them), so that the hand-counted vector-memory waits are exercised at every depth, on interior tiles
+    (buffer-addressed LDS-DMA) and edge tiles alike, with and without the wave-private residual staging of a folded Add"""
     shapes = [  # in_h, in_w, in_c, out_c, kh, kw, s
         (48, 48, 64, 64, 3, 3, 1), (64, 64, 32, 64, 3, 3, 2), (47, 45, 32, 32, 3, 3, 1), (61, 63, 64, 32, 3, 3, 2),
         (32, 48, 32, 48, 5, 5, 1), (40, 32, 64, 16, 3, 1, 1), (64, 64, 32, 32, 1, 3, 2), (33, 31, 64, 128, 3, 3, 1)]
     try:
         gpu.set_tuning("variant", variant)
+        gpu.set_tuning("patch_ring", ring)
+        gpu.set_tuning("patch_lds_kb", 160 if ring > 2 else 80)
         for slots in (0, 3):
             gpu.set_tuning("persist_slots", slots)
             for i, (h, w, ic, oc, kh, kw, s) in enumerate(shapes):
@@ -289,6 +238,8 @@ def test_conv_i8_patch_staged(gpu, orc, variant):
     finally:
         gpu.set_tuning("variant", 0)
         gpu.set_tuning("persist_slots", 0)
+        gpu.set_tuning("patch_ring", 0)
+        gpu.set_tuning("patch_lds_kb", 80)
 
 
 def test_mxu_f32_elementwise(gpu):
@@ -332,46 +283,3 @@ def test_decode_cap_and_maxd(gpu, orc):
     assert len(a) == 37 and a.tobytes() == b.tobytes()
 
 
-def test_conv_i8_two_team_strip(gpu, orc):
-    """variant 17 (conv_i8_duo): one 16-wave workgroup = two teams half a tile apart on a shared weight ring, tiles of
-    256 flat pixels (straddling frames), input patch staged per 64-channel chunk.  3x3 / 5x5 stride-1 layers with 64,
-    128 and 256 input channels (1, 2, 4 chunks), 128 / 256 output channels, maps that do and do not divide into
-    256-pixel tiles, odd tile counts (team 1 idle at the end), several tiles per workgroup; through a graph with several
-    frames so that tiles straddle frame boundaries"""
-    import marsfile
-    from conftest import lcg_frame
-    rng = np.random.default_rng(5)
-    shapes = [  # h, w, ic, oc, k, frames, slots
-        (40, 40, 128, 128, 3, 3, 0), (20, 20, 256, 256, 3, 5, 0), (80, 80, 64, 128, 3, 1, 0), (17, 19, 64, 128, 3, 4, 0),
-        (16, 16, 128, 128, 5, 3, 0), (40, 40, 128, 128, 3, 7, 2), (23, 29, 256, 128, 3, 3, 3), (20, 20, 256, 256, 3, 16, 1)]
-    try:
-        gpu.set_tuning("variant", 17)
-        for i, (h, w, ic, oc, k, frames, slots) in enumerate(shapes):
-            gpu.set_tuning("persist_slots", slots)
-            G = marsfile.Graph()
-            x = G.tensor([1, h, w, ic], scale=4 / 127)
-            a = G.tensor([1, h, w, oc], scale=0.03125)
-            sg = G.tensor([1, h, w, oc], scale=1 / 127)
-            o = G.tensor([1, h, w, oc], scale=4 / 127)
-            wt = G.tensor([oc, k, k, ic], scale=0.0005, data=rng.integers(-127, 128, (oc, k, k, ic), dtype=np.int8))
-            b = G.tensor([oc], dtype=marsfile.I32, scale=1.0, data=rng.integers(-500, 500, oc, dtype=np.int32))
-            G.conv(x, a, wt, b, (k, k), (1, 1))
-            G.layer(marsfile.SIGMOID, [a], [sg])
-            G.layer(marsfile.MUL, [a, sg], [o])
-            d = G.serialise([x], [o])
-            m = gpu.Model(d, batch=frames)
-            xs = [lcg_frame(0xD00000 + 97 * i + f, h * w * ic) for f in range(frames)]
-            for f in range(frames):
-                m.input_view(0)[f] = xs[f]
-            m.run()
-            for f in sorted({0, frames // 2, frames - 1}):
-                g = orc.Graph(d)
-                g.set_input(0, xs[f].tobytes())
-                assert g.run() == 0
-                want, got = g.tensor(3), m.output_view(0)[f]
-                assert np.array_equal(want, got), (i, f, int((want != got).sum()))
-                assert len(np.unique(got)) > 32
-            m.close()
-    finally:
-        gpu.set_tuning("variant", 0)
-        gpu.set_tuning("persist_slots", 0)

@@ -848,7 +848,6 @@ const tune_t &conv_i8_tune_state() {
         g_tune.small_batch = env_int("MARS_HIP_SMALL_BATCH", 1);
         g_tune.patch_ring = env_int("MARS_HIP_PATCH_RING", 0);
         g_tune.patch_lds_kb = env_int("MARS_HIP_PATCH_LDS_KB", 80);
-        g_tune.patch_stagger = env_int("MARS_HIP_PATCH_STAGGER", 0);
         g_tune.init = 1;
     }
     return g_tune;
@@ -858,7 +857,7 @@ extern "C" int mhip_conv_i8_tune(const char *key, int value) {
     (void)conv_i8_tune_state();
     struct { const char *k; int *v; } tab[] = {{"persist", &g_tune.persist}, {"persist_stages", &g_tune.persist_stages},
                                                {"persist_maxk", &g_tune.persist_maxk}, {"persist_slots", &g_tune.persist_slots}, {"wres", &g_tune.wres}, {"rgb_direct", &g_tune.rgb_direct}, {"small_batch", &g_tune.small_batch},
-                                               {"patch_ring", &g_tune.patch_ring}, {"patch_lds_kb", &g_tune.patch_lds_kb}, {"patch_stagger", &g_tune.patch_stagger}, {"stages", &g_tune.stages}, {"bpx", &g_tune.bpx}, {"variant", &g_tune.variant}, {"bufmode", &g_tune.bufmode}};
+                                               {"patch_ring", &g_tune.patch_ring}, {"patch_lds_kb", &g_tune.patch_lds_kb}, {"stages", &g_tune.stages}, {"bpx", &g_tune.bpx}, {"variant", &g_tune.variant}, {"bufmode", &g_tune.bufmode}};
     for (auto &e : tab)
         if (key && !strcmp(key, e.k)) {
             *e.v = value;

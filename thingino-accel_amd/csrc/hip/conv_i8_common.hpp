@@ -420,7 +420,6 @@ struct tune_t {
     int wres;           // MARS_HIP_WRES          bit 0 / 1: the default policy may keep the weights resident in LDS (tile
                         //                        walker) for single / paired launches
     int patch_ring;     // MARS_HIP_PATCH_RING    0: auto, else at most this many patch buffers per workgroup of the patch-staged kernel (1..4)
-    int patch_stagger;  // MARS_HIP_PATCH_STAGGER experiment: the second half of a patch-staged grid starts this many x 64 cycles late
     int patch_lds_kb;   // MARS_HIP_PATCH_LDS_KB  LDS budget of one patch-staged workgroup (default 80: two workgroups per CU)
 };
 const tune_t &conv_i8_tune_state(); // conv_i8.hip

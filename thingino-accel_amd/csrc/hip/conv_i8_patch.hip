@@ -83,8 +83,7 @@ __global__ __launch_bounds__(NTHREADS) void conv_i8_patch(const mhip_conv_i8_t p
                                                           const int PW, const int PWP, const int PWH, const int nblk,
                                                           const int8_t *__restrict__ zeros, const fastdiv_t dtx,
                                                           const fastdiv_t dty, const fastdiv_t dpwp, const unsigned out_bytes,
-                                                          const int ring, const int xmap, const int stagger,
-                                                          const unsigned in_bytes) {
+                                                          const int ring, const int xmap, const unsigned in_bytes) {
     constexpr int WPX = TH / 4;  // tile rows (16-pixel subtiles) per wave
     constexpr int WOC = BN / 16; // every wave covers all BN channels of its rows
     constexpr int NST = WPX;     // buffer stores per wave and tile
@@ -229,8 +228,6 @@ __global__ __launch_bounds__(NTHREADS) void conv_i8_patch(const mhip_conv_i8_t p
     // counter on gfx9, so "patch landed" == "at most yg outstanding").
     const unsigned G = gridDim.x;
     const int D = ring - 1;
-    if (stagger > 0 && blockIdx.x >= (G >> 1)) // experiment: co-resident workgroups half a tile apart
-        for (int i = 0; i < stagger; i += 64) __builtin_amdgcn_s_sleep(64);
     unsigned t = blockIdx.x;
     int yg0 = 0, yg1 = 0, yg2 = 0;
     {
@@ -518,10 +515,11 @@ static bool patch_geom(const mhip_conv_i8_t *p, int th, patch_geom_t *g) {
     if (fixed + pb > budget) return false;
     // as many patch buffers as the budget holds, at most 4 (three patches in flight behind the one being computed);
     // MARS_HIP_PATCH_RING / the "patch_ring" knob caps it (tests force every depth)
-    int ring = (int)((budget - fixed) / pb);
-    ring = ring > 2 ? 2 : ring; // (the kernel takes up to 4: deeper rings measured equal or slower, see patch_lds_budget)
-    if (tune().patch_ring > 2) ring = (int)((budget - fixed) / pb) > 4 ? 4 : (int)((budget - fixed) / pb);
-    if (tune().patch_ring > 0 && tune().patch_ring < ring) ring = tune().patch_ring;
+    // default: at most two buffers (the kernel takes up to 4: deeper rings measured equal or slower, see patch_lds_budget);
+    // the "patch_ring" knob (tests, experiments) sets the cap, 1..4
+    const int fit = (int)((budget - fixed) / pb);
+    const int cap = tune().patch_ring > 0 ? (tune().patch_ring > 4 ? 4 : tune().patch_ring) : 2;
+    int ring = fit < cap ? fit : cap;
     g->ring = ring;
     g->lds = fixed + (size_t)ring * pb;
     if ((long)g->tiles_x * g->tiles_y * p->frames > 0x7fffffffL) return false;
@@ -574,7 +572,7 @@ static int launch_patch_t(const mhip_conv_i8_t *p, int k64, const patch_geom_t &
     hipLaunchKernelGGL(kern, dim3(gx, noc), dim3(NTHREADS), g.lds, mhip_stream_native(), *p, k64,
                        g.tiles_x, g.tiles_y, ntiles, g.PH, g.PW, g.PWP, g.PWH, g.nblk, (const int8_t *)mhip_zero_page(),
                        make_fastdiv((unsigned)g.tiles_x), make_fastdiv((unsigned)g.tiles_y), make_fastdiv((unsigned)g.PWP),
-                       (unsigned)persist_out_bytes(p), g.ring, xmap, tune().patch_stagger,
+                       (unsigned)persist_out_bytes(p), g.ring, xmap,
                        in_extent_bytes(p) <= 0x7fffffffL ? (unsigned)in_extent_bytes(p) : 0u);
     return mhip_check(hipGetLastError(), "conv_i8_patch launch");
 }

@@ -215,6 +215,12 @@ extern "C" void *mhip_event_create(void) {
     if (hipEventCreate(&ev) != hipSuccess) return nullptr;
     return (void *)ev;
 }
+// ordering-only events (stream -> stream hand-offs): no timestamps, so recording and waiting stay on the device's queues
+extern "C" void *mhip_event_create_sync(void) {
+    hipEvent_t ev;
+    if (hipEventCreateWithFlags(&ev, hipEventDisableTiming) != hipSuccess) return nullptr;
+    return (void *)ev;
+}
 extern "C" void mhip_event_destroy(void *ev) {
     if (ev) (void)hipEventDestroy((hipEvent_t)ev);
 }

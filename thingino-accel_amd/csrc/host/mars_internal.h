@@ -85,6 +85,7 @@ typedef struct {
     int batch, fusion, profiling, deferred;
     int plan_err;   /* first allocation failure while planning (build_plan returns it; 0 = none) */
     int no_vconcat; /* virtual concat switched off (a batch too large for 32-bit buffer offsets) */
+    int no_download; /* mars_hip_set_output_mode(MARS_HIP_OUTPUT_ON_DEVICE): mars_run leaves the graph outputs in HBM */
     int no_bottleneck; /* fused bottlenecks (fusion level 2) switched off: one of them cannot launch at this batch */
     mtensor_t *mt;
     mars_op_t *ops;

@@ -48,6 +48,9 @@ static unsigned g_tune_gen = 1;
  * batch 256: 4.76 -> 4.58 ms per batch. */
 static int g_dual_min_batch = 64;
 static int g_dual_ways = 2; /* parts (= streams) such a batch is cut into: 2..4 */
+/* (Round 3, measured and dropped: a LAZY join -- the main stream not waiting for the other part at the end of a run, only
+ * the detection tail, uploads and downloads doing so -- so that back-to-back runs keep both streams busy without meeting
+ * at every run boundary: 1-2 % slower at batch 256 and 128; the aligned start is worth more than the bubble costs.) */
 static void drop_graph(mars_model_ext_t *m) {
     if (m->graph_exec) {
         mhip_sync();
@@ -1634,6 +1637,7 @@ static int launch_op(mars_model_ext_t *m, mars_op_t *op) {
 }
 
 static mars_error_t enqueue_plan(mars_model_t *model);
+static double now_us(void);
 
 mars_error_t mars_hip_run_device_async(mars_model_t *model) {
     if (!model) return MARS_ERR_INVALID_FILE;
@@ -1747,9 +1751,9 @@ static mars_error_t enqueue_plan(mars_model_t *model) {
     int dual = g_dual_min_batch > 0 && B >= g_dual_min_batch && B >= 2 && !m->profiling &&
                !(g_graph_max_batch > 0 && B <= g_graph_max_batch);
     if (dual) {
-        if (!m->ev_fork) m->ev_fork = mhip_event_create();
+        if (!m->ev_fork) m->ev_fork = mhip_event_create_sync();
         for (int k = 0; k < 3; k++) {
-            if (!m->ev_join[k]) m->ev_join[k] = mhip_event_create();
+            if (!m->ev_join[k]) m->ev_join[k] = mhip_event_create_sync();
             if (!m->ev_join[k]) dual = 0;
         }
         if (!m->ev_fork) dual = 0;
@@ -1861,6 +1865,12 @@ mars_error_t mars_hip_download_outputs(mars_model_t *model) {
 /* mars_run at large batches: frames are independent, so the batch goes through in chunks -- chunk k+1 is copied in (upload
  * stream) while chunk k runs (main stream) and chunk k-1 is copied out (download stream).  The caller still gets one
  * synchronous call; the link is busy in both directions nearly all of the time instead of a third of it. */
+/* Round 3, traced (rocprofv3 --kernel-trace --memory-copy-trace): smaller chunks lose because a 32- or 64-frame graph is
+ * launch-bound (1.2 ms per 32 frames = 9.8 ms of graph for 256 frames against 4.6 ms in one piece), not because of the
+ * hand-offs: ordering-only events, all uploads queued up front and copies executed as kernels (mapped host memory) each
+ * left the rate where it was or lowered it.  With 2 x 128 frames the return copy (550 MB, 10.3 ms) stays the long pole:
+ * 14 k images/s against an ideal 16.3 k for this split; callers that do not need the raw heads switch the copy off
+ * (mars_hip_set_output_mode: 24 k images/s, the upload's rate) or use the pipelined calls (mars_pipe.c). */
 static int g_run_chunk = 128; /* frames per chunk; batches below twice this go as one piece (tuning key "run_chunk", 0 = never).
                                * Measured, yolov5s twin: batch 256 12.2k -> 14.6k img/s, batch 512 12.3k -> 17.4k; smaller chunks lose
                                * again (each chunk's hand-off between the three streams costs about a millisecond) */
@@ -1871,20 +1881,30 @@ static mars_error_t run_chunked(mars_model_ext_t *m) {
     if (nch > 8) nch = 8;
     for (int k = 0; k < 2; k++)
         for (int c = 0; c < nch; c++)
-            if (!m->ev_chunk[k][c] && !(m->ev_chunk[k][c] = mhip_event_create())) return MARS_ERR_ALLOC_FAILED;
+            if (!m->ev_chunk[k][c] && !(m->ev_chunk[k][c] = mhip_event_create_sync())) return MARS_ERR_ALLOC_FAILED;
     for (uint32_t i = 0; i < model->header.num_layers; i++) model->layers[i].is_executed = false;
     mars_error_t e = MARS_OK;
     /* the copies may not overtake what the caller put on the main stream before this call */
     mhip_select_stream(0);
     if (mhip_event_record(m->ev_chunk[1][nch - 1]) || mhip_stream_wait(2, m->ev_chunk[1][nch - 1])) e = MARS_ERR_LAYER_FAILED;
+    /* Every upload is queued FIRST, all of them, then the graphs with their downloads.  The copy engines take their commands
+     * in submission order whatever stream they came from: with upload c+1 queued behind download c (the round-2 order:
+     * upload, graph, download per chunk) it could not start before download c did, i.e. before graph c had finished --
+     * traced: uploads 3.7 ms apart for 1.4 ms of copying each, 13.9 k images/s.  Uploads depend on nothing, so up front they
+     * stream back to back and every graph finds its frames waiting. */
     int f0 = 0;
+    mhip_select_stream(2);
     for (int c = 0; c < nch && e == MARS_OK; c++) {
         const int n = (B - f0 + (nch - c) - 1) / (nch - c);
-        mhip_select_stream(2);
         e = enqueue_upload_frames(m, f0, n);
         if (e == MARS_OK && mhip_event_record(m->ev_chunk[0][c])) e = MARS_ERR_LAYER_FAILED;
+        f0 += n;
+    }
+    f0 = 0;
+    for (int c = 0; c < nch && e == MARS_OK; c++) {
+        const int n = (B - f0 + (nch - c) - 1) / (nch - c);
         mhip_select_stream(0);
-        if (e == MARS_OK && mhip_stream_wait(0, m->ev_chunk[0][c])) e = MARS_ERR_LAYER_FAILED;
+        if (mhip_stream_wait(0, m->ev_chunk[0][c])) e = MARS_ERR_LAYER_FAILED;
         if (e == MARS_OK) {
             m->frame0 = f0; m->run_frames = n;
             e = enqueue_range(m, 0, c == 0 ? m->tail_pending : 0);
@@ -1893,7 +1913,7 @@ static mars_error_t run_chunked(mars_model_ext_t *m) {
         if (e == MARS_OK && mhip_event_record(m->ev_chunk[1][c])) e = MARS_ERR_LAYER_FAILED;
         if (e == MARS_OK && mhip_stream_wait(3, m->ev_chunk[1][c])) e = MARS_ERR_LAYER_FAILED;
         mhip_select_stream(3);
-        if (e == MARS_OK) e = enqueue_download_frames(m, f0, n);
+        if (e == MARS_OK && !m->no_download) e = enqueue_download_frames(m, f0, n);
         f0 += n;
     }
     mhip_select_stream(0);
@@ -1921,7 +1941,7 @@ mars_error_t mars_run(mars_model_t *model) {
     } else {
         e = enqueue_upload(m);
         if (e == MARS_OK) e = mars_hip_run_device_async(model);
-        if (e == MARS_OK) e = enqueue_download(m);
+        if (e == MARS_OK && !m->no_download) e = enqueue_download(m);
     }
     if (mhip_sync() && e == MARS_OK) e = MARS_ERR_LAYER_FAILED;
     if (e != MARS_OK) return e;
@@ -1944,6 +1964,12 @@ mars_error_t mars_hip_set_batch(mars_model_t *model, int n) {
 }
 
 int mars_hip_get_batch(const mars_model_t *model) { return model ? ((const mars_model_ext_t *)model)->batch : 0; }
+
+mars_error_t mars_hip_set_output_mode(mars_model_t *model, int mode) {
+    if (!model || (mode != MARS_HIP_OUTPUT_HEADS && mode != MARS_HIP_OUTPUT_ON_DEVICE)) return MARS_ERR_INVALID_FILE;
+    ((mars_model_ext_t *)model)->no_download = mode == MARS_HIP_OUTPUT_ON_DEVICE;
+    return MARS_OK;
+}
 
 mars_error_t mars_hip_set_fusion(mars_model_t *model, int level) {
     if (!model) return MARS_ERR_INVALID_FILE;

@@ -155,9 +155,9 @@ mars_error_t mars_hip_pipe_open(mars_model_t *model, const mars_hip_pipe_opts_t 
             sl->cnt_dev = (int *)mhip_malloc(B * 2 * sizeof(int));
             if (!sl->det_host || !sl->cnt_host || !sl->det_dev || !sl->cnt_dev) err = MARS_ERR_ALLOC_FAILED;
         }
-        sl->ev_up = mhip_event_create();
-        sl->ev_graph = mhip_event_create();
-        sl->ev_tail = mhip_event_create();
+        sl->ev_up = mhip_event_create_sync();
+        sl->ev_graph = mhip_event_create_sync();
+        sl->ev_tail = mhip_event_create_sync();
         sl->ev_down = mhip_event_create();
         if (!sl->ev_up || !sl->ev_graph || !sl->ev_tail || !sl->ev_down) err = MARS_ERR_ALLOC_FAILED;
     }

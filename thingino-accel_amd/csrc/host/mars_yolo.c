@@ -107,8 +107,8 @@ mars_error_t mars_hip_detect_device(mars_model_t *model, const int *output_indic
     /* The tail runs on the auxiliary stream: it starts when the graph launches enqueued so far
      * have finished, and the NEXT run's output-writing layers wait for it (mars_hip_run_device_async),
      * so decode/sort/NMS of batch k overlap the convolutions of batch k+1. */
-    if (!m->ev_graph_done) m->ev_graph_done = mhip_event_create();
-    if (!m->ev_tail_done) m->ev_tail_done = mhip_event_create();
+    if (!m->ev_graph_done) m->ev_graph_done = mhip_event_create_sync();
+    if (!m->ev_tail_done) m->ev_tail_done = mhip_event_create_sync();
     if (!m->ev_graph_done || !m->ev_tail_done) return MARS_ERR_ALLOC_FAILED;
     if (mhip_event_record(m->ev_graph_done)) return MARS_ERR_LAYER_FAILED;
     mhip_select_aux(1);

@@ -42,6 +42,7 @@ int mhip_h2d_2d_async(void *dst, size_t dpitch, const void *src, size_t spitch, 
 int mhip_d2h_2d_async(void *dst, size_t dpitch, const void *src, size_t spitch, size_t row_bytes, size_t rows);
 /* event pairs for per-op timing */
 void *mhip_event_create(void);
+void *mhip_event_create_sync(void); /* ordering only (no timing): for stream -> stream hand-offs */
 void mhip_event_destroy(void *ev);
 int mhip_event_record(void *ev);
 float mhip_event_elapsed_ms(void *start, void *stop); /* waits for stop */
