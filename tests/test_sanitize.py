@@ -82,3 +82,26 @@ def test_fuzz_shipped_and_synthetic_models(fuzz_bin, tmp_path, marsrt):
     assert r.returncode == 0, r.stdout + r.stderr
     assert "ERROR: AddressSanitizer" not in r.stderr and "runtime error" not in r.stderr, r.stderr[-4000:]
     assert "fuzz_loader:" in r.stdout
+
+
+def test_compile_step_under_sanitizers(tmp_path):
+    """the ONNX -> .mars compile step (host-only C++) built with ASan + UBSan and driven by tests/c/fuzz_compile.cpp over
+    the compile tests' graphs: whole, truncated, bit-flipped and with over-long varints spliced in"""
+    import numpy as np
+    import test_compile as tc
+    out = tmp_path / "fuzz_compile"
+    cmd = ["g++", "-O1", "-g", "-std=c++17", "-fsanitize=address,undefined", "-fno-sanitize-recover=undefined", "-fno-omit-frame-pointer",
+           "-I" + os.path.join(ROOT, "include"), os.path.join(ROOT, "tests", "c", "fuzz_compile.cpp"),
+           os.path.join(HOST, "mars_compile.cpp"), "-o", str(out)]
+    subprocess.check_call(cmd)
+    files = []
+    for i, data in enumerate([tc.small_graph(np.random.default_rng(1), True)[0], tc.small_graph(np.random.default_rng(2), False)[0],
+                              tc.qdq_graph(np.random.default_rng(3))[0], tc.runnable_graph(np.random.default_rng(4))]):
+        p = tmp_path / ("g%d.onnx" % i)
+        p.write_bytes(data)
+        files.append(str(p))
+    env = dict(os.environ, ASAN_OPTIONS="detect_leaks=1:abort_on_error=0", UBSAN_OPTIONS="print_stacktrace=1")
+    r = subprocess.run([str(out), "1500", "11"] + files, env=env, capture_output=True, timeout=240)
+    err = r.stderr.decode(errors="replace")
+    assert r.returncode == 0, r.stdout.decode()[-2000:] + err[-4000:]
+    assert "ERROR: AddressSanitizer" not in err and "runtime error" not in err and "LeakSanitizer" not in err, err[-4000:]

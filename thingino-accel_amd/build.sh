@@ -38,3 +38,6 @@ done
 for p in "${pids[@]:-}"; do [ -n "$p" ] && wait "$p"; done
 $HIPCC --offload-arch=gfx950 -shared -fPIC -Wl,-Bsymbolic -o "$OUT/libnna_mars.so" "$OBJ"/*.o -lm
 echo "built $OUT/libnna_mars.so"
+# the ONNX -> .mars compile step as the reference's command-line tool (host-only: no GPU runtime linked)
+$CC -O2 -Wall $INC "$SRC/cli/mars_main.c" "$OBJ/mars_compile.o" -lstdc++ -lm -o "$OUT/mars"
+echo "built $OUT/mars"

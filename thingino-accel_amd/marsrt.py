@@ -87,6 +87,10 @@ class PipeOpts(C.Structure):
 
 assert C.sizeof(MarsHeader) == 76 and C.sizeof(MarsTensorDesc) == 124
 
+
+class CompileOpts(C.Structure):  # mars_compile_opts_t (include/mars_compile.h)
+    _fields_ = [("float32", C.c_int), ("nhwc", C.c_int), ("verbose", C.c_int)]
+
 # every symbol the headers under include/ declare (checked by tests/test_abi.py)
 EXPORTS = {
     "nna.h": ["nna_init", "nna_deinit", "nna_get_hw_info", "nna_is_ready", "nna_get_version", "nna_lock",
@@ -112,6 +116,7 @@ EXPORTS = {
                    "mars_hip_detect", "mars_hip_detect_device", "mars_synth_model", "mars_hip_set_tuning", "mars_hip_autotune", "mars_yolo_letterbox",
                    "mars_hip_preprocess", "mars_hip_tensor_frame_bytes", "mars_hip_tensor_byte_size", "mars_hip_pipe_open",
                    "mars_hip_pipe_input", "mars_hip_pipe_submit", "mars_hip_pipe_wait", "mars_hip_pipe_close", "mars_hip_clock_mhz", "mars_hip_set_output_mode"],
+    "mars_compile.h": ["mars_compile_onnx", "mars_compile_file", "mars_compile_last_error"],
 }
 
 _lib = None
@@ -193,6 +198,10 @@ def lib():
     L.mars_yolo_nms.argtypes = [C.c_void_p, C.c_int, C.c_float]
     L.mars_hip_detect.argtypes = [P(MarsModel), P(C.c_int), C.c_int, C.c_float, C.c_void_p, P(C.c_int)]
     L.mars_hip_detect_device.argtypes = [P(MarsModel), P(C.c_int), C.c_int, C.c_float]
+    L.mars_compile_onnx.restype = C.c_size_t
+    L.mars_compile_onnx.argtypes = [C.c_char_p, C.c_size_t, P(CompileOpts), C.c_void_p, C.c_size_t]
+    L.mars_compile_file.argtypes = [C.c_char_p, C.c_char_p, P(CompileOpts)]
+    L.mars_compile_last_error.restype = C.c_char_p
     L.mars_synth_model.restype = C.c_size_t
     L.mars_synth_model.argtypes = [P(SynthOpts), C.c_void_p, C.c_size_t]
     conv_args = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p,
@@ -243,6 +252,17 @@ def synth_model(width_x16=8, depth_x3=1, input_hw=640, float32=False, nchw_int8=
     buf = (C.c_uint8 * n)()
     assert lib().mars_synth_model(C.byref(o), buf, n) == n
     return bytes(buf)
+
+
+def compile_onnx(onnx_bytes, float32=False, nhwc=False, verbose=False):
+    """ONNX model bytes -> .mars file bytes (mars_compile_onnx; host-only, needs no GPU)."""
+    o = CompileOpts(int(float32), int(nhwc), int(verbose))
+    n = lib().mars_compile_onnx(onnx_bytes, len(onnx_bytes), C.byref(o), None, 0)
+    if n == 0:
+        raise ValueError(lib().mars_compile_last_error().decode())
+    buf = C.create_string_buffer(n)
+    assert lib().mars_compile_onnx(onnx_bytes, len(onnx_bytes), C.byref(o), buf, n) == n
+    return buf.raw
 
 
 def nna_init():
