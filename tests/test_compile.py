@@ -471,7 +471,7 @@ def test_compiled_file_runs_bit_identically_on_the_device(marsrt):
         rng = np.random.default_rng(seed + 100)
         x = rng.integers(0, 256, m.input_view(0).shape, dtype=np.uint8)
         m.input_view(0)[:] = x
-        assert m.run() == 0
+        m.run()  # raises on a non-zero mars_run
         got = m.output_view(0).copy()
         for f in range(3):
             g = orcbind.Graph(d)

@@ -46,6 +46,20 @@ def test_bench_line_has_the_contract_fields():
     assert lat["graph_resident_ms"] > 0 and lat["mars_run_ms"] >= lat["graph_resident_ms"] * 0.5 and lat["launches"] > 0
     assert d["config"]["frames_total"] == 4 and d["config"]["ranks"] == 1
     assert d["graph_only_images_per_s"] > 0 and d["config"]["kept_boxes_per_frame"] >= 0
+    # round 3: wall-clock roofline of the execution mode `value` is quoted in, detections compared with the CPU leg's,
+    # a sustained leg with the shader clock it ran at
+    assert 0 < r["frac_wall"] <= 1.0 and abs(r["frac_wall"] - r["wall_achieved"] / r["peak"]) < 1e-9
+    assert c["detections_match_bit_exact"] is True and c["detections_compared"] >= 0 and d["map_delta"] == 0.0
+    assert d["sustained_images_per_s"] > 0 and d["sustained"]["steps"] >= 3 and d["sustained"]["seconds"] > 0
+    assert lat["mars_run_plus_detect_ms"] >= lat["mars_run_ms"]
+
+
+def test_bench_sustained_leg_runs_for_the_asked_time():
+    d = run_bench("--no-cpu-baseline", "--sustain-s", "1.0")
+    s = d["sustained"]
+    assert 0.9 <= s["seconds"] < 5.0 and s["steps"] > 10 and s["shader_clock_mhz"]["median"] > 500
+    d = run_bench("--no-cpu-baseline", "--sustain-s", "0")
+    assert "sustained" not in d and "sustained_images_per_s" not in d
 
 
 def test_bench_flags():
@@ -59,6 +73,12 @@ def test_bench_multi_rank_path_with_one_rank():
     barriers, max over ranks) with one rank on this box's one GPU"""
     d = run_bench("--no-cpu-baseline", env={"BENCH_FORCE_DIST": "1", "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": "29541"})
     assert d["n_gpus"] == 1 and d["value"] > 0 and d["scaling"] == "weak"
+    rc = d["config"]["rccl"]
+    assert rc["ranks_in_group"] == 1 and rc["backend"] == "nccl" and rc["param_arena_bytes"] > 0 and rc["broadcast_ms"] >= 0
+    # --io pipelined is honoured on the multi-rank path: every rank drives its own pinned-host pipeline
+    d = run_bench("--no-cpu-baseline", "--io", "pipelined", "--sustain-s", "0",
+                  env={"BENCH_FORCE_DIST": "1", "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": "29542"})
+    assert d["pipelined_io"]["images_per_s"] > 0 and d["config"]["rccl"]["ranks_in_group"] == 1
 
 
 def test_bench_total_batch_flag():
