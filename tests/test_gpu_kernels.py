@@ -276,6 +276,46 @@ def test_decode_and_nms_bit_exact(gpu, orc, case):
     assert k2.tobytes() == orc.nms(want_raw, 0.1).tobytes()
 
 
+@pytest.mark.parametrize("n,levels,seed", [(1, 1, 0), (2, 1, 1), (3, 2, 2), (64, 3, 3), (65, 2, 4), (257, 7, 5), (513, 40, 6), (999, 2, 7),
+                                            (1000, 1, 8), (1000, 5, 9), (1000, 90, 10), (1000, 700, 11), (1000, 100000, 12), (777, 13, 13)])
+def test_sort_tie_permutation_closed_form(gpu, orc, n, levels, seed):
+    """the reference's exchange sort is not stable; the device derives the permutation it leaves in closed form (bitonic sort +
+    a queue replay per tie group, yolo_tail.hip "sort").  Candidate lists with few distinct confidences -- groups of 2 up to
+    all 1000 -- against the oracle's literal double loop; boxes far apart and in distinct classes so that nothing is suppressed
+    and the kept list IS the sorted list."""
+    rng = np.random.default_rng(seed)
+    d = np.zeros(n, dtype=gpu.DET_DTYPE)
+    vals = (0.25 + 0.7 * rng.random(levels)).astype(np.float32)
+    d["conf"] = vals[rng.integers(0, levels, n)]
+    d["x"] = np.arange(n, dtype=np.float32) * 100.0  # disjoint boxes
+    d["y"] = rng.random(n).astype(np.float32)
+    d["w"] = 1.0
+    d["h"] = 1.0
+    d["cls"] = np.arange(n) % 80
+    want = orc.nms(d, 0.45)
+    got = gpu.nms(d, 0.45)
+    assert len(want) == n and got.tobytes() == want.tobytes()
+    # and with suppression on top: overlapping boxes in few classes
+    d["x"] = rng.integers(0, 20, n).astype(np.float32)
+    d["cls"] = rng.integers(0, 3, n)
+    assert gpu.nms(d, 0.3).tobytes() == orc.nms(d, 0.3).tobytes()
+
+
+def test_sort_with_nan_confidence_follows_the_reference_loop(gpu, orc):
+    """`>` does not order NaN: the device falls back to the literal double loop for such a frame"""
+    rng = np.random.default_rng(3)
+    n = 200
+    d = np.zeros(n, dtype=gpu.DET_DTYPE)
+    d["conf"] = (0.25 + 0.7 * rng.random(n)).astype(np.float32)
+    d["conf"][[3, 50, 51, 199]] = np.nan
+    d["x"] = np.arange(n, dtype=np.float32) * 100.0
+    d["w"] = 1.0
+    d["h"] = 1.0
+    d["cls"] = np.arange(n) % 80
+    want, got = orc.nms(d, 0.45), gpu.nms(d, 0.45)
+    assert len(want) == len(got) and got.tobytes() == want.tobytes()
+
+
 def test_decode_cap_and_maxd(gpu, orc):
     pred, npred, scale = cases.yolo_pred(cases.YOLO_CASES[0])
     a = gpu.parse_output(pred, npred, scale, maxd=37)

@@ -497,7 +497,7 @@ static bool patch_geom(const mhip_conv_i8_t *p, int th, patch_geom_t *g) {
     g->tiles_x = (p->out_w + PT_TW - 1) / PT_TW;
     g->tiles_y = (p->out_h + th - 1) / th;
     // mostly full tiles only: a tile computes th x 16 pixels whether the image has them or not
-    if ((double)p->out_h * p->out_w < 0.85 * (double)g->tiles_x * PT_TW * g->tiles_y * th) return false;
+    if ((double)p->out_h * p->out_w < (C == 128 ? 0.80 : 0.85) * (double)g->tiles_x * PT_TW * g->tiles_y * th) return false;
     g->PH = (th - 1) * s + p->kh;
     g->PW = (PT_TW - 1) * s + p->kw;
     g->PWH = s == 2 ? (g->PW + 1) / 2 : 0;

@@ -112,184 +112,25 @@ __global__ __launch_bounds__(256) void decode_kernel(const mhip_detect_t p) {
 }
 
 // ------------------------------------------------------------------- sort
-// The whole candidate list of a frame sits in REGISTERS (thread T owns slots 4T..4T+3).  Pass i of the
-// reference's exchange sort = one (max, first holder) scan over slots >= i, done with DPP row shifts / broadcasts
-// inside a wave and one LDS hand-off between the waves:
-//   every strict left-to-right record receives the previous record's element,
-//   slot i receives the suffix maximum (first occurrence).
-// After pass i slot i is final, so when the loop ends the registers hold the
-// permutation the reference produces, ties included.
-#define DPP_ROW_SHR(n) (0x110 + (n))
-#define DPP_ROW_BCAST15 0x142
-#define DPP_ROW_BCAST31 0x143
-#define DPP_WAVE_SHR1 0x138
-
-template <int CTRL, int ROW_MASK>
-__device__ __forceinline__ void scan_step(float &v, int &id) {
-    const int ninf = __float_as_int(-INFINITY);
-    const float ov = __int_as_float(__builtin_amdgcn_update_dpp(ninf, __float_as_int(v), CTRL, ROW_MASK, 0xf, false));
-    const int oid = __builtin_amdgcn_update_dpp(-1, id, CTRL, ROW_MASK, 0xf, false);
-    const bool keep = v > ov; // the earlier holder stays unless strictly beaten
-    v = keep ? v : ov;
-    id = keep ? id : oid;
-}
-
-// 4 waves per frame (256 threads, 4 slots per lane: position = 4 * tid + k).  What the tail costs the overlapped
-// convolutions follows how LONG it runs, so a pass is spread over 4 SIMDs: a wave scans its 256 positions, the four
-// wave totals (maximum, first holder) meet in LDS (ping-pong by pass parity: one barrier per pass), and every lane
-// folds the totals of the waves before its own into its running (maximum, holder).  (One wave with 16 slots per
-// lane and no barrier: 0.83 instead of 0.74 ms for the whole tail of 256 frames x 1000 candidates.)
-// A slot that is final holds confidence -inf from then on (only its record id is needed), so no pass has to test
-// "position >= i": finished slots can neither win the maximum nor be records.  Slot i itself turns into -inf by the
-// chain shift of pass i (it is the first record, the running maximum before it is -inf), and receives the maximum's
-// id explicitly.  Passes are unrolled by 4 so that the head slot index is a compile-time constant.
-__global__ __launch_bounds__(256) void sort_kernel(det_rec *all, const int *counts) {
-    __shared__ float tot_v[2][4];
-    __shared__ int tot_id[2][4];
-    const int f = blockIdx.x, tid = threadIdx.x, lane = tid & 63;
-    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
-    det_rec *dets = all + (size_t)f * MAXD;
-    int n = counts[f];
-    if (n > MAXD) n = MAXD;
-    if (n <= 1) return;
-    float c[4];
-    int d[4];
-#pragma unroll
-    for (int k = 0; k < 4; k++) {
-        const int pos = tid * 4 + k;
-        c[k] = pos < n ? dets[pos].conf : -INFINITY;
-        d[k] = pos;
-    }
-    int par = 0;
-    for (int i0 = 0; i0 + 1 < n; i0 += 4) {
-        const bool owner = tid == (i0 >> 2);
-#pragma unroll
-        for (int k0 = 0; k0 < 4; k0++) {
-            if (i0 + k0 + 1 >= n) break; // uniform
-            // (1) this lane's (max, first holder)
-            float v = c[0];
-            int id = d[0];
-#pragma unroll
-            for (int k = 1; k < 4; k++) {
-                const bool take = c[k] > v;
-                v = take ? c[k] : v;
-                id = take ? d[k] : id;
-            }
-            // (2) inclusive scan across the wave; lane 63 publishes the wave's total
-            scan_step<DPP_ROW_SHR(1), 0xf>(v, id);
-            scan_step<DPP_ROW_SHR(2), 0xf>(v, id);
-            scan_step<DPP_ROW_SHR(4), 0xf>(v, id);
-            scan_step<DPP_ROW_SHR(8), 0xf>(v, id);
-            scan_step<DPP_ROW_BCAST15, 0xa>(v, id);
-            scan_step<DPP_ROW_BCAST31, 0xc>(v, id);
-            if (lane == 63) { tot_v[par][wv] = v; tot_id[par][wv] = id; }
-            float rv = __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(-INFINITY), __float_as_int(v), DPP_WAVE_SHR1, 0xf, 0xf, false));
-            int rid = __builtin_amdgcn_update_dpp(-1, id, DPP_WAVE_SHR1, 0xf, 0xf, false);
-            __syncthreads();
-            // (3) totals of the waves before this one come first (earlier positions): they keep the record unless
-            // strictly beaten; all four in order give the global maximum's first holder
-            float av = -INFINITY, gv = -INFINITY;
-            int aid = -1, gid = -1;
-#pragma unroll
-            for (int w = 0; w < 4; w++) {
-                const float tv = tot_v[par][w];
-                const int ti = tot_id[par][w];
-                if (w < wv) { const bool t = tv > av; av = t ? tv : av; aid = t ? ti : aid; }
-                const bool g = tv > gv; gv = g ? tv : gv; gid = g ? ti : gid;
-            }
-            {
-                const bool keep = rv > av;
-                rv = keep ? rv : av;
-                rid = keep ? rid : aid;
-            }
-            par ^= 1;
-            // (4) every strict left-to-right record takes the previous record's element
-#pragma unroll
-            for (int k = 0; k < 4; k++) {
-                const bool rec = c[k] > rv;
-                const float tv = c[k];
-                const int td = d[k];
-                c[k] = rec ? rv : tv;
-                d[k] = rec ? rid : td;
-                rv = rec ? tv : rv;
-                rid = rec ? td : rid;
-            }
-            d[k0] = owner ? gid : d[k0];
-        }
-    }
-    det_rec out[4];
-#pragma unroll
-    for (int k = 0; k < 4; k++)
-        if (tid * 4 + k < n) out[k] = dets[d[k]];
-    __syncthreads();
-#pragma unroll
-    for (int k = 0; k < 4; k++)
-        if (tid * 4 + k < n) dets[tid * 4 + k] = out[k];
-}
-
-// ---- the same permutation as a systolic pipeline (default).  The exchange sort is a fixed sequence of
-// compare-exchanges CE(i, j), i < j, "if conf[j] > conf[i] swap" in lexicographic order: a sorting NETWORK, and
-// comparators that touch disjoint positions commute.  Read as hardware it is a linear array of n cells: cell i keeps
-// position i, takes the first element that reaches it, compare-exchanges (strict >) with every later arrival and
-// passes the loser on; what cell i-1 emits, in order, is exactly what the sequential pass i sees.  One wave per frame:
-// lane L holds cells L*CPL .. L*CPL+CPL-1 in registers, every step one element enters lane 0, walks the lane's cells
-// (CPL dependent compare-exchanges) and is handed to lane L+1 by one wave-wide DPP shift.  n + n/CPL steps of
-// ~5*CPL + 8 vector instructions: for 1000 candidates 94k instructions on ONE wave, against 160k on each of the four
-// waves of the pass-by-pass form -- 7x less issue work beside the next batch's convolutions, and no barrier.
-// Empty cells hold (-inf, -1): the first real arrival beats it and the sentinel it emits beats nothing downstream.
-template <int CPL>
-__device__ __forceinline__ void systolic_sort(const det_rec *__restrict__ dets, int n, int lane, unsigned short *__restrict__ perm) {
-    float hv[CPL];
-    int hid[CPL];
-#pragma unroll
-    for (int k = 0; k < CPL; k++) { hv[k] = -INFINITY; hid[k] = -1; }
-    const int steps = n + (n + CPL - 1) / CPL; // the last element enters at step n-1 and reaches the last lane in use
-    float ov = -INFINITY;                      // what this lane emitted in the previous step
-    int oid = -1;
-    float feed = dets[0].conf; // wave-uniform address: a scalar load, one step ahead of its use
-    for (int t = 0; t < steps; t++) {
-        const float nextfeed = dets[t + 1 < n ? t + 1 : n - 1].conf;
-        float iv = __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(-INFINITY), __float_as_int(ov), DPP_WAVE_SHR1, 0xf, 0xf, false));
-        int iid = __builtin_amdgcn_update_dpp(-1, oid, DPP_WAVE_SHR1, 0xf, 0xf, false);
-        if (lane == 0) { iv = t < n ? feed : -INFINITY; iid = t; }
-#pragma unroll
-        for (int k = 0; k < CPL; k++) {
-            const bool gt = iv > hv[k];
-            const float kv = gt ? iv : hv[k];
-            const int ki = gt ? iid : hid[k];
-            iv = gt ? hv[k] : iv;
-            iid = gt ? hid[k] : iid;
-            hv[k] = kv;
-            hid[k] = ki;
-        }
-        ov = iv;
-        oid = iid;
-        feed = nextfeed;
-    }
-#pragma unroll
-    for (int k = 0; k < CPL; k++)
-        if (lane * CPL + k < n) perm[lane * CPL + k] = (unsigned short)hid[k];
-}
-
-// No LDS and ~50 registers, so that the wave fits beside any convolution workgroup; the records themselves are not
-// moved: perm[f][pos] = original index of the record that the reference's sort leaves at `pos`, applied by the NMS
-// kernel when it loads the boxes.
-__global__ __launch_bounds__(64) void sort_systolic_kernel(const det_rec *__restrict__ all, const int *__restrict__ counts,
-                                                           unsigned short *__restrict__ perm_all) {
-    const int f = blockIdx.x, lane = threadIdx.x;
-    const det_rec *dets = all + (size_t)f * MAXD;
-    unsigned short *perm = perm_all + (size_t)f * 1024;
-    int n = counts[f];
-    if (n > MAXD) n = MAXD;
-    if (n <= 0) return;
-    if (n == 1) { if (lane == 0) perm[0] = 0; return; }
-    const int need = (n + 63) >> 6; // cells per lane
-    if (need <= 1) systolic_sort<1>(dets, n, lane, perm);
-    else if (need <= 2) systolic_sort<2>(dets, n, lane, perm);
-    else if (need <= 4) systolic_sort<4>(dets, n, lane, perm);
-    else if (need <= 8) systolic_sort<8>(dets, n, lane, perm);
-    else systolic_sort<16>(dets, n, lane, perm);
-}
+// The reference orders the candidates with an exchange sort, `for i: for j > i: if d[j].conf > d[i].conf swap`
+// (mars_yolo_test.c:108-110): not stable, and the permutation it leaves among equal confidences is part of the
+// contract.  Rounds 1-2 replayed its n passes (wave-wide scans, then a systolic array: 0.5-0.7 ms per batch beside the
+// convolutions, the longest kernel of the tail).  Round 3 computes the same permutation in closed form:
+//   * the result is non-increasing in confidence, so an element's slot is (number of strictly greater elements) + its
+//     place inside its tie group;
+//   * for a tie group G of value v, let H = the elements > v.  While any of H is left, each pass takes away exactly the
+//     first slot of H in the remaining array -- that element is a strict left-to-right record, so it moves on or is the
+//     maximum and leaves -- and if members of G stand before it, the first of them (a record too) jumps into that slot,
+//     behind the members it passes.  Whatever the values inside H are, G therefore behaves as a QUEUE walked along the
+//     original array: a member of G is appended, an element of H moves the queue's front to its back.  Once H is gone
+//     the passes pick the group's members left to right without moving the others, so the queue IS the group's order.
+// So: one bitonic sort by (confidence descending, original index ascending) -- 55 compare-exchange rounds for 1024 --
+// and, only for tie groups, a replay of that queue by the group's first thread: members arrive in index order, between
+// two arrivals the queue turns by (the H elements passed) mod (its length); a circular linked list in LDS makes a turn
+// one pointer step and an arrival O(1).  Steps per group <= min(|H|, sum of lengths).  Checked against the oracle's
+// literal double loop on tie-heavy inputs (tests/test_gpu_kernels.py, tools/fuzz_tail.py).
+// A NaN confidence (a NaN scale gives one, and `conf < 0.25` lets it through) is not ordered by `>`: a frame that
+// holds one is sorted by the literal double loop on one thread -- slow, exact, and never taken by a real model.
 
 // --------------------------------------------------------------- suppress
 // One 256-thread workgroup per frame, 32 KB of LDS, so that it shares a CU with the convolution workgroups of
@@ -302,23 +143,131 @@ __global__ __launch_bounds__(64) void sort_systolic_kernel(const det_rec *__rest
 #define NMS_SUBS (NMS_THREADS / NMS_CHUNK) // threads that share a row's bucket
 #define NMS_CHUNK 64
 #define NMS_BUCKETS 128
-__global__ __launch_bounds__(NMS_THREADS) void nms_kernel(det_rec *all, int *counts, float thresh, const unsigned short *perm_all) {
+__global__ __launch_bounds__(NMS_THREADS) void sort_nms_kernel(det_rec *all, int *counts, float thresh) {
     __shared__ float bx[1024], by[1024], bw[1024], bh[1024], bconf[1024];
     __shared__ int bc[1024];
     __shared__ unsigned short blist[1024];              // box indices grouped by class bucket
     __shared__ int bstart[NMS_BUCKETS + 1], bfill[NMS_BUCKETS];
-    __shared__ unsigned int mask[NMS_CHUNK][32];        // 64 rows x 1024 bits
+    __shared__ __attribute__((aligned(16))) unsigned int mask[NMS_CHUNK][32]; // 64 rows x 1024 bits
     __shared__ unsigned long long removed_s[16];
     __shared__ int wave_cnt[NMS_THREADS / 64];
+    __shared__ unsigned short sperm[1024];              // sorted slot -> original index
+    __shared__ int flags[2];                            // [0] a NaN confidence in this frame, [1] a tie in this frame
 
     const int f = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     det_rec *dets = all + (size_t)f * MAXD;
     int n = counts[f];
     if (n > MAXD) n = MAXD;
     if (n <= 0) return;
+    // ---- sort (see "sort" above).  Scratch that the suppression only needs later: keys = the bit matrix (8 KB),
+    // queue links = blist, passed-H counts = the class array.
+    {
+        unsigned long long *keys = (unsigned long long *)&mask[0][0];
+        unsigned short *nxt = blist, *gtb = (unsigned short *)bc;
+        int P = 2;
+        while (P < n) P <<= 1;
+        if (tid < 2) flags[tid] = 0;
+        __syncthreads();
+        bool nan = false;
+        for (int r = tid; r < P; r += NMS_THREADS) {
+            unsigned long long k = 0; // padding: below every real key (confidences are >= 0.25)
+            if (r < n) {
+                const float c = dets[r].conf;
+                nan |= c != c;
+                k = ((unsigned long long)__float_as_uint(c) << 10) | (unsigned)(1023 - r);
+            }
+            keys[r] = k;
+        }
+        if (nan) flags[0] = 1;
+        __syncthreads();
+        if (flags[0]) {
+            // the literal double loop on (confidence, index) pairs; float compares, so NaN behaves as in the reference
+            if (tid == 0) {
+                for (int i = 0; i + 1 < n; i++) {
+                    unsigned long long ki = keys[i];
+                    for (int j = i + 1; j < n; j++) {
+                        const unsigned long long kj = keys[j];
+                        if (__uint_as_float((unsigned)(kj >> 10)) > __uint_as_float((unsigned)(ki >> 10))) { keys[i] = kj; keys[j] = ki; ki = kj; }
+                    }
+                }
+            }
+            __syncthreads();
+            for (int r = tid; r < n; r += NMS_THREADS) sperm[r] = (unsigned short)(1023 - (int)(keys[r] & 1023));
+        } else {
+            for (int k = 2; k <= P; k <<= 1)
+                for (int j = k >> 1; j > 0; j >>= 1) {
+                    for (int t = tid; t < (P >> 1); t += NMS_THREADS) {
+                        const int lo = ((t & ~(j - 1)) << 1) | (t & (j - 1)), hi = lo | j;
+                        const unsigned long long a = keys[lo], b = keys[hi];
+                        const bool desc = (lo & k) == 0;
+                        if (desc ? a < b : a > b) { keys[lo] = b; keys[hi] = a; }
+                    }
+                    __syncthreads();
+                }
+            // slots of untied elements are final; tie groups are replayed below
+            bool member[2] = {false, false};
+            for (int q = 0, r = tid; r < n; r += NMS_THREADS, q++) {
+                const unsigned cb = (unsigned)(keys[r] >> 10);
+                const bool tl = r > 0 && (unsigned)(keys[r - 1] >> 10) == cb, tr = r + 1 < n && (unsigned)(keys[r + 1] >> 10) == cb;
+                member[q] = tl || tr;
+                sperm[r] = (unsigned short)(1023 - (int)(keys[r] & 1023));
+            }
+            if (member[0] || member[1]) flags[1] = 1;
+            __syncthreads();
+            if (flags[1]) { // uniform
+                // every member: how many greater elements stand before it in the original order
+                for (int q = 0, r = tid; r < n; r += NMS_THREADS, q++) {
+                    if (!member[q]) continue;
+                    const unsigned cb = (unsigned)(keys[r] >> 10);
+                    int g0 = r;
+                    while (g0 > 0 && (unsigned)(keys[g0 - 1] >> 10) == cb) g0--;
+                    const int pos = sperm[r];
+                    int cnt = 0;
+                    for (int s2 = 0; s2 < g0; s2++) cnt += sperm[s2] < pos;
+                    gtb[r] = (unsigned short)cnt;
+                }
+                __syncthreads();
+                unsigned short first[2] = {0, 0};
+                int glen[2] = {0, 0};
+                for (int q = 0, r = tid; r < n; r += NMS_THREADS, q++) {
+                    if (!member[q]) continue;
+                    const unsigned cb = (unsigned)(keys[r] >> 10);
+                    if (r > 0 && (unsigned)(keys[r - 1] >> 10) == cb) continue; // not the group's first thread
+                    // members r .. r+m-1 arrive in original-index order (the sort's second key)
+                    int back = r, len = 1;
+                    nxt[r] = (unsigned short)r;
+                    int prev = gtb[r];
+                    int x = r + 1;
+                    for (; x < n && (unsigned)(keys[x] >> 10) == cb; x++) {
+                        const int g = gtb[x];
+                        for (int turn = (g - prev) % len; turn > 0; turn--) back = nxt[back];
+                        prev = g;
+                        nxt[x] = nxt[back];
+                        nxt[back] = (unsigned short)x;
+                        back = x;
+                        len++;
+                    }
+                    for (int turn = (r - prev) % len; turn > 0; turn--) back = nxt[back]; // r = the count of greater elements
+                    first[q] = nxt[back];
+                    glen[q] = len;
+                }
+                __syncthreads(); // sperm is read (as the members' original indices) before it is rewritten
+                for (int q = 0, r = tid; r < n; r += NMS_THREADS, q++) {
+                    if (!glen[q]) continue;
+                    // walk the queue front to back; the original indices are still in keys
+                    int e = first[q];
+                    for (int k2 = 0; k2 < glen[q]; k2++) {
+                        sperm[r + k2] = (unsigned short)(1023 - (int)(keys[e] & 1023));
+                        e = nxt[e];
+                    }
+                }
+            }
+        }
+        __syncthreads();
+    }
     if (tid < NMS_BUCKETS) bfill[tid] = 0;
-    for (int j = tid; j < n; j += NMS_THREADS) { // in the sorted order: through the permutation when the sort left one
-        det_rec d = dets[perm_all ? perm_all[(size_t)f * 1024 + j] : j];
+    for (int j = tid; j < n; j += NMS_THREADS) { // in the sorted order
+        det_rec d = dets[sperm[j]];
         bx[j] = d.x; by[j] = d.y; bw[j] = d.w; bh[j] = d.h; bc[j] = d.cls; bconf[j] = d.conf;
     }
     __syncthreads();
@@ -406,40 +355,10 @@ __global__ __launch_bounds__(NMS_THREADS) void nms_kernel(det_rec *all, int *cou
     if (tid == 0) counts[f] = total;
 }
 
-// permutation buffer of the systolic sort: [frames][1024] indices, grown on demand (a hipMalloc synchronises; it
-// happens at the first call and when a larger batch appears)
-static unsigned short *g_perm = nullptr;
-static int g_perm_frames = 0;
-extern "C" void mhip_tail_release(void) {
-    if (g_perm) (void)hipFree(g_perm);
-    g_perm = nullptr;
-    g_perm_frames = 0;
-}
+extern "C" void mhip_tail_release(void) {} // (the systolic sort's permutation buffer lived here until round 3)
 static int launch_sort_nms(det_rec *dets, int *counts, int frames, float thresh) {
-    static int form = -1; // MARS_HIP_SORT=passes: the pass-by-pass kernel (4 waves per frame); default: the systolic form
-    if (form < 0) {
-        const char *e = getenv("MARS_HIP_SORT");
-        form = (e && !strcmp(e, "passes")) ? 1 : 0;
-    }
-    const unsigned short *perm = nullptr;
-    if (form) {
-        hipLaunchKernelGGL(sort_kernel, dim3(frames), dim3(256), 0, mhip_stream_native(), dets, counts);
-    } else {
-        if (frames > g_perm_frames) {
-            if (hipDeviceSynchronize() != hipSuccess) return -1;
-            if (g_perm) (void)hipFree(g_perm);
-            g_perm = nullptr;
-            g_perm_frames = 0;
-            if (mhip_check(hipMalloc((void **)&g_perm, (size_t)frames * 1024 * sizeof(unsigned short)), "hipMalloc sort permutation")) return -1;
-            g_perm_frames = frames;
-        }
-        hipLaunchKernelGGL(sort_systolic_kernel, dim3(frames), dim3(64), 0, mhip_stream_native(), dets, counts, g_perm);
-        perm = g_perm;
-    }
-    int rc = mhip_check(hipGetLastError(), "sort");
-    if (rc) return rc;
-    hipLaunchKernelGGL(nms_kernel, dim3(frames), dim3(NMS_THREADS), 0, mhip_stream_native(), dets, counts, thresh, perm);
-    return mhip_check(hipGetLastError(), "nms");
+    hipLaunchKernelGGL(sort_nms_kernel, dim3(frames), dim3(NMS_THREADS), 0, mhip_stream_native(), dets, counts, thresh);
+    return mhip_check(hipGetLastError(), "sort + nms");
 }
 
 extern "C" int mhip_detect(const mhip_detect_t *p) {
