@@ -98,6 +98,13 @@ mars_error_t mars_hip_set_fusion(mars_model_t *model, int level);
  * The defaults are the measured optimum; tests use "persist_slots" to force the multi-tile walk
  * of the persistent kernel on small inputs.  Results never depend on these.  0 = ok, -1 = unknown key. */
 int mars_hip_set_tuning(const char *key, int value);
+int mars_hip_get_tuning(const char *key, int *value); /* the process-wide value in force; -1 = unknown key */
+/* The same knobs per model: an override is kept on `model`, put in force for the duration of each of ITS runs (mars_run,
+ * mars_hip_run_device[_async], the pipelined submit, mars_hip_autotune) and taken back afterwards, so models that want
+ * different launch policies can share a process; mars_hip_set_tuning stays the process default.  At most 16 keys per
+ * model.  mars_hip_model_get_tuning returns the override, or the process default where there is none. */
+int mars_hip_model_set_tuning(mars_model_t *model, const char *key, int value);
+int mars_hip_model_get_tuning(mars_model_t *model, const char *key, int *value);
 /* Times the launch variants of every int8 convolution of `model` on the device at the current batch
  * (`reps` launches each, <= 0: 3) and pins the fastest per layer until the plan is rebuilt
  * (set_fusion); call after mars_hip_set_batch.  A one-time load cost; outputs are unaffected. */

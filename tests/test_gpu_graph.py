@@ -1176,6 +1176,44 @@ def test_concat_of_96_channels_is_materialised(gpu, orc):
         m.close()
 
 
+def test_per_model_tuning_overrides(gpu, orc):
+    """mars_hip_model_set_tuning: a knob kept on one model, in force during ITS runs only.  Observable on a float32 twin:
+    f32_mfma = 0 (the reference's summation order) is bit-exact against the oracle, f32_mfma = 2 (matrix cores everywhere) is
+    not (another summation order, then byte-wise max-pools over the float bits); the process default stays 1 throughout."""
+    d = gpu.synth_model(width_x16=4, input_hw=64, seed=5, float32=True)
+    hdr, tensors, _ = marsfile.parse(d)
+    n = marsfile.tensor_nbytes(tensors[hdr["inputs"][0]]) // 4
+    x = cases.f32(0x7E570001, n, 0.0, 1.0).view(np.uint8)
+    a, b = gpu.Model(d, batch=1), gpu.Model(d, batch=1)
+    assert gpu.get_tuning("f32_mfma") == 1
+    a.set_tuning("f32_mfma", 0)
+    b.set_tuning("f32_mfma", 2)
+    b.set_tuning("graph_max_batch", 0)
+    assert (a.get_tuning("f32_mfma"), b.get_tuning("f32_mfma"), gpu.get_tuning("f32_mfma")) == (0, 2, 1)
+    assert a.get_tuning("graph_max_batch") == gpu.get_tuning("graph_max_batch") and b.get_tuning("graph_max_batch") == 0
+    with pytest.raises(KeyError):
+        a.set_tuning("no_such_knob", 1)
+    with pytest.raises(KeyError):
+        a.set_tuning("dual_stream_ways", 9)  # a value the knob refuses
+    assert a.get_tuning("dual_stream_ways") == gpu.get_tuning("dual_stream_ways")
+    g, rc = run_oracle(orc, d, x)
+    assert rc == 0
+    for rounds in range(3):  # interleaved runs (the third ones replay a's captured graph): each under its own policy
+        for m in (a, b):
+            m.input_view(0)[0] = x
+            m.run()
+            assert gpu.get_tuning("f32_mfma") == 1
+    diff = 0
+    for i, ti in enumerate(hdr["outputs"]):
+        want = g.tensor(ti)
+        assert np.array_equal(a.output_view(i)[0].view(np.uint8).ravel(), want.view(np.uint8).ravel())
+        diff += int((b.output_view(i)[0].view(np.uint8).ravel() != want.view(np.uint8).ravel()).sum())
+    assert diff > 0  # the matrix-core order did run for b
+    g.close()
+    a.close()
+    b.close()
+
+
 def test_mars_run_in_overlapped_chunks(gpu, orc):
     """"run_chunk": mars_run at a large batch copies chunk k+1 in while chunk k runs and chunk k-1 is copied out (three
     streams, one synchronisation at the end); forced here at 2 frames per chunk on a batch of 5 (chunks of 2, 2, 1) and

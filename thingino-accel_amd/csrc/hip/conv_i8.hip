@@ -853,18 +853,22 @@ const tune_t &conv_i8_tune_state() {
     return g_tune;
 }
 static inline const tune_t &tune() { return conv_i8_tune_state(); }
-extern "C" int mhip_conv_i8_tune(const char *key, int value) {
+// value == NULL-safe accessor pair: set (get == nullptr) or read (get != nullptr) one launch-policy knob
+static int tune_access(const char *key, int value, int *get) {
     (void)conv_i8_tune_state();
     struct { const char *k; int *v; } tab[] = {{"persist", &g_tune.persist}, {"persist_stages", &g_tune.persist_stages},
                                                {"persist_maxk", &g_tune.persist_maxk}, {"persist_slots", &g_tune.persist_slots}, {"wres", &g_tune.wres}, {"rgb_direct", &g_tune.rgb_direct}, {"small_batch", &g_tune.small_batch},
                                                {"patch_ring", &g_tune.patch_ring}, {"patch_lds_kb", &g_tune.patch_lds_kb}, {"stages", &g_tune.stages}, {"bpx", &g_tune.bpx}, {"variant", &g_tune.variant}, {"bufmode", &g_tune.bufmode}};
     for (auto &e : tab)
         if (key && !strcmp(key, e.k)) {
-            *e.v = value;
+            if (get) *get = *e.v;
+            else *e.v = value;
             return 0;
         }
     return -1;
 }
+extern "C" int mhip_conv_i8_tune(const char *key, int value) { return tune_access(key, value, nullptr); }
+extern "C" int mhip_conv_i8_tune_get(const char *key, int *value) { return value ? tune_access(key, 0, value) : -1; }
 
 // buffer-addressed K loop: a 64-byte step inside one tap (in_c >= 64, power of two), 31-bit offsets, tap masks
 static int buf_mode(const mhip_conv_i8_t *p, int k64) {

@@ -32,6 +32,7 @@ enum {
 
 #define NO_OFF ((size_t)-1)
 #define MARS_MAX_IO 4 /* graph inputs / outputs (header arrays of the .mars format) */
+#define MARS_MAX_MODEL_TUNE 16 /* per-model tuning overrides (mars_hip_model_set_tuning) */
 
 typedef struct {
     size_t bytes;    /* numel * elemsize by shape */
@@ -116,6 +117,8 @@ typedef struct {
     unsigned graph_gen; /* tuning generation it was captured under */
     int ran_plain;      /* the plan has run launch by launch at this batch: every launcher's one-time set-up is done */
     void *pipe; /* double-buffered I/O state (mars_pipe.c), NULL when closed */
+    struct { char key[28]; int value, saved; } tune[MARS_MAX_MODEL_TUNE]; /* launch-policy overrides of this model */
+    int n_tune, tune_depth;
 } mars_model_ext_t;
 
 /* detection tail pieces shared with the pipelined I/O (mars_yolo.c) */

@@ -48,6 +48,9 @@ static unsigned g_tune_gen = 1;
  * batch 256: 4.76 -> 4.58 ms per batch. */
 static int g_dual_min_batch = 64;
 static int g_dual_ways = 2; /* parts (= streams) such a batch is cut into: 2..4 */
+/* (Round 3, measured and dropped: a DEPTH-FIRST head -- the first 2 / 3 / 5 / 8 launches of the plan run in chunks of
+ * 16 / 32 / 64 frames, so that the stem's 3.3 MB per frame is still in the 256 MB Infinity Cache when the next layer reads
+ * it: 4.55-4.65 ms per batch against 4.54-4.59 without, at every setting.  The early layers are not waiting for HBM reads.) */
 /* (Round 3, measured and dropped: a LAZY join -- the main stream not waiting for the other part at the end of a run, only
  * the detection tail, uploads and downloads doing so -- so that back-to-back runs keep both streams busy without meeting
  * at every run boundary: 1-2 % slower at batch 256 and 128; the aligned start is worth more than the bubble costs.) */
@@ -1638,9 +1641,30 @@ static int launch_op(mars_model_ext_t *m, mars_op_t *op) {
 
 static mars_error_t enqueue_plan(mars_model_t *model);
 static double now_us(void);
+static int tune_raw(const char *key, int value, int *get);
 
+/* a model's tuning overrides in force / taken back (nested calls count: mars_run -> run_device_async) */
+static void tune_push(mars_model_ext_t *m) {
+    if (m->tune_depth++ || !m->n_tune) return;
+    for (int i = 0; i < m->n_tune; i++) {
+        tune_raw(m->tune[i].key, 0, &m->tune[i].saved);
+        tune_raw(m->tune[i].key, m->tune[i].value, NULL);
+    }
+}
+static void tune_pop(mars_model_ext_t *m) {
+    if (--m->tune_depth || !m->n_tune) return;
+    for (int i = m->n_tune - 1; i >= 0; i--) tune_raw(m->tune[i].key, m->tune[i].saved, NULL);
+}
+static mars_error_t run_device_async(mars_model_t *model);
 mars_error_t mars_hip_run_device_async(mars_model_t *model) {
     if (!model) return MARS_ERR_INVALID_FILE;
+    tune_push((mars_model_ext_t *)model);
+    mars_error_t e = run_device_async(model);
+    tune_pop((mars_model_ext_t *)model);
+    return e;
+}
+
+static mars_error_t run_device_async(mars_model_t *model) {
     mars_model_ext_t *m = (mars_model_ext_t *)model;
     if (!m->act_dev || !m->arena_dev) return MARS_ERR_NNA_INIT_FAILED;
     /* graph path: small batch, no per-launch events, buffers not being swapped.  A detection tail still running on the
@@ -1927,8 +1951,15 @@ static mars_error_t run_chunked(mars_model_ext_t *m) {
 
 /* The reference's call: copy in, run, copy out -- synchronous for the caller, but one stream-ordered sequence with ONE
  * synchronisation at its end (three of them cost a single frame 0.05 ms of its 0.7) */
+static mars_error_t run_whole(mars_model_t *model);
 mars_error_t mars_run(mars_model_t *model) {
     if (!model) return MARS_ERR_INVALID_FILE; /* reference :440 */
+    tune_push((mars_model_ext_t *)model);
+    mars_error_t e = run_whole(model);
+    tune_pop((mars_model_ext_t *)model);
+    return e;
+}
+static mars_error_t run_whole(mars_model_t *model) {
     mars_model_ext_t *m = (mars_model_ext_t *)model;
     if (!m->act_dev || !m->arena_dev) return MARS_ERR_NNA_INIT_FAILED;
     const double t0 = now_us();
@@ -1983,40 +2014,78 @@ mars_error_t mars_hip_set_fusion(mars_model_t *model, int level) {
     return e;
 }
 
-int mars_hip_set_tuning(const char *key, int value) {
-    g_tune_gen++; /* captured graphs froze the launch policy they were recorded under */
-    if (key && !strcmp(key, "graph_max_batch")) { /* largest batch whose plan is replayed as a HIP graph (0 = never) */
-        if (value < 0) return -1;
-        g_graph_max_batch = value;
-        return 0;
-    }
-    if (key && !strcmp(key, "dual_stream_min_batch")) { /* smallest batch that runs as two halves on two streams (0 = never) */
-        if (value < 0) return -1;
-        g_dual_min_batch = value;
-        return 0;
-    }
-    if (key && !strcmp(key, "run_chunk")) { /* mars_run: frames per overlapped chunk at batches of at least twice this (0 = never) */
-        if (value < 0) return -1;
-        g_run_chunk = value;
-        return 0;
-    }
-    if (key && !strcmp(key, "dual_stream_ways")) {
-        if (value < 2 || value > 4) return -1;
-        g_dual_ways = value;
-        return 0;
-    }
-    if (key && !strcmp(key, "f32_mfma")) { /* 0 exact everywhere, 1 matrix cores where provably safe (default), 2 everywhere */
+/* Launch-policy knobs.  Host-side ones live here, the convolution's in conv_i8.hip; tune_raw sets or reads one without
+ * touching the graph generation (the per-model overrides below go through it around every run). */
+static int tune_raw(const char *key, int value, int *get) {
+    if (!key) return -1;
+    struct { const char *k; int *v; int lo, hi; } tab[] = {
+        {"graph_max_batch", &g_graph_max_batch, 0, 1 << 30},      /* largest batch whose plan is replayed as a HIP graph (0 = never) */
+        {"dual_stream_min_batch", &g_dual_min_batch, 0, 1 << 30}, /* smallest batch that runs as two halves on two streams (0 = never) */
+        {"run_chunk", &g_run_chunk, 0, 1 << 30}, /* mars_run: frames per overlapped chunk at batches of at least twice this (0 = never) */
+        {"dual_stream_ways", &g_dual_ways, 2, 4},
+    };
+    for (size_t i = 0; i < sizeof tab / sizeof tab[0]; i++)
+        if (!strcmp(key, tab[i].k)) {
+            if (get) { *get = *tab[i].v; return 0; }
+            if (value < tab[i].lo || value > tab[i].hi) return -1;
+            *tab[i].v = value;
+            return 0;
+        }
+    if (!strcmp(key, "f32_mfma")) { /* 0 exact everywhere, 1 matrix cores where provably safe (default), 2 everywhere */
+        if (get) { *get = mhip_conv_f32_mode(-1); return 0; }
         if (value < 0 || value > 2) return -1;
         mhip_conv_f32_mode(value);
         return 0;
     }
-    return mhip_conv_i8_tune(key, value);
+    return get ? mhip_conv_i8_tune_get(key, get) : mhip_conv_i8_tune(key, value);
+}
+
+int mars_hip_set_tuning(const char *key, int value) {
+    g_tune_gen++; /* captured graphs froze the launch policy they were recorded under */
+    return tune_raw(key, value, NULL);
+}
+
+int mars_hip_get_tuning(const char *key, int *value) { return value ? tune_raw(key, 0, value) : -1; }
+
+/* Per-model overrides: kept on the model, put in force for the duration of each of ITS runs (tune_push / tune_pop around
+ * mars_run, mars_hip_run_device_async, mars_hip_autotune) and taken back afterwards, so two models in one process can run
+ * under different policies while mars_hip_set_tuning stays the process default. */
+int mars_hip_model_set_tuning(mars_model_t *model, const char *key, int value) {
+    mars_model_ext_t *m = (mars_model_ext_t *)model;
+    int cur;
+    if (!m || !key || strlen(key) >= sizeof m->tune[0].key || tune_raw(key, 0, &cur)) return -1;
+    if (tune_raw(key, value, NULL)) return -1; /* validates the value ... */
+    tune_raw(key, cur, NULL);                  /* ... without leaving it in force */
+    int i = 0;
+    while (i < m->n_tune && strcmp(m->tune[i].key, key)) i++;
+    if (i == m->n_tune) {
+        if (m->n_tune == MARS_MAX_MODEL_TUNE) return -1;
+        strcpy(m->tune[m->n_tune++].key, key);
+    }
+    m->tune[i].value = value;
+    drop_graph(m); /* its captured graph froze the old policy */
+    return 0;
+}
+
+int mars_hip_model_get_tuning(mars_model_t *model, const char *key, int *value) {
+    mars_model_ext_t *m = (mars_model_ext_t *)model;
+    if (!m || !key || !value) return -1;
+    for (int i = 0; i < m->n_tune; i++)
+        if (!strcmp(m->tune[i].key, key)) { *value = m->tune[i].value; return 0; }
+    return tune_raw(key, 0, value); /* not overridden: the process default */
 }
 
 /* Time every launch variant of every int8 convolution on the device, at the current batch, and pin the fastest
  * (all variants write the same bytes; the layer's real buffers are used, so the tensors stay valid). */
+static mars_error_t autotune_model(mars_model_t *model, int reps);
 mars_error_t mars_hip_autotune(mars_model_t *model, int reps) {
     if (!model) return MARS_ERR_INVALID_FILE;
+    tune_push((mars_model_ext_t *)model);
+    mars_error_t e = autotune_model(model, reps);
+    tune_pop((mars_model_ext_t *)model);
+    return e;
+}
+static mars_error_t autotune_model(mars_model_t *model, int reps) {
     mars_model_ext_t *m = (mars_model_ext_t *)model;
     if (!m->act_dev || !m->arena_dev) return MARS_ERR_NNA_INIT_FAILED;
     drop_graph(m);

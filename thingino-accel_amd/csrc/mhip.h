@@ -115,6 +115,7 @@ int mhip_conv_i8_is_safe(float cs);
 /* may the half-step LUT be used for this combined scale?  (no int32 accumulator may requantise to +-0x3EFFFFFF) */
 int mhip_conv_i8_lut2_ok(float cs);
 int mhip_conv_i8_tune(const char *key, int value); /* launch-policy knobs, see mars_hip_set_tuning */
+int mhip_conv_i8_tune_get(const char *key, int *value);
 /* launch variants that can run this layer (same bytes out, different speed), the default first; 0 if none */
 int mhip_conv_i8_variants(const mhip_conv_i8_t *p, int *codes, int max);
 /* can this (shape-only: pointers may be dummies) segmented convolution run?  frames/out_stride as they will be */

@@ -115,7 +115,8 @@ EXPORTS = {
                    "mars_hip_load_memory_ex", "mars_hip_param_arena", "mars_yolo_parse_output", "mars_yolo_nms",
                    "mars_hip_detect", "mars_hip_detect_device", "mars_synth_model", "mars_hip_set_tuning", "mars_hip_autotune", "mars_yolo_letterbox",
                    "mars_hip_preprocess", "mars_hip_tensor_frame_bytes", "mars_hip_tensor_byte_size", "mars_hip_pipe_open",
-                   "mars_hip_pipe_input", "mars_hip_pipe_submit", "mars_hip_pipe_wait", "mars_hip_pipe_close", "mars_hip_clock_mhz", "mars_hip_set_output_mode"],
+                   "mars_hip_pipe_input", "mars_hip_pipe_submit", "mars_hip_pipe_wait", "mars_hip_pipe_close", "mars_hip_clock_mhz", "mars_hip_set_output_mode",
+                   "mars_hip_get_tuning", "mars_hip_model_set_tuning", "mars_hip_model_get_tuning"],
     "mars_compile.h": ["mars_compile_onnx", "mars_compile_file", "mars_compile_last_error"],
 }
 
@@ -179,6 +180,9 @@ def lib():
     L.mars_hip_set_batch.argtypes = [P(MarsModel), C.c_int]
     L.mars_hip_set_fusion.argtypes = [P(MarsModel), C.c_int]
     L.mars_hip_set_tuning.argtypes = [C.c_char_p, C.c_int]
+    L.mars_hip_get_tuning.argtypes = [C.c_char_p, P(C.c_int)]
+    L.mars_hip_model_set_tuning.argtypes = [C.c_void_p, C.c_char_p, C.c_int]
+    L.mars_hip_model_get_tuning.argtypes = [C.c_void_p, C.c_char_p, P(C.c_int)]
     L.mars_hip_autotune.argtypes = [P(MarsModel), C.c_int]
     L.mars_yolo_letterbox.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]
     L.mars_hip_preprocess.argtypes = [P(MarsModel), C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int]
@@ -231,6 +235,13 @@ def set_tuning(key, value):
     """Launch-policy knob of the conv kernels (mars_hip_set_tuning); results never depend on it."""
     if lib().mars_hip_set_tuning(key.encode(), int(value)) != 0:
         raise KeyError(key)
+
+
+def get_tuning(key):
+    v = C.c_int(0)
+    if lib().mars_hip_get_tuning(key.encode(), C.byref(v)) != 0:
+        raise KeyError(key)
+    return v.value
 
 
 def letterbox(rgb, tw, th, nhwc=True):
@@ -372,6 +383,17 @@ class Model:
         rc = lib().mars_hip_preprocess(self.p, input_index, a.ctypes.data, w, h, first_frame, n)
         if rc != MARS_OK:
             raise MarsError(rc, "mars_hip_preprocess")
+
+    def set_tuning(self, key, value):
+        """per-model override of a launch-policy knob (mars_hip_model_set_tuning)"""
+        if lib().mars_hip_model_set_tuning(self.p, key.encode(), int(value)) != 0:
+            raise KeyError(key)
+
+    def get_tuning(self, key):
+        v = C.c_int(0)
+        if lib().mars_hip_model_get_tuning(self.p, key.encode(), C.byref(v)) != 0:
+            raise KeyError(key)
+        return v.value
 
     def autotune(self, reps=3):
         rc = lib().mars_hip_autotune(self.p, reps)
