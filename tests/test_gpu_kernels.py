@@ -316,6 +316,24 @@ def test_sort_with_nan_confidence_follows_the_reference_loop(gpu, orc):
     assert len(want) == len(got) and got.tobytes() == want.tobytes()
 
 
+@pytest.mark.parametrize("scale", [0.05, -0.05, 0.0, 1e8, 3e9, 1e-45, 1e-40, float("nan"), float("inf"), 1e-3])
+def test_decode_odd_scales(gpu, orc, scale):
+    """the class argmax compares int8 bytes when value[q] = q * scale is strictly increasing, and walks the float table
+    otherwise (negative / zero / NaN / underflowing scales); huge scales exercise the reference's `top = -1e9` start"""
+    rng = np.random.default_rng(17)
+    npred = 3000
+    p = rng.integers(-128, 128, (npred, 85), dtype=np.int8)
+    p[::3, 5:] = rng.integers(-128, -9, (len(p[::3]), 80), dtype=np.int8)  # rows whose classes all sit below -1e9 at scale 1e8
+    p[1::7, 5:] = -128
+    p[:, 4] = rng.integers(-20, 128, npred, dtype=np.int8)
+    raw = gpu.parse_output(p.ravel(), npred, scale)
+    want = orc.parse_output(p.ravel(), npred, scale)
+    assert len(raw) == len(want) and np.array_equal(raw["cls"], want["cls"])
+    for k in ("x", "y", "w", "h", "conf"):  # bit for bit, except that a NaN's sign and payload are nobody's contract
+        a, b = raw[k], want[k]
+        assert np.array_equal(np.isnan(a), np.isnan(b)) and a[~np.isnan(a)].tobytes() == b[~np.isnan(b)].tobytes(), k
+
+
 def test_decode_cap_and_maxd(gpu, orc):
     pred, npred, scale = cases.yolo_pred(cases.YOLO_CASES[0])
     a = gpu.parse_output(pred, npred, scale, maxd=37)

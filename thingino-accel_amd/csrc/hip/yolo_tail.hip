@@ -33,6 +33,8 @@ extern "C" int mhip_check(hipError_t e, const char *what);
 #define NCLS 80
 #define CONF_MIN 0.25f
 
+typedef int v4i __attribute__((ext_vector_type(4)));
+
 struct det_rec {
     float x, y, w, h, conf;
     int cls;
@@ -72,10 +74,33 @@ __global__ __launch_bounds__(256) void decode_kernel(const mhip_detect_t p) {
                 if (!(o < CONF_MIN)) {
                     int arg = 0, argq = -1000;
                     float top = -1e9f;
-                    for (int c = 0; c < NCLS; c++) {
-                        int q = at(5 + c);
-                        float s = val[q + 128];
-                        if (s > top) { top = s; arg = c; argq = q; }
+                    if (p.mono[sgi] && !bytewise) {
+                        // value[q] strictly increasing (the host checked the table): the first maximum of value[q] is the
+                        // first maximum of q.  The 80 class bytes come as five 16-byte loads (any alignment is served) and
+                        // are compared as integers; one table read at the end restores `top`.
+                        v4i w[5];
+#pragma unroll
+                        for (int k = 0; k < 5; k++) __builtin_memcpy(&w[k], rowp + 5 + 16 * k, 16);
+                        int best = -129;
+#pragma unroll
+                        for (int k = 0; k < 20; k++) {
+                            const int d = w[k >> 2][k & 3];
+#pragma unroll
+                            for (int b = 0; b < 4; b++) {
+                                const int q = (d << (24 - 8 * b)) >> 24;
+                                const bool gt = q > best;
+                                best = gt ? q : best;
+                                arg = gt ? 4 * k + b : arg;
+                            }
+                        }
+                        const float s = val[best + 128];
+                        if (s > top) { top = s; argq = best; } else arg = 0; // nothing above -1e9: as if no class had been seen
+                    } else {
+                        for (int c = 0; c < NCLS; c++) {
+                            int q = at(5 + c);
+                            float s = val[q + 128];
+                            if (s > top) { top = s; arg = c; argq = q; }
+                        }
                     }
                     // 1 + expf(-top); with no class above -1e9 the reference divides by +inf
                     float dn = argq == -1000 ? INFINITY : den[argq + 128];

@@ -108,6 +108,7 @@ typedef struct {
     int det_cap;
     float det_lut_scale[4]; /* scales the uploaded decode LUTs were built for */
     int det_lut_n;
+    int det_lut_mono[4];    /* value table of that segment strictly increasing (mhip_detect_t.mono) */
     void *ev_graph_done, *ev_tail_done; /* main->aux and aux->main hand-offs */
     int tail_pending;
     int frame0, run_frames; /* frame range the launches being enqueued cover (a large batch runs as two halves on two streams) */

@@ -24,6 +24,14 @@ static void build_decode_lut(float scale, float *lut) {
     }
 }
 
+/* value[q] strictly increasing over the whole table: the decode kernel may then take the class argmax on the int8 bytes
+ * (first maximum of q == first maximum of value[q]); any NaN, a zero / negative / underflowing scale says no */
+static int lut_increasing(const float *lut) {
+    for (int i = 1; i < 256; i++)
+        if (!(lut[i] > lut[i - 1])) return 0;
+    return 1;
+}
+
 static int ensure_det_buffers(mars_model_ext_t *m, int frames) {
     if (m->det_cap >= frames && m->det_dev) return 0;
     if (m->det_dev) mhip_free(m->det_dev);
@@ -54,6 +62,7 @@ mars_error_t mars_detect_prepare(mars_model_ext_t *m, const int *output_indices,
         float sc = mars_get_output(model, output_indices[s])->desc.scale;
         build_decode_lut(sc, lut + s * 768);
         m->det_lut_scale[s] = sc;
+        m->det_lut_mono[s] = lut_increasing(lut + s * 768);
     }
     if (mhip_sync()) return MARS_ERR_LAYER_FAILED;
     if (mhip_h2d_async(m->det_lut_dev, lut, (size_t)n_outputs * 768 * sizeof(float)) || mhip_sync())
@@ -78,6 +87,7 @@ int mars_detect_launch(mars_model_ext_t *m, const int *output_indices, int n_out
         p.pix_c[s] = m->mt[ti].pix_c; p.pix_stride[s] = m->mt[ti].pix_stride;
         p.npred[s] = (int)(m->mt[ti].bytes / 85); /* rows of 85 int8: x,y,w,h,obj,80 classes */
         p.lut[s] = m->det_lut_dev + s * 768;
+        p.mono[s] = m->det_lut_mono[s];
     }
     p.nseg = n_outputs;
     p.frames = m->batch;
@@ -157,6 +167,7 @@ int mars_yolo_parse_output(const int8_t *data, int npred, float scale, mars_det_
     mhip_detect_t p;
     memset(&p, 0, sizeof(p));
     p.pred[0] = (const int8_t *)d; p.stride[0] = 0; p.npred[0] = npred; p.lut[0] = (const float *)dl;
+    p.mono[0] = lut_increasing(lut);
     p.nseg = 1; p.frames = 1; p.dets = dd; p.counts = dc; p.raw_counts = NULL; p.do_nms = 0;
     int n = -1;
     if (!mhip_h2d_async(d, data, pb) && !mhip_h2d_async(dl, lut, sizeof(lut)) && !mhip_detect(&p) &&

@@ -188,6 +188,7 @@ typedef struct {
     const int8_t *pred[4]; size_t stride[4]; int npred[4];
     int pix_c[4], pix_stride[4]; /* pix_stride != 0: every pix_c prediction bytes sit at the start of a pix_stride-byte pixel row */
     const float *lut[4];   /* per segment, device: 3 x 256 floats: value[q], obj[q], den[q] */
+    int mono[4];           /* value[q] is strictly increasing in q (finite scale > 0): the class argmax may compare bytes */
     int nseg;
     int frames;
     float nms_thresh;

@@ -3,7 +3,7 @@
 #   tools/profile_round.sh TAG      -> gpurun_out/TAG_*  (copy what should be judged into profiles/)
 # rocprofv3 gets the interpreter directly after `--`; PMC passes are separate and carry no trace flags.
 set -e
-TAG=${1:-r02}
+TAG=${1:-r03}
 OUT=$PWD/gpurun_out
 mkdir -p $OUT
 W=2; K=4
@@ -24,15 +24,22 @@ python3 tools/pmc_summary.py --fetch $OUT/${TAG}_pmc_fetch --write $OUT/${TAG}_p
 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_MFMA \
     --output-format csv -d $OUT/${TAG}_pmc_mfma -o m -- python3 $BENCH > /dev/null 2> $OUT/${TAG}_pmc_mfma.err
 python3 tools/mfma_busy.py $OUT/${TAG}_pmc_mfma $OUT/${TAG}_trace $((W + K)) > $OUT/${TAG}_mfma_busy.json
+# instruction mix per kernel symbol (vector and scalar instructions per MFMA)
+rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_MFMA SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_SMEM SQ_WAVES \
+    --output-format csv -d $OUT/${TAG}_pmc_mix -o x -- python3 $BENCH > /dev/null 2> $OUT/${TAG}_pmc_mix.err
+{ echo "# ${TAG}: instruction mix per convolution kernel symbol"; echo; echo "\`rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_MFMA SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_SMEM SQ_WAVES -- python3 $BENCH\` (tools/inst_mix.py; per step = per batch of 256 frames, every launch of the symbol summed)"; echo; python3 tools/inst_mix.py $OUT/${TAG}_pmc_mix $((W + K)); } > $OUT/${TAG}_deep_sq_counters.md
 find $OUT/${TAG}_trace -name '*kernel_stats.csv' -exec cp {} $OUT/${TAG}_bench_kernel_stats.csv \;
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/${TAG}_trace2 -o t -- python3 $BENCH2 > $OUT/${TAG}_two_streams_line_under_rocprof.json 2> $OUT/${TAG}_trace2.err
 find $OUT/${TAG}_trace2 -name '*kernel_stats.csv' -exec cp {} $OUT/${TAG}_two_streams_kernel_stats.csv \;
 find $OUT/${TAG}_trace2 -name '*kernel_trace.csv' -delete
-rm -rf $OUT/${TAG}_pmc_fetch $OUT/${TAG}_pmc_write $OUT/${TAG}_pmc_mfma
+rm -rf $OUT/${TAG}_pmc_fetch $OUT/${TAG}_pmc_write $OUT/${TAG}_pmc_mfma $OUT/${TAG}_pmc_mix
 find $OUT/${TAG}_trace -name '*kernel_trace.csv' -delete
-# un-profiled lines: per-launch table, the 320x320 workloads, the float32 workload (config 5), the default line
+# un-profiled lines: per-launch table, config 3 and the 320x320 workloads WITH their CPU-baseline / bit-exact legs (shorter
+# sustained leg: these are secondary lines), the float32 workload (config 5), the default line last
 python3 bench.py --timed-only --ops $OUT/${TAG}_ops.txt > $OUT/${TAG}_bench_ops.json 2> $OUT/${TAG}_ops.err
-python3 bench.py --timed-only --hw 320 > $OUT/${TAG}_bench_320_yolov5s.json 2>> $OUT/${TAG}_ops.err
-python3 bench.py --timed-only --hw 320 --width 4 > $OUT/${TAG}_bench_320_yolov5n.json 2>> $OUT/${TAG}_ops.err
-python3 bench.py --dtype f32 --steps 10 --warmup 3 > $OUT/${TAG}_f32_bench.json 2>> $OUT/${TAG}_ops.err
+python3 bench.py --width 4 --sustain-s 1 > $OUT/${TAG}_bench_640_yolov5n.json 2>> $OUT/${TAG}_ops.err
+python3 bench.py --hw 320 --sustain-s 1 > $OUT/${TAG}_bench_320_yolov5s.json 2>> $OUT/${TAG}_ops.err
+python3 bench.py --hw 320 --width 4 --sustain-s 1 > $OUT/${TAG}_bench_320_yolov5n.json 2>> $OUT/${TAG}_ops.err
+python3 bench.py --dtype f32 --steps 10 --warmup 3 --sustain-s 1 > $OUT/${TAG}_f32_bench.json 2>> $OUT/${TAG}_ops.err
+cp $OUT/${TAG}_pmc_traffic.json profiles/pmc_traffic.json  # bench.py reads it (and checks the kernel-source hash inside) for roofline.traffic
 python3 bench.py > $OUT/${TAG}_bench_default.json 2>> $OUT/${TAG}_ops.err
