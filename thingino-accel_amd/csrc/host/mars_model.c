@@ -51,9 +51,12 @@ static int g_dual_ways = 2; /* parts (= streams) such a batch is cut into: 2..4 
 /* (Round 3, measured and dropped: a DEPTH-FIRST head -- the first 2 / 3 / 5 / 8 launches of the plan run in chunks of
  * 16 / 32 / 64 frames, so that the stem's 3.3 MB per frame is still in the 256 MB Infinity Cache when the next layer reads
  * it: 4.55-4.65 ms per batch against 4.54-4.59 without, at every setting.  The early layers are not waiting for HBM reads.) */
-/* (Round 3, measured and dropped: a LAZY join -- the main stream not waiting for the other part at the end of a run, only
- * the detection tail, uploads and downloads doing so -- so that back-to-back runs keep both streams busy without meeting
- * at every run boundary: 1-2 % slower at batch 256 and 128; the aligned start is worth more than the bubble costs.) */
+/* (Round 3, measured and dropped, twice: a LAZY join -- the main stream not waiting for the other part at the end of a run,
+ * only the detection tail, uploads and downloads doing so -- so that back-to-back runs keep both streams busy without
+ * meeting at every run boundary: 1-2 % slower at batch 256 and 128.  And the same with a deliberate OFFSET: the second part
+ * started once, 8 / 16 / ... / 48 launches behind the first, so that one stream sits in the early HBM-bound layers while the
+ * other is in the deep matrix-bound ones from then on: 4.45-4.50 ms per batch at every offset against 4.43 joined, 2.47
+ * against 2.37 at batch 128.  The aligned start of the two halves is worth more than the bubble at the join costs.) */
 static void drop_graph(mars_model_ext_t *m) {
     if (m->graph_exec) {
         mhip_sync();
