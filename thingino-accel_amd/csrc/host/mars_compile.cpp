@@ -757,7 +757,7 @@ struct compiler_t {
         }
         uint32_t oc = (uint32_t)at_or(wt->dims, 0, 1), ic = (uint32_t)at_or(wt->dims, 1, 1);
         uint32_t kh = (uint32_t)at_or(wt->dims, 2, 3), kw = (uint32_t)at_or(wt->dims, 3, 3);
-        if ((uint64_t)oc * ic * kh * kw > ((uint64_t)1 << 31)) bail("Conv weight dims out of range");
+        if ((uint64_t)oc * ic * kh * kw > ((uint64_t)1 << 28)) bail("Conv weight dims out of range"); /* the --nhwc re-order allocates that many bytes */
 
         std::vector<uint8_t> wdata;
         float w_scale = 1.0f;
