@@ -22,6 +22,8 @@ its Makefile:21) on one host core over a bounded sample (as many frames of the s
 16); the GPU's head tensors AND its detections (kept boxes, order, classes: the reference's parse_output + nms on
 the reference's head tensors) for those frames are compared with it bit for bit (`map_delta`).
 `sustained_images_per_s` = >= 3 s of back-to-back steps after the timed region, with the shader clock the chip held.
+`roofline.copy_rate_measured` / `frac_of_copy_rate`: what a plain 1 GiB device copy reaches on the same box (read + write),
+and the conv family's byte rate against it -- beside `frac`, which stays against the guide's 8 TB/s.
 `--io pipelined` (any N): every rank also feeds its frames from pinned host memory through mars_hip_pipe_* and reports
 the I/O-inclusive rate (MAX over ranks), the first thing an 8-GPU run is bound by.
 """
@@ -355,7 +357,9 @@ def main():
     # (mars_hip_clock_mhz: one probe wave on its own stream): the chip lowers its clock under a sustained int8 MFMA load.
     sustained = None
     if args.sustain_s > 0 and not args.timed_only:
-        nsteps = max(args.steps, int(args.sustain_s / max(dt / args.steps, 1e-4)) + 1)
+        # 8 % more steps than the timed region's pace predicts: back to back the steps run a little faster than in the
+        # 30-step burst, and the leg must not end short of --sustain-s
+        nsteps = max(args.steps, int(1.08 * args.sustain_s / max(dt / args.steps, 1e-4)) + 1)
         clocks = []
         barrier()
         t1 = time.perf_counter()
@@ -499,6 +503,16 @@ def main():
                 result["pipelined_raw_outputs_images_per_s"] = pipe_rates.get("raw_outputs")
         if multi:
             result["config"]["rccl"] = rccl_info
+        if world == 1 and not args.timed_only and not f32:
+            # What a plain copy reaches on THIS box: `peak` stays the guide's 8 TB/s, but no kernel that reads and writes HBM
+            # gets there -- a 1 GiB device-to-device copy (read + write bytes over its time) is the practical ceiling the
+            # conv family's byte rate can be held against.  Untimed for `value`: it runs after the timed region.
+            copy_gbs = float(M.lib().mars_hip_copy_rate_gbs(1 << 30, 10))
+            result["roofline"]["copy_rate_measured"] = copy_gbs if copy_gbs > 0 else None
+            if copy_gbs > 0:
+                result["roofline"]["frac_of_copy_rate"] = result["roofline"]["achieved"] / copy_gbs
+                result["roofline"]["frac_wall_of_copy_rate"] = result["roofline"]["wall_achieved"] / copy_gbs
+            result["roofline"]["copy_rate_how"] = "mars_hip_copy_rate_gbs: device-to-device copy of 1 GiB, 10 back to back, the better of hipMemcpyAsync and a 16-byte-per-lane kernel, (read + write bytes) / time, GB/s"
         if world == 1 and not args.timed_only:
             # not the headline value: the same batch INCLUDING host->HBM input copies and HBM->host
             # output copies through the reference API's mars_run() (pinned staging, one stream)

@@ -57,6 +57,9 @@ mars_error_t mars_hip_set_output_mode(mars_model_t *model, int mode);
  * 100 MHz reference counters around a ~micros us pause, beside whatever the library's other streams are running (the
  * benchmark's sustained leg reports it: the chip lowers its clock under load).  < 0: no device. */
 float mars_hip_clock_mhz(int micros);
+/* Diagnostic: what a plain device-to-device copy of `bytes` reaches on this device, `reps` copies back to back: (read +
+ * write bytes) / time in GB/s, or -1.  The practical HBM ceiling bench.py quotes beside the data-sheet peak. */
+double mars_hip_copy_rate_gbs(size_t bytes, int reps);
 
 /* Device address / per-frame stride of any tensor (weights: stride 0). */
 void *mars_hip_tensor_device(mars_model_t *model, int tensor_index, size_t *frame_stride);

@@ -52,6 +52,8 @@ def test_bench_line_has_the_contract_fields():
     assert c["detections_match_bit_exact"] is True and c["detections_compared"] >= 0 and d["map_delta"] == 0.0
     assert d["sustained_images_per_s"] > 0 and d["sustained"]["steps"] >= 3 and d["sustained"]["seconds"] > 0
     assert lat["mars_run_plus_detect_ms"] >= lat["mars_run_ms"]
+    # the practical ceiling of the box (a plain device copy) beside the data-sheet peak
+    assert 2000 < r["copy_rate_measured"] < 8000 and abs(r["frac_of_copy_rate"] - r["achieved"] / r["copy_rate_measured"]) < 1e-9
 
 
 def test_bench_sustained_leg_runs_for_the_asked_time():

@@ -345,13 +345,24 @@ __global__ __launch_bounds__(NMS_THREADS) void sort_nms_kernel(det_rec *all, int
         }
         __syncthreads();
         if (tid < 64) {
-            for (int r = 0; r < rows; r++) {
-                const int i = i0 + r;
-                const unsigned lo = __builtin_amdgcn_readlane((unsigned)removed, i >> 6);
-                const unsigned hi = __builtin_amdgcn_readlane((unsigned)(removed >> 32), i >> 6);
-                const unsigned long long word = ((unsigned long long)hi << 32) | lo;
-                if ((word >> (i & 63)) & 1ull) continue; // suppressed boxes suppress nothing
-                if (tid < nw) removed |= (unsigned long long)mask[r][2 * tid] | ((unsigned long long)mask[r][2 * tid + 1] << 32);
+            // the greedy walk is a dependent chain of `rows` steps; its matrix rows do not depend on it, so they are fetched
+            // 16 at a time ahead of the steps that use them (one LDS latency per 16 rows instead of one per row) and a
+            // suppressed row is skipped by a select, not a branch
+            const int wl = tid < 16 ? tid : 15, c = i0 >> 6; // lane w holds word w of the removed set; rows i0.. live in word c
+            for (int r0 = 0; r0 < rows; r0 += 16) {
+                unsigned long long mrow[16];
+#pragma unroll
+                for (int k = 0; k < 16; k++) {
+                    const int r = r0 + k < NMS_CHUNK ? r0 + k : NMS_CHUNK - 1;
+                    mrow[k] = *(const unsigned long long *)&mask[r][2 * wl];
+                }
+#pragma unroll
+                for (int k = 0; k < 16; k++) {
+                    const int r = r0 + k; // bit r of word c: rows >= `rows` hold an all-zero matrix row
+                    const unsigned half = r < 32 ? __builtin_amdgcn_readlane((unsigned)removed, c) : __builtin_amdgcn_readlane((unsigned)(removed >> 32), c);
+                    const bool dead = (half >> (r & 31)) & 1u; // suppressed boxes suppress nothing
+                    removed |= (dead || tid >= nw || r >= rows) ? 0ull : mrow[k];
+                }
             }
         }
         __syncthreads(); // the next chunk overwrites the bit matrix

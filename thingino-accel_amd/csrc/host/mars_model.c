@@ -1990,6 +1990,7 @@ static mars_error_t run_whole(mars_model_t *model) {
 mars_error_t mars_hip_sync(void) { return mhip_sync() ? MARS_ERR_LAYER_FAILED : MARS_OK; }
 
 float mars_hip_clock_mhz(int micros) { return mhip_clock_probe_mhz(micros); }
+double mars_hip_copy_rate_gbs(size_t bytes, int reps) { return mhip_copy_rate_gbs(bytes, reps); }
 
 /* --------------------------------------------------------------- extensions */
 mars_error_t mars_hip_set_batch(mars_model_t *model, int n) {

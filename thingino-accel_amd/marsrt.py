@@ -116,7 +116,7 @@ EXPORTS = {
                    "mars_hip_detect", "mars_hip_detect_device", "mars_synth_model", "mars_hip_set_tuning", "mars_hip_autotune", "mars_yolo_letterbox",
                    "mars_hip_preprocess", "mars_hip_tensor_frame_bytes", "mars_hip_tensor_byte_size", "mars_hip_pipe_open",
                    "mars_hip_pipe_input", "mars_hip_pipe_submit", "mars_hip_pipe_wait", "mars_hip_pipe_close", "mars_hip_clock_mhz", "mars_hip_set_output_mode",
-                   "mars_hip_get_tuning", "mars_hip_model_set_tuning", "mars_hip_model_get_tuning"],
+                   "mars_hip_get_tuning", "mars_hip_model_set_tuning", "mars_hip_model_get_tuning", "mars_hip_copy_rate_gbs"],
     "mars_compile.h": ["mars_compile_onnx", "mars_compile_file", "mars_compile_last_error"],
 }
 
@@ -180,6 +180,8 @@ def lib():
     L.mars_hip_set_batch.argtypes = [P(MarsModel), C.c_int]
     L.mars_hip_set_fusion.argtypes = [P(MarsModel), C.c_int]
     L.mars_hip_set_tuning.argtypes = [C.c_char_p, C.c_int]
+    L.mars_hip_copy_rate_gbs.restype = C.c_double
+    L.mars_hip_copy_rate_gbs.argtypes = [C.c_size_t, C.c_int]
     L.mars_hip_get_tuning.argtypes = [C.c_char_p, P(C.c_int)]
     L.mars_hip_model_set_tuning.argtypes = [C.c_void_p, C.c_char_p, C.c_int]
     L.mars_hip_model_get_tuning.argtypes = [C.c_void_p, C.c_char_p, P(C.c_int)]
