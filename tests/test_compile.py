@@ -399,13 +399,15 @@ def test_command_line_tool_writes_the_same_file(marsrt, tmp_path):
     assert subprocess.run([exe], capture_output=True).returncode == 2
 
 
-def runnable_graph(rng):
+def runnable_graph(rng, float_bias=False):
     """a graph whose compiled form the executor can run: 1x1 / 3x3 convolutions with int32 bias bit patterns (the runtime
     reads the bias bytes as int32), SiLU pairs, a residual Add, MaxPool, Resize, Concat"""
     def w(o, i, k):
         return rng.standard_normal((o, i, k, k)).astype(np.float32)
 
     def bias(n):
+        if float_bias:
+            return rng.standard_normal(n).astype(np.float32)
         return rng.integers(-40, 40, n).astype(np.int32).view(np.float32)
 
     inits = [ox.tensor("w0", w(16, 3, 3)), ox.tensor("b0", bias(16)), ox.tensor("w1", w(32, 16, 1)), ox.tensor("b1", bias(32)),
@@ -480,3 +482,22 @@ def test_compiled_file_runs_bit_identically_on_the_device(marsrt):
             want = g.tensor(hdr["outputs"][0])
             assert np.array_equal(want.ravel().view(np.uint8), got[f].ravel().view(np.uint8)), (nhwc, seed, f)
         m.close()
+    # --float32: float weights and NCHW features; real float biases this time (the float path reads them as floats).  With the
+    # reference's summation order forced (f32_mfma = 0, per model) the device is bit-identical to the oracle here too
+    rng = np.random.default_rng(77)
+    onnx = runnable_graph(rng, float_bias=True)
+    d = marsrt.compile_onnx(onnx, float32=True)
+    hdr, T, L = marsfile.parse(d)
+    m = marsrt.Model(d, batch=2)
+    m.set_tuning("f32_mfma", 0)
+    x = rng.random((2, 3 * 32 * 32), dtype=np.float32)
+    m.input_view(0).reshape(2, -1)[:] = x.view(np.uint8).reshape(2, -1)
+    m.run()
+    got = m.output_view(0).copy()
+    for f in range(2):
+        g = orcbind.Graph(d)
+        g.set_input(0, x[f].tobytes())
+        assert g.run() == 0
+        want = g.tensor(hdr["outputs"][0])
+        assert np.array_equal(want.ravel().view(np.uint8), got[f].ravel().view(np.uint8)), f
+    m.close()
