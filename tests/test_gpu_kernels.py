@@ -192,6 +192,57 @@ def test_conv_i8_wide_one_tile_forms(gpu, orc, variant, slots):
         gpu.set_tuning("persist_slots", 0)
 
 
+@pytest.mark.parametrize("slots", [0, 2, 5])
+def test_conv_i8_rows_persistent_deep(gpu, orc, slots):
+    """variant 20 (round 4, conv_i8_rows): deep 3x3 stride-1 layers as one persistent 8-wave workgroup per CU over tiles of
+    256 consecutive pixels -- patch-staged input (64-channel chunks, double buffered), streamed weights in K-step blocks,
+    two accumulator sets with the previous tile's epilogue inside the next tile's K loop, hand-counted vmcnt.  Map widths
+    20 / 40 / 80 (the instantiated patch pitches), heights that make tiles straddle rows and FRAMES (the zero rows between
+    stacked frames), 128 / 256 / 512 input channels (2 / 4 / 8 chunks), 128 / 256 output channels, partial last tiles;
+    `slots` forces 2 or 5 workgroups so that each walks many tiles.  Direct calls (no table, one frame) and whole graphs
+    with the fused SiLU table and several frames."""
+    shapes = [  # in_h, in_w, in_c, out_c
+        (40, 40, 128, 128), (20, 20, 256, 256), (7, 80, 128, 128), (23, 40, 128, 256), (9, 20, 512, 128), (3, 40, 256, 128)]
+    try:
+        gpu.set_tuning("variant", 20)
+        gpu.set_tuning("persist_slots", slots)
+        for i, (h, w, ic, oc) in enumerate(shapes):
+            case = ("rows%d" % i, 1, h, w, ic, oc, 3, 3, 1, 1, 1, 1, h, w, 0.03, 0.003 / (9 * ic) ** 0.5 * 8, 0.05, True)
+            a = cases.conv_i8_call(gpu.conv2d_int8, case, 9)
+            b = cases.conv_i8_call(orc.conv2d_int8, case, 9)
+            assert np.array_equal(a, b), (case[0], slots, int((a != b).sum()))
+            assert len(np.unique(a)) > 32
+        import marsfile
+        for (h, w, ic, oc, frames) in [(20, 20, 256, 256, 7), (13, 40, 128, 128, 5), (5, 80, 128, 128, 3)]:
+            G = marsfile.Graph()
+            rng = np.random.default_rng(h * 100 + w)
+            x = G.tensor([1, h, w, ic], scale=4 / 127)
+            a_ = G.tensor([1, h, w, oc], scale=0.03125)
+            g_ = G.tensor([1, h, w, oc], scale=1 / 127)
+            o = G.tensor([1, h, w, oc], scale=4 / 127)
+            wt = G.tensor([oc, 3, 3, ic], scale=0.0005, data=rng.integers(-127, 128, (oc, 3, 3, ic), dtype=np.int8))
+            bt = G.tensor([oc], dtype=marsfile.I32, scale=1.0, data=rng.integers(-500, 500, oc, dtype=np.int32))
+            G.conv(x, a_, wt, bt, (3, 3), (1, 1))
+            G.layer(marsfile.SIGMOID, [a_], [g_])
+            G.layer(marsfile.MUL, [a_, g_], [o])
+            d = G.serialise([x], [o])
+            hdr, tensors, _ = marsfile.parse(d)
+            m = gpu.Model(d, batch=frames)
+            xs = rng.integers(0, 256, m.input_view(0).shape, dtype=np.uint8)
+            m.input_view(0)[:] = xs
+            m.run()
+            for f in range(frames):
+                gr = orc.Graph(d)
+                gr.set_input(0, xs[f].tobytes())
+                assert gr.run() == 0
+                want = gr.tensor(hdr["outputs"][0])
+                assert np.array_equal(m.output_view(0)[f], want), (h, w, ic, oc, f, slots)
+            m.close()
+    finally:
+        gpu.set_tuning("variant", 0)
+        gpu.set_tuning("persist_slots", 0)
+
+
 @pytest.mark.parametrize("variant,ring", [(9, 0), (10, 0), (11, 0), (10, 1), (9, 3), (11, 4), (10, 4)])
 def test_conv_i8_patch_staged(gpu, orc, variant, ring):
     """the patch-staged kernel (input patch of a tile staged once in LDS, weights resident, taps fed from LDS):

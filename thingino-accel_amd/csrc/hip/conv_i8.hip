@@ -846,6 +846,7 @@ const tune_t &conv_i8_tune_state() {
         g_tune.wres = env_int("MARS_HIP_WRES", 3);
         g_tune.rgb_direct = env_int("MARS_HIP_RGB_DIRECT", 1);
         g_tune.small_batch = env_int("MARS_HIP_SMALL_BATCH", 1);
+        g_tune.rows = env_int("MARS_HIP_ROWS", 1);
         g_tune.patch_ring = env_int("MARS_HIP_PATCH_RING", 0);
         g_tune.patch_lds_kb = env_int("MARS_HIP_PATCH_LDS_KB", 80);
         g_tune.init = 1;
@@ -858,7 +859,7 @@ static int tune_access(const char *key, int value, int *get) {
     (void)conv_i8_tune_state();
     struct { const char *k; int *v; } tab[] = {{"persist", &g_tune.persist}, {"persist_stages", &g_tune.persist_stages},
                                                {"persist_maxk", &g_tune.persist_maxk}, {"persist_slots", &g_tune.persist_slots}, {"wres", &g_tune.wres}, {"rgb_direct", &g_tune.rgb_direct}, {"small_batch", &g_tune.small_batch},
-                                               {"patch_ring", &g_tune.patch_ring}, {"patch_lds_kb", &g_tune.patch_lds_kb}, {"stages", &g_tune.stages}, {"bpx", &g_tune.bpx}, {"variant", &g_tune.variant}, {"bufmode", &g_tune.bufmode}};
+                                               {"rows", &g_tune.rows}, {"patch_ring", &g_tune.patch_ring}, {"patch_lds_kb", &g_tune.patch_lds_kb}, {"stages", &g_tune.stages}, {"bpx", &g_tune.bpx}, {"variant", &g_tune.variant}, {"bufmode", &g_tune.bufmode}};
     for (auto &e : tab)
         if (key && !strcmp(key, e.k)) {
             if (get) *get = *e.v;
@@ -978,11 +979,13 @@ static int launch_persist_t(const mhip_conv_i8_t *p, long total_pix, int k64, in
 //   code = 13: one 256 x 128 tile per 8-wave workgroup, 3 stages
 //   code = 14 / 15: tile walker with the weights of its channel tile resident in LDS, 128 / 256 pixels
 //   code = 18 / 19: 128-byte K steps (whole-line DMA requests), 128 x 128 tile on 4 waves / 256 x 128 tile on 8 waves
-#define NVARIANTS 19 // 16, 17 (and the former 20) were measured-and-dropped forms: round 2, DESIGN.md section 5
+//   code = 20: conv_i8_rows (round 4): whole-row tiles, patch-staged input, streamed weights, persistent, deep 3x3 stride 1
+#define NVARIANTS 20 // 16, 17 were measured-and-dropped forms: round 2, DESIGN.md section 5
 struct variant_t {
-    int persist, bpx, stages, patch, ks2, w8, wres, r128;
+    int persist, bpx, stages, patch, ks2, w8, wres, r128, rows;
 };
 static int variant_code(const variant_t &v) {
+    if (v.rows) return 20;
     if (v.r128) return 17 + v.r128;
     if (v.wres) return v.bpx == 256 ? 15 : 14;
     if (v.w8) return 13;
@@ -991,14 +994,15 @@ static int variant_code(const variant_t &v) {
     return 1 + (v.persist ? 1 : 0) + (v.bpx == 256 ? 2 : 0) + (v.stages == 3 ? 4 : 0);
 }
 static variant_t variant_of(int code) {
-    if (code == 18 || code == 19) return variant_t{0, 0, 0, 0, 0, 0, 0, code - 17};
-    if (code == 14 || code == 15) return variant_t{1, code == 15 ? 256 : 128, 2, 0, 0, 0, 1, 0};
-    if (code == 13) return variant_t{0, 256, 3, 0, 0, 1, 0, 0};
-    if (code == 12) return variant_t{0, 128, 2, 0, 1, 0, 0, 0};
-    if (code >= 9 && code <= 11) return variant_t{0, 0, 0, code == 10 ? 16 : (code == 9 ? 8 : 4), 0, 0, 0, 0};
-    if (code > 8) return variant_t{-1, 0, 0, 0, 0, 0, 0, 0}; // 16, 17: retired codes
+    if (code == 20) return variant_t{0, 0, 0, 0, 0, 0, 0, 0, 1};
+    if (code == 18 || code == 19) return variant_t{0, 0, 0, 0, 0, 0, 0, code - 17, 0};
+    if (code == 14 || code == 15) return variant_t{1, code == 15 ? 256 : 128, 2, 0, 0, 0, 1, 0, 0};
+    if (code == 13) return variant_t{0, 256, 3, 0, 0, 1, 0, 0, 0};
+    if (code == 12) return variant_t{0, 128, 2, 0, 1, 0, 0, 0, 0};
+    if (code >= 9 && code <= 11) return variant_t{0, 0, 0, code == 10 ? 16 : (code == 9 ? 8 : 4), 0, 0, 0, 0, 0};
+    if (code > 8) return variant_t{-1, 0, 0, 0, 0, 0, 0, 0, 0}; // 16, 17: retired codes
     const int c = code - 1;
-    return variant_t{c & 1, (c & 2) ? 256 : 128, (c & 4) ? 3 : 2, 0, 0, 0, 0, 0};
+    return variant_t{c & 1, (c & 2) ? 256 : 128, (c & 4) ? 3 : 2, 0, 0, 0, 0, 0, 0};
 }
 
 // ---- 128-byte K steps (conv_i8_r128): eligibility, launch
@@ -1068,6 +1072,7 @@ static variant_t default_variant(const mhip_conv_i8_t *p, int nks) {
     v.w8 = 0;
     v.wres = 0;
     v.r128 = 0;
+    v.rows = 0;
     // wide, shallow k x k layers: the patch-staged kernel wins wherever its double-buffered form fits (measured on the
     // 160x160 and 80x80 layers of yolov5s: 1.25-1.9x over the implicit-GEMM forms)
     int ring = 0;
@@ -1091,6 +1096,13 @@ static variant_t default_variant(const mhip_conv_i8_t *p, int nks) {
         v.persist = nks <= tune().persist_maxk && persist_eligible(p);
         if (((p->out_c | p->out_pix_stride | p->out_ch_off) & 15) != 0 && p->nseg <= 1) v.persist = 0;
         v.stages = v.persist ? 2 : 3;
+        return v;
+    }
+    // deep 3x3 stride-1 layers on 20-wide maps with 256+ input channels: the persistent whole-row form (conv_i8_rows) --
+    // measured 70.8 vs 77.7 us (3x3 256->256 @20x20) and 204 vs 252 us (512->512) at batch 256; on 40-wide maps with 128
+    // channels (two chunks per tile: the in-line epilogue is a fifth of a tile) it loses, 81.5 vs 79.2 us
+    if (tune().persist && !tune().bpx && !tune().stages && tune().rows && p->out_w <= 20 && p->in_c >= 256 && conv_i8_rows_ok(p)) {
+        v.persist = 0; v.bpx = 0; v.stages = 0; v.rows = 1;
         return v;
     }
     if (tune().persist && !tune().bpx && !tune().stages) {
@@ -1157,6 +1169,7 @@ static int launch_variant_t(const mhip_conv_i8_t *p, long total_pix, int k64, co
 
 static int launch_variant(const mhip_conv_i8_t *p, long total_pix, int k64, const variant_t &v) {
     if (v.persist < 0) return -1; // a retired variant code
+    if (v.rows) return conv_i8_launch_rows(p);
     if (v.r128) return launch_r128(p, total_pix, v.r128);
     if (v.patch) return conv_i8_launch_patch(p, k64, v.patch);
     const int bn = p->oc_pad % 128 == 0 ? 128 : (p->oc_pad % 64 == 0 ? 64 : 32);
@@ -1257,6 +1270,7 @@ extern "C" int mhip_conv_i8_variants(const mhip_conv_i8_t *p, int *codes, int ma
         if (v.w8 && (p->oc_pad % 128 != 0 || nks < 3)) continue;
         if (v.persist < 0) continue; // retired codes
         if (v.r128 && !r128_ok(p)) continue;
+        if (v.rows && !conv_i8_rows_ok(p)) continue;
         if (v.wres) {
             const int bn = p->oc_pad % 128 == 0 ? 128 : (p->oc_pad % 64 == 0 ? 64 : 32);
             if (LUTB + 2 * (size_t)v.bpx * BK + (size_t)nks * bn * BK > 80 * 1024) continue;

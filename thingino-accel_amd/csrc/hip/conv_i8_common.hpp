@@ -419,6 +419,7 @@ struct tune_t {
     int rgb_direct;     // MARS_HIP_RGB_DIRECT    1: the RGB stem runs in its operand-direct form (conv_i8_rgb) where eligible
     int wres;           // MARS_HIP_WRES          bit 0 / 1: the default policy may keep the weights resident in LDS (tile
                         //                        walker) for single / paired launches
+    int rows;           // MARS_HIP_ROWS          1: the default policy may pick conv_i8_rows (variant 20) where it measured faster
     int patch_ring;     // MARS_HIP_PATCH_RING    0: auto, else at most this many patch buffers per workgroup of the patch-staged kernel (1..4)
     int patch_lds_kb;   // MARS_HIP_PATCH_LDS_KB  LDS budget of one patch-staged workgroup (default 80: two workgroups per CU)
 };
@@ -444,6 +445,9 @@ static inline bool conv_i8_direct_rows(const mhip_conv_i8_t *p) { // NHWC rows s
 bool conv_i8_patch_ok(const mhip_conv_i8_t *p, int th, int *ring);
 int conv_i8_launch_patch(const mhip_conv_i8_t *p, int k64, int th); // -1: not eligible
 int conv_i8_pre_tile_rows(const mhip_conv_i8_t *p);                 // fused bottleneck: tallest tile that fits, 0 = none
+// conv_i8_rows.hip: whole-row tiles, patch-staged input, streamed weights, one persistent workgroup per CU (variant 20)
+bool conv_i8_rows_ok(const mhip_conv_i8_t *p);
+int conv_i8_launch_rows(const mhip_conv_i8_t *p); // -1: not eligible
 // conv_i8_stem.hip: -2 = not a shape that kernel takes, else the launch result
 int conv_i8_try_rgb(const mhip_conv_i8_t *p, int k64);
 int conv_i8_try_smallc(const mhip_conv_i8_t *p, int k64);

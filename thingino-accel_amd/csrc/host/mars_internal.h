@@ -70,7 +70,9 @@ typedef struct {
     int pre;         /* fused bottleneck: a 1x1 + SiLU evaluated on the staged patch before this convolution (fuse_bottleneck) */
     size_t pre_w_off, pre_b_off, pre_lut2_off;
     float pre_cs;
-    size_t w2_off;   /* the RGB stem's weights as conv_i8_rgb keeps them in LDS (mhip_conv_i8_rgb_pack), or NO_OFF */
+    size_t w2_off;   /* a second image of the weights, or NO_OFF: the RGB stem's as conv_i8_rgb keeps them in LDS
+                        (mhip_conv_i8_rgb_pack), or (w2_rows) a deep 3x3 layer's as conv_i8_rows streams them (mhip_conv_i8_rows_pack) */
+    int w2_rows;
     size_t lut2_off; /* 512-entry half-step form of the fused LUT (4-instruction requantisation), or NO_OFF */
     size_t w_blob_off[2];     /* operands that live in the blob mirror */
     double macs, bytes;       /* algorithmic work per frame */

@@ -368,6 +368,17 @@ static void plan_conv(mars_model_ext_t *m, int li) {
                                       (int8_t *)m->arena_host + op->w2_off);
         }
     }
+    if (!op->nchw && op->w2_off == NO_OFF) { /* deep 3x3 stride-1 layers: the weight image conv_i8_rows streams (same bytes, K-step blocks) */
+        const size_t n3 = mhip_conv_i8_rows_pack(in_c, kh, kw, sh, sw, op->oc_pad, (int)k64, NULL, NULL);
+        if (n3) {
+            op->w2_off = arena_reserve(m, n3);
+            if (op->w2_off == NO_OFF) return;
+            op->w2_rows = 1;
+            if (!m->deferred)
+                mhip_conv_i8_rows_pack(in_c, kh, kw, sh, sw, op->oc_pad, (int)k64, (const int8_t *)m->arena_host + op->w_off,
+                                       (int8_t *)m->arena_host + op->w2_off);
+        }
+    }
     if (tb >= 0) { /* raw bytes reinterpreted as int32, whatever the tensor says it is (:645,656) */
         op->b_off = arena_reserve(m, (size_t)op->oc_pad * 4);
         if (op->b_off != NO_OFF && !m->deferred) {
@@ -1515,7 +1526,8 @@ static void conv_i8_params(const mars_model_ext_t *m, const mars_op_t *op, mhip_
     p->bias = op->b_off != NO_OFF ? (const int32_t *)(A + op->b_off) : NULL;
     p->lut = op->lut_off != NO_OFF ? A + op->lut_off : NULL;
     p->lut2 = op->lut_off != NO_OFF && op->lut2_off != NO_OFF ? A + op->lut2_off : NULL;
-    p->w_rgb = op->w2_off != NO_OFF ? (const int8_t *)(A + op->w2_off) : NULL;
+    p->w_rgb = op->w2_off != NO_OFF && !op->w2_rows ? (const int8_t *)(A + op->w2_off) : NULL;
+    p->w_rows = op->w2_off != NO_OFF && op->w2_rows ? (const int8_t *)(A + op->w2_off) : NULL;
     if (op->pre) {
         p->pre_w = (const int8_t *)(A + op->pre_w_off);
         p->pre_bias = (const int32_t *)(A + op->pre_b_off);

@@ -68,10 +68,13 @@ static void conv_i8_host(int nchw, const signed char *input, int in_h, int in_w,
     const size_t k64 = ((size_t)kh * row_pad + 63) & ~(size_t)63;
     const size_t in_b = (size_t)in_h * in_w * in_c, out_b = (size_t)out_h * out_w * out_c;
     const size_t w_b = (size_t)oc_pad * k64, scr_b = nchw ? (size_t)in_h * in_w * c_pad : 0;
+    /* deep 3x3 stride-1 shapes: also the K-step image conv_i8_rows streams (launch variant 20; 0 bytes otherwise) */
+    const size_t w3_b = nchw ? 0 : mhip_conv_i8_rows_pack(in_c, kh, kw, stride_h, stride_w, oc_pad, (int)k64, NULL, NULL);
+    int8_t *hw3 = w3_b ? (int8_t *)malloc(w3_b) : NULL;
     int8_t *hw = (int8_t *)malloc(w_b);
     int32_t *hb = (int32_t *)calloc((size_t)oc_pad, 4);
-    uint8_t *d = (uint8_t *)mhip_malloc(A256(in_b) + A256(out_b) + A256(w_b) + A256((size_t)oc_pad * 4) + A256(scr_b) + 256);
-    if (!hw || !hb || !d) { fprintf(stderr, "%s: allocation failed\n", who); goto done; }
+    uint8_t *d = (uint8_t *)mhip_malloc(A256(in_b) + A256(out_b) + A256(w_b) + A256((size_t)oc_pad * 4) + A256(scr_b) + A256(w3_b) + 256);
+    if (!hw || !hb || !d || (w3_b && !hw3)) { fprintf(stderr, "%s: allocation failed\n", who); goto done; }
     mars_pack_conv_i8((const int8_t *)weight, (size_t)out_c * in_c * kh * kw, nchw, out_c, in_c, kh, kw, c_eff, row_pad,
                       oc_pad, hw);
     for (int oc = 0; bias && oc < out_c; oc++) hb[mhip_conv_i8_oc_row(oc, oc_pad)] = bias[oc];
@@ -79,8 +82,13 @@ static void conv_i8_host(int nchw, const signed char *input, int in_h, int in_w,
         int8_t *din = (int8_t *)d, *dout = din + A256(in_b), *dw = dout + A256(out_b);
         int32_t *db = (int32_t *)(dw + A256(w_b));
         int8_t *dscr = (int8_t *)db + A256((size_t)oc_pad * 4);
+        int8_t *dw3 = dscr + A256(scr_b);
         int rc = mhip_h2d_async(din, input, in_b);
         if (!rc) rc = mhip_h2d_async(dw, hw, w_b);
+        if (!rc && w3_b) {
+            mhip_conv_i8_rows_pack(in_c, kh, kw, stride_h, stride_w, oc_pad, (int)k64, hw, hw3);
+            rc = mhip_h2d_async(dw3, hw3, w3_b);
+        }
         if (!rc) rc = mhip_h2d_async(db, hb, (size_t)oc_pad * 4);
         mhip_conv_i8_t p;
         memset(&p, 0, sizeof(p));
@@ -89,7 +97,7 @@ static void conv_i8_host(int nchw, const signed char *input, int in_h, int in_w,
             rc = mhip_nchw_to_nhwc_pad(din, 0, dscr, 0, 1, in_c, in_h * in_w, c_pad);
             p.in = dscr; p.in_c = c_pad;
         }
-        p.out = dout; p.w = dw; p.bias = bias ? db : NULL; p.frames = 1;
+        p.out = dout; p.w = dw; p.w_rows = w3_b ? dw3 : NULL; p.bias = bias ? db : NULL; p.frames = 1;
         p.in_h = in_h; p.in_w = in_w; p.out_h = out_h; p.out_w = out_w; p.out_c = out_c;
         p.kh = kh; p.kw = kw; p.stride_h = stride_h; p.stride_w = stride_w; p.pad_top = pad_top; p.pad_left = pad_left;
         p.row_pad = row_pad; p.oc_pad = oc_pad;
@@ -101,6 +109,7 @@ static void conv_i8_host(int nchw, const signed char *input, int in_h, int in_w,
         if (mhip_sync() || rc) fprintf(stderr, "%s: GPU execution failed: %s\n", who, mhip_last_error());
     }
 done:
+    free(hw3);
     free(hw);
     free(hb);
     if (d) mhip_free(d);

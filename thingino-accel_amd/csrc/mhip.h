@@ -74,6 +74,8 @@ typedef struct {
     float pre_cs;
     const int8_t *w_rgb;        /* optional: the RGB stem's A operands in the layout conv_i8_rgb keeps in LDS
                                  * (mhip_conv_i8_rgb_pack); NULL = the kernel re-lays p.w itself, once per workgroup */
+    const int8_t *w_rows;       /* optional: the weights as conv_i8_rows streams them (mhip_conv_i8_rows_pack): one 8 KB LDS
+                                 * image per (channel tile, 64-channel chunk, tap); NULL = that launch variant is not offered */
     int frames;
     int in_h, in_w, in_c;       /* input as NHWC */
     int out_h, out_w, out_c;
@@ -111,6 +113,9 @@ int mhip_conv_i8_oc_row(int oc, int oc_pad);
 int mhip_conv_i8_pre_ok(const mhip_conv_i8_t *p);
 size_t mhip_conv_i8_rgb_pack(int in_c, int kh, int kw, int stride_h, int stride_w, int pad_left, int oc_pad, int k64,
                              const int8_t *packed, int8_t *out);
+/* Bytes of, and (out != NULL) the content of, conv_i8_rows' weight image (deep 3x3 stride-1 layers); 0 = not such a shape */
+size_t mhip_conv_i8_rows_pack(int in_c, int kh, int kw, int stride_h, int stride_w, int oc_pad, int k64,
+                              const int8_t *packed, int8_t *out);
 /* is the float->int conversion of acc*cs provably in range for every int32 accumulator? */
 int mhip_conv_i8_is_safe(float cs);
 /* may the half-step LUT be used for this combined scale?  (no int32 accumulator may requantise to +-0x3EFFFFFF) */
