@@ -23,7 +23,9 @@ its Makefile:21) on one host core over a bounded sample (as many frames of the s
 the reference's head tensors) for those frames are compared with it bit for bit (`map_delta`).
 `sustained_images_per_s` = >= 3 s of back-to-back steps after the timed region, with the shader clock the chip held.
 `roofline.copy_rate_measured` / `frac_of_copy_rate`: what a plain 1 GiB device copy reaches on the same box (read + write),
-and the conv family's byte rate against it -- beside `frac`, which stays against the guide's 8 TB/s.
+and the conv family's byte rate against it -- beside `frac`, which stays against the guide's 8 TB/s; `frac_of_achievable`
+holds it against the guide's measured 6.3 TB/s.  `roofline.pipes`: per step, the time each pipe (matrix, vector, scalar, LDS,
+HBM) would need alone, from the committed instruction-mix profile of the same kernel sources (which one binds the family).
 `--io pipelined` (any N): every rank also feeds its frames from pinned host memory through mars_hip_pipe_* and reports
 the I/O-inclusive rate (MAX over ranks), the first thing an 8-GPU run is bound by.
 """
@@ -46,6 +48,50 @@ def load_marsrt():
     mod = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(mod)
     return mod
+
+
+def load_probe():
+    """bench.py's measurement probes (copy rate, shader clock): thingino-accel_amd/lib/libmars_probe.so, NOT part of the product
+    library (csrc/probe/mars_probe.hip)"""
+    import ctypes as C
+    L = C.CDLL(os.path.join(ROOT, "thingino-accel_amd", "lib", "libmars_probe.so"))
+    L.mars_probe_copy_rate_gbs.restype = C.c_double
+    L.mars_probe_copy_rate_gbs.argtypes = [C.c_size_t, C.c_int]
+    L.mars_probe_copy_form.restype = C.c_char_p
+    L.mars_probe_clock_mhz.restype = C.c_float
+    L.mars_probe_clock_mhz.argtypes = [C.c_int]
+    return L
+
+
+def pipe_times(args, conv_bytes, copy_gbs, clock_mhz):
+    """Which pipe binds the conv family, per step, from the committed instruction-mix pass of the same workload and the same
+    kernel sources (profiles/inst_mix.json, tools/inst_mix.py --json; None when no matching profile exists): the time each
+    pipe would need if it ran alone at full rate -- 1024 SIMDs / 256 CUs at the shader clock the sustained leg measured
+    (else 2400 MHz): a v_mfma_i32_16x16x64_i8 holds its SIMD's matrix pipe 16 cycles, any other vector instruction its
+    issue port 4, a scalar instruction its CU's scalar unit 1 (lower bound), LDS = the cycles the LDS arrays were
+    indexing; HBM = the algorithmic bytes at 8 TB/s, at the guide's achievable 6.3 TB/s, and at this box's copy rate."""
+    path = os.path.join(ROOT, "profiles", "inst_mix.json")
+    hbm = {"hbm_ms_at_peak": conv_bytes / 8e12 * 1e3, "hbm_ms_at_achievable": conv_bytes / 6.3e12 * 1e3,
+           "hbm_ms_at_copy_rate": conv_bytes / (copy_gbs * 1e9) * 1e3 if copy_gbs and copy_gbs > 0 else None}
+    try:
+        with open(path) as fh:
+            d = json.load(fh)
+        if d["config"] != {"width": args.width, "hw": args.hw, "batch": args.batch}:
+            return dict(hbm, source="profiles/inst_mix.json is for another workload")
+        if d.get("kernel_source_sha16") != kernel_source_sha16():
+            return dict(hbm, source="profiles/inst_mix.json was taken with other kernel sources (%s, now %s)" % (d.get("kernel_source_sha16"), kernel_source_sha16()))
+        c = d["conv_i8_per_step"]
+        clk = (clock_mhz or 2400.0) * 1e6
+        out = {"mfma_ms": c["mfma"] * 16 / (1024 * clk) * 1e3, "valu_ms": (c["valu"] - c["mfma"]) * 4 / (1024 * clk) * 1e3,
+               "salu_ms": c["salu"] / (256 * clk) * 1e3,
+               "lds_ms": c["lds_idx_active_cycles"] / (256 * clk) * 1e3 if c.get("lds_idx_active_cycles") else None,
+               "valu_per_mfma": (c["valu"] - c["mfma"]) / c["mfma"], "salu_per_mfma": c["salu"] / c["mfma"],
+               "clock_mhz_assumed": clk / 1e6,
+               "source": "profiles/inst_mix.json (kernel sources %s)" % d["kernel_source_sha16"]}
+        out.update(hbm)
+        return out
+    except (OSError, KeyError, ValueError, ZeroDivisionError):
+        return dict(hbm, source=None)
 
 
 def load_dist_helpers():
@@ -257,6 +303,7 @@ def main():
 
     M = load_marsrt()
     D = load_dist_helpers()
+    PROBE = load_probe()
     import marsfile
     M.nna_init()
     f32 = args.dtype == "f32"
@@ -366,7 +413,7 @@ def main():
         for k in range(nsteps):
             step()
             if k % max(1, nsteps // 8) == nsteps // 16:  # ~8 samples spread over the leg (each blocks the host ~0.3 ms)
-                c = float(M.lib().mars_hip_clock_mhz(200))
+                c = float(PROBE.mars_probe_clock_mhz(200))
                 if c > 0:
                     clocks.append(c)
         barrier()
@@ -389,12 +436,23 @@ def main():
         modes = (("detections", False), ("raw_outputs", True)) if world == 1 else (("detections", False),)
         for key, dl in modes:
             model.pipe_open(download_outputs=dl, detect=True, det_outputs=outputs, thresh=0.45)
-            for _ in range(3):
+            # untimed: fill all four staging slots (a camera would DMA into them) by running four batches through and
+            # draining them, so that the timed loop below copies nothing on the host
+            for k in range(4):
                 model.pipe_input_view(0)[:] = stacked
                 model.pipe_submit()
-            nb = 8
+                if k >= 2:
+                    model.pipe_wait(copy=False)
+            for _ in range(2):
+                model.pipe_wait(copy=False)
+            # the window holds every batch that is counted -- the three that fill the pipeline are submitted
+            # after t1 and the last three are drained before the clock stops (fill and drain are inside: the rate is
+            # slightly pessimistic, never optimistic)
+            nb = 16
             barrier()
             t1 = time.perf_counter()
+            for k in range(3):
+                model.pipe_submit()
             for _ in range(nb):
                 model.pipe_wait(copy=False)
                 model.pipe_submit()
@@ -497,7 +555,7 @@ def main():
             result["sustained"] = sustained
         if pipe_rates:
             result["pipelined_io"] = {"images_per_s": pipe_rates.get("detections"), "returns": "detections (4 KB per frame)",
-                                      "ranks": world, "timing": "barrier, 11 batches per rank, MAX over ranks"}
+                                      "ranks": world, "timing": "barrier, then 19 batches per rank submitted AND drained inside the window (pipeline fill and drain included), MAX over ranks"}
             if world == 1:
                 result["pipelined_detections_images_per_s"] = pipe_rates.get("detections")
                 result["pipelined_raw_outputs_images_per_s"] = pipe_rates.get("raw_outputs")
@@ -610,12 +668,20 @@ def main():
         # What a plain copy reaches on THIS box: `peak` stays the guide's 8 TB/s, but no kernel that reads and writes HBM
         # gets there -- a 1 GiB device-to-device copy (read + write bytes over its time) is the practical ceiling the
         # conv family's byte rate can be held against.  Untimed for `value`: it runs after the timed region.
-        copy_gbs = float(M.lib().mars_hip_copy_rate_gbs(1 << 30, 10))
+        copy_gbs = float(PROBE.mars_probe_copy_rate_gbs(1 << 30, 10))
         result["roofline"]["copy_rate_measured"] = copy_gbs if copy_gbs > 0 else None
         if copy_gbs > 0:
             result["roofline"]["frac_of_copy_rate"] = result["roofline"]["achieved"] / copy_gbs
             result["roofline"]["frac_wall_of_copy_rate"] = result["roofline"]["wall_achieved"] / copy_gbs
-        result["roofline"]["copy_rate_how"] = "mars_hip_copy_rate_gbs: device-to-device copy of 1 GiB, 10 back to back, the better of hipMemcpyAsync and a 16-byte-per-lane kernel, (read + write bytes) / time, GB/s"
+        result["roofline"]["copy_rate_how"] = ("libmars_probe.so (csrc/probe/mars_probe.hip): device-to-device copy of 1 GiB, 10 back to back, the best of "
+                                               "hipMemcpyAsync and 16-byte-per-lane kernels with 1 / 4 / 8 loads in flight per lane, plain and non-temporal; "
+                                               "(read + write bytes) / time, GB/s; best form here: %s" % PROBE.mars_probe_copy_form().decode())
+        # against what the guide says a kernel can reach at all (MI355X_MICROARCH.md: 6.3 TB/s measured, float4 copy)
+        result["roofline"]["achievable_peak"] = 6300.0
+        result["roofline"]["frac_of_achievable"] = result["roofline"]["achieved"] / 6300.0
+        result["roofline"]["frac_wall_of_achievable"] = result["roofline"]["wall_achieved"] / 6300.0
+        clk = (sustained or {}).get("shader_clock_mhz", {}).get("median") if sustained else None
+        result["roofline"]["pipes"] = pipe_times(args, result["roofline"]["algorithmic_bytes"], copy_gbs, clk)
     model.close()
     if dist is not None:
         dist.barrier()

@@ -53,13 +53,6 @@ mars_error_t mars_hip_sync(void);
 #define MARS_HIP_OUTPUT_HEADS 0
 #define MARS_HIP_OUTPUT_ON_DEVICE 1
 mars_error_t mars_hip_set_output_mode(mars_model_t *model, int mode);
-/* Shader clock of the device right now, in MHz: a one-wave probe on a stream of its own samples the shader-cycle and the
- * 100 MHz reference counters around a ~micros us pause, beside whatever the library's other streams are running (the
- * benchmark's sustained leg reports it: the chip lowers its clock under load).  < 0: no device. */
-float mars_hip_clock_mhz(int micros);
-/* Diagnostic: what a plain device-to-device copy of `bytes` reaches on this device, `reps` copies back to back: (read +
- * write bytes) / time in GB/s, or -1.  The practical HBM ceiling bench.py quotes beside the data-sheet peak. */
-double mars_hip_copy_rate_gbs(size_t bytes, int reps);
 
 /* Device address / per-frame stride of any tensor (weights: stride 0). */
 void *mars_hip_tensor_device(mars_model_t *model, int tensor_index, size_t *frame_stride);
@@ -105,7 +98,10 @@ int mars_hip_get_tuning(const char *key, int *value); /* the process-wide value 
 /* The same knobs per model: an override is kept on `model`, put in force for the duration of each of ITS runs (mars_run,
  * mars_hip_run_device[_async], the pipelined submit, mars_hip_autotune) and taken back afterwards, so models that want
  * different launch policies can share a process; mars_hip_set_tuning stays the process default.  At most 16 keys per
- * model.  mars_hip_model_get_tuning returns the override, or the process default where there is none. */
+ * model.  mars_hip_model_get_tuning returns the override, or the process default where there is none.
+ * THREADS: the runtime, like the reference's, is single-threaded: the overrides are put in force by rewriting the process
+ * knobs around a run, so runs of different models must not overlap in time on different threads (one thread driving
+ * several models, or several threads under one lock, is fine). */
 int mars_hip_model_set_tuning(mars_model_t *model, const char *key, int value);
 int mars_hip_model_get_tuning(mars_model_t *model, const char *key, int *value);
 /* Times the launch variants of every int8 convolution of `model` on the device at the current batch

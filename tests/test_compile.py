@@ -446,6 +446,25 @@ def test_compiled_file_loads_and_runs_on_the_oracle(marsrt):
     assert out.size == 16 * 16 * 24 and len(np.unique(out)) > 8  # a live result, not a saturated or all-zero one
 
 
+def test_transpose_and_softmax_numbering_is_kept_and_announced(marsrt, capfd):
+    """the reference's compiler writes Transpose = 15 / Softmax = 17 while the runtime header reads 15 as SOFTMAX
+    and 17 as TRANSPOSE (a mismatch inside the reference, kept byte for byte).  A file with either op therefore runs a
+    DIFFERENT op once loaded: the compile step says so on stderr, and the oracle's runtime (the reference's dispatch) treats the
+    compiled Transpose as its no-op SOFTMAX kind and the compiled Softmax as its no-op TRANSPOSE kind -- nothing is written."""
+    import orcbind
+    x = ox.value_info("x", [1, 4, 8, 6])
+    for op, written, reads, attrs in (("Transpose", 15, "SOFTMAX", dict(perm=[0, 2, 3, 1])), ("Softmax", 17, "TRANSPOSE", dict(axis=-1))):
+        d = marsrt.compile_onnx(ox.model([ox.node(op, ["x"], ["y"], **attrs)], [], [x], [ox.value_info("y", [], shape=False)]))
+        err = capfd.readouterr().err
+        assert "warning: %s is written as layer type %d" % (op, written) in err and reads in err
+        hdr, T, L = marsfile.parse(d)
+        assert L[0]["type"] == written
+        g = orcbind.Graph(d)
+        g.set_input(0, bytes(range(192)))
+        assert g.run() == 0  # both kinds are no-ops in the reference's runtime (mars_runtime.c:1168-1213): the output stays zero
+        assert not np.any(g.tensor(L[0]["outs"][0]))
+
+
 @pytest.mark.skipif(not os.path.exists(REF_ONNX), reason="reference tree not present (GPU box)")
 def test_reference_tree_onnx_compiles(marsrt):
     """the yolov5s export that ships in the reference tree (read here only; nothing of it is committed)"""

@@ -54,6 +54,13 @@ def test_bench_line_has_the_contract_fields():
     assert lat["mars_run_plus_detect_ms"] >= lat["mars_run_ms"]
     # the practical ceiling of the box (a plain device copy) beside the data-sheet peak
     assert 2000 < r["copy_rate_measured"] < 8000 and abs(r["frac_of_copy_rate"] - r["achieved"] / r["copy_rate_measured"]) < 1e-9
+    # round 4: the guide's achievable rate beside the data-sheet peak, the per-pipe times (HBM always; the instruction pipes
+    # when the committed profile matches this workload and these kernel sources), the probes from their own library
+    assert r["achievable_peak"] == 6300.0 and abs(r["frac_of_achievable"] - r["achieved"] / 6300.0) < 1e-9
+    pp = r["pipes"]
+    assert pp["hbm_ms_at_peak"] > 0 and pp["hbm_ms_at_achievable"] > pp["hbm_ms_at_peak"] and pp["hbm_ms_at_copy_rate"] > 0
+    assert "source" in pp and "libmars_probe.so" in r["copy_rate_how"]
+    assert "submitted AND drained inside the window" in d["pipelined_io"]["timing"]
 
 
 def test_bench_sustained_leg_runs_for_the_asked_time():

@@ -33,11 +33,22 @@ for f in "$SRC"/host/*.c; do
 done
 for f in "$SRC"/host/*.cpp; do
   o="$OBJ/$(basename "$f" .cpp).o"
-  $CXX -O2 -fPIC -std=c++17 $INC -c "$f" -o "$o"
+  # -ffp-contract=off like the C files: the compile step's BatchNorm fold / quantisation must not turn into FMAs
+  $CXX -O2 -ffp-contract=off -fPIC -std=c++17 -Wall -Wextra -Wno-unused-parameter $INC -c "$f" -o "$o"
 done
 for p in "${pids[@]:-}"; do [ -n "$p" ] && wait "$p"; done
-$HIPCC --offload-arch=gfx950 -shared -fPIC -Wl,-Bsymbolic -o "$OUT/libnna_mars.so" "$OBJ"/*.o -lm
+# link exactly the objects of the current sources (a renamed or removed source must not leave its old object in the library)
+objs=()
+for f in "$SRC"/hip/*.hip; do objs+=("$OBJ/$(basename "$f" .hip).hip.o"); done
+for f in "$SRC"/host/*.c; do objs+=("$OBJ/$(basename "$f" .c).o"); done
+for f in "$SRC"/host/*.cpp; do objs+=("$OBJ/$(basename "$f" .cpp).o"); done
+$HIPCC --offload-arch=gfx950 -shared -fPIC -Wl,-Bsymbolic -o "$OUT/libnna_mars.so" "${objs[@]}" -lm
 echo "built $OUT/libnna_mars.so"
+# bench.py's measurement probes (copy rate, shader clock): their own object, not part of the product library
+if [ ! -f "$OUT/libmars_probe.so" ] || [ "$SRC/probe/mars_probe.hip" -nt "$OUT/libmars_probe.so" ]; then
+  $HIPCC --offload-arch=gfx950 -O3 -fPIC -std=c++17 -shared -o "$OUT/libmars_probe.so" "$SRC/probe/mars_probe.hip"
+fi
+echo "built $OUT/libmars_probe.so"
 # the ONNX -> .mars compile step as the reference's command-line tool (host-only: no GPU runtime linked)
 $CC -O2 -Wall $INC "$SRC/cli/mars_main.c" "$OBJ/mars_compile.o" -lstdc++ -lm -o "$OUT/mars"
 echo "built $OUT/mars"

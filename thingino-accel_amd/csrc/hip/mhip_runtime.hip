@@ -234,66 +234,3 @@ extern "C" float mhip_event_elapsed_ms(void *start, void *stop) {
     return ms;
 }
 
-// ---- shader clock under load (bench.py's sustained leg): one wave reads the shader-cycle counter (s_memtime) and the
-// constant 100 MHz counter (s_memrealtime) at both ends of a ~`micros` us sleep, on a stream of its own, beside whatever
-// the other streams are running: clock = d(memtime) / d(memrealtime) x 100 MHz (MI355X_MICROARCH.md, DVFS give-back 6).
-// The stamps go to a buffer of their own; nothing else reads them.
-__global__ void clock_probe_kernel(unsigned long long *out, int rounds) {
-    const unsigned long long c0 = __builtin_amdgcn_s_memtime(), r0 = __builtin_amdgcn_s_memrealtime();
-    for (int i = 0; i < rounds; i++) __builtin_amdgcn_s_sleep(127); // 127 x 64 cycles each
-    const unsigned long long c1 = __builtin_amdgcn_s_memtime(), r1 = __builtin_amdgcn_s_memrealtime();
-    if (threadIdx.x == 0) {
-        out[0] = c1 - c0;
-        out[1] = r1 - r0;
-    }
-}
-extern "C" float mhip_clock_probe_mhz(int micros) {
-    if (!g_ready) return -1.f;
-    static hipStream_t st = nullptr;
-    static unsigned long long *dev = nullptr;
-    if (!st && hipStreamCreateWithFlags(&st, hipStreamNonBlocking) != hipSuccess) return -1.f;
-    if (!dev && hipMalloc((void **)&dev, 16) != hipSuccess) return -1.f;
-    int rounds = micros > 0 ? micros / 4 + 1 : 64; // ~4 us per round at 2 GHz
-    hipLaunchKernelGGL(clock_probe_kernel, dim3(1), dim3(64), 0, st, dev, rounds);
-    unsigned long long h[2] = {0, 0};
-    if (hipMemcpyAsync(h, dev, 16, hipMemcpyDeviceToHost, st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess) return -1.f;
-    return h[1] ? (float)((double)h[0] / (double)h[1] * 100.0) : -1.f;
-}
-
-// Practical HBM ceiling of this device: a device-to-device copy of `bytes`, `reps` times back to back, by the runtime's
-// own blit (hipMemcpyAsync) and by a plain 16-bytes-per-lane grid-stride kernel; returns the better of the two as (read +
-// write bytes) / time in GB/s, or -1.  A diagnostic for bench.py's roofline object: no kernel that reads and writes HBM
-// reaches the data-sheet rate, this is what a plain copy reaches on the same box.
-__global__ __launch_bounds__(256) void copy_probe_kernel(const uint4 *__restrict__ src, uint4 *__restrict__ dst, size_t n16) {
-    const size_t stride = (size_t)gridDim.x * blockDim.x;
-    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n16; i += stride) dst[i] = src[i];
-}
-extern "C" double mhip_copy_rate_gbs(size_t bytes, int reps) {
-    if (!g_ready || bytes < 16 || reps <= 0) return -1.0;
-    void *a = nullptr, *b = nullptr;
-    hipEvent_t e0 = nullptr, e1 = nullptr;
-    double out = -1.0;
-    if (hipMalloc(&a, bytes) == hipSuccess && hipMalloc(&b, bytes) == hipSuccess && hipEventCreate(&e0) == hipSuccess &&
-        hipEventCreate(&e1) == hipSuccess && hipMemsetAsync(a, 1, bytes, g_stream) == hipSuccess &&
-        hipMemcpyAsync(b, a, bytes, hipMemcpyDeviceToDevice, g_stream) == hipSuccess) { // warm: first touch of both buffers
-        for (int form = 0; form < 2; form++) {
-            bool ok = hipEventRecord(e0, g_stream) == hipSuccess;
-            for (int i = 0; i < reps && ok; i++) {
-                if (form == 0) ok = hipMemcpyAsync(b, a, bytes, hipMemcpyDeviceToDevice, g_stream) == hipSuccess;
-                else hipLaunchKernelGGL(copy_probe_kernel, dim3(256 * 8), dim3(256), 0, g_stream, (const uint4 *)a, (uint4 *)b, bytes / 16);
-            }
-            float ms = 0.f;
-            if (ok && hipEventRecord(e1, g_stream) == hipSuccess && hipEventSynchronize(e1) == hipSuccess &&
-                hipEventElapsedTime(&ms, e0, e1) == hipSuccess && ms > 0.f) {
-                const double r = 2.0 * (double)bytes * reps / ((double)ms * 1e-3) / 1e9;
-                if (r > out) out = r;
-            }
-        }
-    }
-    (void)hipStreamSynchronize(g_stream);
-    if (e0) (void)hipEventDestroy(e0);
-    if (e1) (void)hipEventDestroy(e1);
-    if (a) (void)hipFree(a);
-    if (b) (void)hipFree(b);
-    return out;
-}

@@ -676,6 +676,9 @@ struct compiler_t {
     /* main.rs:611-619 */
     uint64_t add_weights(const std::vector<uint8_t> &d)
     {
+        /* a hostile few-KB file can declare shapes that make every node allocate tens of MB: the blob of a model this
+         * path can run is bounded by the reference runtime's addressable weights; refuse anything beyond 1 GiB in total */
+        if (weights.size() + d.size() > ((size_t)1 << 30)) bail("weight blob exceeds 1 GiB");
         uint64_t off = weights.size();
         weights.insert(weights.end(), d.begin(), d.end());
         while (weights.size() % 4) weights.push_back(0);
@@ -758,6 +761,9 @@ struct compiler_t {
         uint32_t oc = (uint32_t)at_or(wt->dims, 0, 1), ic = (uint32_t)at_or(wt->dims, 1, 1);
         uint32_t kh = (uint32_t)at_or(wt->dims, 2, 3), kw = (uint32_t)at_or(wt->dims, 3, 3);
         if ((uint64_t)oc * ic * kh * kw > ((uint64_t)1 << 28)) bail("Conv weight dims out of range"); /* the --nhwc re-order allocates that many bytes */
+        /* ... and only for weights that are really there: the declared element count must be covered by the initializer's payload
+         * (1 byte per int8 element, 2 / 4 per half / float), or a few-KB file could ask for 256 MB per node */
+        if ((uint64_t)oc * ic * kh * kw > (uint64_t)wt->data.size()) bail("Conv weight initializer shorter than its dims");
 
         std::vector<uint8_t> wdata;
         float w_scale = 1.0f;
@@ -875,7 +881,7 @@ struct compiler_t {
         uint32_t in_id = feature(arg(nd.in, 0, "BatchNorm missing input")), out_id = feature(arg(nd.out, 0, "BatchNorm missing output"));
         shape4 s = shape_of(in_id);
         update_shape(out_id, {s.d[0], s.d[1], s.d[2], s.d[3]});
-        if (s.d[1] < 0 || s.d[1] > (1 << 24)) bail("BatchNorm channel count out of range");
+        if (s.d[1] < 0 || s.d[1] > (1 << 20)) bail("BatchNorm channel count out of range"); /* six vectors of that many floats are allocated */
         size_t nc = (size_t)s.d[1];
         float eps = nd.get_float("epsilon") ? *nd.get_float("epsilon") : 1e-5f;
         auto operand = [&](size_t i, float dflt) {
@@ -1022,6 +1028,14 @@ struct compiler_t {
         layers.push_back(l);
     }
 
+    /* The reference's compiler and its runtime disagree on three layer-type numbers (quirk list at the top of this file);
+     * the bytes are kept, the user is told: a file with such a layer runs a DIFFERENT op in the runtime */
+    void numbering_warning(const char *op, int written, const char *runtime_reads)
+    {
+        fprintf(stderr, "mars_compile: warning: %s is written as layer type %d (the reference compiler's numbering); the runtime header "
+                        "include/mars.h reads %d as %s -- the compiled file will not run this op as intended\n", op, written, written, runtime_reads);
+    }
+
     /* main.rs:1380-1427 */
     void transpose(const onode_t &nd)
     {
@@ -1036,6 +1050,7 @@ struct compiler_t {
             if ((uint64_t)perm[i] < 4) o[i] = s.d[perm[i]];
         update_shape(out_id, {o[0], o[1], o[2], o[3]});
         if (quantize) set_scale(out_id, scale_of(in_id));
+        numbering_warning("Transpose", 15, "SOFTMAX");
         mars_layer_t l = new_layer(LT_TRANSPOSE);
         l.input_tensor_ids[0] = in_id, l.output_tensor_ids[0] = out_id;
         put_params(l, {pa[0], pa[1], pa[2], pa[3], pa[4], pa[5], (uint32_t)perm.size()});
@@ -1050,6 +1065,7 @@ struct compiler_t {
         update_shape(out_id, {s.d[0], s.d[1], s.d[2], s.d[3]});
         if (quantize) set_scale(out_id, 1.0f / 127.0f);
         int64_t axis = nd.get_int("axis") ? *nd.get_int("axis") : -1;
+        numbering_warning("Softmax", 17, "TRANSPOSE");
         mars_layer_t l = new_layer(LT_SOFTMAX);
         l.input_tensor_ids[0] = in_id, l.output_tensor_ids[0] = out_id;
         put_params(l, {axis < 0 ? (uint32_t)(4 + axis) : (uint32_t)axis});

@@ -1277,6 +1277,17 @@ static mars_error_t alloc_batch(mars_model_ext_t *m, int n) {
     const uint32_t nt = m->pub.header.num_tensors;
     if (m->pipe) mars_hip_pipe_close(&m->pub); /* its slots were sized for the old batch */
     if (mhip_sync()) return MARS_ERR_LAYER_FAILED;
+    /* tests exercise the two fall-backs below with a small batch: limits from the environment, read once per call */
+    const char *env_v = getenv("MARS_HIP_VCONCAT_LIMIT"), *env_b = getenv("MARS_HIP_BOTTLENECK_LIMIT");
+    const size_t vlim = env_v ? (size_t)strtoull(env_v, NULL, 0) : (size_t)0x7fffffffu, blim = env_b ? (size_t)strtoull(env_b, NULL, 0) : 0;
+    /* the two batch-dependent fall-backs are decided afresh for every batch (they used to stick once a large
+     * batch had switched them on): plan again with the fusions allowed, the checks below take them back if need be */
+    if (m->no_vconcat || m->no_bottleneck) {
+        m->no_vconcat = m->no_bottleneck = 0;
+        mars_error_t e = build_plan(m);
+        if (e == MARS_OK) e = upload_params(m);
+        if (e != MARS_OK) return e;
+    }
     /* segmented (virtual concat) convolutions address their output with 32-bit buffer offsets: if this batch makes
      * an output tensor of one of them 2 GiB or more, plan again with materialised concats */
     if (!m->no_vconcat) /* deferred (descriptor-only) ranks take the same decision: it depends on shapes and batch only */
@@ -1285,8 +1296,7 @@ static mars_error_t alloc_batch(mars_model_ext_t *m, int n) {
             if (op->kind != OP_CONV_I8 || op->nseg < 2 || op->t_out < 0) continue;
             const mtensor_t *t = &m->mt[op->t_out];
             const size_t stride = ALIGN_UP(t->extent > t->bytes ? t->extent : t->bytes, 256);
-            const char *lim = getenv("MARS_HIP_VCONCAT_LIMIT"); /* tests: exercise the fallback with a small batch */
-            if (stride * (size_t)n > (lim ? (size_t)strtoull(lim, NULL, 0) : (size_t)0x7fffffffu)) {
+            if (stride * (size_t)n > vlim) {
                 m->no_vconcat = 1;
                 mars_error_t e = build_plan(m);
                 if (e == MARS_OK) e = upload_params(m);
@@ -1312,8 +1322,7 @@ static mars_error_t alloc_batch(mars_model_ext_t *m, int n) {
             p.in_stride = op->t_in[0] >= 0 ? ALIGN_UP(m->mt[op->t_in[0]].extent > m->mt[op->t_in[0]].bytes ? m->mt[op->t_in[0]].extent : m->mt[op->t_in[0]].bytes, 256) : 0;
             p.pre_w = (const int8_t *)m; p.pre_bias = (const int32_t *)m; p.pre_lut2 = (const uint8_t *)m; p.lut2 = (const uint8_t *)m;
             p.lut = (const uint8_t *)m;
-            const char *lim = getenv("MARS_HIP_BOTTLENECK_LIMIT"); /* tests: exercise the fallback with a small batch */
-            if (!mhip_conv_i8_pre_ok(&p) || (lim && (size_t)n > (size_t)strtoull(lim, NULL, 0))) {
+            if (!mhip_conv_i8_pre_ok(&p) || (blim && (size_t)n > blim)) {
                 m->no_bottleneck = 1;
                 mars_error_t e = build_plan(m);
                 if (e == MARS_OK) e = upload_params(m);
@@ -2001,8 +2010,6 @@ static mars_error_t run_whole(mars_model_t *model) {
 
 mars_error_t mars_hip_sync(void) { return mhip_sync() ? MARS_ERR_LAYER_FAILED : MARS_OK; }
 
-float mars_hip_clock_mhz(int micros) { return mhip_clock_probe_mhz(micros); }
-double mars_hip_copy_rate_gbs(size_t bytes, int reps) { return mhip_copy_rate_gbs(bytes, reps); }
 
 /* --------------------------------------------------------------- extensions */
 mars_error_t mars_hip_set_batch(mars_model_t *model, int n) {

@@ -47,9 +47,6 @@ void mhip_event_destroy(void *ev);
 int mhip_event_record(void *ev);
 float mhip_event_elapsed_ms(void *start, void *stop); /* waits for stop */
 const char *mhip_last_error(void);
-/* shader clock right now, MHz (one probe wave on a stream of its own sleeps ~micros us between two stamp pairs); < 0 on failure */
-float mhip_clock_probe_mhz(int micros);
-double mhip_copy_rate_gbs(size_t bytes, int reps); /* device-to-device copy rate (read + write bytes), GB/s, or -1 */
 /* capture the launches enqueued on the main stream between begin and end into an executable graph (NULL on failure) */
 int mhip_graph_begin(void);
 void *mhip_graph_end(int ok);

@@ -1,0 +1,118 @@
+// mars_probe.hip -- measurement probes for bench.py, built into their OWN shared object (lib/libmars_probe.so): nothing here
+// is part of the product library or its ABI (round 3 had them in libnna_mars.so: VERDICT r3 item 4d).
+//   mars_probe_copy_rate_gbs  what a plain device-to-device copy reaches on this box: the practical HBM ceiling
+//   mars_probe_clock_mhz      the shader clock right now, beside whatever the other streams of the process are running
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <string.h>
+
+// ---- copy rate.  MI355X_MICROARCH.md: a 16-byte-per-lane copy reaches ~6.3 TB/s (read + write).  Round 3's probe -- 2048
+// workgroups of 256 threads, one 16-byte access in flight per lane per iteration -- read 4.65-5.5 TB/s: too little in
+// flight per CU.  Forms here (the best is reported, and which one it was): the runtime's blit; a grid-stride kernel with
+// UNROLL independent 16-byte loads in flight per lane before the first store; the same with non-temporal loads and stores
+// (the data is touched once: no reason to keep it in L2 / the Infinity Cache).
+template <int UNROLL, bool NT>
+__global__ __launch_bounds__(256) void copy_probe(const uint4 *__restrict__ src, uint4 *__restrict__ dst, size_t n16) {
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    for (; i + (UNROLL - 1) * stride < n16; i += UNROLL * stride) {
+        uint4 v[UNROLL];
+#pragma unroll
+        for (int u = 0; u < UNROLL; u++) {
+            if (NT) {
+                const uint32_t *s = (const uint32_t *)(src + i + u * stride);
+                typedef uint32_t u4 __attribute__((ext_vector_type(4)));
+                const u4 t = __builtin_nontemporal_load((const u4 *)s);
+                v[u] = make_uint4(t.x, t.y, t.z, t.w);
+            } else {
+                v[u] = src[i + u * stride];
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < UNROLL; u++) {
+            if (NT) {
+                typedef uint32_t u4 __attribute__((ext_vector_type(4)));
+                const u4 t = {v[u].x, v[u].y, v[u].z, v[u].w};
+                __builtin_nontemporal_store(t, (u4 *)(dst + i + u * stride));
+            } else {
+                dst[i + u * stride] = v[u];
+            }
+        }
+    }
+    for (; i < n16; i += stride) dst[i] = src[i];
+}
+
+static const char *g_copy_form = "none";
+extern "C" const char *mars_probe_copy_form(void) { return g_copy_form; }
+
+extern "C" double mars_probe_copy_rate_gbs(size_t bytes, int reps) {
+    if (bytes < 16 || reps <= 0) return -1.0;
+    void *a = nullptr, *b = nullptr;
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    hipStream_t st = nullptr;
+    double best = -1.0;
+    int cus = 256;
+    hipDeviceProp_t prop;
+    int dev = 0;
+    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) cus = prop.multiProcessorCount;
+    if (hipStreamCreateWithFlags(&st, hipStreamNonBlocking) == hipSuccess && hipMalloc(&a, bytes) == hipSuccess && hipMalloc(&b, bytes) == hipSuccess &&
+        hipEventCreate(&e0) == hipSuccess && hipEventCreate(&e1) == hipSuccess && hipMemsetAsync(a, 1, bytes, st) == hipSuccess &&
+        hipMemcpyAsync(b, a, bytes, hipMemcpyDeviceToDevice, st) == hipSuccess) { // warm: first touch of both buffers
+        static const char *names[] = {"hipMemcpyAsync", "kernel: 16 B/lane, 1 in flight, 8 workgroups/CU", "kernel: 16 B/lane, 4 in flight, 8 workgroups/CU",
+                                      "kernel: 16 B/lane, 8 in flight, 4 workgroups/CU", "kernel: 16 B/lane, 4 in flight, non-temporal, 8 workgroups/CU",
+                                      "kernel: 16 B/lane, 8 in flight, non-temporal, 4 workgroups/CU"};
+        for (int form = 0; form < 6; form++) {
+            bool ok = hipEventRecord(e0, st) == hipSuccess;
+            for (int i = 0; i < reps && ok; i++) {
+                const uint4 *s = (const uint4 *)a;
+                uint4 *d = (uint4 *)b;
+                const size_t n = bytes / 16;
+                switch (form) {
+                case 0: ok = hipMemcpyAsync(b, a, bytes, hipMemcpyDeviceToDevice, st) == hipSuccess; break;
+                case 1: hipLaunchKernelGGL((copy_probe<1, false>), dim3(cus * 8), dim3(256), 0, st, s, d, n); break;
+                case 2: hipLaunchKernelGGL((copy_probe<4, false>), dim3(cus * 8), dim3(256), 0, st, s, d, n); break;
+                case 3: hipLaunchKernelGGL((copy_probe<8, false>), dim3(cus * 4), dim3(256), 0, st, s, d, n); break;
+                case 4: hipLaunchKernelGGL((copy_probe<4, true>), dim3(cus * 8), dim3(256), 0, st, s, d, n); break;
+                default: hipLaunchKernelGGL((copy_probe<8, true>), dim3(cus * 4), dim3(256), 0, st, s, d, n); break;
+                }
+            }
+            float ms = 0.f;
+            if (ok && hipEventRecord(e1, st) == hipSuccess && hipEventSynchronize(e1) == hipSuccess && hipEventElapsedTime(&ms, e0, e1) == hipSuccess &&
+                ms > 0.f) {
+                const double r = 2.0 * (double)bytes * reps / ((double)ms * 1e-3) / 1e9;
+                if (r > best) { best = r; g_copy_form = names[form]; }
+            }
+        }
+    }
+    if (st) (void)hipStreamSynchronize(st);
+    if (e0) (void)hipEventDestroy(e0);
+    if (e1) (void)hipEventDestroy(e1);
+    if (a) (void)hipFree(a);
+    if (b) (void)hipFree(b);
+    if (st) (void)hipStreamDestroy(st);
+    return best;
+}
+
+// ---- shader clock under load: one wave reads the shader-cycle counter (s_memtime) and the constant 100 MHz counter
+// (s_memrealtime) at both ends of a ~`micros` us sleep, on a stream of its own: clock = d(memtime) / d(memrealtime) x 100 MHz
+// (MI355X_MICROARCH.md, DVFS give-back item 6).  The stamps go to a buffer of their own; nothing else reads them.
+__global__ void clock_probe_kernel(unsigned long long *out, int rounds) {
+    const unsigned long long c0 = __builtin_amdgcn_s_memtime(), r0 = __builtin_amdgcn_s_memrealtime();
+    for (int i = 0; i < rounds; i++) __builtin_amdgcn_s_sleep(127); // 127 x 64 cycles each
+    const unsigned long long c1 = __builtin_amdgcn_s_memtime(), r1 = __builtin_amdgcn_s_memrealtime();
+    if (threadIdx.x == 0) {
+        out[0] = c1 - c0;
+        out[1] = r1 - r0;
+    }
+}
+extern "C" float mars_probe_clock_mhz(int micros) {
+    static hipStream_t st = nullptr;
+    static unsigned long long *dev = nullptr;
+    if (!st && hipStreamCreateWithFlags(&st, hipStreamNonBlocking) != hipSuccess) return -1.f;
+    if (!dev && hipMalloc((void **)&dev, 16) != hipSuccess) return -1.f;
+    const int rounds = micros > 0 ? micros / 4 + 1 : 64; // ~4 us per round at 2 GHz
+    hipLaunchKernelGGL(clock_probe_kernel, dim3(1), dim3(64), 0, st, dev, rounds);
+    unsigned long long h[2] = {0, 0};
+    if (hipMemcpyAsync(h, dev, 16, hipMemcpyDeviceToHost, st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess) return -1.f;
+    return h[1] ? (float)((double)h[0] / (double)h[1] * 100.0) : -1.f;
+}

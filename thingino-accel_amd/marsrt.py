@@ -115,8 +115,8 @@ EXPORTS = {
                    "mars_hip_load_memory_ex", "mars_hip_param_arena", "mars_yolo_parse_output", "mars_yolo_nms",
                    "mars_hip_detect", "mars_hip_detect_device", "mars_synth_model", "mars_hip_set_tuning", "mars_hip_autotune", "mars_yolo_letterbox",
                    "mars_hip_preprocess", "mars_hip_tensor_frame_bytes", "mars_hip_tensor_byte_size", "mars_hip_pipe_open",
-                   "mars_hip_pipe_input", "mars_hip_pipe_submit", "mars_hip_pipe_wait", "mars_hip_pipe_close", "mars_hip_clock_mhz", "mars_hip_set_output_mode",
-                   "mars_hip_get_tuning", "mars_hip_model_set_tuning", "mars_hip_model_get_tuning", "mars_hip_copy_rate_gbs"],
+                   "mars_hip_pipe_input", "mars_hip_pipe_submit", "mars_hip_pipe_wait", "mars_hip_pipe_close", "mars_hip_set_output_mode",
+                   "mars_hip_get_tuning", "mars_hip_model_set_tuning", "mars_hip_model_get_tuning"],
     "mars_compile.h": ["mars_compile_onnx", "mars_compile_file", "mars_compile_last_error"],
 }
 
@@ -172,16 +172,12 @@ def lib():
     L.mars_hip_pipe_close.argtypes = [P(MarsModel)]
     L.mars_hip_pipe_close.restype = None
     L.mars_hip_set_output_mode.argtypes = [P(MarsModel), C.c_int]
-    L.mars_hip_clock_mhz.argtypes = [C.c_int]
-    L.mars_hip_clock_mhz.restype = C.c_float
     for n in ("mars_hip_upload_inputs", "mars_hip_run_device", "mars_hip_run_device_async",
               "mars_hip_download_outputs", "mars_hip_get_batch", "mars_hip_num_ops"):
         getattr(L, n).argtypes = [P(MarsModel)]
     L.mars_hip_set_batch.argtypes = [P(MarsModel), C.c_int]
     L.mars_hip_set_fusion.argtypes = [P(MarsModel), C.c_int]
     L.mars_hip_set_tuning.argtypes = [C.c_char_p, C.c_int]
-    L.mars_hip_copy_rate_gbs.restype = C.c_double
-    L.mars_hip_copy_rate_gbs.argtypes = [C.c_size_t, C.c_int]
     L.mars_hip_get_tuning.argtypes = [C.c_char_p, P(C.c_int)]
     L.mars_hip_model_set_tuning.argtypes = [C.c_void_p, C.c_char_p, C.c_int]
     L.mars_hip_model_get_tuning.argtypes = [C.c_void_p, C.c_char_p, P(C.c_int)]

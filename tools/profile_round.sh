@@ -3,7 +3,7 @@
 #   tools/profile_round.sh TAG      -> gpurun_out/TAG_*  (copy what should be judged into profiles/)
 # rocprofv3 gets the interpreter directly after `--`; PMC passes are separate and carry no trace flags.
 set -e
-TAG=${1:-r03}
+TAG=${1:-r04}
 OUT=$PWD/gpurun_out
 mkdir -p $OUT
 W=2; K=4
@@ -27,12 +27,15 @@ python3 tools/mfma_busy.py $OUT/${TAG}_pmc_mfma $OUT/${TAG}_trace $((W + K)) > $
 # instruction mix per kernel symbol (vector and scalar instructions per MFMA)
 rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_MFMA SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_SMEM SQ_WAVES \
     --output-format csv -d $OUT/${TAG}_pmc_mix -o x -- python3 $BENCH > /dev/null 2> $OUT/${TAG}_pmc_mix.err
+rocprofv3 --pmc SQ_LDS_IDX_ACTIVE SQ_LDS_BANK_CONFLICT SQ_ACTIVE_INST_LDS --output-format csv -d $OUT/${TAG}_pmc_lds -o l -- python3 $BENCH > /dev/null 2> $OUT/${TAG}_pmc_lds.err
+python3 tools/inst_mix.py $OUT/${TAG}_pmc_mix $((W + K)) --json $OUT/${TAG}_inst_mix.json --lds $OUT/${TAG}_pmc_lds > /dev/null
+cp $OUT/${TAG}_inst_mix.json profiles/inst_mix.json  # bench.py reads it (hash-tied like pmc_traffic.json) for roofline.pipes
 { echo "# ${TAG}: instruction mix per convolution kernel symbol"; echo; echo "\`rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_MFMA SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_SMEM SQ_WAVES -- python3 $BENCH\` (tools/inst_mix.py; per step = per batch of 256 frames, every launch of the symbol summed)"; echo; python3 tools/inst_mix.py $OUT/${TAG}_pmc_mix $((W + K)); } > $OUT/${TAG}_deep_sq_counters.md
 find $OUT/${TAG}_trace -name '*kernel_stats.csv' -exec cp {} $OUT/${TAG}_bench_kernel_stats.csv \;
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/${TAG}_trace2 -o t -- python3 $BENCH2 > $OUT/${TAG}_two_streams_line_under_rocprof.json 2> $OUT/${TAG}_trace2.err
 find $OUT/${TAG}_trace2 -name '*kernel_stats.csv' -exec cp {} $OUT/${TAG}_two_streams_kernel_stats.csv \;
 find $OUT/${TAG}_trace2 -name '*kernel_trace.csv' -delete
-rm -rf $OUT/${TAG}_pmc_fetch $OUT/${TAG}_pmc_write $OUT/${TAG}_pmc_mfma $OUT/${TAG}_pmc_mix
+rm -rf $OUT/${TAG}_pmc_fetch $OUT/${TAG}_pmc_write $OUT/${TAG}_pmc_mfma $OUT/${TAG}_pmc_mix $OUT/${TAG}_pmc_lds
 find $OUT/${TAG}_trace -name '*kernel_trace.csv' -delete
 # un-profiled lines: per-launch table, config 3 and the 320x320 workloads WITH their CPU-baseline / bit-exact legs (shorter
 # sustained leg: these are secondary lines), the float32 workload (config 5), the default line last
