@@ -351,10 +351,11 @@ def test_config2_tiny160_batch64(gpu, orc):
         m.close()
 
 
-@pytest.mark.parametrize("mode", [2, 1])
+@pytest.mark.parametrize("mode", [3, 2, 1])
 def test_config5_yolov5s_f32_twin_640(gpu, orc, mode):
     """BASELINE config 5 at size: the yolov5s_float32 twin (width 8, NCHW/OIHW f32), 640x640, with the float32
-    convolutions on the f32 matrix cores -- everywhere (mode 2, what bench.py --dtype f32 measures) and under the
+    convolutions on the matrix cores -- everywhere on the bf16 cores with split operands (mode 3, conv_f32_split: what
+    bench.py --dtype f32 measures since round 4), everywhere on the f32 cores (mode 2) and under the
     default policy (mode 1: exact upstream of the byte-wise SPPF max-pools, matrix cores for the head).  One frame
     against the CPU oracle within north_star's tolerance |a-b| <= 1e-4*max(1,|b|) on all three heads; frames of a batch
     are independent bit for bit (same kernels, same order)."""
@@ -388,11 +389,51 @@ def test_config5_yolov5s_f32_twin_640(gpu, orc, mode):
         gpu.set_tuning("f32_mfma", 1)
 
 
+def test_config5_at_batch_256(gpu, orc):
+    """BASELINE config 5 AT ITS BATCH (verdict r3: the f32 tests ran at batch <= 3): the yolov5s_float32 twin, 640x640, 256
+    frames in one run -- i.e. the two-stream execution of the float kernels -- in mode 3 (split-bf16 matrix-core path, the
+    benchmark's).  Frames 0 and 255 against the CPU oracle within |a-b| <= 1e-4*max(1,|b|) on all three heads; frame 128 (the
+    first of the second stream's half) bit-identical to a batch-1 run of the same input."""
+    d = gpu.synth_model(width_x16=8, input_hw=640, seed=1, float32=True)
+    hdr, tensors, _ = marsfile.parse(d)
+    n = marsfile.tensor_nbytes(tensors[hdr["inputs"][0]]) // 4
+    B = 256
+    probe = {0: 0, 255: 1, 128: 2}
+    xs = [cases.f32(0x5EED0000 + 7 * k, n, 0.0, 1.0).view(np.uint8) for k in range(3)]
+    try:
+        gpu.set_tuning("f32_mfma", 3)
+        m = gpu.Model(d, batch=B)
+        iv = m.input_view(0)
+        for f in range(B):
+            iv[f] = xs[probe.get(f, f % 3)]
+        m.run()
+        outs = {f: [m.output_view(i)[f].copy() for i in range(3)] for f in probe}
+        m.close()
+        for f in (0, 255):
+            g, rc = run_oracle(orc, d, xs[probe[f]])
+            assert rc == 0
+            for i, ti in enumerate(hdr["outputs"]):
+                ok = close_f32(outs[f][i], g.tensor(ti))
+                a = outs[f][i].view(np.float32).astype(np.float64)
+                b = g.tensor(ti).view(np.float32).astype(np.float64)
+                assert ok.all(), "frame %d head %d: %d of %d values out of tolerance, worst %.3g" % (
+                    f, i, int((~ok).sum()), a.size, float(np.nanmax(np.abs(a - b) / np.maximum(1.0, np.abs(b)))))
+            g.close()
+        m1 = gpu.Model(d, batch=1)
+        m1.input_view(0)[0] = xs[probe[128]]
+        m1.run()
+        for i in range(3):
+            assert np.array_equal(m1.output_view(i)[0], outs[128][i])
+        m1.close()
+    finally:
+        gpu.set_tuning("f32_mfma", 1)
+
+
 @pytest.mark.parametrize("name,kw", [c for c in cases.SYNTH if c[1].get("float32")], ids=lambda v: v if isinstance(v, str) else "")
 def test_f32_matrix_core_path_within_tolerance(gpu, orc, name, kw):
-    """float32 convolutions on v_mfma_f32_16x16x4_f32 against the oracle, tensor by tensor (unfused plan), on the float
-    twins and the shipped tiny_160_f32.mars.
-    * matrix cores everywhere (mode 2): every float tensor written BEFORE the first byte-wise MAXPOOL / fused-ReLU clamp
+    """float32 convolutions on v_mfma_f32_16x16x4_f32 (modes 2 / 1) and on v_mfma_f32_16x16x32_bf16 with split operands (mode
+    3) against the oracle, tensor by tensor (unfused plan), on the float twins and the shipped tiny_160_f32.mars.
+    * matrix cores everywhere (modes 3 and 2): every float tensor written BEFORE the first byte-wise MAXPOOL / fused-ReLU clamp
       is within 1e-4 of the tensor's magnitude.  (Behind the SPPF pools the reference's byte-maxed floats reach 1e38 and cancel: any
       change of rounding there moves values by percents, in the reference's own terms too -- those tensors say nothing
       about a kernel; the full-size graph outputs are held to the bar by test_config5_yolov5s_f32_twin_640.)
@@ -414,7 +455,7 @@ def test_f32_matrix_core_path_within_tolerance(gpu, orc, name, kw):
                 break
             upstream += list(L["outs"])
         try:
-            for mode in (2, 1):
+            for mode in (3, 2, 1):
                 gpu.set_tuning("f32_mfma", mode)
                 m = gpu.Model(d, batch=2, fusion=0)
                 m.input_view(0)[0] = x

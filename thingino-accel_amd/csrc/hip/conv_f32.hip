@@ -16,8 +16,8 @@
 // Which form a layer gets is the host's decision (mars_model.c, plan_conv / f32_policy): a byte-wise MAXPOOL over float
 // bytes (reference mars_runtime.c:919-957 runs int8 byte logic whatever the dtype) is discontinuous in its input, so by
 // default every convolution UPSTREAM of such a pool stays exact and only the rest takes the matrix cores;
-// mars_hip_set_tuning("f32_mfma", 2) uses them everywhere (the config-5 benchmark: tolerance verified on its output),
-// 0 nowhere.
+// mars_hip_set_tuning("f32_mfma", 2) uses them everywhere (tolerance verified on the config-5 output), 0 nowhere; 3 (round 4) =
+// everywhere AND on the bf16 matrix cores with every operand split in three (conv_f32_split.hip): the config-5 benchmark.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <string.h>
@@ -216,14 +216,16 @@ __global__ __launch_bounds__(256) void conv_f32_mfma(const mhip_conv_f32_t p, co
     }
 }
 
+int conv_f32_try_split(const mhip_conv_f32_t *p); // conv_f32_split.hip: -2 = not a shape it takes
+
 static int g_f32_mode = -1; // -1: environment not read yet
 extern "C" int mhip_conv_f32_mode(int set) { // set >= 0: new mode; returns the mode in force
     if (g_f32_mode < 0) {
         const char *e = getenv("MARS_HIP_F32_MFMA");
         g_f32_mode = e ? atoi(e) : 1;
-        if (g_f32_mode < 0 || g_f32_mode > 2) g_f32_mode = 1;
+        if (g_f32_mode < 0 || g_f32_mode > 3) g_f32_mode = 1;
     }
-    if (set >= 0 && set <= 2) g_f32_mode = set;
+    if (set >= 0 && set <= 3) g_f32_mode = set;
     return g_f32_mode;
 }
 
@@ -234,6 +236,10 @@ extern "C" int mhip_conv_f32(const mhip_conv_f32_t *p) {
         return -1;
     if (p->out_c > 65535 || p->frames > 65535) return -1;
     const long hw = (long)p->out_h * p->out_w, total = hw * p->frames, K = (long)p->in_c * p->kh * p->kw;
+    if (p->use_mfma == 2) { // the bf16 matrix cores on split operands (conv_f32_split.hip)
+        const int rc = conv_f32_try_split(p);
+        if (rc != -2) return rc;
+    }
     if (p->use_mfma && total <= 0x7fffffffL - F_BN && K <= 0x7fffffffL - F_BK) {
         const unsigned npt = (unsigned)((total + F_BN - 1) / F_BN), noc = (unsigned)((p->out_c + F_BM - 1) / F_BM);
         if ((unsigned long long)npt * noc <= 0x7fffffffull) {

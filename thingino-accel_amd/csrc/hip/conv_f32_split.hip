@@ -1,0 +1,428 @@
+// conv_f32_split.hip -- float32 convolution (NCHW / OIHW, reference src/mars/mxu_conv.c:673-710) on the bf16 matrix cores
+// by operand splitting.  Round 4, verdict item 3; mhip_conv_f32_t.use_mfma == 2, tuning "f32_mfma" = 3.
+//
+// The f32-input MFMA (conv_f32.hip, v_mfma_f32_16x16x4_f32) runs at the f32 VECTOR rate, 1/16 of the bf16 matrix rate, and
+// gfx950 has no xf32: config 5 sat at 0.37 of a 157 TFLOP/s ceiling.  Here every float is cut, exactly, into three bf16
+// pieces by truncation,  x = hi + mid + lo  (hi = top 16 bits of x, mid = top 16 bits of x - hi, lo = x - hi - mid: 8 + 8 + 8
+// significant bits, every subtraction exact), and a product a * b is summed from the six piece products that carry more than
+// 2^-24 of it,  a.hi b.hi + (a.hi b.mid + a.mid b.hi) + (a.mid b.mid + a.hi b.lo + a.lo b.hi)  -- each exact in f32, added
+// into f32 accumulators by v_mfma_f32_16x16x32_bf16: six MFMAs at 16x the f32 rate = 2.7x the f32 matrix peak, with the
+// per-product error (the three dropped terms) below 2^-23 relative -- the size of one f32 rounding, inside north_star's 1e-4
+// tolerance, not bit-equal (like conv_f32_mfma; the exact-order kernel stays where a byte-wise consumer follows).
+//
+// Implicit GEMM  D[oc][pixel] = bias[oc] + sum_k W[oc][k] X[k][pixel],  k = (ic, ky, kx) in the reference's order.  Workgroup =
+// 512 threads = 8 waves; tile = BM output channels x 256 pixels (all frames flattened), K step = 32 taps.
+//  * weights: cut into their three planes ONCE, on the host at load time (mhip_conv_f32_split_pack: [plane][oc_pad][k_pad]
+//    bf16); a step's tile is three 16-byte copies per thread;
+//  * input: gathered through registers, split there (the vector instructions hide in the MFMAs' issue shadow) and written as
+//    K-contiguous bf16 rows -- the MFMA's fragment layout -- into the three planes of the LDS tile.  What bounded the first
+//    version was the gather itself: one dword per lane and tap = 128 wave-loads per step through the texture addresser, ~12
+//    vector instructions per element (440 per wave and step against 96 MFMAs).  So: 16-BYTE loads.  Stride 1 (GATHER 1): a
+//    lane owns 4 consecutive pixels of a map row and loads them for one tap in one instruction; stride 2 (GATHER 2): a lane
+//    owns 2 pixels and a load brings taps (kx, kx + 1) of both -- kernel rows are padded to an even length there (one zero
+//    weight column).  A tap left of the image (pad 1) loads one element further right and shifts; columns outside the image
+//    are masked by a per-lane bit table, rows outside by an out-of-range offset the buffer unit turns into zeros.  GATHER 0
+//    (any other geometry): one dword per tap.
+//  * LDS: A rows as in the int8 kernels (64-byte rows, chunk swizzle).  B rows (pixels) are dealt over four 64-row blocks
+//    (pixel r -> block r % 4, row r / 4) with the 16-byte chunk XOR-ed by (block ^ row / 4 % 4): the 4-pixel-per-lane
+//    writes, the pixel-per-lane writes and the 16-pixel fragment reads are all bank-conflict free.
+//  * two stages, two register sets: step ks + 2's loads are in flight while step ks multiplies and step ks + 1's operands
+//    are split and written (sched_group_barrier interleaves them with the MFMAs).
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include "../expf_exact.h"
+#include "../mhip.h"
+
+extern "C" hipStream_t mhip_stream_native(void);
+extern "C" int mhip_check(hipError_t e, const char *what);
+
+typedef float v4f __attribute__((ext_vector_type(4)));
+typedef int v4i __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+
+#define S_BN 256  // pixels per workgroup
+#define S_BK 32   // taps per K step = one v_mfma_f32_16x16x32_bf16
+#define S_NT 512
+
+__device__ __forceinline__ float silu_split(float v) { // as conv_f32.hip: the exporter's SiLU with the reference's roundings
+    const float s = 1.0f / (1.0f + expf_exact(-v, expf_exact_tab));
+    return v * s;
+}
+__device__ __forceinline__ int a_lds_off(int row, int chunk) { return row * 64 + ((chunk ^ ((row >> 1) & 2)) << 4); }
+__device__ __forceinline__ int b_lds_off(int r, int chunk) { // pixel r of the tile, 16-byte chunk (8 taps) of its 64-byte row
+    return ((((r & 3) << 6) + (r >> 2)) << 6) + (((chunk ^ r ^ (r >> 4)) & 3) << 4);
+}
+
+struct sdiv_t {
+    unsigned m, s1, s2;
+};
+__device__ __forceinline__ unsigned sdiv(unsigned n, const sdiv_t d) {
+    const unsigned q = __umulhi(d.m, n);
+    return (q + ((n - q) >> d.s1)) >> d.s2;
+}
+static sdiv_t make_sdiv(unsigned d) {
+    sdiv_t r;
+    unsigned l = 0;
+    while ((1ull << l) < d) l++;
+    r.m = (unsigned)(((1ull << 32) * ((1ull << l) - d)) / d + 1);
+    r.s1 = l < 1 ? l : 1;
+    r.s2 = l > 0 ? l - 1 : 0;
+    return r;
+}
+
+// N floats -> N bf16 in each of the three planes (N / 2 dwords each), truncation split: x == hi + mid + lo exactly
+template <int N>
+__device__ __forceinline__ void splitn(const float (&x)[N], int (&hi)[N / 2], int (&mid)[N / 2], int (&lo)[N / 2]) {
+    uint32_t xb[N], r1[N], r2[N];
+#pragma unroll
+    for (int i = 0; i < N; i++) {
+        xb[i] = __float_as_uint(x[i]);
+        const float a = x[i] - __uint_as_float(xb[i] & 0xffff0000u); // exact: the low 16 significant bits
+        r1[i] = __float_as_uint(a);
+        r2[i] = __float_as_uint(a - __uint_as_float(r1[i] & 0xffff0000u)); // exact: at most 8 significant bits, a bf16 value
+    }
+#pragma unroll
+    for (int i = 0; i < N / 2; i++) { // top halves of (element 2i, element 2i + 1) -> one dword, element 2i in the low half
+        hi[i] = (int)__builtin_amdgcn_perm(xb[2 * i + 1], xb[2 * i], 0x07060302u);
+        mid[i] = (int)__builtin_amdgcn_perm(r1[2 * i + 1], r1[2 * i], 0x07060302u);
+        lo[i] = (int)__builtin_amdgcn_perm(r2[2 * i + 1], r2[2 * i], 0x07060302u);
+    }
+}
+
+struct split_args_t {
+    unsigned total_pix, npt, in_bytes;
+    int K;       // taps in the packed K space (kernel rows padded to kwp)
+    int kp;      // row length of the weight planes (bf16 elements): K rounded up to 64, + 64 of slack (the loop fetches two steps ahead)
+    int nks;     // K steps: roundup64(K) / 32 (even)
+    int kwp;     // kernel row length in the packed K space (kw, or kw + 1 for GATHER 2 with an odd kw)
+    int oc_pad;  // rows of a weight plane
+    sdiv_t dhw, dow, dtaps, dkwp;
+};
+
+// BM = output channels per workgroup (128 | 64 | 32); waves: WM along channels x WN along pixels, WM * WN == 8
+template <int BM, int WM, int WN, int GATHER, int NPROD = 6>
+__global__ __launch_bounds__(S_NT) void conv_f32_split(const mhip_conv_f32_t p, const split_args_t g) {
+    constexpr int TM = BM / WM, TN = S_BN / WN; // wave tile
+    constexpr int MI = TM / 16, NI = TN / 16;   // MFMA tiles per wave
+    constexpr int APLANE = BM * 64, BPLANE = S_BN * 64;
+    constexpr int STAGE = 3 * (APLANE + BPLANE);
+    constexpr int AE = BM * S_BK / S_NT;        // weight elements per thread, plane and step: 8 | 4 | 2 consecutive taps of one row
+    constexpr int ATPR = S_BK / AE;             // threads per weight row
+    constexpr int AD = AE / 2;                  // ... in dwords
+    extern __shared__ __attribute__((aligned(16))) int8_t lds[];
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wv % WM, wn = wv / WM;
+    const unsigned pt = blockIdx.x % g.npt, ot = blockIdx.x / g.npt;
+    const unsigned p0 = pt * S_BN;
+    const int oc0 = (int)ot * BM;
+    const unsigned hw = (unsigned)(p.out_h * p.out_w);
+    const int K = g.K, kwp = g.kwp;
+    const int taps = p.kh * kwp;
+    const int plane = p.in_h * p.in_w;
+    const __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc((void *)p.in, 0, (int)g.in_bytes, 0x00020000);
+
+    // ---- this thread's share of the input gather: PPL consecutive pixels of one map row, TPL taps per step
+    constexpr int PPL = GATHER == 1 ? 4 : (GATHER == 2 ? 2 : 1); // pixels per lane
+    constexpr int TPL = 16 / PPL;                                 // taps per lane and step
+    const int pl_ = tid % (S_BN / PPL);                           // pixel group inside the tile
+    const int tg = __builtin_amdgcn_readfirstlane(tid / (S_BN / PPL)); // tap group (wave-uniform): taps tg * TPL .. of the step
+    unsigned vbase;     // byte offset of the window origin (channel 0) of the lane's FIRST pixel; "negative" values wrap
+    unsigned rowbits = 0, colbits = 0; // kernel rows inside the image; (tap column, element) pairs inside the image
+    int ix0;
+    {
+        const unsigned px = p0 + (unsigned)(pl_ * PPL);
+        const bool valid = px < g.total_pix; // (GATHER 1 / 2: out_w % PPL == 0, so the lane's pixels share row, frame and validity)
+        const unsigned f = sdiv(valid ? px : 0u, g.dhw), rem = (valid ? px : 0u) - f * hw;
+        const int oy = (int)sdiv(rem, g.dow), ox = (int)rem - oy * p.out_w;
+        const int iy0 = oy * p.stride_h - p.pad_top;
+        ix0 = ox * p.stride_w - p.pad_left;
+        vbase = (unsigned)(f * (unsigned)p.in_stride) + (unsigned)((iy0 * p.in_w + ix0) * 4);
+        if (valid)
+            for (int ky = 0; ky < p.kh; ky++)
+                if ((unsigned)(iy0 + ky) < (unsigned)p.in_h) rowbits |= 1u << ky;
+        if (GATHER == 0) {
+            for (int kx = 0; kx < kwp; kx++)
+                if (kx < p.kw && (unsigned)(ix0 + kx) < (unsigned)p.in_w) colbits |= 1u << kx;
+        } else if (GATHER == 1) { // element i of the load for tap column kx = pixel i: column ix0 + i + kx
+            for (int kx = 0; kx < p.kw; kx++)
+                for (int i = 0; i < 4; i++)
+                    if ((unsigned)(ix0 + i + kx) < (unsigned)p.in_w) colbits |= 1u << (kx * 4 + i);
+        } else { // element i of the load for tap columns (kx, kx + 1), kx even: pixel i / 2, tap kx + i % 2: column ix0 + 2 (i / 2) + kx + i % 2
+            for (int kx = 0; kx < kwp; kx += 2)
+                for (int i = 0; i < 4; i++)
+                    if (kx + (i & 1) < p.kw && (unsigned)(ix0 + 2 * (i >> 1) + kx + (i & 1)) < (unsigned)p.in_w) colbits |= 1u << ((kx >> 1) * 4 + i);
+        }
+    }
+    // weights: row oc0 + tid / ATPR of every plane, taps (tid % ATPR) * AE .. + AE - 1 of the step
+    const int arow = tid / ATPR, akc = (tid % ATPR) * AE;
+    const int8_t *wrow = (const int8_t *)p.w_split + ((size_t)(oc0 + arow) * g.kp + akc) * 2;
+    const size_t wplane = (size_t)g.oc_pad * g.kp * 2;
+
+    float bregs[2][16];
+    int aregs[2][3][AD];
+    auto fetch = [&](int ks, float (&breg)[16], int (&areg)[3][AD]) __attribute__((always_inline)) {
+        // the lane's taps of this step: (ic, ky, kx) carried from the first one (wave-uniform: scalar registers)
+        const int k0 = ks * S_BK + tg * TPL;
+        int ic = (int)sdiv((unsigned)(k0 < K ? k0 : 0), g.dtaps);
+        const int t0 = (k0 < K ? k0 : 0) - ic * taps;
+        int ky = (int)sdiv((unsigned)t0, g.dkwp), kx = t0 - ky * kwp;
+        int soff = (ic * plane + ky * p.in_w + kx) * 4; // byte offset of tap (ic, ky, kx) relative to the window origin
+        constexpr int STEP = GATHER == 2 ? 2 : 1;       // taps per load
+#pragma unroll
+        for (int j = 0; j < TPL / STEP; j++) {
+            const bool kok = k0 + j * STEP < K;
+            const bool rowok = kok && ((rowbits >> ky) & 1u) != 0u;
+            if (GATHER == 0) {
+                const bool ok = rowok && ((colbits >> kx) & 1u) != 0u;
+                // (the per-lane part alone may be "negative" -- first row / column of frame 0 -- and a vector offset beyond the
+                // range reads zero whatever a scalar offset would add: the sum goes into the vector offset)
+                breg[j] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(xrs, ok ? vbase + (unsigned)soff : 0xffffffffu, 0, 0));
+            } else {
+                const bool lsh = ix0 + kx < 0; // the load would start left of the image (pad 1, first group of a row): start one
+                                               // element later and shift -- the element shifted in is masked below anyway
+                const v4i v = __builtin_bit_cast(v4i, __builtin_amdgcn_raw_buffer_load_b128(xrs, rowok ? vbase + (unsigned)soff + (lsh ? 4u : 0u) : 0xffffffffu, 0, 0));
+                const unsigned bits = colbits >> ((GATHER == 2 ? (kx >> 1) : kx) * 4);
+                int e[4] = {v[0], v[1], v[2], v[3]};
+                if (kx < p.pad_left) { // wave-uniform: only such taps can start left of the image
+                    e[3] = lsh ? v[2] : v[3]; e[2] = lsh ? v[1] : v[2]; e[1] = lsh ? v[0] : v[1];
+                }
+#pragma unroll
+                for (int i = 0; i < 4; i++) breg[j * 4 + i] = __builtin_bit_cast(float, (bits >> i) & 1u ? e[i] : 0);
+            }
+            kx += STEP; soff += 4 * STEP;
+            if (kx >= kwp) {
+                kx = 0; ky++; soff += (p.in_w - kwp) * 4;
+                if (ky == p.kh) { ky = 0; ic++; soff += (plane - p.kh * p.in_w) * 4; }
+            }
+        }
+#pragma unroll
+        for (int pl = 0; pl < 3; pl++) {
+            const int8_t *src = wrow + pl * wplane + (size_t)ks * (S_BK * 2);
+            if (AE == 8) { const v4i t = *(const v4i *)src; areg[pl][0] = t[0]; areg[pl][1 % AD] = t[1]; areg[pl][2 % AD] = t[2]; areg[pl][3 % AD] = t[3]; }
+            else if (AE == 4) { const int2 t = *(const int2 *)src; areg[pl][0] = t.x; areg[pl][1 % AD] = t.y; }
+            else areg[pl][0] = *(const int *)src;
+        }
+    };
+    auto commit = [&](int buf, const float (&breg)[16], const int (&areg)[3][AD]) __attribute__((always_inline)) {
+        int8_t *st = lds + buf * STAGE;
+        int8_t *bp = st + 3 * APLANE;
+        if (GATHER == 1) { // pixel i of the lane: taps tg * 4 .. + 3 = half a chunk
+#pragma unroll
+            for (int i = 0; i < 4; i++) {
+                const float x[4] = {breg[i], breg[4 + i], breg[8 + i], breg[12 + i]};
+                int hi[2], mid[2], lo[2];
+                splitn<4>(x, hi, mid, lo);
+                const int off = b_lds_off(pl_ * 4 + i, tg >> 1) + (tg & 1) * 8;
+                *(int2 *)(bp + off) = make_int2(hi[0], hi[1]);
+                *(int2 *)(bp + BPLANE + off) = make_int2(mid[0], mid[1]);
+                *(int2 *)(bp + 2 * BPLANE + off) = make_int2(lo[0], lo[1]);
+            }
+        } else if (GATHER == 2) { // pixel q of the lane: taps tg * 8 .. + 7 = one chunk; load j holds (q, tap 2j) at 2q, (q, 2j + 1) at 2q + 1
+#pragma unroll
+            for (int q = 0; q < 2; q++) {
+                const float x[8] = {breg[2 * q], breg[2 * q + 1], breg[4 + 2 * q], breg[5 + 2 * q], breg[8 + 2 * q], breg[9 + 2 * q], breg[12 + 2 * q], breg[13 + 2 * q]};
+                int hi[4], mid[4], lo[4];
+                splitn<8>(x, hi, mid, lo);
+                const int off = b_lds_off(pl_ * 2 + q, tg);
+                *(v4i *)(bp + off) = (v4i){hi[0], hi[1], hi[2], hi[3]};
+                *(v4i *)(bp + BPLANE + off) = (v4i){mid[0], mid[1], mid[2], mid[3]};
+                *(v4i *)(bp + 2 * BPLANE + off) = (v4i){lo[0], lo[1], lo[2], lo[3]};
+            }
+        } else { // one pixel, taps tg * 16 .. + 15 = two chunks
+#pragma unroll
+            for (int h = 0; h < 2; h++) {
+                const float x[8] = {breg[8 * h], breg[8 * h + 1], breg[8 * h + 2], breg[8 * h + 3], breg[8 * h + 4], breg[8 * h + 5], breg[8 * h + 6], breg[8 * h + 7]};
+                int hi[4], mid[4], lo[4];
+                splitn<8>(x, hi, mid, lo);
+                const int off = b_lds_off(pl_, tg * 2 + h);
+                *(v4i *)(bp + off) = (v4i){hi[0], hi[1], hi[2], hi[3]};
+                *(v4i *)(bp + BPLANE + off) = (v4i){mid[0], mid[1], mid[2], mid[3]};
+                *(v4i *)(bp + 2 * BPLANE + off) = (v4i){lo[0], lo[1], lo[2], lo[3]};
+            }
+        }
+        const int aoff = a_lds_off(arow, akc >> 3) + (akc & 7) * 2; // AE bf16 = AE * 2 bytes inside the 16-byte chunk
+#pragma unroll
+        for (int pl = 0; pl < 3; pl++) {
+            if (AE == 8) *(v4i *)(st + pl * APLANE + aoff) = (v4i){areg[pl][0], areg[pl][1 % AD], areg[pl][2 % AD], areg[pl][3 % AD]};
+            else if (AE == 4) *(int2 *)(st + pl * APLANE + aoff) = make_int2(areg[pl][0], areg[pl][1 % AD]);
+            else *(int *)(st + pl * APLANE + aoff) = areg[pl][0];
+        }
+    };
+
+    // accumulators start at the bias: lane holds channels 4 * (lane / 16) + j of an MFMA tile, pixel lane % 16
+    const int fr = lane & 15, fc = lane >> 4;
+    v4f acc[MI][NI];
+#pragma unroll
+    for (int a = 0; a < MI; a++) {
+        v4f b = {0.f, 0.f, 0.f, 0.f};
+        if (p.bias) {
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                const int oc = oc0 + wm * TM + a * 16 + fc * 4 + j;
+                b[j] = oc < p.out_c ? p.bias[oc] : 0.f;
+            }
+        }
+#pragma unroll
+        for (int c = 0; c < NI; c++) acc[a][c] = b;
+    }
+
+    // one K step: the MFMAs of LDS stage `buf`, and the operands in (breg, areg) split into the other stage (last read in the
+    // previous step, every wave is past that step's barrier; after the last step it receives stale registers nobody reads --
+    // unconditional, so that it shares the MFMAs' basic block and the scheduler can interleave the two)
+    auto step = [&](int buf, const float (&breg)[16], const int (&areg)[3][AD]) __attribute__((always_inline)) {
+        const int8_t *ap = lds + buf * STAGE, *bp = ap + 3 * APLANE;
+        bf16x8 af[3][MI], bf[3][NI];
+#pragma unroll
+        for (int a = 0; a < MI; a++)
+#pragma unroll
+            for (int pl = 0; pl < 3; pl++)
+                af[pl][a] = __builtin_bit_cast(bf16x8, *(const v4i *)(ap + pl * APLANE + a_lds_off(wm * TM + a * 16 + fr, fc)));
+#pragma unroll
+        for (int pl = 0; pl < 3; pl++)
+#pragma unroll
+            for (int c = 0; c < NI; c++) bf[pl][c] = __builtin_bit_cast(bf16x8, *(const v4i *)(bp + pl * BPLANE + b_lds_off(wn * TN + c * 16 + fr, fc)));
+        // six piece products per product, smallest terms first
+#pragma unroll
+        for (int a = 0; a < MI; a++)
+#pragma unroll
+            for (int c = 0; c < NI; c++) {
+                if (NPROD >= 6) {
+                    acc[a][c] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[2][a], bf[0][c], acc[a][c], 0, 0, 0); // lo * hi
+                    acc[a][c] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[0][a], bf[2][c], acc[a][c], 0, 0, 0); // hi * lo
+                }
+                if (NPROD >= 4) acc[a][c] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[1][a], bf[1][c], acc[a][c], 0, 0, 0); // mid * mid
+                acc[a][c] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[0][a], bf[1][c], acc[a][c], 0, 0, 0); // hi * mid
+                acc[a][c] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[1][a], bf[0][c], acc[a][c], 0, 0, 0); // mid * hi
+                acc[a][c] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[0][a], bf[0][c], acc[a][c], 0, 0, 0); // hi * hi
+            }
+        commit(buf ^ 1, breg, areg);
+#pragma unroll
+        for (int i = 0; i < MI * NI * NPROD; i++) { // issue order: every MFMA followed by what fits in its shadow
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); // MFMA
+            __builtin_amdgcn_sched_group_barrier(0x002, 2, 0); // VALU
+            if ((i & 7) == 7) __builtin_amdgcn_sched_group_barrier(0x200, 1, 0); // a DS write now and then
+        }
+        // the stage just written is visible, the stage just read is free: LDS operations only.  NOT __syncthreads(): it waits
+        // vmcnt(0) as well, i.e. for the loads of step ks + 2 issued a moment ago -- a full memory latency per K step (5600
+        // cycles per step whatever the MFMA count: 899 / 761 / 729 us with 6 / 4 / 3 piece products); the compiler's own
+        // counted vmcnt wait sits where those registers are first used, one step later
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+    };
+
+    const int nks = g.nks;
+    fetch(0, bregs[0], aregs[0]);
+    commit(0, bregs[0], aregs[0]);
+    fetch(1, bregs[1], aregs[1]);
+    __syncthreads();
+    // nks is even (the weight planes' rows are padded to 64 taps): two steps per iteration, no exit in between -- with a
+    // `break` after the first step the compiler lost count of the loads in flight at the loop's merge points and waited
+    // vmcnt(0..3) right behind every fetch, i.e. for the loads it had just issued
+    for (int ks = 0; ks < nks; ks += 2) {
+        fetch(ks + 2, bregs[0], aregs[0]); // (past the last step: taps beyond K load zeros, the weight rows' padding is zero)
+        step(0, bregs[1], aregs[1]);
+        fetch(ks + 3, bregs[1], aregs[1]);
+        step(1, bregs[0], aregs[0]);
+    }
+    // store: 16 lanes write 16 consecutive floats of one channel row
+#pragma unroll
+    for (int c = 0; c < NI; c++) {
+        const unsigned px = p0 + (unsigned)(wn * TN + c * 16 + fr);
+        if (px >= g.total_pix) continue;
+        const unsigned f = sdiv(px, g.dhw), rem = px - f * hw;
+        float *out = (float *)((char *)p.out + (size_t)f * p.out_stride);
+#pragma unroll
+        for (int a = 0; a < MI; a++)
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                const int oc = oc0 + wm * TM + a * 16 + fc * 4 + j;
+                if (oc < p.out_c) out[(size_t)oc * hw + rem] = p.silu ? silu_split(acc[a][c][j]) : acc[a][c][j];
+            }
+    }
+}
+
+// kernel row length in the packed K space: an odd kernel width under stride 2 gets one zero column (taps come in pairs there)
+static int split_kwp(int kw, int stride_w) { return stride_w == 2 && kw > 1 && (kw & 1) ? kw + 1 : kw; }
+
+template <int BM, int WM, int WN, int GATHER, int NPROD = 6>
+static int launch_split(const mhip_conv_f32_t *p, split_args_t g) {
+    auto kern = conv_f32_split<BM, WM, WN, GATHER, NPROD>;
+    const size_t ldsb = 2 * 3 * (size_t)(BM * 64 + S_BN * 64);
+    static bool attr = false;
+    if (!attr && hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsb) != hipSuccess)
+        return mhip_check(hipErrorUnknown, "conv_f32_split LDS attribute");
+    attr = true;
+    const unsigned noc = (unsigned)((p->out_c + BM - 1) / BM);
+    if ((unsigned long long)g.npt * noc > 0x7fffffffull) return -2;
+    hipLaunchKernelGGL(kern, dim3(g.npt * noc), dim3(S_NT), ldsb, mhip_stream_native(), *p, g);
+    return mhip_check(hipGetLastError(), "conv_f32_split");
+}
+template <int GATHER>
+static int launch_split_bm(const mhip_conv_f32_t *p, const split_args_t &g) {
+    // MARS_HIP_F32_NPROD=4 | 3 (experiments; 128-channel tiles, stride 1): drop the three / two smallest piece products.  Measured on the
+    // config-5 twin: 4913 / 5145 / 5210 img/s and 3.7e-7 / 2.2e-6 / 3.7e-6 worst relative error with 6 / 4 / 3 -- the default stays 6
+    static const int nprod = getenv("MARS_HIP_F32_NPROD") ? atoi(getenv("MARS_HIP_F32_NPROD")) : 6;
+    if (GATHER == 1 && p->out_c > 64 && nprod == 4) return launch_split<128, 2, 4, GATHER, 4>(p, g);
+    if (GATHER == 1 && p->out_c > 64 && nprod == 3) return launch_split<128, 2, 4, GATHER, 3>(p, g);
+    if (p->out_c > 64) return launch_split<128, 2, 4, GATHER>(p, g);
+    if (p->out_c > 32) return launch_split<64, 1, 8, GATHER>(p, g);
+    return launch_split<32, 1, 8, GATHER>(p, g);
+}
+
+// -2: not a shape this kernel takes (the caller falls back to conv_f32_mfma), else the launch result
+int conv_f32_try_split(const mhip_conv_f32_t *p) {
+    if (!p->w_split) return -2;
+    const long hw = (long)p->out_h * p->out_w, total = hw * p->frames;
+    const int kwp = split_kwp(p->kw, p->stride_w);
+    const long K = (long)p->in_c * p->kh * kwp;
+    const size_t in_bytes = (size_t)(p->frames - 1) * p->in_stride + (size_t)p->in_c * p->in_h * p->in_w * 4;
+    // 32-bit buffer offsets over the whole input (all frames); validity bit tables per kernel row / column
+    if (total > 0x7fffffffL - S_BN || K > 0x7fffffffL - S_BK || in_bytes > 0xfffffff0ull || p->kh > 32 || kwp > 32) return -2;
+    split_args_t g;
+    g.total_pix = (unsigned)total; g.npt = (unsigned)((total + S_BN - 1) / S_BN); g.in_bytes = (unsigned)in_bytes;
+    g.K = (int)K; g.kp = (int)((K + 63) / 64 * 64) + 64; g.nks = (g.kp - 64) / 32; g.kwp = kwp; g.oc_pad = (p->out_c + 127) / 128 * 128;
+    g.dhw = make_sdiv((unsigned)hw); g.dow = make_sdiv((unsigned)p->out_w); g.dtaps = make_sdiv((unsigned)(p->kh * kwp)); g.dkwp = make_sdiv((unsigned)kwp);
+    // 16-byte gathers: 4 pixels x 1 tap (stride 1) or 2 pixels x 2 taps (stride 2) per load; pixel groups must not cross map rows
+    if (p->stride_w == 1 && p->out_w % 4 == 0 && p->pad_left <= 1 && p->kw <= 8 && p->in_w >= 4) return launch_split_bm<1>(p, g);
+    if (p->stride_w == 2 && p->out_w % 2 == 0 && p->pad_left <= 1 && kwp % 2 == 0 && kwp <= 16 && p->in_w >= 4) return launch_split_bm<2>(p, g);
+    if (kwp != p->kw) return -2; // (the padded K space is GATHER 2's; nothing else reads it)
+    return launch_split_bm<0>(p, g);
+}
+
+extern "C" size_t mhip_conv_f32_split_pack(int out_c, int in_c, int kh, int kw, int stride_w, const float *w, void *out) {
+    if (out_c <= 0 || in_c <= 0 || kh <= 0 || kw <= 0) return 0;
+    const int kwp = split_kwp(kw, stride_w);
+    const size_t K = (size_t)in_c * kh * kwp, kp = (K + 63) / 64 * 64 + 64, ocp = ((size_t)out_c + 127) / 128 * 128;
+    const size_t bytes = 3 * ocp * kp * 2;
+    if (!w || !out) return bytes;
+    uint16_t *o = (uint16_t *)out;
+    memset(o, 0, bytes);
+    for (int oc = 0; oc < out_c; oc++)
+        for (int ic = 0; ic < in_c; ic++)
+            for (int ky = 0; ky < kh; ky++)
+                for (int kx = 0; kx < kw; kx++) {
+                    const float x = w[((size_t)(oc * (size_t)in_c + ic) * kh + ky) * kw + kx];
+                    uint32_t xb, r1b, r2b;
+                    memcpy(&xb, &x, 4);
+                    const uint32_t hb = xb & 0xffff0000u;
+                    float h, m;
+                    memcpy(&h, &hb, 4);
+                    const float r1 = x - h; // exact
+                    memcpy(&r1b, &r1, 4);
+                    const uint32_t mb = r1b & 0xffff0000u;
+                    memcpy(&m, &mb, 4);
+                    const float r2 = r1 - m; // exact, a bf16 value
+                    memcpy(&r2b, &r2, 4);
+                    const size_t k = ((size_t)ic * kh + ky) * kwp + kx;
+                    o[(size_t)oc * kp + k] = (uint16_t)(xb >> 16);
+                    o[ocp * kp + (size_t)oc * kp + k] = (uint16_t)(r1b >> 16);
+                    o[2 * ocp * kp + (size_t)oc * kp + k] = (uint16_t)(r2b >> 16);
+                }
+    return bytes;
+}

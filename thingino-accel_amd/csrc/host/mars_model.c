@@ -330,6 +330,15 @@ static void plan_conv(mars_model_ext_t *m, int li) {
         op->w_off = arena_reserve(m, wcount * 4);
         if (op->w_off == NO_OFF) return;
         if (!m->deferred) blob_read(m, (size_t)w->data_offset, wcount * 4, m->arena_host + op->w_off);
+        { /* the same weights cut into three bf16 planes for the split-operand matrix-core kernel (conv_f32_split.hip, f32_mfma = 3) */
+            const size_t n2 = mhip_conv_f32_split_pack(out_c, in_c, kh, kw, sw, NULL, NULL);
+            if (n2) {
+                op->w2_off = arena_reserve(m, n2);
+                if (op->w2_off == NO_OFF) return;
+                if (!m->deferred)
+                    mhip_conv_f32_split_pack(out_c, in_c, kh, kw, sw, (const float *)(m->arena_host + op->w_off), m->arena_host + op->w2_off);
+            }
+        }
         if (tb >= 0) {
             op->b_off = arena_reserve(m, (size_t)out_c * 4);
             if (op->b_off != NO_OFF && !m->deferred)
@@ -1594,6 +1603,7 @@ static int launch_op(mars_model_ext_t *m, mars_op_t *op) {
             p.in = (const float *)tdev(m, op->t_in[0]); p.in_stride = tstride(m, op->t_in[0]);
             p.out = (float *)tdev(m, op->t_out); p.out_stride = tstride(m, op->t_out);
             p.w = (const float *)(A + op->w_off);
+            p.w_split = op->w2_off != NO_OFF ? (const void *)(A + op->w2_off) : NULL;
             p.bias = op->b_off != NO_OFF ? (const float *)(A + op->b_off) : NULL;
             p.frames = B;
             p.in_h = op->in_h; p.in_w = op->in_w; p.in_c = op->in_c;
@@ -1602,7 +1612,7 @@ static int launch_op(mars_model_ext_t *m, mars_op_t *op) {
             p.silu = op->silu_f32;
             {
                 const int mode = mhip_conv_f32_mode(-1);
-                p.use_mfma = mode == 2 || (mode == 1 && !op->f32_exact);
+                p.use_mfma = mode == 3 ? 2 : (mode == 2 || (mode == 1 && !op->f32_exact));
             }
             return mhip_conv_f32(&p);
         }
@@ -2054,9 +2064,9 @@ static int tune_raw(const char *key, int value, int *get) {
             *tab[i].v = value;
             return 0;
         }
-    if (!strcmp(key, "f32_mfma")) { /* 0 exact everywhere, 1 matrix cores where provably safe (default), 2 everywhere */
+    if (!strcmp(key, "f32_mfma")) { /* 0 exact everywhere, 1 matrix cores where provably safe (default), 2 everywhere, 3 everywhere + split bf16 */
         if (get) { *get = mhip_conv_f32_mode(-1); return 0; }
-        if (value < 0 || value > 2) return -1;
+        if (value < 0 || value > 3) return -1;
         mhip_conv_f32_mode(value);
         return 0;
     }

@@ -136,15 +136,24 @@ typedef struct {
     const float *in;  size_t in_stride;
     float *out;       size_t out_stride;
     const float *w;   const float *bias;
+    const void *w_split; /* optional: the weights cut into three bf16 planes (mhip_conv_f32_split_pack): conv_f32_split needs it */
     int frames;
     int in_h, in_w, in_c, out_h, out_w, out_c;
     int kh, kw, stride_h, stride_w, pad_top, pad_left;
     int silu;     /* fused conv -> SIGMOID -> MUL chain (float forms): out = v * (1 / (1 + expf(-v))), libm-exact expf */
     int use_mfma; /* 0: reference summation order, bit-identical; 1: implicit GEMM on v_mfma_f32_16x16x4_f32 (fused
-                     rounding per tap: inside the 1e-4 tolerance of the float32 models, not bit-equal) */
+                     rounding per tap: inside the 1e-4 tolerance of the float32 models, not bit-equal); 2: implicit GEMM on
+                     v_mfma_f32_16x16x32_bf16 with every operand split into three bf16 pieces, six piece products per
+                     product (conv_f32_split.hip: same tolerance class, 2.7x the f32 matrix peak) */
 } mhip_conv_f32_t;
 int mhip_conv_f32(const mhip_conv_f32_t *p);
-/* policy knob: 0 never the matrix cores, 1 (default) wherever the host proves it safe, 2 everywhere.  set < 0 only
+/* Bytes of, and (out != NULL) the content of, the weight image conv_f32_split reads: three planes (hi, mid, lo) of bf16
+ * [oc_pad][k_pad] -- oc_pad = roundup128(out_c), k_pad = roundup64(K') + 64, zero filled -- with w = hi + mid + lo exactly
+ * (truncation split).  K' = in_c * kh * kw, or in_c * kh * (kw + 1) for stride_w == 2 with an odd kw (one zero column
+ * appended to every kernel row: taps come in pairs there). */
+size_t mhip_conv_f32_split_pack(int out_c, int in_c, int kh, int kw, int stride_w, const float *w, void *out);
+/* policy knob: 0 never the matrix cores, 1 (default) wherever the host proves it safe, 2 everywhere, 3 everywhere on the
+ * bf16 matrix cores with split operands.  set < 0 only
  * reads; returns the mode in force (first call reads MARS_HIP_F32_MFMA) */
 int mhip_conv_f32_mode(int set);
 

@@ -43,6 +43,25 @@ LAYERS = {  # yolov5s twin at 640 x 640: h, w, in_c, out_c, k, stride, fused Add
 }
 
 
+def build_f32(h, w, ic, oc, k, s):
+    """the float32 form of the same layer: NCHW / OIHW float32 convolution + SIGMOID + MUL (folded into the conv's epilogue)"""
+    G = marsfile.Graph()
+    rng = np.random.default_rng(1)
+    F, N = marsfile.F32, marsfile.NCHW
+    x = G.tensor([1, ic, h, w], dtype=F, fmt=N)
+    oh, ow = (h + s - 1) // s, (w + s - 1) // s
+    a = G.tensor([1, oc, oh, ow], dtype=F, fmt=N)
+    g = G.tensor([1, oc, oh, ow], dtype=F, fmt=N)
+    o = G.tensor([1, oc, oh, ow], dtype=F, fmt=N)
+    amp = 1.7 / (k * k * ic) ** 0.5
+    wt = G.tensor([oc, ic, k, k], dtype=F, fmt=marsfile.OIHW, data=((rng.random((oc, ic, k, k), dtype=np.float32) * 2 - 1) * amp).astype(np.float32))
+    b = G.tensor([oc], dtype=F, fmt=marsfile.D1, data=((rng.random(oc, dtype=np.float32) * 2 - 1) * 0.1).astype(np.float32))
+    G.conv(x, a, wt, b, (k, k), (s, s))
+    G.layer(marsfile.SIGMOID, [a], [g])
+    G.layer(marsfile.MUL, [a, g], [o])
+    return G.serialise([x], [o])
+
+
 def build(h, w, ic, oc, k, s, add):
     G = marsfile.Graph()
     rng = np.random.default_rng(1)
@@ -75,9 +94,9 @@ def parse_cfg(text):
     return out
 
 
-def run(name, cfg, configs, batch, oracle):
+def run(name, cfg, configs, batch, oracle, f32=False):
     h, w, ic, oc, k, s, add = cfg
-    d = build(*cfg)
+    d = build_f32(h, w, ic, oc, k, s) if f32 else build(*cfg)
     rng = np.random.default_rng(7)
     ref = None
     inp = None
@@ -88,7 +107,8 @@ def run(name, cfg, configs, batch, oracle):
             M.set_tuning(kk, vv)
         m = M.Model(d, batch=batch)
         if inp is None:
-            inp = rng.integers(0, 256, m.input_view(0).shape, dtype=np.uint8)
+            inp = (rng.random(m.input_view(0).shape[0] * (m.input_view(0).shape[1] // 4), dtype=np.float32).view(np.uint8).reshape(m.input_view(0).shape)
+                   if f32 else rng.integers(0, 256, m.input_view(0).shape, dtype=np.uint8))
         m.input_view(0)[:] = inp
         m.upload()
         m.run_device()
@@ -113,17 +133,22 @@ def run(name, cfg, configs, batch, oracle):
                 g.set_input(0, inp[0].tobytes())
                 assert g.run() == 0
                 hdr, _, _ = marsfile.parse(d)
-                verdict = "oracle frame 0: " + ("OK" if np.array_equal(g.tensor(hdr["outputs"][0]), out[0]) else "MISMATCH")
+                want = g.tensor(hdr["outputs"][0])
+                if f32:
+                    a_, b_ = out[0].view(np.float32).astype(np.float64), want.view(np.float32).astype(np.float64)
+                    verdict = "oracle frame 0: worst |a-b|/max(1,|b|) = %.2g" % float(np.max(np.abs(a_ - b_) / np.maximum(1.0, np.abs(b_))))
+                else:
+                    verdict = "oracle frame 0: " + ("OK" if np.array_equal(want, out[0]) else "MISMATCH")
         elif crc != ref:
-            verdict = "DIFFERENT BYTES"
+            verdict = "different bytes (expected between float32 modes)" if f32 else "DIFFERENT BYTES"
         oh, ow = (h + s - 1) // s, (w + s - 1) // s
         macs = oh * ow * oc * ic * k * k * batch
-        byts = (h * w * ic + oh * ow * oc * (2 if add else 1)) * batch
+        byts = (h * w * ic + oh * ow * oc * (2 if add else 1)) * batch * (4 if f32 else 1)
         print("   %-40s %7.1f us  %5.0f TOP/s  %5.0f GB/s  %d launch(es)  %s" %
               (text, best * 1e3, 2 * macs / best / 1e9, byts / best / 1e6, nlaunch, verdict), flush=True)
         m.close()
         for kk in tune:
-            M.set_tuning(kk, 80 if kk == "patch_lds_kb" else 0)
+            M.set_tuning(kk, 80 if kk == "patch_lds_kb" else 1 if kk == "f32_mfma" else 0)
 
 
 def main():
@@ -131,6 +156,7 @@ def main():
     ap.add_argument("layers", nargs="*", default=["D40", "D20"])
     ap.add_argument("--cfg", action="append", default=None, help="default | key=value[,key=value...]; repeatable")
     ap.add_argument("--no-oracle", action="store_true")
+    ap.add_argument("--f32", action="store_true", help="the float32 (NCHW) form of the layer; pick the kernel with --cfg f32_mfma=0|2|3")
     args = ap.parse_args()
     if os.environ.get("LIB"):
         M.LIB_PATH = os.path.abspath(os.environ["LIB"])
@@ -139,7 +165,7 @@ def main():
     for name in args.layers:
         cfg = LAYERS[name] if name in LAYERS else tuple(int(v) for v in name.split(","))
         cfg = tuple(cfg[:6]) + (bool(cfg[6]),)
-        run(name, cfg, args.cfg or ["default"], batch, not args.no_oracle)
+        run(name, cfg, args.cfg or ["default"], batch, not args.no_oracle, args.f32)
 
 
 if __name__ == "__main__":
