@@ -71,7 +71,7 @@ def test_conv_i8_stem_edges(gpu, orc):
         assert len(np.unique(a)) > 32
 
 
-@pytest.mark.parametrize("slots,stages", [(1, 2), (3, 2), (5, 3), (0, 3)])
+@pytest.mark.parametrize("slots,stages", [(1, 2), (3, 2), (5, 2), (0, 2)])  # (the three-stage walker was pruned in round 4)
 def test_conv_i8_persistent_tile_walk(gpu, orc, slots, stages):
     """the persistent kernel walking SEVERAL pixel tiles per workgroup (cross-tile prefetch, counted vmcnt
     across the epilogue's buffer stores): force few workgroups so that small inputs exercise it; both ring

@@ -365,11 +365,8 @@ static int launch_split(const mhip_conv_f32_t *p, split_args_t g) {
 }
 template <int GATHER>
 static int launch_split_bm(const mhip_conv_f32_t *p, const split_args_t &g) {
-    // MARS_HIP_F32_NPROD=4 | 3 (experiments; 128-channel tiles, stride 1): drop the three / two smallest piece products.  Measured on the
-    // config-5 twin: 4913 / 5145 / 5210 img/s and 3.7e-7 / 2.2e-6 / 3.7e-6 worst relative error with 6 / 4 / 3 -- the default stays 6
-    static const int nprod = getenv("MARS_HIP_F32_NPROD") ? atoi(getenv("MARS_HIP_F32_NPROD")) : 6;
-    if (GATHER == 1 && p->out_c > 64 && nprod == 4) return launch_split<128, 2, 4, GATHER, 4>(p, g);
-    if (GATHER == 1 && p->out_c > 64 && nprod == 3) return launch_split<128, 2, 4, GATHER, 3>(p, g);
+    // (round 4 experiment, MARS_HIP_F32_NPROD: with only the 4 / 3 largest piece products on the 128-channel stride-1 tiles the
+    // config-5 twin ran 5145 / 5210 instead of 4913 img/s at 2.2e-6 / 3.7e-6 instead of 3.7e-7 worst relative error: not kept)
     if (p->out_c > 64) return launch_split<128, 2, 4, GATHER>(p, g);
     if (p->out_c > 32) return launch_split<64, 1, 8, GATHER>(p, g);
     return launch_split<32, 1, 8, GATHER>(p, g);

@@ -980,7 +980,7 @@ static int launch_persist_t(const mhip_conv_i8_t *p, long total_pix, int k64, in
 //   code = 14 / 15: tile walker with the weights of its channel tile resident in LDS, 128 / 256 pixels
 //   code = 18 / 19: 128-byte K steps (whole-line DMA requests), 128 x 128 tile on 4 waves / 256 x 128 tile on 8 waves
 //   code = 20: conv_i8_rows (round 4): whole-row tiles, patch-staged input, streamed weights, persistent, deep 3x3 stride 1
-#define NVARIANTS 20 // 16, 17 were measured-and-dropped forms: round 2, DESIGN.md section 5
+#define NVARIANTS 20 // 16, 17 were measured-and-dropped forms (round 2), 6 / 8 = the three-stage tile walker (pruned in round 4)
 struct variant_t {
     int persist, bpx, stages, patch, ks2, w8, wres, r128, rows;
 };
@@ -1000,7 +1000,7 @@ static variant_t variant_of(int code) {
     if (code == 13) return variant_t{0, 256, 3, 0, 0, 1, 0, 0, 0};
     if (code == 12) return variant_t{0, 128, 2, 0, 1, 0, 0, 0, 0};
     if (code >= 9 && code <= 11) return variant_t{0, 0, 0, code == 10 ? 16 : (code == 9 ? 8 : 4), 0, 0, 0, 0, 0};
-    if (code > 8) return variant_t{-1, 0, 0, 0, 0, 0, 0, 0, 0}; // 16, 17: retired codes
+    if (code > 8 || code == 6 || code == 8) return variant_t{-1, 0, 0, 0, 0, 0, 0, 0, 0}; // 6, 8, 16, 17: retired codes
     const int c = code - 1;
     return variant_t{c & 1, (c & 2) ? 256 : 128, (c & 4) ? 3 : 2, 0, 0, 0, 0, 0, 0};
 }
@@ -1125,7 +1125,7 @@ static variant_t default_variant(const mhip_conv_i8_t *p, int nks) {
     // beats the ragged buffer stores of the tile walker (measured 233 vs 298 us on the 80x80 head)
     if (((p->out_c | p->out_pix_stride | p->out_ch_off) & 15) != 0 && p->nseg <= 1) v.persist = 0;
     // ring depth: 3 stages beat 4 everywhere (occupancy > depth); the tile-walking form is best with 2
-    v.stages = v.persist ? tune().persist_stages : (tune().stages ? tune().stages : (nks <= 4 ? 2 : 3));
+    v.stages = v.persist ? 2 : (tune().stages ? tune().stages : (nks <= 4 ? 2 : 3));
     if (v.stages != 3) v.stages = 2;
     // 1x1 layers of 64+ input channels on maps up to 80x80: the tile walker with its weights resident in LDS (the ring
     // carries pixel tiles only -- half the LDS-DMA bytes; measured 5-25 % faster on every such layer of yolov5s, and
@@ -1159,8 +1159,7 @@ static int launch_variant_t(const mhip_conv_i8_t *p, long total_pix, int k64, co
         if (v.stages == 2)
             return p->lut ? launch_persist_t<BPX, BN, 2, true>(p, total_pix, k64, lg, magic)
                           : launch_persist_t<BPX, BN, 2, false>(p, total_pix, k64, lg, magic);
-        return p->lut ? launch_persist_t<BPX, BN, 3, true>(p, total_pix, k64, lg, magic)
-                      : launch_persist_t<BPX, BN, 3, false>(p, total_pix, k64, lg, magic);
+        return -1; // the three-stage tile walker (variants 6 / 8) is retired: round 4 pruning, never picked by the policy or the tuner
     }
     if (v.w8) return BN == 128 ? launch_mfma<256, 128, 3, 1, 8>(p, total_pix, k64) : -1;
     if (v.ks2) return BPX == 128 && BN >= 64 ? launch_mfma<128, (BN >= 64 ? BN : 64), 2, 2>(p, total_pix, k64) : -1;
@@ -1188,8 +1187,7 @@ static int launch_variant(const mhip_conv_i8_t *p, long total_pix, int k64, cons
 template <int BPX, int BN>
 static int launch_pair_t(const mhip_conv_i8_t *a, const mhip_conv_i8_t *b, long total_pix, int k64, int lg, unsigned magic,
                          int wres) {
-    if (a->nseg > 1)
-        return launch_persist_t<BPX, BN, 2, true, true, true>(a, total_pix, k64, lg, magic, b, wres);
+    if (a->nseg > 1) return -2; // pairs over a never-materialised concat measured slower than two tuned launches: not built (round 4)
     return launch_persist_t<BPX, BN, 2, true, false, true>(a, total_pix, k64, lg, magic, b, wres);
 }
 extern "C" int mhip_conv_i8_pair(const mhip_conv_i8_t *a, const mhip_conv_i8_t *b) {

@@ -398,7 +398,7 @@ static bool rows_geom(const mhip_conv_i8_t *p, rows_geom_t *g) {
         p->pad_left != 1 || p->in_h != H || p->in_w != W || C < 128 || (C & 63) || p->oc_pad % RW_BN != 0 || p->row_pad != 3 * C ||
         p->nseg > 1 || p->add || p->pre_w || (p->lut && !p->lut2))
         return false;
-    if (W != 20 && W != 40 && W != 80) return false; // instantiated patch pitches
+    if (W != 20 && W != 40) return false; // instantiated patch pitches (80-wide maps: two 48 KB patch buffers + the ring exceed 160 KB)
     if (in_extent_bytes(p) > 0x7fffffffL || persist_out_bytes(p) > 0x7fffffffL || (long)p->oc_pad * 9 * C > 0x7fffffffL) return false;
     rows_args_t &a = g->a;
     a.W = W; a.H = H; a.C = C; a.nchunk = C / 64;
@@ -461,7 +461,6 @@ int conv_i8_launch_rows(const mhip_conv_i8_t *p) {
 #define ROWS(P) (p->lut ? launch_rows_t<P, true>(p, g) : launch_rows_t<P, false>(p, g))
     if (g.pwp == 24) return ROWS(24);
     if (g.pwp == 48) return ROWS(48);
-    if (g.pwp == 88) return ROWS(88);
 #undef ROWS
     return -1;
 }

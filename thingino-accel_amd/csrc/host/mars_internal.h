@@ -124,6 +124,40 @@ typedef struct {
     int n_tune, tune_depth;
 } mars_model_ext_t;
 
+
+/* ---- shared between mars_model.c (loader), mars_plan.c (planner) and mars_run.c (run paths); hidden from the library's ABI */
+#define MARS_INTERNAL __attribute__((visibility("hidden")))
+#define ALIGN_UP(x, a) (((x) + (size_t)(a) - 1) & ~((size_t)(a) - 1))
+#define NO_TENSOR 0xFFFFFFFFu
+#define MAX_DIM_PRODUCT ((size_t)1 << 40)
+#define ARENA_MAX ((size_t)1 << 40) /* parameter arena: anything beyond is a corrupt file, not a model */
+#define MAX_CHANNELS 65536    /* per-tensor channel count the planners accept */
+MARS_INTERNAL int mars_verbose(void);
+#define VLOG(...) do { if (mars_verbose()) fprintf(stderr, "Mars: " __VA_ARGS__); } while (0)
+/* mars_model.c */
+MARS_INTERNAL void drop_graph(mars_model_ext_t *m);
+MARS_INTERNAL mars_error_t build_plan(mars_model_ext_t *m);
+MARS_INTERNAL mars_error_t upload_params(mars_model_ext_t *m);
+MARS_INTERNAL mars_error_t alloc_batch(mars_model_ext_t *m, int n);
+/* mars_plan.c */
+MARS_INTERNAL size_t elem_size(uint32_t dtype);
+MARS_INTERNAL size_t shape_numel(const mars_tensor_t *d);
+MARS_INTERNAL size_t reference_buffer_size(const mars_model_ext_t *m);
+MARS_INTERNAL size_t arena_reserve(mars_model_ext_t *m, size_t bytes);
+MARS_INTERNAL void blob_read(const mars_model_ext_t *m, size_t off, size_t n, void *dst);
+MARS_INTERNAL void plan_layer(mars_model_ext_t *m, int li);
+MARS_INTERNAL void fuse_silu(mars_model_ext_t *m);
+MARS_INTERNAL void fuse_silu_f32(mars_model_ext_t *m);
+MARS_INTERNAL void elide_concat(mars_model_ext_t *m);
+MARS_INTERNAL void fuse_add(mars_model_ext_t *m);
+MARS_INTERNAL void fuse_bottleneck(mars_model_ext_t *m);
+MARS_INTERNAL void virtual_concat(mars_model_ext_t *m);
+MARS_INTERNAL void pair_convs(mars_model_ext_t *m);
+MARS_INTERNAL void fuse_pool_chains(mars_model_ext_t *m);
+MARS_INTERNAL void f32_policy(mars_model_ext_t *m);
+/* mars_run.c */
+MARS_INTERNAL void conv_i8_params(const mars_model_ext_t *m, const mars_op_t *op, mhip_conv_i8_t *p);
+
 /* detection tail pieces shared with the pipelined I/O (mars_yolo.c) */
 mars_error_t mars_detect_prepare(mars_model_ext_t *m, const int *output_indices, int n_outputs);
 int mars_detect_launch(mars_model_ext_t *m, const int *output_indices, int n_outputs, float nms_thresh, void *dets_dev,

@@ -1,0 +1,1070 @@
+/*
+ * mars_plan.c -- the launch planner of the .mars executor: one planner per layer kind (each cites the reference lines it
+ * mirrors: src/mars/mars_runtime.c:511-1224), the host arithmetic they share, the parameter arena, and the fusion passes
+ * (SiLU tables, residual Adds, virtual / zero-copy concats, paired launches, pool chains, the float32 policy).
+ * Split out of mars_model.c in round 4; loader: mars_model.c, run paths: mars_run.c.
+ */
+#include <math.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <time.h>
+
+#include "mars_internal.h"
+#include "nna.h"
+
+/* ------------------------------------------------------- host arithmetic */
+int32_t mars_trunc_x86(float x) {
+    /* x86 cvttss2si: out of range or NaN -> INT32_MIN */
+    if (x >= -2147483648.0f && x < 2147483648.0f) return (int32_t)x;
+    return INT32_MIN;
+}
+static int sat8(int32_t v) { return v > 127 ? 127 : (v < -128 ? -128 : v); }
+static int q_half_up(float v) { return sat8(mars_trunc_x86(v + 0.5f)); }
+
+size_t elem_size(uint32_t dtype) {
+    switch (dtype) {
+        case MARS_DTYPE_FLOAT32: case MARS_DTYPE_INT32: return 4;
+        case MARS_DTYPE_INT16: return 2;
+        default: return 1;
+    }
+}
+
+size_t shape_numel(const mars_tensor_t *d) {
+    size_t n = 1;
+    for (uint32_t i = 0; i < d->ndims && i < MARS_MAX_DIMS; i++) {
+        if (d->shape[i] <= 0) return 0;
+        n *= (size_t)d->shape[i];
+        if (n > MAX_DIM_PRODUCT) return 0;
+    }
+    return n;
+}
+
+/* Format-aware byte size of a tensor, reference mars_runtime.c:80-124 (`tensor_byte_size`): NDHWC32 rounds the
+ * channel count (shape[1]) up to 32, NMHWSOIB2 counts 1024-byte blocks, UINT4 packs two elements per byte; every
+ * other tag is numel * element size.  The reference evaluates the products in `int` and converts to size_t; the
+ * same wrap-around is kept by computing in 32-bit unsigned arithmetic and sign-extending. */
+size_t mars_hip_tensor_byte_size(const mars_tensor_t *t) {
+    if (!t) return 0;
+    size_t es;
+    switch (t->dtype) {
+        case MARS_DTYPE_FLOAT32: case MARS_DTYPE_INT32: es = 4; break;
+        case MARS_DTYPE_INT16: es = 2; break;
+        default: es = 1; break; /* INT8, UINT8, UINT4 (two per byte, handled below), unknown */
+    }
+    if (t->format == MARS_FORMAT_NDHWC32 && t->ndims >= 4) {
+        const uint32_t n = (uint32_t)t->shape[0], h = (uint32_t)t->shape[2], w = (uint32_t)t->shape[3];
+        const uint32_t d = (uint32_t)((int32_t)((uint32_t)t->shape[1] + 31u) / 32); /* the reference's int sum, wrapped without UB */
+        return (size_t)(int32_t)(n * d * h * w * 32u) * es; /* int product, then * size_t (:101) */
+    }
+    if (t->format == MARS_FORMAT_NMHWSOIB2 && t->ndims >= 4) {
+        const uint32_t no = (uint32_t)((int32_t)((uint32_t)t->shape[0] + 31u) / 32), mi = (uint32_t)((int32_t)((uint32_t)t->shape[1] + 31u) / 32);
+        return (size_t)(int32_t)(no * mi * (uint32_t)t->shape[2] * (uint32_t)t->shape[3] * 1024u);
+    }
+    size_t numel = 1;
+    for (uint32_t i = 0; i < t->ndims && i < MARS_MAX_DIMS; i++) numel *= (size_t)(int64_t)t->shape[i];
+    if (t->dtype == MARS_DTYPE_UINT4) return (numel + 1) / 2;
+    return numel * es;
+}
+
+/* What the reference reports as `alloc_size` of every activation tensor (mars_runtime.c:250-334): all of them share
+ * working buffers of ONE size, the largest 64-byte-rounded tensor_byte_size of any activation -- or less when three,
+ * then two such buffers do not fit behind the weights in its 8 MiB arena.  Callers fill / scan `alloc_size` bytes
+ * through vaddr (mars_test.c:73-84, 117-127), so single-frame I/O tensors report the same number here and their
+ * staging is at least that large.  Where the reference would refuse to load (weights > 8 MiB, < 64 KiB per buffer)
+ * this build still loads and reports the unreduced size. */
+size_t reference_buffer_size(const mars_model_ext_t *m) {
+    size_t max_sz = 0;
+    for (uint32_t i = 0; i < m->pub.header.num_tensors; i++) {
+        const mars_tensor_t *d = &m->pub.tensors[i].desc;
+        if (d->data_size != 0) continue;
+        size_t sz = ALIGN_UP(mars_hip_tensor_byte_size(d), 64);
+        if (sz > max_sz) max_sz = sz;
+    }
+    const size_t ddr = (size_t)8 << 20;
+    if (m->pub.weights_size > ddr) return max_sz;
+    const size_t remaining = ddr - m->pub.weights_size;
+    if (max_sz * 3 <= remaining || max_sz * 2 <= remaining) return max_sz;
+    const size_t reduced = (remaining / 2) & ~(size_t)63;
+    return reduced >= 65536 ? reduced : max_sz;
+}
+
+/* --------------------------------------------------------- parameter arena */
+size_t arena_reserve(mars_model_ext_t *m, size_t bytes) {
+    /* any failure here fails the whole plan (build_plan returns plan_err): no op keeps an unset offset */
+    if (bytes > ARENA_MAX || m->arena_size > ARENA_MAX) { m->plan_err = MARS_ERR_ALLOC_FAILED; return NO_OFF; }
+    size_t off = ALIGN_UP(m->arena_size, 256);
+    size_t end = off + ALIGN_UP(bytes ? bytes : 1, 256);
+    if (end > ARENA_MAX) { m->plan_err = MARS_ERR_ALLOC_FAILED; return NO_OFF; }
+    if (end > m->arena_cap) {
+        size_t cap = m->arena_cap ? m->arena_cap : (1u << 20);
+        while (cap < end) cap *= 2; /* end <= 2^40: cannot overflow */
+        uint8_t *p = (uint8_t *)realloc(m->arena_host, cap);
+        if (!p) { m->plan_err = MARS_ERR_ALLOC_FAILED; return NO_OFF; }
+        memset(p + m->arena_cap, 0, cap - m->arena_cap);
+        m->arena_host = p;
+        m->arena_cap = cap;
+    }
+    m->arena_size = end;
+    return off;
+}
+
+/* bytes [off, off+n) of the weight blob; beyond its end the blob reads as zeros */
+void blob_read(const mars_model_ext_t *m, size_t off, size_t n, void *dst) {
+    const uint8_t *blob = (const uint8_t *)m->pub.weights;
+    size_t have = m->pub.weights_size;
+    memset(dst, 0, n);
+    if (!blob || off >= have) return;
+    size_t c = have - off < n ? have - off : n;
+    memcpy(dst, blob + off, c);
+}
+
+/* weights -> [oc_pad][k64] rows, each kernel row padded to row_pad bytes.
+ * nchw: source is OIHW and the (transposed) input has c_pad channels. */
+void mars_pack_conv_i8(const int8_t *w, size_t avail, int nchw, int out_c, int in_c, int kh, int kw,
+                       int c_pad, int row_pad, int oc_pad, int8_t *dst) {
+    const int k64 = (int)ALIGN_UP((size_t)kh * row_pad, 64);
+    memset(dst, 0, (size_t)oc_pad * k64);
+    for (int oc = 0; oc < out_c; oc++)
+        for (int ky = 0; ky < kh; ky++)
+            for (int kx = 0; kx < kw; kx++)
+                for (int ic = 0; ic < in_c; ic++) {
+                    size_t src = nchw ? (((size_t)oc * in_c + ic) * kh + ky) * kw + kx
+                                      : (((size_t)oc * kh + ky) * kw + kx) * in_c + ic;
+                    int8_t v = src < avail ? w[src] : 0;
+                    dst[(size_t)mhip_conv_i8_oc_row(oc, oc_pad) * k64 + (size_t)ky * row_pad + (size_t)kx * c_pad + ic] = v;
+                }
+}
+
+/* ------------------------------------------------------------------- ops */
+static mars_op_t *new_op(mars_model_ext_t *m, int kind, int layer) {
+    if (m->n_ops == m->cap_ops) {
+        int cap = m->cap_ops ? m->cap_ops * 2 : 64;
+        mars_op_t *p = (mars_op_t *)realloc(m->ops, (size_t)cap * sizeof(mars_op_t));
+        if (!p) { m->plan_err = MARS_ERR_ALLOC_FAILED; return NULL; }
+        m->ops = p;
+        m->cap_ops = cap;
+    }
+    mars_op_t *op = &m->ops[m->n_ops++];
+    memset(op, 0, sizeof(*op));
+    op->kind = kind;
+    op->layer = layer;
+    op->t_in[0] = op->t_in[1] = op->t_in[2] = op->t_in[3] = op->t_out = -1;
+    op->w_off = op->b_off = op->lut_off = op->lut2_off = op->s_off = op->w2_off = NO_OFF;
+    op->w_blob_off[0] = op->w_blob_off[1] = NO_OFF;
+    op->prof_kind = 4;
+    return op;
+}
+
+static void fail_op(mars_model_ext_t *m, int layer, int err) {
+    mars_op_t *op = new_op(m, OP_FAIL, layer);
+    if (op) op->err = err;
+}
+
+/* the executor searches tensors by desc.id, first match (mars_runtime.c:516-558, 713-721) */
+static int find_tensor(const mars_model_ext_t *m, uint32_t id) {
+    if (id == NO_TENSOR) return -1;
+    for (uint32_t i = 0; i < m->pub.header.num_tensors; i++)
+        if (m->pub.tensors[i].desc.id == id) return (int)i;
+    return -1;
+}
+
+static void touch(mars_model_ext_t *m, int ti, size_t extent) {
+    if (ti < 0) return;
+    mtensor_t *t = &m->mt[ti];
+    t->needed = 1;
+    if (t->is_weight) {
+        size_t end = (size_t)m->pub.tensors[ti].desc.data_offset + extent;
+        if (end > m->blob_mirror_bytes) m->blob_mirror_bytes = end;
+    } else if (extent > t->extent) {
+        t->extent = extent;
+    }
+}
+
+static size_t lut_i8(mars_model_ext_t *m, const int8_t table[256]) {
+    size_t off = arena_reserve(m, 256);
+    if (off != NO_OFF) memcpy(m->arena_host + off, table, 256);
+    return off;
+}
+
+/* int8 sigmoid of one value, reference mars_runtime.c:758-768 */
+static int sigmoid_q(int q, float in_scale, float out_scale) {
+    float os = out_scale > 0 ? out_scale : 1.0f;
+    float x = (float)q * in_scale;
+    float y = 1.0f / (1.0f + expf(-x));
+    return q_half_up(y / os);
+}
+/* int8 mul/add of one pair, reference mars_runtime.c:822-835 / :889-902 */
+static int binary_q(int is_mul, int a, int b, float sa, float sb, float so) {
+    float inv = 1.0f / (so > 0 ? so : 1.0f);
+    float va = (float)a * sa, vb = (float)b * sb;
+    float y = is_mul ? va * vb : va + vb;
+    return q_half_up(y * inv);
+}
+
+/* ---- CONV2D: reference mars_runtime.c:511-710 */
+static void plan_conv(mars_model_ext_t *m, int li) {
+    const mars_layer_t *L = &m->pub.layers[li].desc;
+    const mars_conv_params_t *cp = &L->params.conv;
+    int ti = find_tensor(m, L->input_tensor_ids[0]);
+    int to = find_tensor(m, L->output_tensor_ids[0]);
+    int tw = find_tensor(m, cp->weight_tensor_id);
+    int tb = find_tensor(m, cp->bias_tensor_id);
+    if (ti < 0 || to < 0 || tw < 0) { fail_op(m, li, MARS_ERR_INVALID_TENSOR); return; }
+    const mars_tensor_t *in = &m->pub.tensors[ti].desc, *out = &m->pub.tensors[to].desc;
+    const mars_tensor_t *w = &m->pub.tensors[tw].desc;
+    /* weights / bias must come from the blob, the result must be an activation, and a
+     * parallel kernel cannot run a layer in place */
+    if (!m->mt[tw].is_weight || (tb >= 0 && !m->mt[tb].is_weight) || m->mt[to].is_weight || ti == to) {
+        fail_op(m, li, MARS_ERR_LAYER_FAILED);
+        return;
+    }
+    const int in_nhwc = in->format == MARS_FORMAT_NHWC, out_nhwc = out->format == MARS_FORMAT_NHWC;
+    int in_h, in_w, in_c, out_h, out_w, out_c;
+    if (in_nhwc) { in_h = in->shape[1]; in_w = in->shape[2]; in_c = in->shape[3]; }
+    else         { in_c = in->shape[1]; in_h = in->shape[2]; in_w = in->shape[3]; }
+    if (out_nhwc) { out_h = out->shape[1]; out_w = out->shape[2]; out_c = out->shape[3]; }
+    else          { out_c = out->shape[1]; out_h = out->shape[2]; out_w = out->shape[3]; }
+    const int kh = (int)cp->kernel_h, kw = (int)cp->kernel_w, sh = (int)cp->stride_h, sw = (int)cp->stride_w;
+    int pt = 0, pl = 0;
+    if (cp->padding == MARS_PAD_SAME) { /* EXPLICIT / VALID run unpadded (:592-598) */
+        int32_t ph = (int32_t)((uint32_t)(out_h - 1) * cp->stride_h + cp->kernel_h - (uint32_t)in_h);
+        int32_t pw = (int32_t)((uint32_t)(out_w - 1) * cp->stride_w + cp->kernel_w - (uint32_t)in_w);
+        pt = ph / 2;
+        pl = pw / 2;
+    }
+    if (out_h <= 0 || out_w <= 0 || out_c <= 0) return; /* empty loops in the reference: nothing is written */
+    /* channel counts are bounded so that every packed-weight product below (kw * c_pad, kh * row_pad, oc_pad * k64)
+     * stays far inside int / size_t: a crafted in_c once wrapped kw * in_c and let the packer write past its slot */
+    if (in_h <= 0 || in_w <= 0 || in_c <= 0 || kh <= 0 || kw <= 0 || sh < 0 || sw < 0 || kh > 64 || kw > 64 ||
+        in_c > MAX_CHANNELS || out_c > MAX_CHANNELS ||
+        (size_t)in_h * in_w * in_c > MAX_DIM_PRODUCT || (size_t)out_h * out_w * out_c > MAX_DIM_PRODUCT ||
+        (size_t)out_c * in_c * kh * kw > ((size_t)1 << 31)) {
+        fail_op(m, li, MARS_ERR_LAYER_FAILED); /* degenerate geometry this build does not launch */
+        return;
+    }
+    const int is_f32 = in->dtype == MARS_DTYPE_FLOAT32;
+    mars_op_t *op = new_op(m, is_f32 ? OP_CONV_F32 : OP_CONV_I8, li);
+    if (!op) return;
+    op->t_in[0] = ti; op->n_in = 1; op->t_out = to;
+    op->in_h = in_h; op->in_w = in_w; op->in_c = in_c;
+    op->out_h = out_h; op->out_w = out_w; op->out_c = out_c;
+    op->kh = kh; op->kw = kw; op->sh = sh; op->sw = sw; op->pt = pt; op->pl = pl;
+    op->is_f32 = is_f32;
+    op->macs = (double)out_h * out_w * out_c * in_c * kh * kw;
+    const size_t es = is_f32 ? 4 : 1;
+    touch(m, ti, (size_t)in_h * in_w * in_c * es);
+    touch(m, to, (size_t)out_h * out_w * out_c * es);
+    m->mt[tw].needed = 1;
+    op->bytes = (double)((size_t)in_h * in_w * in_c + (size_t)out_h * out_w * out_c) * es;
+    const size_t wcount = (size_t)out_c * in_c * kh * kw;
+
+    if (is_f32) {
+        op->prof_kind = 1;
+        op->w_off = arena_reserve(m, wcount * 4);
+        if (op->w_off == NO_OFF) return;
+        if (!m->deferred) blob_read(m, (size_t)w->data_offset, wcount * 4, m->arena_host + op->w_off);
+        { /* the same weights cut into three bf16 planes for the split-operand matrix-core kernel (conv_f32_split.hip, f32_mfma = 3) */
+            const size_t n2 = mhip_conv_f32_split_pack(out_c, in_c, kh, kw, sw, NULL, NULL);
+            if (n2) {
+                op->w2_off = arena_reserve(m, n2);
+                if (op->w2_off == NO_OFF) return;
+                if (!m->deferred)
+                    mhip_conv_f32_split_pack(out_c, in_c, kh, kw, sw, (const float *)(m->arena_host + op->w_off), m->arena_host + op->w2_off);
+            }
+        }
+        if (tb >= 0) {
+            op->b_off = arena_reserve(m, (size_t)out_c * 4);
+            if (op->b_off != NO_OFF && !m->deferred)
+                blob_read(m, (size_t)m->pub.tensors[tb].desc.data_offset, (size_t)out_c * 4, m->arena_host + op->b_off);
+        }
+        if (cp->activation == MARS_ACT_RELU) { /* byte-wise clamp over H*W*C BYTES of the f32 result (:700-707) */
+            mars_op_t *r = new_op(m, OP_RELU_BYTES, li);
+            if (r) { r->t_out = to; r->n = (size_t)out_h * out_w * out_c; r->prof_kind = 2; r->bytes = 2.0 * r->n; }
+        }
+        return;
+    }
+
+    op->prof_kind = 0;
+    op->nchw = !in_nhwc; /* the kernel is chosen by the INPUT tag (:640-662) */
+    op->c_pad = op->nchw ? (int)ALIGN_UP((size_t)in_c, 16) : in_c;
+    int c_eff = op->c_pad; /* bytes per pixel in the packed K layout (4 in small-channel mode) */
+    mhip_conv_i8_pack_geom(op->c_pad, kw, out_c, &op->row_pad, &op->oc_pad, &c_eff);
+    const size_t k64 = ALIGN_UP((size_t)kh * op->row_pad, 64);
+    op->w_off = arena_reserve(m, (size_t)op->oc_pad * k64);
+    if (op->w_off == NO_OFF) return;
+    if (!m->deferred) {
+        int8_t *tmp = (int8_t *)malloc(wcount ? wcount : 1);
+        if (!tmp) { m->plan_err = MARS_ERR_ALLOC_FAILED; return; }
+        blob_read(m, (size_t)w->data_offset, wcount, tmp);
+        mars_pack_conv_i8(tmp, wcount, op->nchw, out_c, in_c, kh, kw, c_eff, op->row_pad, op->oc_pad,
+                          (int8_t *)m->arena_host + op->w_off);
+        free(tmp);
+    }
+    if (!op->nchw) { /* RGB stem: its matrix-core operands pre-laid for conv_i8_rgb (12 KB for 32 channels, 6 x 6) */
+        const size_t n2 = mhip_conv_i8_rgb_pack(in_c, kh, kw, sh, sw, pl, op->oc_pad, (int)k64, NULL, NULL);
+        if (n2) {
+            op->w2_off = arena_reserve(m, n2);
+            if (op->w2_off == NO_OFF) return;
+            if (!m->deferred)
+                mhip_conv_i8_rgb_pack(in_c, kh, kw, sh, sw, pl, op->oc_pad, (int)k64, (const int8_t *)m->arena_host + op->w_off,
+                                      (int8_t *)m->arena_host + op->w2_off);
+        }
+    }
+    if (!op->nchw && op->w2_off == NO_OFF) { /* deep 3x3 stride-1 layers: the weight image conv_i8_rows streams (same bytes, K-step blocks) */
+        const size_t n3 = mhip_conv_i8_rows_pack(in_c, kh, kw, sh, sw, op->oc_pad, (int)k64, NULL, NULL);
+        if (n3) {
+            op->w2_off = arena_reserve(m, n3);
+            if (op->w2_off == NO_OFF) return;
+            op->w2_rows = 1;
+            if (!m->deferred)
+                mhip_conv_i8_rows_pack(in_c, kh, kw, sh, sw, op->oc_pad, (int)k64, (const int8_t *)m->arena_host + op->w_off,
+                                       (int8_t *)m->arena_host + op->w2_off);
+        }
+    }
+    if (tb >= 0) { /* raw bytes reinterpreted as int32, whatever the tensor says it is (:645,656) */
+        op->b_off = arena_reserve(m, (size_t)op->oc_pad * 4);
+        if (op->b_off != NO_OFF && !m->deferred) {
+            int32_t *raw = (int32_t *)calloc((size_t)out_c, 4), *dstb = (int32_t *)(m->arena_host + op->b_off);
+            if (!raw) { m->plan_err = MARS_ERR_ALLOC_FAILED; return; }
+            blob_read(m, (size_t)m->pub.tensors[tb].desc.data_offset, (size_t)out_c * 4, raw);
+            for (int oc = 0; oc < out_c; oc++) dstb[mhip_conv_i8_oc_row(oc, op->oc_pad)] = raw[oc]; /* same row order as the weights */
+            free(raw);
+        }
+    }
+    op->cs = (in->scale * w->scale) / out->scale; /* float32, this order (mxu_conv.c:639,722) */
+    op->safe = mhip_conv_i8_is_safe(op->cs);
+    op->relu = cp->activation == MARS_ACT_RELU;
+    if (op->nchw) {
+        size_t need = (size_t)in_h * in_w * op->c_pad;
+        if (need > m->scratch_per_frame) m->scratch_per_frame = need;
+        op->bytes += 2.0 * need;
+    }
+}
+
+static size_t numel_of(const mars_model_ext_t *m, int ti) { return shape_numel(&m->pub.tensors[ti].desc); }
+
+/* ---- SIGMOID / RELU family: unary maps (mars_runtime.c:724-771, 1047-1089) */
+static void plan_unary(mars_model_ext_t *m, int li) {
+    const mars_layer_t *L = &m->pub.layers[li].desc;
+    int ti = find_tensor(m, L->input_tensor_ids[0]), to = find_tensor(m, L->output_tensor_ids[0]);
+    if (ti < 0 || to < 0) { fail_op(m, li, MARS_ERR_INVALID_TENSOR); return; }
+    if (m->mt[to].is_weight) { fail_op(m, li, MARS_ERR_LAYER_FAILED); return; }
+    const mars_tensor_t *in = &m->pub.tensors[ti].desc, *out = &m->pub.tensors[to].desc;
+    const size_t n = numel_of(m, ti);
+    if (n == 0) return;
+    const int is_sig = L->type == MARS_LAYER_SIGMOID;
+    const int leaky = L->type == MARS_LAYER_LEAKY_RELU;
+    if (in->dtype == MARS_DTYPE_FLOAT32) {
+        mars_op_t *op = new_op(m, is_sig ? OP_SIGMOID_F32 : OP_RELU_F32, li);
+        if (!op) return;
+        op->t_in[0] = ti; op->n_in = 1; op->t_out = to; op->n = n;
+        op->f0 = leaky ? 0.01f : 0.0f; /* slope is a constant in the reference (:1064) */
+        op->prof_kind = 2; op->bytes = 8.0 * n;
+        touch(m, ti, n * 4); touch(m, to, n * 4);
+        return;
+    }
+    int8_t tab[256];
+    for (int q = -128; q < 128; q++) {
+        int r;
+        if (is_sig) r = sigmoid_q(q, in->scale, out->scale);
+        else if (q > 0) r = q;
+        else if (leaky) { int32_t v = mars_trunc_x86((float)q * 0.01f); r = (int8_t)(v < -128 ? -128 : v); }
+        else r = 0; /* RELU and RELU6 alike: no upper clamp (:1179-1182) */
+        tab[q + 128] = (int8_t)r;
+    }
+    mars_op_t *op = new_op(m, OP_LUT_I8, li);
+    if (!op) return;
+    op->t_in[0] = ti; op->n_in = 1; op->t_out = to; op->n = n;
+    op->lut_off = lut_i8(m, tab);
+    op->prof_kind = 2; op->bytes = 2.0 * n;
+    touch(m, ti, n); touch(m, to, n);
+}
+
+/* ---- MUL / ADD (mars_runtime.c:774-905): extent from operand A only */
+static void plan_binary(mars_model_ext_t *m, int li) {
+    const mars_layer_t *L = &m->pub.layers[li].desc;
+    int ta = find_tensor(m, L->input_tensor_ids[0]), tb = find_tensor(m, L->input_tensor_ids[1]);
+    int to = find_tensor(m, L->output_tensor_ids[0]);
+    if (ta < 0 || tb < 0 || to < 0) { fail_op(m, li, MARS_ERR_INVALID_TENSOR); return; }
+    if (m->mt[to].is_weight) { fail_op(m, li, MARS_ERR_LAYER_FAILED); return; }
+    const mars_tensor_t *a = &m->pub.tensors[ta].desc, *b = &m->pub.tensors[tb].desc, *o = &m->pub.tensors[to].desc;
+    const size_t n = numel_of(m, ta);
+    if (n == 0) return;
+    const int f32 = a->dtype == MARS_DTYPE_FLOAT32;
+    mars_op_t *op = new_op(m, f32 ? OP_BINARY_F32 : OP_BINARY_I8, li);
+    if (!op) return;
+    op->t_in[0] = ta; op->t_in[1] = tb; op->n_in = 2; op->t_out = to; op->n = n;
+    op->is_mul = L->type == MARS_LAYER_MUL;
+    op->f0 = a->scale; op->f1 = b->scale;
+    op->f2 = 1.0f / (o->scale > 0 ? o->scale : 1.0f);
+    op->prof_kind = 2; op->bytes = 3.0 * n * (f32 ? 4 : 1);
+    const size_t es = f32 ? 4 : 1;
+    touch(m, ta, n * es); touch(m, tb, n * es); touch(m, to, n * es);
+}
+
+/* ---- MAXPOOL (mars_runtime.c:908-960) */
+static void plan_maxpool(mars_model_ext_t *m, int li) {
+    const mars_layer_t *L = &m->pub.layers[li].desc;
+    const mars_pool_params_t *pp = &L->params.pool;
+    int ti = find_tensor(m, L->input_tensor_ids[0]), to = find_tensor(m, L->output_tensor_ids[0]);
+    if (ti < 0 || to < 0) { fail_op(m, li, MARS_ERR_INVALID_TENSOR); return; }
+    if (m->mt[to].is_weight || ti == to) { fail_op(m, li, MARS_ERR_LAYER_FAILED); return; }
+    const mars_tensor_t *in = &m->pub.tensors[ti].desc, *out = &m->pub.tensors[to].desc;
+    int in_h = in->shape[1], in_w = in->shape[2], ch = in->shape[3], out_h = out->shape[1], out_w = out->shape[2];
+    if (out_h <= 0 || out_w <= 0 || ch <= 0) return;
+    if (in_h < 0 || in_w < 0 || (int)pp->kernel_h < 0 || (int)pp->kernel_w < 0 || (int)pp->stride_h < 0 ||
+        (int)pp->stride_w < 0 || pp->kernel_h > 4096 || pp->kernel_w > 4096) {
+        fail_op(m, li, MARS_ERR_LAYER_FAILED);
+        return;
+    }
+    mars_op_t *op = new_op(m, OP_MAXPOOL, li);
+    if (!op) return;
+    op->t_in[0] = ti; op->n_in = 1; op->t_out = to;
+    op->in_h = in_h; op->in_w = in_w; op->in_c = ch; op->out_h = out_h; op->out_w = out_w;
+    op->kh = (int)pp->kernel_h; op->kw = (int)pp->kernel_w; op->sh = (int)pp->stride_h; op->sw = (int)pp->stride_w;
+    op->prof_kind = 3;
+    op->bytes = (double)in_h * in_w * ch + (double)out_h * out_w * ch;
+    /* reads stay inside in_h*in_w*ch by the window clip; writes cover out_h*out_w*ch */
+    if (op->kh > 0 && op->kw > 0) touch(m, ti, (size_t)in_h * in_w * ch);
+    else m->mt[ti].needed = 1;
+    touch(m, to, (size_t)out_h * out_w * ch);
+}
+
+/* ---- CONCAT (mars_runtime.c:963-1000): one copy kernel per input, in order */
+static void plan_concat(mars_model_ext_t *m, int li) {
+    const mars_layer_t *L = &m->pub.layers[li].desc;
+    int to = find_tensor(m, L->output_tensor_ids[0]);
+    if (to < 0) { fail_op(m, li, MARS_ERR_INVALID_TENSOR); return; }
+    if (m->mt[to].is_weight) { fail_op(m, li, MARS_ERR_LAYER_FAILED); return; }
+    const mars_tensor_t *out = &m->pub.tensors[to].desc;
+    const int out_h = out->shape[1], out_w = out->shape[2], out_c = out->shape[3];
+    if (L->num_inputs > 4) { fail_op(m, li, MARS_ERR_INVALID_LAYER); return; }
+    int off = 0;
+    for (uint32_t k = 0; k < L->num_inputs; k++) {
+        int ti = find_tensor(m, L->input_tensor_ids[k]);
+        if (ti < 0) continue; /* skipped without advancing the channel offset (:980) */
+        const int in_c = m->pub.tensors[ti].desc.shape[3];
+        if (out_h > 0 && out_w > 0 && in_c > 0) {
+            /* pixel slots of one input may not overlap each other in a parallel copy */
+            if (in_c > out_c || out_c <= 0 || ti == to) { fail_op(m, li, MARS_ERR_LAYER_FAILED); return; }
+            mars_op_t *op = new_op(m, OP_CONCAT_SLICE, li);
+            if (!op) return;
+            op->t_in[0] = ti; op->n_in = 1; op->t_out = to;
+            op->out_h = out_h; op->out_w = out_w; op->in_c = in_c; op->out_c = out_c; op->ch_off = off;
+            op->prof_kind = 3;
+            const size_t npix = (size_t)out_h * out_w;
+            op->bytes = 2.0 * npix * in_c;
+            touch(m, ti, npix * in_c);
+            touch(m, to, (npix - 1) * out_c + off + in_c);
+        }
+        off += in_c;
+    }
+}
+
+/* ---- UPSAMPLE (mars_runtime.c:1003-1044) */
+static void plan_upsample(mars_model_ext_t *m, int li) {
+    const mars_layer_t *L = &m->pub.layers[li].desc;
+    const mars_upsample_params_t *up = &L->params.upsample;
+    int ti = find_tensor(m, L->input_tensor_ids[0]), to = find_tensor(m, L->output_tensor_ids[0]);
+    if (ti < 0 || to < 0) { fail_op(m, li, MARS_ERR_INVALID_TENSOR); return; }
+    if (m->mt[to].is_weight || ti == to) { fail_op(m, li, MARS_ERR_LAYER_FAILED); return; }
+    const mars_tensor_t *in = &m->pub.tensors[ti].desc, *out = &m->pub.tensors[to].desc;
+    int in_h = in->shape[1], in_w = in->shape[2], ch = in->shape[3], out_h = out->shape[1], out_w = out->shape[2];
+    if ((up->scale_h == 0 && in_h == 0) || (up->scale_w == 0 && in_w == 0)) { fail_op(m, li, MARS_ERR_LAYER_FAILED); return; }
+    int sh = up->scale_h > 0 ? (int)up->scale_h : out_h / in_h;
+    int sw = up->scale_w > 0 ? (int)up->scale_w : out_w / in_w;
+    if (out_h <= 0 || out_w <= 0 || ch <= 0) return;
+    if (sh <= 0 || sw <= 0 || in_h <= 0 || in_w <= 0) { fail_op(m, li, MARS_ERR_LAYER_FAILED); return; }
+    mars_op_t *op = new_op(m, OP_UPSAMPLE, li);
+    if (!op) return;
+    op->t_in[0] = ti; op->n_in = 1; op->t_out = to;
+    op->in_h = in_h; op->in_w = in_w; op->in_c = ch; op->out_h = out_h; op->out_w = out_w;
+    op->scale_h = sh; op->scale_w = sw;
+    op->prof_kind = 3;
+    op->bytes = (double)in_h * in_w * ch + (double)out_h * out_w * ch;
+    touch(m, ti, (size_t)in_h * in_w * ch);
+    touch(m, to, (size_t)out_h * out_w * ch);
+}
+
+/* ---- BATCHNORM (mars_runtime.c:1092-1158) */
+static void plan_batchnorm(mars_model_ext_t *m, int li) {
+    const mars_layer_t *L = &m->pub.layers[li].desc;
+    int ti = find_tensor(m, L->input_tensor_ids[0]), to = find_tensor(m, L->output_tensor_ids[0]);
+    int ts = find_tensor(m, L->input_tensor_ids[1]), tb = find_tensor(m, L->input_tensor_ids[2]);
+    if (ti < 0 || to < 0) { fail_op(m, li, MARS_ERR_INVALID_TENSOR); return; }
+    if (m->mt[to].is_weight || (ts >= 0 && !m->mt[ts].is_weight) || (tb >= 0 && !m->mt[tb].is_weight)) {
+        fail_op(m, li, MARS_ERR_LAYER_FAILED);
+        return;
+    }
+    const mars_tensor_t *in = &m->pub.tensors[ti].desc, *out = &m->pub.tensors[to].desc;
+    int n = in->shape[0] > 0 ? in->shape[0] : 1, c = in->shape[1] > 0 ? in->shape[1] : 1;
+    int h = in->shape[2] > 0 ? in->shape[2] : 1, w = in->shape[3] > 0 ? in->shape[3] : 1;
+    if ((size_t)n * c * h * w > MAX_DIM_PRODUCT || c > MAX_CHANNELS) { fail_op(m, li, MARS_ERR_LAYER_FAILED); return; }
+    const int f32 = in->dtype == MARS_DTYPE_FLOAT32;
+    mars_op_t *op = new_op(m, OP_BN, li);
+    if (!op) return;
+    op->t_in[0] = ti; op->n_in = 1; op->t_out = to;
+    op->bn_n = n; op->in_c = c; op->in_h = h; op->in_w = w; op->is_f32 = f32;
+    op->f0 = in->scale > 0 ? in->scale : 1.0f;
+    op->f1 = out->scale > 0 ? out->scale : 1.0f;
+    if (ts >= 0) {
+        op->s_off = arena_reserve(m, (size_t)c * 4);
+        if (op->s_off != NO_OFF && !m->deferred)
+            blob_read(m, (size_t)m->pub.tensors[ts].desc.data_offset, (size_t)c * 4, m->arena_host + op->s_off);
+    }
+    if (tb >= 0) {
+        op->b_off = arena_reserve(m, (size_t)c * 4);
+        if (op->b_off != NO_OFF && !m->deferred)
+            blob_read(m, (size_t)m->pub.tensors[tb].desc.data_offset, (size_t)c * 4, m->arena_host + op->b_off);
+    }
+    const size_t total = (size_t)n * c * h * w * (f32 ? 4 : 1);
+    op->prof_kind = 2; op->bytes = 2.0 * total;
+    touch(m, ti, total); touch(m, to, total);
+}
+
+/* dispatcher, reference mars_runtime.c:1161-1224 */
+void plan_layer(mars_model_ext_t *m, int li) {
+    switch (m->pub.layers[li].desc.type) {
+        case MARS_LAYER_CONV2D: plan_conv(m, li); break;
+        case MARS_LAYER_SIGMOID:
+        case MARS_LAYER_RELU:
+        case MARS_LAYER_RELU6:
+        case MARS_LAYER_LEAKY_RELU: plan_unary(m, li); break;
+        case MARS_LAYER_MUL:
+        case MARS_LAYER_ADD: plan_binary(m, li); break;
+        case MARS_LAYER_MAXPOOL: plan_maxpool(m, li); break;
+        case MARS_LAYER_CONCAT: plan_concat(m, li); break;
+        case MARS_LAYER_UPSAMPLE: plan_upsample(m, li); break;
+        case MARS_LAYER_BATCHNORM: plan_batchnorm(m, li); break;
+        case MARS_LAYER_DEPTHWISE_CONV2D: /* accepted, not executed (:1168-1213) */
+        case MARS_LAYER_AVGPOOL:
+        case MARS_LAYER_SILU:
+        case MARS_LAYER_RESHAPE:
+        case MARS_LAYER_TRANSPOSE:
+        case MARS_LAYER_SOFTMAX: break;
+        default: fail_op(m, li, MARS_ERR_INVALID_LAYER); break; /* GLOBAL_AVGPOOL, FC, unknown (:1218-1220) */
+    }
+}
+
+/* ------------------------------------------------------------------ fusion
+ * conv -> sigmoid -> mul (SiLU as exported to ONNX) collapses into the conv
+ * epilogue: every value of the chain is a function of the conv's int8 result
+ * q1 alone, so lut[q1] = mul(q1, sigmoid(q1)) computed on the host with the
+ * reference's own float steps is bit-identical.
+ * Only done when q1 and sigmoid(q1) have no other reader and are not outputs. */
+void fuse_silu(mars_model_ext_t *m) {
+    const int nt = (int)m->pub.header.num_tensors;
+    int *readers = (int *)calloc((size_t)nt + 1, sizeof(int));
+    int *writers = (int *)calloc((size_t)nt + 1, sizeof(int));
+    if (!readers || !writers) { free(readers); free(writers); return; }
+    for (int i = 0; i < m->n_ops; i++) {
+        for (int k = 0; k < m->ops[i].n_in; k++)
+            if (m->ops[i].t_in[k] >= 0) readers[m->ops[i].t_in[k]]++;
+        if (m->ops[i].t_out >= 0) writers[m->ops[i].t_out]++;
+    }
+    for (int i = 0; i + 2 < m->n_ops; i++) {
+        mars_op_t *c = &m->ops[i], *s = &m->ops[i + 1], *mu = &m->ops[i + 2];
+        if (c->kind != OP_CONV_I8 || s->kind != OP_LUT_I8 || mu->kind != OP_BINARY_I8 || !mu->is_mul) continue;
+        if (m->pub.layers[s->layer].desc.type != MARS_LAYER_SIGMOID) continue;
+        const int q1 = c->t_out, q2 = s->t_out, q3 = mu->t_out;
+        if (s->t_in[0] != q1) continue;
+        const int fwd = mu->t_in[0] == q1 && mu->t_in[1] == q2, rev = mu->t_in[0] == q2 && mu->t_in[1] == q1;
+        if (!fwd && !rev) continue;
+        if (q1 == q2 || q2 == q3 || q1 == q3) continue;
+        { /* redirecting the result onto one of the convolution's own inputs would make a parallel launch run in place */
+            int inplace = 0;
+            for (int k = 0; k < c->n_in; k++)
+                if (c->t_in[k] == q3) inplace = 1;
+            if (inplace) continue;
+        }
+        if (readers[q1] != 2 || readers[q2] != 1 || writers[q1] != 1 || writers[q2] != 1 || writers[q3] != 1) continue;
+        if (m->mt[q1].io_out || m->mt[q2].io_out || m->mt[q1].io_in || m->mt[q2].io_in) continue;
+        const size_t n1 = (size_t)c->out_h * c->out_w * c->out_c;
+        if (s->n != n1 || mu->n != n1) continue; /* the chain must cover exactly the conv's result */
+        const mars_tensor_t *d1 = &m->pub.tensors[q1].desc, *d2 = &m->pub.tensors[q2].desc, *d3 = &m->pub.tensors[q3].desc;
+        int8_t tab[256];
+        for (int q = -128; q < 128; q++) {
+            int sg = sigmoid_q(q, d1->scale, d2->scale);
+            tab[q + 128] = (int8_t)(fwd ? binary_q(1, q, sg, d1->scale, d2->scale, d3->scale)
+                                        : binary_q(1, sg, q, d2->scale, d1->scale, d3->scale));
+        }
+        c->lut_off = lut_i8(m, tab);
+        if (mhip_conv_i8_lut2_ok(c->cs)) {
+            /* half-step form: index k = trunc(2 * acc * cs) in [-256, 255] determines round-half-away(acc * cs) =
+             * (k >= 0 ? (k+1)>>1 : -((1-k)>>1)) exactly (conv_i8.hip, requant_pack FAST); the ReLU clamp folds in */
+            int8_t tab2[512];
+            for (int k = -256; k < 256; k++) {
+                int r = k >= 0 ? (k + 1) >> 1 : -((1 - k) >> 1);
+                const int lo = c->relu ? 0 : -128;
+                r = r < lo ? lo : (r > 127 ? 127 : r);
+                tab2[k + 256] = tab[r + 128];
+            }
+            c->lut2_off = arena_reserve(m, 512);
+            if (c->lut2_off != NO_OFF) memcpy(m->arena_host + c->lut2_off, tab2, 512);
+        }
+        c->t_out = q3;
+        c->bytes += 0; /* same bytes written, to q3 instead of q1 */
+        touch(m, q3, n1);
+        m->mt[q1].needed = 0;
+        m->mt[q2].needed = 0;
+        /* drop the two element-wise ops */
+        memmove(&m->ops[i + 1], &m->ops[i + 3], (size_t)(m->n_ops - i - 3) * sizeof(mars_op_t));
+        m->n_ops -= 2;
+    }
+    free(readers);
+    free(writers);
+}
+
+/* float32 form of the same chain: conv_f32 -> SIGMOID (float, :742-749) -> MUL (float, :807-816).  The epilogue evaluates
+ * s = 1.0f / (1.0f + expf(-v)), out = v * s with the reference's roundings and this image's libm expf (expf_exact.h), so
+ * the fused result is the same float bit for bit; the two intermediates are never written (5 of the 7 float passes over
+ * the tensor disappear: the element-wise layers were 36 % of the float32 graph's time). */
+void fuse_silu_f32(mars_model_ext_t *m) {
+    const int nt = (int)m->pub.header.num_tensors;
+    int *readers = (int *)calloc((size_t)nt + 1, sizeof(int));
+    int *writers = (int *)calloc((size_t)nt + 1, sizeof(int));
+    if (!readers || !writers) { free(readers); free(writers); return; }
+    for (int i = 0; i < m->n_ops; i++) {
+        for (int k = 0; k < m->ops[i].n_in; k++)
+            if (m->ops[i].t_in[k] >= 0) readers[m->ops[i].t_in[k]]++;
+        if (m->ops[i].t_out >= 0) writers[m->ops[i].t_out]++;
+    }
+    for (int i = 0; i + 2 < m->n_ops; i++) {
+        mars_op_t *c = &m->ops[i], *s = &m->ops[i + 1], *mu = &m->ops[i + 2];
+        if (c->kind != OP_CONV_F32 || s->kind != OP_SIGMOID_F32 || mu->kind != OP_BINARY_F32 || !mu->is_mul) continue;
+        const int q1 = c->t_out, q2 = s->t_out, q3 = mu->t_out;
+        if (s->t_in[0] != q1 || q1 == q2 || q2 == q3 || q1 == q3 || q3 == c->t_in[0]) continue;
+        if (!((mu->t_in[0] == q1 && mu->t_in[1] == q2) || (mu->t_in[0] == q2 && mu->t_in[1] == q1))) continue;
+        if (readers[q1] != 2 || readers[q2] != 1 || writers[q1] != 1 || writers[q2] != 1 || writers[q3] != 1) continue;
+        if (m->mt[q1].io_out || m->mt[q2].io_out || m->mt[q1].io_in || m->mt[q2].io_in || m->mt[q3].is_weight) continue;
+        const size_t n1 = (size_t)c->out_h * c->out_w * c->out_c;
+        if (s->n != n1 || mu->n != n1) continue; /* the chain must cover exactly the conv's result */
+        c->silu_f32 = 1;
+        c->t_out = q3;
+        touch(m, q3, n1 * 4);
+        m->mt[q1].needed = 0;
+        m->mt[q2].needed = 0;
+        memmove(&m->ops[i + 1], &m->ops[i + 3], (size_t)(m->n_ops - i - 3) * sizeof(mars_op_t));
+        m->n_ops -= 2;
+    }
+    free(readers);
+    free(writers);
+}
+
+/* ------------------------------------------------------------- zero-copy concat
+ * A concat input that (a) has exactly one producer launch of a kind that can write a channel slice
+ * (int8 NHWC conv, int8 add/mul, max-pool, upsample), (b) is read by nothing but that concat, and
+ * (c) has the concat's pixel grid, is produced directly inside the concat's output tensor: the
+ * producer gets (pixel stride = concat channels, channel offset) and the copy launch disappears.
+ * Same bytes end up in the concat output; the intermediate tensor is never materialised. */
+void elide_concat(mars_model_ext_t *m) {
+    const int nt = (int)m->pub.header.num_tensors;
+    int *readers = (int *)calloc((size_t)nt + 1, sizeof(int));
+    int *writers = (int *)calloc((size_t)nt + 1, sizeof(int));
+    if (!readers || !writers) { free(readers); free(writers); return; }
+    for (int i = 0; i < m->n_ops; i++) {
+        for (int k = 0; k < m->ops[i].n_in; k++)
+            if (m->ops[i].t_in[k] >= 0) readers[m->ops[i].t_in[k]]++;
+        if (m->ops[i].t_out >= 0) writers[m->ops[i].t_out]++;
+    }
+    for (int i = 0; i < m->n_ops; i++) {
+        mars_op_t *cs = &m->ops[i];
+        if (cs->kind != OP_CONCAT_SLICE) continue;
+        const int ti = cs->t_in[0], to = cs->t_out;
+        const mtensor_t *mt = &m->mt[ti];
+        if (mt->is_weight || mt->io_in || mt->io_out || readers[ti] != 1 || writers[ti] != 1) continue;
+        int j = -1;
+        for (int k = 0; k < i; k++)
+            if (m->ops[k].t_out == ti) j = k;
+        if (j < 0) continue;
+        mars_op_t *pr = &m->ops[j];
+        if (pr->out_pix_stride || pr->add_t) continue; /* a folded Add needs its other operand laid out like the output */
+        const size_t npix = (size_t)cs->out_h * cs->out_w;
+        int ok = 0;
+        if (pr->kind == OP_CONV_I8 && !pr->nchw) ok = (size_t)pr->out_h * pr->out_w == npix && pr->out_c == cs->in_c;
+        else if (pr->kind == OP_BINARY_I8) ok = pr->n == npix * (size_t)cs->in_c;
+        else if (pr->kind == OP_MAXPOOL || pr->kind == OP_UPSAMPLE) ok = (size_t)pr->out_h * pr->out_w == npix && pr->in_c == cs->in_c;
+        if (!ok || cs->ch_off + cs->in_c > cs->out_c) continue;
+        /* nothing between producer and the copy may touch the concat output except its other slices */
+        int clash = 0;
+        for (int k = j; k < i && !clash; k++) {
+            const mars_op_t *o = &m->ops[k];
+            if (o->kind == -1) continue; /* a slice copy already elided */
+            for (int q = 0; q < o->n_in; q++)
+                if (o->t_in[q] == to) clash = 1;
+            if (o->t_out == to && o->kind != OP_CONCAT_SLICE && !o->out_pix_stride) clash = 1;
+        }
+        if (clash) continue;
+        pr->t_out = to;
+        pr->out_pix_stride = cs->out_c;
+        pr->out_ch_off = cs->ch_off;
+        if (pr->kind == OP_BINARY_I8) pr->in_c = cs->in_c; /* channel run of the slice */
+        pr->bytes += 0;
+        m->mt[ti].needed = 0;
+        cs->kind = -1; /* dropped below */
+    }
+    int w = 0;
+    for (int i = 0; i < m->n_ops; i++)
+        if (m->ops[i].kind != -1) m->ops[w++] = m->ops[i];
+    m->n_ops = w;
+    free(readers);
+    free(writers);
+}
+
+/* Residual Add folded into the convolution that produces one of its operands (the bottleneck shortcut of C3):
+ * out = Add(conv_result, x) is evaluated in the convolution's epilogue with the reference's float steps
+ * (mars_runtime.c ADD branch: (a*sa + b*sb) * (1/so) + 0.5f, truncated, saturated), reading x where the output
+ * goes.  Saves writing the convolution result and reading it back.  Conditions: the convolution result has no
+ * other reader, x and the Add output have the same dense layout and frame stride, nothing touches them in
+ * between, and the scales keep the float -> int conversion in range (so no x86 fix-up is needed). */
+static size_t planned_stride(const mtensor_t *t) {
+    size_t s = ALIGN_UP(t->extent > t->bytes ? t->extent : t->bytes, 256);
+    return s ? s : 256;
+}
+void fuse_add(mars_model_ext_t *m) {
+    const int nt = (int)m->pub.header.num_tensors;
+    int *readers = (int *)calloc((size_t)nt + 1, sizeof(int));
+    int *writers = (int *)calloc((size_t)nt + 1, sizeof(int));
+    if (!readers || !writers) { free(readers); free(writers); return; }
+    for (int i = 0; i < m->n_ops; i++) {
+        for (int k = 0; k < m->ops[i].n_in; k++)
+            if (m->ops[i].t_in[k] >= 0) readers[m->ops[i].t_in[k]]++;
+        if (m->ops[i].t_out >= 0) writers[m->ops[i].t_out]++;
+    }
+    for (int j = 0; j < m->n_ops; j++) {
+        mars_op_t *ad = &m->ops[j];
+        if (ad->kind != OP_BINARY_I8 || ad->is_mul || ad->n_in != 2 || ad->out_pix_stride) continue;
+        for (int side = 0; side < 2; side++) {
+            const int A = ad->t_in[side], X = ad->t_in[1 - side], O = ad->t_out;
+            if (A < 0 || X < 0 || O < 0 || A == X || O == X || O == A) continue;
+            if (readers[A] != 1 || writers[A] != 1 || m->mt[A].io_in || m->mt[A].io_out || m->mt[A].is_weight) continue;
+            if (m->mt[X].is_weight || m->mt[O].is_weight || writers[O] != 1) continue;
+            int i = -1;
+            for (int k = 0; k < j; k++)
+                if (m->ops[k].t_out == A) i = k;
+            if (i < 0) continue;
+            mars_op_t *c = &m->ops[i];
+            if (c->kind != OP_CONV_I8 || c->nchw || !c->safe || c->out_pix_stride || (c->out_c & 15) || (c->in_c & 15) ||
+                c->nseg || c->add_t || c->n_in != 1)
+                continue;
+            if (ad->n != (size_t)c->out_h * c->out_w * c->out_c) continue;
+            if (c->t_in[0] == O) continue; /* add(conv(X), Y) -> X: sequential in the reference, a race when fused */
+            if (planned_stride(&m->mt[X]) != planned_stride(&m->mt[O])) continue;
+            const float s_conv = side == 0 ? ad->f0 : ad->f1, s_other = side == 0 ? ad->f1 : ad->f0, inv = ad->f2;
+            const double bound = 128.0 * (fabs((double)s_conv) + fabs((double)s_other)) * fabs((double)inv) + 1.0;
+            if (!(bound < 2147483000.0)) continue; /* also rejects NaN / inf */
+            int clash = 0;
+            for (int k = i; k <= j && !clash; k++) {
+                const mars_op_t *o = &m->ops[k];
+                if (o->t_out == X) clash = 1; /* x must be complete before the convolution runs */
+                if (k > i && k < j) {
+                    if (o->t_out == O) clash = 1;
+                    for (int q = 0; q < o->n_in; q++)
+                        if (o->t_in[q] == O) clash = 1;
+                }
+            }
+            if (clash) continue;
+            c->t_out = O;
+            c->add_t = X + 1;
+            c->add_s_conv = s_conv; c->add_s_other = s_other; c->add_inv = inv;
+            c->t_in[c->n_in++] = X;
+            c->bytes += (double)ad->n;
+            m->mt[A].needed = 0;
+            ad->kind = -1;
+            readers[A] = 0;
+            break;
+        }
+    }
+    int w = 0;
+    for (int i = 0; i < m->n_ops; i++)
+        if (m->ops[i].kind != -1) m->ops[w++] = m->ops[i];
+    m->n_ops = w;
+    free(readers);
+    free(writers);
+}
+
+/* Fused C3 bottleneck: conv1x1 + SiLU (A) whose only reader is the k x k convolution B right behind it (B usually
+ * carries the folded residual Add of A's input) -> B evaluates A on its staged input patch (conv_i8_patch<PRE>); A's
+ * output tensor is never written.  Same bytes: B sees, at every in-image pixel of its window, exactly the int8 value A
+ * would have stored there, and zeros outside the image as its SAME padding prescribes.  Only where the device code can
+ * take it (mhip_conv_i8_pre_ok: stride 1, 32 / 64 channels, patch fits); everything else keeps the two launches.
+ * Fusion level 2 only: measured on the yolov5s twin it removes 4 launches (batch 1: 0.494 -> 0.485 ms) but returns
+ * nothing at batch 256 -- these 32 / 64-channel layers are bound by the requantisation's vector instructions, not by
+ * the bytes the fusion saves, and the halo makes the fused kernel requantise 1.3x the pixels. */
+void fuse_bottleneck(mars_model_ext_t *m) {
+    const int nt = (int)m->pub.header.num_tensors;
+    int *readers = (int *)calloc((size_t)nt + 1, sizeof(int));
+    if (!readers) return;
+    for (int i = 0; i < m->n_ops; i++)
+        for (int k = 0; k < m->ops[i].n_in; k++)
+            if (m->ops[i].t_in[k] >= 0) readers[m->ops[i].t_in[k]]++;
+    for (int i = 0; i + 1 < m->n_ops; i++) {
+        mars_op_t *a = &m->ops[i], *b = &m->ops[i + 1];
+        if (a->kind != OP_CONV_I8 || b->kind != OP_CONV_I8 || a->pre || b->pre) continue;
+        const int T = a->t_out;
+        if (T < 0 || b->t_in[0] != T || readers[T] != 1 || m->mt[T].io_in || m->mt[T].io_out || m->mt[T].is_weight) continue;
+        if (a->kh != 1 || a->kw != 1 || a->sh != 1 || a->sw != 1 || a->nchw || b->nchw || !a->safe || !b->safe || a->nseg || b->nseg ||
+            a->add_t || a->n_in != 1 || a->out_pix_stride || a->relu || a->lut2_off == NO_OFF || b->lut2_off == NO_OFF ||
+            a->in_c != a->out_c || a->out_c != b->in_c || (a->in_c != 32 && a->in_c != 64) || b->sh != 1 || b->sw != 1 ||
+            a->in_h != b->in_h || a->in_w != b->in_w || a->b_off == NO_OFF || a->pair_next || b->pair_next ||
+            (i > 0 && m->ops[i - 1].pair_next))
+            continue;
+        const int X = a->t_in[0];
+        if (X < 0 || X == b->t_out || m->mt[X].is_weight) continue;
+        /* the device side decides on geometry: describe B with A folded in (pointers only need to be non-null here) */
+        mars_op_t trial = *b;
+        trial.pre = 1;
+        trial.t_in[0] = X;
+        mhip_conv_i8_t p;
+        memset(&p, 0, sizeof(p));
+        p.frames = 1; p.in_c = trial.in_c; p.in_h = trial.in_h; p.in_w = trial.in_w; p.out_h = trial.out_h; p.out_w = trial.out_w;
+        p.out_c = trial.store_c ? trial.store_c : trial.out_c; p.kh = trial.kh; p.kw = trial.kw; p.stride_h = trial.sh; p.stride_w = trial.sw;
+        p.pad_top = trial.pt; p.pad_left = trial.pl; p.row_pad = trial.row_pad; p.oc_pad = trial.oc_pad; p.safe = trial.safe;
+        p.out_pix_stride = trial.out_pix_stride; p.out_ch_off = trial.out_ch_off;
+        p.pre_w = (const int8_t *)m; p.pre_bias = (const int32_t *)m; p.pre_lut2 = (const uint8_t *)m; p.lut2 = (const uint8_t *)m;
+        p.lut = (const uint8_t *)m;
+        if (!mhip_conv_i8_pre_ok(&p)) continue;
+        b->pre = 1;
+        b->pre_w_off = a->w_off; b->pre_b_off = a->b_off; b->pre_lut2_off = a->lut2_off; b->pre_cs = a->cs;
+        b->t_in[0] = X;
+        b->macs += a->macs;
+        m->mt[T].needed = 0;
+        readers[T] = 0;
+        a->kind = -1;
+    }
+    int w = 0;
+    for (int i = 0; i < m->n_ops; i++)
+        if (m->ops[i].kind != -1) m->ops[w++] = m->ops[i];
+    m->n_ops = w;
+    free(readers);
+}
+
+/* Virtual concat: when every reader of a Concat output is a plain 1x1 convolution, the concat tensor is never
+ * written -- the convolution's K loop takes each run of channels straight from the tensor that owns it
+ * (conv_i8_persist<SEG>).  The slice copies disappear and every producer keeps writing dense rows.  Same bytes
+ * as the reference: the copy would have put pixel p, channels [off, off+in_c) of the concat tensor = pixel p of the
+ * input, which is exactly what the segmented read fetches (checked: nothing rewrites an input between the copy's
+ * position and the last reader). */
+void virtual_concat(mars_model_ext_t *m) {
+    const int nt = (int)m->pub.header.num_tensors;
+    for (int T = 0; T < nt; T++) {
+        const mtensor_t *mt = &m->mt[T];
+        if (mt->is_weight || mt->io_in || mt->io_out) continue;
+        int sl[4], ns = 0, bad = 0, first_reader = -1, last_reader = -1, last_slice = -1;
+        for (int i = 0; i < m->n_ops && !bad; i++) {
+            const mars_op_t *o = &m->ops[i];
+            if (o->t_out == T) {
+                if (o->kind != OP_CONCAT_SLICE || ns >= 4) bad = 1;
+                else { sl[ns++] = i; last_slice = i; }
+            }
+            for (int k = 0; k < o->n_in; k++)
+                if (o->t_in[k] == T) {
+                    if (o->kind != OP_CONV_I8 || k != 0 || o->n_in != 1 || o->nchw || o->kh != 1 || o->kw != 1 || o->sh != 1 ||
+                        o->sw != 1 || o->pt || o->pl || !o->safe || o->nseg || (o->out_c & 15) || o->in_h != o->out_h ||
+                        o->in_w != o->out_w || (o->in_c & (o->in_c - 1)) != 0 || o->add_t) /* the tile walker: K position by
+                                                                                            * shifts, no folded Add */
+                        bad = 1;
+                    if (first_reader < 0) first_reader = i;
+                    last_reader = i;
+                }
+        }
+        if (bad || ns < 2 || first_reader < 0 || last_slice > first_reader) continue;
+        /* slices in channel order, tiling [0, out_c) in multiples of 32, all over the same pixels */
+        for (int a = 0; a < ns; a++)
+            for (int b = a + 1; b < ns; b++)
+                if (m->ops[sl[b]].ch_off < m->ops[sl[a]].ch_off) { int t = sl[a]; sl[a] = sl[b]; sl[b] = t; }
+        int c = 0;
+        const mars_op_t *s0 = &m->ops[sl[0]];
+        for (int a = 0; a < ns && !bad; a++) {
+            const mars_op_t *o = &m->ops[sl[a]];
+            if (o->ch_off != c || (o->in_c & 31) || o->out_h != s0->out_h || o->out_w != s0->out_w || o->out_c != s0->out_c ||
+                o->t_in[0] == T || o->t_in[0] < 0)
+                bad = 1;
+            c += o->in_c;
+            /* the input must still hold at the last reader what it held where the copy stood */
+            for (int i = sl[a] + 1; i <= last_reader && !bad; i++)
+                if (m->ops[i].t_out == o->t_in[0]) bad = 1;
+        }
+        if (bad || c != s0->out_c) continue;
+        for (int i = 0; i < m->n_ops && !bad; i++) {
+            const mars_op_t *o = &m->ops[i];
+            if (o->kind == OP_CONV_I8 && o->n_in == 1 && o->t_in[0] == T &&
+                (o->in_c != c || (size_t)o->in_h * o->in_w != (size_t)s0->out_h * s0->out_w))
+                bad = 1;
+        }
+        if (bad) continue;
+        for (int i = 0; i < m->n_ops; i++) {
+            mars_op_t *o = &m->ops[i];
+            if (o->kind != OP_CONV_I8 || o->n_in != 1 || o->t_in[0] != T) continue;
+            o->nseg = ns;
+            o->n_in = ns;
+            for (int a = 0; a < ns; a++) {
+                o->seg_t[a] = o->t_in[a] = m->ops[sl[a]].t_in[0];
+                o->seg_c[a] = m->ops[sl[a]].in_c;
+            }
+        }
+        for (int a = 0; a < ns; a++) m->ops[sl[a]].kind = -1;
+        m->mt[T].needed = 0;
+        /* a segment that is a 2x2 nearest upsample (reference :1003-1044) of a half-size tensor, read by nothing
+         * else: the convolution reads the half-size tensor at pixel (y/2, x/2) and the upsample launch goes too */
+        for (int a = 0; a < ns; a++) {
+            const int S = m->ops[sl[a]].t_in[0];
+            int up = -1, nread = 0, nwrite = 0, ok = 1;
+            for (int i = 0; i < m->n_ops; i++) {
+                const mars_op_t *o = &m->ops[i];
+                if (o->kind == -1) continue;
+                if (o->t_out == S) { nwrite++; up = i; }
+                for (int k = 0; k < o->n_in; k++)
+                    if (o->t_in[k] == S && !(o->kind == OP_CONV_I8 && o->nseg == ns && o->seg_t[a] == S)) nread++;
+            }
+            if (nwrite != 1 || nread != 0 || up < 0 || m->mt[S].io_out || m->mt[S].io_in || m->mt[S].is_weight) continue;
+            const mars_op_t *u = &m->ops[up];
+            if (u->kind != OP_UPSAMPLE || u->out_pix_stride || u->scale_h != 2 || u->scale_w != 2 || u->out_h != 2 * u->in_h ||
+                u->out_w != 2 * u->in_w || u->in_c != m->ops[sl[a]].in_c || u->out_h != s0->out_h || u->out_w != s0->out_w)
+                continue;
+            const int U = u->t_in[0];
+            if (U < 0 || U == S) continue;
+            int last = -1;
+            for (int i = 0; i < m->n_ops; i++)
+                if (m->ops[i].kind == OP_CONV_I8 && m->ops[i].nseg == ns && m->ops[i].seg_t[a] == S) last = i;
+            for (int i = up; i <= last && ok; i++)
+                if (m->ops[i].kind != -1 && m->ops[i].t_out == U) ok = 0; /* the half-size tensor must stay as it was */
+            if (!ok) continue;
+            for (int i = 0; i < m->n_ops; i++) {
+                mars_op_t *o = &m->ops[i];
+                if (o->kind == OP_CONV_I8 && o->nseg == ns && o->seg_t[a] == S) {
+                    o->seg_t[a] = o->t_in[a] = U;
+                    o->seg_up |= 1 << a;
+                }
+            }
+            m->ops[up].kind = -1;
+            m->mt[S].needed = 0;
+        }
+    }
+    int w = 0;
+    for (int i = 0; i < m->n_ops; i++)
+        if (m->ops[i].kind != -1) m->ops[w++] = m->ops[i];
+    m->n_ops = w;
+}
+
+/* Two convolutions that read the same input with the same geometry (C3's cv1 and cv2, which the exporter emits
+ * a few layers apart) are launched as ONE grid (conv_i8_persist<PAIR>): the workgroups that need a pixel tile run
+ * next to each other, so the input is read from HBM once.  The later one is moved up behind the earlier one when
+ * nothing in between touches its operands or its output. */
+static int same_conv_input(const mars_op_t *a, const mars_op_t *b) {
+    if (a->n_in != b->n_in || a->nseg != b->nseg || a->seg_up != b->seg_up) return 0;
+    for (int k = 0; k < a->n_in; k++)
+        if (a->t_in[k] != b->t_in[k]) return 0;
+    for (int k = 0; k < a->nseg; k++)
+        if (a->seg_t[k] != b->seg_t[k] || a->seg_c[k] != b->seg_c[k]) return 0;
+    return a->in_h == b->in_h && a->in_w == b->in_w && a->in_c == b->in_c && a->out_h == b->out_h && a->out_w == b->out_w &&
+           a->kh == b->kh && a->kw == b->kw && a->sh == b->sh && a->sw == b->sw && a->pt == b->pt && a->pl == b->pl &&
+           a->row_pad == b->row_pad && a->oc_pad == b->oc_pad;
+}
+static int pairable(const mars_op_t *o) {
+    /* measured: pairs with a plain input gain 10-20 %, pairs reading a virtual concat lose (their single launches are
+     * tuned individually), so only the former are formed */
+    return o->kind == OP_CONV_I8 && !o->nchw && !o->add_t && !o->nseg && o->safe && o->lut_off != NO_OFF && !o->pair_next &&
+           (o->in_c & 15) == 0 && o->in_c > 4 && (o->out_c & 15) == 0 && !o->out_pix_stride;
+}
+static int op_writes(const mars_op_t *o, int t) {
+    if (o->t_out == t) return 1;
+    for (int k = 0; k < o->chain_n; k++)
+        if (o->chain_out[k] == t) return 1;
+    return 0;
+}
+void pair_convs(mars_model_ext_t *m) {
+    for (int i = 0; i + 1 < m->n_ops; i++) {
+        mars_op_t *a = &m->ops[i];
+        if (!pairable(a) || (i > 0 && m->ops[i - 1].pair_next)) continue;
+        for (int j = i + 1; j < m->n_ops && j <= i + 48; j++) {
+            mars_op_t *b = &m->ops[j];
+            if (!pairable(b) || !same_conv_input(a, b) || b->t_out == a->t_out) continue;
+            int ok = 1;
+            for (int k = 0; k < b->n_in; k++)
+                if (b->t_in[k] == b->t_out || b->t_in[k] == a->t_out) ok = 0;
+            for (int q = i + 1; q < j && ok; q++) {
+                const mars_op_t *o = &m->ops[q];
+                if (op_writes(o, b->t_out)) ok = 0;
+                for (int k = 0; k < o->n_in; k++)
+                    if (o->t_in[k] == b->t_out) ok = 0;
+                for (int k = 0; k < b->n_in; k++)
+                    if (op_writes(o, b->t_in[k])) ok = 0;
+            }
+            if (!ok) continue;
+            mars_op_t moved = *b;
+            memmove(&m->ops[i + 2], &m->ops[i + 1], sizeof(mars_op_t) * (size_t)(j - i - 1));
+            m->ops[i + 1] = moved;
+            m->ops[i].pair_next = 1;
+            break;
+        }
+    }
+}
+
+/* SPPF: MaxPool -> MaxPool -> MaxPool, stride 1, same window, each feeding the next: one launch that keeps the
+ * frame in LDS (mhip_pool_chain_i8).  Every stage's tensor is still written (the concat / convolution reads them). */
+void fuse_pool_chains(mars_model_ext_t *m) {
+    for (int i = 0; i + 1 < m->n_ops; i++) {
+        mars_op_t *a = &m->ops[i];
+        if (a->kind != OP_MAXPOOL || a->chain_n || a->sh != 1 || a->sw != 1 || a->out_pix_stride || (a->in_c & 15) ||
+            a->out_h != a->in_h || a->out_w != a->in_w || a->kh <= 0 || a->kw <= 0 || (size_t)a->in_h * a->in_w * 64 > 60 * 1024 ||
+            a->t_out < 0 || m->mt[a->t_out].io_out)
+            continue;
+        int n = 1;
+        a->chain_out[0] = a->t_out;
+        while (n < 3 && i + n < m->n_ops) {
+            const mars_op_t *b = &m->ops[i + n];
+            if (b->kind != OP_MAXPOOL || b->t_in[0] != a->chain_out[n - 1] || b->sh != 1 || b->sw != 1 || b->out_pix_stride ||
+                b->in_c != a->in_c || b->in_h != a->in_h || b->in_w != a->in_w || b->out_h != a->in_h || b->out_w != a->in_w ||
+                b->kh != a->kh || b->kw != a->kw || b->t_out < 0 || m->mt[b->t_out].io_out || b->t_out == a->t_in[0])
+                break;
+            a->chain_out[n] = b->t_out;
+            n++;
+        }
+        if (n < 2) continue;
+        a->chain_n = n;
+        for (int k = 1; k < n; k++) {
+            a->bytes += m->ops[i + k].bytes - (double)a->in_h * a->in_w * a->in_c; /* later stages re-read nothing */
+            m->ops[i + k].kind = -1;
+        }
+        a->t_out = a->chain_out[n - 1];
+    }
+    int w = 0;
+    for (int i = 0; i < m->n_ops; i++)
+        if (m->ops[i].kind != -1) m->ops[w++] = m->ops[i];
+    m->n_ops = w;
+}
+
+/* float32 graphs: which convolutions may take the f32 matrix cores (fused rounding per tap, inside the 1e-4 tolerance)?
+ * The reference's MAXPOOL runs int8 byte logic on whatever bytes it is given (mars_runtime.c:919-957), and so does the
+ * fused-ReLU clamp of a float convolution (:700-707): over float bytes both are DISCONTINUOUS functions of their input (a
+ * last-bit change can flip which byte wins / whether a mantissa byte is zeroed: measured, 1 value in 16 384 left the
+ * tolerance), so every convolution from which one of them can be reached keeps the reference's summation order (conv_f32_kernel, bit-identical); byte-copying
+ * layers (concat, upsample) and the float element-wise layers only pass small differences on. */
+void f32_policy(mars_model_ext_t *m) {
+    const int nt = (int)m->pub.header.num_tensors;
+    unsigned char *hot = (unsigned char *)calloc((size_t)nt + 1, 1);
+    if (!hot) {
+        for (int i = 0; i < m->n_ops; i++) m->ops[i].f32_exact = 1;
+        return;
+    }
+    for (int i = m->n_ops - 1; i >= 0; i--) {
+        mars_op_t *o = &m->ops[i];
+        int reach = 0;
+        if (o->kind == OP_MAXPOOL && o->t_in[0] >= 0 && m->pub.tensors[o->t_in[0]].desc.dtype == MARS_DTYPE_FLOAT32) reach = 1;
+        if (o->kind == OP_RELU_BYTES && o->t_out >= 0) { /* the fused-ReLU byte clamp over float bytes (:700-707): in place */
+            hot[o->t_out] = 1;
+            continue;
+        }
+        if (o->t_out >= 0 && hot[o->t_out]) reach = 1;
+        for (int k = 0; k < o->chain_n; k++)
+            if (o->chain_out[k] >= 0 && hot[o->chain_out[k]]) reach = 1;
+        if (!reach) continue;
+        for (int k = 0; k < o->n_in; k++)
+            if (o->t_in[k] >= 0) hot[o->t_in[k]] = 1;
+        if (o->kind == OP_CONV_F32) o->f32_exact = 1;
+    }
+    free(hot);
+}
+
