@@ -847,6 +847,7 @@ const tune_t &conv_i8_tune_state() {
         g_tune.rgb_direct = env_int("MARS_HIP_RGB_DIRECT", 1);
         g_tune.small_batch = env_int("MARS_HIP_SMALL_BATCH", 1);
         g_tune.rows = env_int("MARS_HIP_ROWS", 1);
+        g_tune.few_wgs = env_int("MARS_HIP_FEW_WGS", 256);
         g_tune.patch_ring = env_int("MARS_HIP_PATCH_RING", 0);
         g_tune.patch_lds_kb = env_int("MARS_HIP_PATCH_LDS_KB", 80);
         g_tune.init = 1;
@@ -859,7 +860,7 @@ static int tune_access(const char *key, int value, int *get) {
     (void)conv_i8_tune_state();
     struct { const char *k; int *v; } tab[] = {{"persist", &g_tune.persist}, {"persist_stages", &g_tune.persist_stages},
                                                {"persist_maxk", &g_tune.persist_maxk}, {"persist_slots", &g_tune.persist_slots}, {"wres", &g_tune.wres}, {"rgb_direct", &g_tune.rgb_direct}, {"small_batch", &g_tune.small_batch},
-                                               {"rows", &g_tune.rows}, {"patch_ring", &g_tune.patch_ring}, {"patch_lds_kb", &g_tune.patch_lds_kb}, {"stages", &g_tune.stages}, {"bpx", &g_tune.bpx}, {"variant", &g_tune.variant}, {"bufmode", &g_tune.bufmode}};
+                                               {"rows", &g_tune.rows}, {"few_wgs", &g_tune.few_wgs}, {"patch_ring", &g_tune.patch_ring}, {"patch_lds_kb", &g_tune.patch_lds_kb}, {"stages", &g_tune.stages}, {"bpx", &g_tune.bpx}, {"variant", &g_tune.variant}, {"bufmode", &g_tune.bufmode}};
     for (auto &e : tab)
         if (key && !strcmp(key, e.k)) {
             if (get) *get = *e.v;
@@ -1082,7 +1083,7 @@ static variant_t default_variant(const mhip_conv_i8_t *p, int nks) {
     // waves), the plain two-stage tile walker without the up-front weight fetch for 1 x 1 layers.  These are the
     // autotuner's choices at batch 1 (yolov5s twin, 640 x 640: 0.62 -> 0.53 ms per frame).
     const long wg_large = ((long)p->frames * p->out_h * p->out_w + 255) / 256 * ((p->oc_pad + 127) / 128);
-    const bool few = wg_large < 256 && tune().persist && !tune().bpx && !tune().stages && tune().small_batch;
+    const bool few = wg_large < tune().few_wgs && tune().persist && !tune().bpx && !tune().stages && tune().small_batch;
     if (few) {
         if (conv_i8_patch_ok(p, 4, &ring)) {
             v.persist = 0; v.bpx = 0; v.stages = 0; v.patch = 4;

@@ -419,6 +419,7 @@ struct tune_t {
     int rgb_direct;     // MARS_HIP_RGB_DIRECT    1: the RGB stem runs in its operand-direct form (conv_i8_rgb) where eligible
     int wres;           // MARS_HIP_WRES          bit 0 / 1: the default policy may keep the weights resident in LDS (tile
                         //                        walker) for single / paired launches
+    int few_wgs;        // MARS_HIP_FEW_WGS       a launch whose large-batch tiling gives fewer workgroups than this takes the small-tile policy
     int rows;           // MARS_HIP_ROWS          1: the default policy may pick conv_i8_rows (variant 20) where it measured faster
     int patch_ring;     // MARS_HIP_PATCH_RING    0: auto, else at most this many patch buffers per workgroup of the patch-staged kernel (1..4)
     int patch_lds_kb;   // MARS_HIP_PATCH_LDS_KB  LDS budget of one patch-staged workgroup (default 80: two workgroups per CU)
