@@ -246,7 +246,7 @@ def main():
                          "float32) with its convolutions on the f32 matrix cores (mars_hip_set_tuning f32_mfma=2); graph only "
                          "(float heads have no int8 decode), outputs checked against the CPU reference within 1e-4*max(1,|b|)")
     ap.add_argument("--f32-mode", type=int, default=3, help="--dtype f32: 0 exact order, 1 default policy, 2 f32 matrix cores everywhere, "
-                                                            "3 (default) bf16 matrix cores with split operands everywhere")
+                                                            "3 (default) bf16 matrix cores everywhere, operands split in two (three piece products), 4 split in three (six)")
     ap.add_argument("--timed-only", action="store_true",
                     help="skip the legs after the timed region (mars_run / pipelined I/O / batch-1 latency / CPU baselines): "
                          "what profiling passes want")
@@ -485,7 +485,7 @@ def main():
         traffic, traffic_src = (None, None) if f32 else pmc_traffic(args)
         # f32: the ceiling of the path that runs -- v_mfma_f32_16x16x4_f32 at 157.3 TF, or (mode 3) six bf16 MFMAs per product on
         # the 2.5 PF bf16 cores = 417 TF of float32 work; int8: the dense int8 MFMA rate
-        mpeak = (2.5e15 / 6.0 if args.f32_mode == 3 else 157.3e12) if f32 else 5e15
+        mpeak = (2.5e15 / 3.0 if args.f32_mode == 3 else 2.5e15 / 6.0 if args.f32_mode == 4 else 157.3e12) if f32 else 5e15
         floor_ms = sum(max(op["bytes"] * args.batch / 8e12, 2.0 * op["macs"] * args.batch / mpeak)
                        for op in model.ops() if op["kind"] == ckind) * 1e3
         peak = mpeak / 1e12  # dense int8 MFMA, TOP/s: 2x the ~2.5 PF bf16 dense peak (MI355X_MICROARCH.md, Matrix cores)
@@ -496,7 +496,7 @@ def main():
         # summed durations; the matrix-roof view of the same launches is reported next to it.  f32: 4-byte activations but
         # a 32x lower matrix peak (157.3 TF, v_mfma_f32_16x16x4_f32): ridge 20 flop/B against ~65 flop/B -> the roof is MFMA.
         roof = {"bound": "mfma" if f32 else "hbm",
-                "kernel": (("conv_f32_split (v_mfma_f32_16x16x32_bf16, 6 per product)" if args.f32_mode == 3 else "conv_f32_mfma / conv_f32_kernel") if f32 else "conv_i8_*") + " (%d launches per step)" % n_conv,
+                "kernel": (("conv_f32_split (v_mfma_f32_16x16x32_bf16, %d per product)" % (3 if args.f32_mode == 3 else 6) if args.f32_mode >= 3 else "conv_f32_mfma / conv_f32_kernel") if f32 else "conv_i8_*") + " (%d launches per step)" % n_conv,
                 "achieved": achieved if f32 else hbm_gbs, "peak": peak if f32 else 8000.0, "unit": "TFLOP/s" if f32 else "GB/s",
                 "frac": (achieved / peak) if f32 else hbm_gbs / 8000.0,
                 "traffic": traffic, "traffic_source": traffic_src,

@@ -351,10 +351,10 @@ def test_config2_tiny160_batch64(gpu, orc):
         m.close()
 
 
-@pytest.mark.parametrize("mode", [3, 2, 1])
+@pytest.mark.parametrize("mode", [3, 4, 2, 1])
 def test_config5_yolov5s_f32_twin_640(gpu, orc, mode):
     """BASELINE config 5 at size: the yolov5s_float32 twin (width 8, NCHW/OIHW f32), 640x640, with the float32
-    convolutions on the matrix cores -- everywhere on the bf16 cores with split operands (mode 3, conv_f32_split: what
+    convolutions on the matrix cores -- everywhere on the bf16 cores with split operands (modes 3 / 4 = three / six piece products, conv_f32_split; 3 is what
     bench.py --dtype f32 measures since round 4), everywhere on the f32 cores (mode 2) and under the
     default policy (mode 1: exact upstream of the byte-wise SPPF max-pools, matrix cores for the head).  One frame
     against the CPU oracle within north_star's tolerance |a-b| <= 1e-4*max(1,|b|) on all three heads; frames of a batch
@@ -431,9 +431,9 @@ def test_config5_at_batch_256(gpu, orc):
 
 @pytest.mark.parametrize("name,kw", [c for c in cases.SYNTH if c[1].get("float32")], ids=lambda v: v if isinstance(v, str) else "")
 def test_f32_matrix_core_path_within_tolerance(gpu, orc, name, kw):
-    """float32 convolutions on v_mfma_f32_16x16x4_f32 (modes 2 / 1) and on v_mfma_f32_16x16x32_bf16 with split operands (mode
-    3) against the oracle, tensor by tensor (unfused plan), on the float twins and the shipped tiny_160_f32.mars.
-    * matrix cores everywhere (modes 3 and 2): every float tensor written BEFORE the first byte-wise MAXPOOL / fused-ReLU clamp
+    """float32 convolutions on v_mfma_f32_16x16x4_f32 (modes 2 / 1) and on v_mfma_f32_16x16x32_bf16 with split operands (modes
+    3 and 4: three / six piece products) against the oracle, tensor by tensor (unfused plan), on the float twins and the shipped tiny_160_f32.mars.
+    * matrix cores everywhere (modes 3, 4 and 2): every float tensor written BEFORE the first byte-wise MAXPOOL / fused-ReLU clamp
       is within 1e-4 of the tensor's magnitude.  (Behind the SPPF pools the reference's byte-maxed floats reach 1e38 and cancel: any
       change of rounding there moves values by percents, in the reference's own terms too -- those tensors say nothing
       about a kernel; the full-size graph outputs are held to the bar by test_config5_yolov5s_f32_twin_640.)
@@ -455,7 +455,7 @@ def test_f32_matrix_core_path_within_tolerance(gpu, orc, name, kw):
                 break
             upstream += list(L["outs"])
         try:
-            for mode in (3, 2, 1):
+            for mode in (3, 4, 2, 1):
                 gpu.set_tuning("f32_mfma", mode)
                 m = gpu.Model(d, batch=2, fusion=0)
                 m.input_view(0)[0] = x

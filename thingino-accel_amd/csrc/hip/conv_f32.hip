@@ -16,8 +16,9 @@
 // Which form a layer gets is the host's decision (mars_model.c, plan_conv / f32_policy): a byte-wise MAXPOOL over float
 // bytes (reference mars_runtime.c:919-957 runs int8 byte logic whatever the dtype) is discontinuous in its input, so by
 // default every convolution UPSTREAM of such a pool stays exact and only the rest takes the matrix cores;
-// mars_hip_set_tuning("f32_mfma", 2) uses them everywhere (tolerance verified on the config-5 output), 0 nowhere; 3 (round 4) =
-// everywhere AND on the bf16 matrix cores with every operand split in three (conv_f32_split.hip): the config-5 benchmark.
+// mars_hip_set_tuning("f32_mfma", 2) uses them everywhere (tolerance verified on the config-5 output), 0 nowhere; 3 / 4 (round 4) =
+// everywhere AND on the bf16 matrix cores with every operand split into two / three bf16 pieces, three / six piece products per
+// product (conv_f32_split.hip); 3 is the config-5 benchmark.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <string.h>
@@ -223,9 +224,9 @@ extern "C" int mhip_conv_f32_mode(int set) { // set >= 0: new mode; returns the 
     if (g_f32_mode < 0) {
         const char *e = getenv("MARS_HIP_F32_MFMA");
         g_f32_mode = e ? atoi(e) : 1;
-        if (g_f32_mode < 0 || g_f32_mode > 3) g_f32_mode = 1;
+        if (g_f32_mode < 0 || g_f32_mode > 4) g_f32_mode = 1;
     }
-    if (set >= 0 && set <= 3) g_f32_mode = set;
+    if (set >= 0 && set <= 4) g_f32_mode = set;
     return g_f32_mode;
 }
 
@@ -236,7 +237,7 @@ extern "C" int mhip_conv_f32(const mhip_conv_f32_t *p) {
         return -1;
     if (p->out_c > 65535 || p->frames > 65535) return -1;
     const long hw = (long)p->out_h * p->out_w, total = hw * p->frames, K = (long)p->in_c * p->kh * p->kw;
-    if (p->use_mfma == 2) { // the bf16 matrix cores on split operands (conv_f32_split.hip)
+    if (p->use_mfma >= 2) { // the bf16 matrix cores on split operands (conv_f32_split.hip): 2 = six piece products, 3 = three
         const int rc = conv_f32_try_split(p);
         if (rc != -2) return rc;
     }

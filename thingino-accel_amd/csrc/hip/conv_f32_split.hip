@@ -46,10 +46,19 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 #define S_BN 256  // pixels per workgroup
 #define S_BK 32   // taps per K step = one v_mfma_f32_16x16x32_bf16
 #define S_NT 512
+#ifndef SPLIT_ABL // timing-only ablations (tools/stamps_build.sh split N; wrong results): 1 no MFMAs, 2 no gather loads, 4 no
+#define SPLIT_ABL 0 // split / LDS writes of the input, 8 no fragment reads, 16 plain stores (no SiLU), 32 no stores
+#endif
 
 __device__ __forceinline__ float silu_split(float v) { // as conv_f32.hip: the exporter's SiLU with the reference's roundings
     const float s = 1.0f / (1.0f + expf_exact(-v, expf_exact_tab));
     return v * s;
+}
+// three piece products (relative error per product up to 2^-16) do not need libm's last bit: v_exp_f32 and v_rcp_f32, 1 ulp each --
+// the exact form above is double-precision arithmetic and a table, a fifth of the kernel's time on every layer
+__device__ __forceinline__ float silu_fast(float v) {
+    const float e = __builtin_amdgcn_exp2f(v * -1.44269504088896341f); // exp(-v); +inf for v << 0: rcp -> 0, v * 0 = -0
+    return v * __builtin_amdgcn_rcpf(1.0f + e);
 }
 __device__ __forceinline__ int a_lds_off(int row, int chunk) { return row * 64 + ((chunk ^ ((row >> 1) & 2)) << 4); }
 __device__ __forceinline__ int b_lds_off(int r, int chunk) { // pixel r of the tile, 16-byte chunk (8 taps) of its 64-byte row
@@ -73,22 +82,27 @@ static sdiv_t make_sdiv(unsigned d) {
     return r;
 }
 
-// N floats -> N bf16 in each of the three planes (N / 2 dwords each), truncation split: x == hi + mid + lo exactly
-template <int N>
+// N floats -> N bf16 in each of NPL planes (N / 2 dwords each), round-to-nearest split (v_cvt_pk_bf16_f32 converts and packs
+// two at a time): hi = bf16(x), mid = bf16(x - hi), lo = x - hi - mid.  Every subtraction is exact (x - hi has at most 16
+// significant bits, x - hi - mid at most 8, a bf16 value), so x == hi + mid + lo exactly; with two planes |x - hi - mid| <=
+// 2^-17 |x|, errors of either sign.
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+template <int N, int NPL>
 __device__ __forceinline__ void splitn(const float (&x)[N], int (&hi)[N / 2], int (&mid)[N / 2], int (&lo)[N / 2]) {
-    uint32_t xb[N], r1[N], r2[N];
 #pragma unroll
-    for (int i = 0; i < N; i++) {
-        xb[i] = __float_as_uint(x[i]);
-        const float a = x[i] - __uint_as_float(xb[i] & 0xffff0000u); // exact: the low 16 significant bits
-        r1[i] = __float_as_uint(a);
-        r2[i] = __float_as_uint(a - __uint_as_float(r1[i] & 0xffff0000u)); // exact: at most 8 significant bits, a bf16 value
-    }
-#pragma unroll
-    for (int i = 0; i < N / 2; i++) { // top halves of (element 2i, element 2i + 1) -> one dword, element 2i in the low half
-        hi[i] = (int)__builtin_amdgcn_perm(xb[2 * i + 1], xb[2 * i], 0x07060302u);
-        mid[i] = (int)__builtin_amdgcn_perm(r1[2 * i + 1], r1[2 * i], 0x07060302u);
-        lo[i] = (int)__builtin_amdgcn_perm(r2[2 * i + 1], r2[2 * i], 0x07060302u);
+    for (int i = 0; i < N / 2; i++) { // (element 2i, element 2i + 1) -> one dword per plane, element 2i in the low half
+        const f32x2 v = {x[2 * i], x[2 * i + 1]};
+        const int h = __builtin_bit_cast(int, __builtin_convertvector(v, bf16x2));
+        const f32x2 hf = {__int_as_float(h << 16), __int_as_float(h & (int)0xffff0000)};
+        const f32x2 r = v - hf;
+        const int m = __builtin_bit_cast(int, __builtin_convertvector(r, bf16x2));
+        hi[i] = h;
+        mid[i] = m;
+        if (NPL == 3) {
+            const f32x2 mf = {__int_as_float(m << 16), __int_as_float(m & (int)0xffff0000)};
+            lo[i] = __builtin_bit_cast(int, __builtin_convertvector(r - mf, bf16x2)); // exact
+        } else lo[i] = 0;
     }
 }
 
@@ -103,12 +117,13 @@ struct split_args_t {
 };
 
 // BM = output channels per workgroup (128 | 64 | 32); waves: WM along channels x WN along pixels, WM * WN == 8
-template <int BM, int WM, int WN, int GATHER, int NPROD = 6>
+template <int BM, int WM, int WN, int GATHER, int NPL>
 __global__ __launch_bounds__(S_NT) void conv_f32_split(const mhip_conv_f32_t p, const split_args_t g) {
     constexpr int TM = BM / WM, TN = S_BN / WN; // wave tile
     constexpr int MI = TM / 16, NI = TN / 16;   // MFMA tiles per wave
     constexpr int APLANE = BM * 64, BPLANE = S_BN * 64;
-    constexpr int STAGE = 3 * (APLANE + BPLANE);
+    constexpr int NPROD = NPL == 3 ? 6 : 3; // piece products per product
+    constexpr int STAGE = NPL * (APLANE + BPLANE);
     constexpr int AE = BM * S_BK / S_NT;        // weight elements per thread, plane and step: 8 | 4 | 2 consecutive taps of one row
     constexpr int ATPR = S_BK / AE;             // threads per weight row
     constexpr int AD = AE / 2;                  // ... in dwords
@@ -163,9 +178,14 @@ __global__ __launch_bounds__(S_NT) void conv_f32_split(const mhip_conv_f32_t p, 
     const int8_t *wrow = (const int8_t *)p.w_split + ((size_t)(oc0 + arow) * g.kp + akc) * 2;
     const size_t wplane = (size_t)g.oc_pad * g.kp * 2;
 
-    float bregs[2][16];
-    int aregs[2][3][AD];
-    auto fetch = [&](int ks, float (&breg)[16], int (&areg)[3][AD]) __attribute__((always_inline)) {
+    v4i bregs[2][4]; // GATHER 1 / 2: one 16-byte load each; GATHER 0: four dword loads each
+    unsigned metas[2], smetas[2];
+    int aregs[2][NPL][AD];
+    // fetch ISSUES loads and nothing else (a scheduler fence follows it): what has to happen to the loaded vectors -- the shift
+    // of a load that started one element late, the column masks -- is recorded per lane in `meta` (per load: 4 mask bits, 1
+    // shift bit) and per wave in `smeta` (loads whose tap can start left of the image) and applied by commit one step later
+    auto fetch = [&](int ks, v4i (&breg)[4], int (&areg)[NPL][AD], unsigned &meta, unsigned &smeta) __attribute__((always_inline)) {
+        meta = 0; smeta = 0;
         // the lane's taps of this step: (ic, ky, kx) carried from the first one (wave-uniform: scalar registers)
         const int k0 = ks * S_BK + tg * TPL;
         int ic = (int)sdiv((unsigned)(k0 < K ? k0 : 0), g.dtaps);
@@ -181,18 +201,17 @@ __global__ __launch_bounds__(S_NT) void conv_f32_split(const mhip_conv_f32_t p, 
                 const bool ok = rowok && ((colbits >> kx) & 1u) != 0u;
                 // (the per-lane part alone may be "negative" -- first row / column of frame 0 -- and a vector offset beyond the
                 // range reads zero whatever a scalar offset would add: the sum goes into the vector offset)
-                breg[j] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(xrs, ok ? vbase + (unsigned)soff : 0xffffffffu, 0, 0));
+                if (SPLIT_ABL & 2) breg[j >> 2][j & 3] = (int)(vbase + (unsigned)soff) | (int)ok;
+                else breg[j >> 2][j & 3] = (int)__builtin_amdgcn_raw_buffer_load_b32(xrs, ok ? vbase + (unsigned)soff : 0xffffffffu, 0, 0);
             } else {
                 const bool lsh = ix0 + kx < 0; // the load would start left of the image (pad 1, first group of a row): start one
                                                // element later and shift -- the element shifted in is masked below anyway
-                const v4i v = __builtin_bit_cast(v4i, __builtin_amdgcn_raw_buffer_load_b128(xrs, rowok ? vbase + (unsigned)soff + (lsh ? 4u : 0u) : 0xffffffffu, 0, 0));
-                const unsigned bits = colbits >> ((GATHER == 2 ? (kx >> 1) : kx) * 4);
-                int e[4] = {v[0], v[1], v[2], v[3]};
-                if (kx < p.pad_left) { // wave-uniform: only such taps can start left of the image
-                    e[3] = lsh ? v[2] : v[3]; e[2] = lsh ? v[1] : v[2]; e[1] = lsh ? v[0] : v[1];
-                }
-#pragma unroll
-                for (int i = 0; i < 4; i++) breg[j * 4 + i] = __builtin_bit_cast(float, (bits >> i) & 1u ? e[i] : 0);
+                const unsigned vo = rowok ? vbase + (unsigned)soff + (lsh ? 4u : 0u) : 0xffffffffu;
+                if (SPLIT_ABL & 2) breg[j] = (v4i){(int)vo, (int)vo + 1, (int)vo + 2, (int)vo + 3};
+                else breg[j] = __builtin_bit_cast(v4i, __builtin_amdgcn_raw_buffer_load_b128(xrs, vo, 0, 0));
+                const unsigned bits = (colbits >> ((GATHER == 2 ? (kx >> 1) : kx) * 4)) & 15u;
+                meta |= (bits | (lsh ? 16u : 0u)) << (5 * j);
+                if (kx < p.pad_left) smeta |= 1u << j; // wave-uniform: only such taps can start left of the image
             }
             kx += STEP; soff += 4 * STEP;
             if (kx >= kwp) {
@@ -201,53 +220,72 @@ __global__ __launch_bounds__(S_NT) void conv_f32_split(const mhip_conv_f32_t p, 
             }
         }
 #pragma unroll
-        for (int pl = 0; pl < 3; pl++) {
+        for (int pl = 0; pl < NPL; pl++) {
             const int8_t *src = wrow + pl * wplane + (size_t)ks * (S_BK * 2);
             if (AE == 8) { const v4i t = *(const v4i *)src; areg[pl][0] = t[0]; areg[pl][1 % AD] = t[1]; areg[pl][2 % AD] = t[2]; areg[pl][3 % AD] = t[3]; }
             else if (AE == 4) { const int2 t = *(const int2 *)src; areg[pl][0] = t.x; areg[pl][1 % AD] = t.y; }
             else areg[pl][0] = *(const int *)src;
         }
     };
-    auto commit = [&](int buf, const float (&breg)[16], const int (&areg)[3][AD]) __attribute__((always_inline)) {
+    auto commit = [&](int buf, const v4i (&braw)[4], const int (&areg)[NPL][AD], const unsigned meta, const unsigned smeta) __attribute__((always_inline)) {
         int8_t *st = lds + buf * STAGE;
-        int8_t *bp = st + 3 * APLANE;
-        if (GATHER == 1) { // pixel i of the lane: taps tg * 4 .. + 3 = half a chunk
+        int8_t *bp = st + NPL * APLANE;
+        float breg[16];
+        if (GATHER == 0) {
+#pragma unroll
+            for (int i = 0; i < 16; i++) breg[i] = __int_as_float(braw[i >> 2][i & 3]);
+        } else {
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                int e[4] = {braw[j][0], braw[j][1], braw[j][2], braw[j][3]};
+                if ((smeta >> j) & 1u) {
+                    const bool lsh = ((meta >> (5 * j + 4)) & 1u) != 0u;
+                    e[3] = lsh ? e[2] : e[3]; e[2] = lsh ? e[1] : e[2]; e[1] = lsh ? e[0] : e[1];
+                }
+#pragma unroll
+                for (int i = 0; i < 4; i++) breg[4 * j + i] = __int_as_float(e[i] & __builtin_amdgcn_sbfe((int)meta, 5 * j + i, 1)); // 0 / ~0
+            }
+        }
+        if (SPLIT_ABL & 4) {
+#pragma unroll
+            for (int i = 0; i < 16; i++) asm volatile("" ::"v"(breg[i]));
+        } else if (GATHER == 1) { // pixel i of the lane: taps tg * 4 .. + 3 = half a chunk
 #pragma unroll
             for (int i = 0; i < 4; i++) {
                 const float x[4] = {breg[i], breg[4 + i], breg[8 + i], breg[12 + i]};
                 int hi[2], mid[2], lo[2];
-                splitn<4>(x, hi, mid, lo);
+                splitn<4, NPL>(x, hi, mid, lo);
                 const int off = b_lds_off(pl_ * 4 + i, tg >> 1) + (tg & 1) * 8;
                 *(int2 *)(bp + off) = make_int2(hi[0], hi[1]);
                 *(int2 *)(bp + BPLANE + off) = make_int2(mid[0], mid[1]);
-                *(int2 *)(bp + 2 * BPLANE + off) = make_int2(lo[0], lo[1]);
+                if (NPL == 3) *(int2 *)(bp + 2 * BPLANE + off) = make_int2(lo[0], lo[1]);
             }
         } else if (GATHER == 2) { // pixel q of the lane: taps tg * 8 .. + 7 = one chunk; load j holds (q, tap 2j) at 2q, (q, 2j + 1) at 2q + 1
 #pragma unroll
             for (int q = 0; q < 2; q++) {
                 const float x[8] = {breg[2 * q], breg[2 * q + 1], breg[4 + 2 * q], breg[5 + 2 * q], breg[8 + 2 * q], breg[9 + 2 * q], breg[12 + 2 * q], breg[13 + 2 * q]};
                 int hi[4], mid[4], lo[4];
-                splitn<8>(x, hi, mid, lo);
+                splitn<8, NPL>(x, hi, mid, lo);
                 const int off = b_lds_off(pl_ * 2 + q, tg);
                 *(v4i *)(bp + off) = (v4i){hi[0], hi[1], hi[2], hi[3]};
                 *(v4i *)(bp + BPLANE + off) = (v4i){mid[0], mid[1], mid[2], mid[3]};
-                *(v4i *)(bp + 2 * BPLANE + off) = (v4i){lo[0], lo[1], lo[2], lo[3]};
+                if (NPL == 3) *(v4i *)(bp + 2 * BPLANE + off) = (v4i){lo[0], lo[1], lo[2], lo[3]};
             }
         } else { // one pixel, taps tg * 16 .. + 15 = two chunks
 #pragma unroll
             for (int h = 0; h < 2; h++) {
                 const float x[8] = {breg[8 * h], breg[8 * h + 1], breg[8 * h + 2], breg[8 * h + 3], breg[8 * h + 4], breg[8 * h + 5], breg[8 * h + 6], breg[8 * h + 7]};
                 int hi[4], mid[4], lo[4];
-                splitn<8>(x, hi, mid, lo);
+                splitn<8, NPL>(x, hi, mid, lo);
                 const int off = b_lds_off(pl_, tg * 2 + h);
                 *(v4i *)(bp + off) = (v4i){hi[0], hi[1], hi[2], hi[3]};
                 *(v4i *)(bp + BPLANE + off) = (v4i){mid[0], mid[1], mid[2], mid[3]};
-                *(v4i *)(bp + 2 * BPLANE + off) = (v4i){lo[0], lo[1], lo[2], lo[3]};
+                if (NPL == 3) *(v4i *)(bp + 2 * BPLANE + off) = (v4i){lo[0], lo[1], lo[2], lo[3]};
             }
         }
         const int aoff = a_lds_off(arow, akc >> 3) + (akc & 7) * 2; // AE bf16 = AE * 2 bytes inside the 16-byte chunk
 #pragma unroll
-        for (int pl = 0; pl < 3; pl++) {
+        for (int pl = 0; pl < NPL; pl++) {
             if (AE == 8) *(v4i *)(st + pl * APLANE + aoff) = (v4i){areg[pl][0], areg[pl][1 % AD], areg[pl][2 % AD], areg[pl][3 % AD]};
             else if (AE == 4) *(int2 *)(st + pl * APLANE + aoff) = make_int2(areg[pl][0], areg[pl][1 % AD]);
             else *(int *)(st + pl * APLANE + aoff) = areg[pl][0];
@@ -274,33 +312,45 @@ __global__ __launch_bounds__(S_NT) void conv_f32_split(const mhip_conv_f32_t p, 
     // one K step: the MFMAs of LDS stage `buf`, and the operands in (breg, areg) split into the other stage (last read in the
     // previous step, every wave is past that step's barrier; after the last step it receives stale registers nobody reads --
     // unconditional, so that it shares the MFMAs' basic block and the scheduler can interleave the two)
-    auto step = [&](int buf, const float (&breg)[16], const int (&areg)[3][AD]) __attribute__((always_inline)) {
-        const int8_t *ap = lds + buf * STAGE, *bp = ap + 3 * APLANE;
-        bf16x8 af[3][MI], bf[3][NI];
+    auto step = [&](int buf, const v4i (&breg)[4], const int (&areg)[NPL][AD], const unsigned meta, const unsigned smeta) __attribute__((always_inline)) {
+        const int8_t *ap = lds + buf * STAGE, *bp = ap + NPL * APLANE;
+        bf16x8 af[NPL][MI], bf[NPL][NI];
 #pragma unroll
         for (int a = 0; a < MI; a++)
 #pragma unroll
-            for (int pl = 0; pl < 3; pl++)
-                af[pl][a] = __builtin_bit_cast(bf16x8, *(const v4i *)(ap + pl * APLANE + a_lds_off(wm * TM + a * 16 + fr, fc)));
+            for (int pl = 0; pl < NPL; pl++)
+                af[pl][a] = SPLIT_ABL & 8 ? __builtin_bit_cast(bf16x8, (v4i){buf, a, pl, lane})
+                                          : __builtin_bit_cast(bf16x8, *(const v4i *)(ap + pl * APLANE + a_lds_off(wm * TM + a * 16 + fr, fc)));
 #pragma unroll
-        for (int pl = 0; pl < 3; pl++)
+        for (int pl = 0; pl < NPL; pl++)
 #pragma unroll
-            for (int c = 0; c < NI; c++) bf[pl][c] = __builtin_bit_cast(bf16x8, *(const v4i *)(bp + pl * BPLANE + b_lds_off(wn * TN + c * 16 + fr, fc)));
-        // six piece products per product, smallest terms first
+            for (int c = 0; c < NI; c++)
+                bf[pl][c] = SPLIT_ABL & 8 ? __builtin_bit_cast(bf16x8, (v4i){buf, c, pl, lane})
+                                          : __builtin_bit_cast(bf16x8, *(const v4i *)(bp + pl * BPLANE + b_lds_off(wn * TN + c * 16 + fr, fc)));
+        if (SPLIT_ABL & 1) {
 #pragma unroll
-        for (int a = 0; a < MI; a++)
+            for (int pl = 0; pl < NPL; pl++) {
+#pragma unroll
+                for (int a = 0; a < MI; a++) asm volatile("" ::"v"(af[pl][a]));
+#pragma unroll
+                for (int c = 0; c < NI; c++) asm volatile("" ::"v"(bf[pl][c]));
+            }
+        }
+        // the piece products of a product, smallest terms first
+#pragma unroll
+        for (int a = 0; a < (SPLIT_ABL & 1 ? 0 : MI); a++)
 #pragma unroll
             for (int c = 0; c < NI; c++) {
-                if (NPROD >= 6) {
-                    acc[a][c] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[2][a], bf[0][c], acc[a][c], 0, 0, 0); // lo * hi
-                    acc[a][c] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[0][a], bf[2][c], acc[a][c], 0, 0, 0); // hi * lo
+                if (NPL == 3) {
+                    acc[a][c] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[NPL - 1][a], bf[0][c], acc[a][c], 0, 0, 0); // lo * hi
+                    acc[a][c] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[0][a], bf[NPL - 1][c], acc[a][c], 0, 0, 0); // hi * lo
+                    acc[a][c] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[1][a], bf[1][c], acc[a][c], 0, 0, 0);       // mid * mid
                 }
-                if (NPROD >= 4) acc[a][c] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[1][a], bf[1][c], acc[a][c], 0, 0, 0); // mid * mid
                 acc[a][c] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[0][a], bf[1][c], acc[a][c], 0, 0, 0); // hi * mid
                 acc[a][c] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[1][a], bf[0][c], acc[a][c], 0, 0, 0); // mid * hi
                 acc[a][c] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[0][a], bf[0][c], acc[a][c], 0, 0, 0); // hi * hi
             }
-        commit(buf ^ 1, breg, areg);
+        commit(buf ^ 1, breg, areg, meta, smeta);
 #pragma unroll
         for (int i = 0; i < MI * NI * NPROD; i++) { // issue order: every MFMA followed by what fits in its shadow
             __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); // MFMA
@@ -317,18 +367,23 @@ __global__ __launch_bounds__(S_NT) void conv_f32_split(const mhip_conv_f32_t p, 
     };
 
     const int nks = g.nks;
-    fetch(0, bregs[0], aregs[0]);
-    commit(0, bregs[0], aregs[0]);
-    fetch(1, bregs[1], aregs[1]);
+    fetch(0, bregs[0], aregs[0], metas[0], smetas[0]);
+    commit(0, bregs[0], aregs[0], metas[0], smetas[0]);
+    fetch(1, bregs[1], aregs[1], metas[1], smetas[1]);
     __syncthreads();
     // nks is even (the weight planes' rows are padded to 64 taps): two steps per iteration, no exit in between -- with a
     // `break` after the first step the compiler lost count of the loads in flight at the loop's merge points and waited
     // vmcnt(0..3) right behind every fetch, i.e. for the loads it had just issued
     for (int ks = 0; ks < nks; ks += 2) {
-        fetch(ks + 2, bregs[0], aregs[0]); // (past the last step: taps beyond K load zeros, the weight rows' padding is zero)
-        step(0, bregs[1], aregs[1]);
-        fetch(ks + 3, bregs[1], aregs[1]);
-        step(1, bregs[0], aregs[0]);
+        // the scheduler fence keeps a fetch's six loads AHEAD of the step's MFMAs: left alone, the compiler sinks them (with their
+        // scalar address arithmetic) to the end of the step, 400 cycles before the next step needs them -- a memory latency
+        // exposed per step (vmcnt(1..3) in the middle of the MFMAs)
+        fetch(ks + 2, bregs[0], aregs[0], metas[0], smetas[0]); // (past the last step: taps beyond K load zeros, the weight rows' padding is zero)
+        __builtin_amdgcn_sched_barrier(0);
+        step(0, bregs[1], aregs[1], metas[1], smetas[1]);
+        fetch(ks + 3, bregs[1], aregs[1], metas[1], smetas[1]);
+        __builtin_amdgcn_sched_barrier(0);
+        step(1, bregs[0], aregs[0], metas[0], smetas[0]);
     }
     // store: 16 lanes write 16 consecutive floats of one channel row
 #pragma unroll
@@ -342,7 +397,8 @@ __global__ __launch_bounds__(S_NT) void conv_f32_split(const mhip_conv_f32_t p, 
 #pragma unroll
             for (int j = 0; j < 4; j++) {
                 const int oc = oc0 + wm * TM + a * 16 + fc * 4 + j;
-                if (oc < p.out_c) out[(size_t)oc * hw + rem] = p.silu ? silu_split(acc[a][c][j]) : acc[a][c][j];
+                if (SPLIT_ABL & 32) asm volatile("" ::"v"(acc[a][c][j]));
+                else if (oc < p.out_c) out[(size_t)oc * hw + rem] = p.silu && !(SPLIT_ABL & 16) ? (NPL == 2 ? silu_fast(acc[a][c][j]) : silu_split(acc[a][c][j])) : acc[a][c][j];
             }
     }
 }
@@ -350,10 +406,10 @@ __global__ __launch_bounds__(S_NT) void conv_f32_split(const mhip_conv_f32_t p, 
 // kernel row length in the packed K space: an odd kernel width under stride 2 gets one zero column (taps come in pairs there)
 static int split_kwp(int kw, int stride_w) { return stride_w == 2 && kw > 1 && (kw & 1) ? kw + 1 : kw; }
 
-template <int BM, int WM, int WN, int GATHER, int NPROD = 6>
+template <int BM, int WM, int WN, int GATHER, int NPL>
 static int launch_split(const mhip_conv_f32_t *p, split_args_t g) {
-    auto kern = conv_f32_split<BM, WM, WN, GATHER, NPROD>;
-    const size_t ldsb = 2 * 3 * (size_t)(BM * 64 + S_BN * 64);
+    auto kern = conv_f32_split<BM, WM, WN, GATHER, NPL>;
+    const size_t ldsb = 2 * NPL * (size_t)(BM * 64 + S_BN * 64);
     static bool attr = false;
     if (!attr && hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsb) != hipSuccess)
         return mhip_check(hipErrorUnknown, "conv_f32_split LDS attribute");
@@ -363,13 +419,15 @@ static int launch_split(const mhip_conv_f32_t *p, split_args_t g) {
     hipLaunchKernelGGL(kern, dim3(g.npt * noc), dim3(S_NT), ldsb, mhip_stream_native(), *p, g);
     return mhip_check(hipGetLastError(), "conv_f32_split");
 }
-template <int GATHER>
+template <int GATHER, int NPL>
 static int launch_split_bm(const mhip_conv_f32_t *p, const split_args_t &g) {
-    // (round 4 experiment, MARS_HIP_F32_NPROD: with only the 4 / 3 largest piece products on the 128-channel stride-1 tiles the
-    // config-5 twin ran 5145 / 5210 instead of 4913 img/s at 2.2e-6 / 3.7e-6 instead of 3.7e-7 worst relative error: not kept)
-    if (p->out_c > 64) return launch_split<128, 2, 4, GATHER>(p, g);
-    if (p->out_c > 32) return launch_split<64, 1, 8, GATHER>(p, g);
-    return launch_split<32, 1, 8, GATHER>(p, g);
+    if (p->out_c > 64) return launch_split<128, 2, 4, GATHER, NPL>(p, g);
+    if (p->out_c > 32) return launch_split<64, 1, 8, GATHER, NPL>(p, g);
+    return launch_split<32, 1, 8, GATHER, NPL>(p, g);
+}
+template <int GATHER>
+static int launch_split_npl(const mhip_conv_f32_t *p, const split_args_t &g) { // use_mfma 3: two pieces, three products; 2: three, six
+    return p->use_mfma == 3 ? launch_split_bm<GATHER, 2>(p, g) : launch_split_bm<GATHER, 3>(p, g);
 }
 
 // -2: not a shape this kernel takes (the caller falls back to conv_f32_mfma), else the launch result
@@ -386,12 +444,24 @@ int conv_f32_try_split(const mhip_conv_f32_t *p) {
     g.K = (int)K; g.kp = (int)((K + 63) / 64 * 64) + 64; g.nks = (g.kp - 64) / 32; g.kwp = kwp; g.oc_pad = (p->out_c + 127) / 128 * 128;
     g.dhw = make_sdiv((unsigned)hw); g.dow = make_sdiv((unsigned)p->out_w); g.dtaps = make_sdiv((unsigned)(p->kh * kwp)); g.dkwp = make_sdiv((unsigned)kwp);
     // 16-byte gathers: 4 pixels x 1 tap (stride 1) or 2 pixels x 2 taps (stride 2) per load; pixel groups must not cross map rows
-    if (p->stride_w == 1 && p->out_w % 4 == 0 && p->pad_left <= 1 && p->kw <= 8 && p->in_w >= 4) return launch_split_bm<1>(p, g);
-    if (p->stride_w == 2 && p->out_w % 2 == 0 && p->pad_left <= 1 && kwp % 2 == 0 && kwp <= 16 && p->in_w >= 4) return launch_split_bm<2>(p, g);
+    if (p->stride_w == 1 && p->out_w % 4 == 0 && p->pad_left <= 1 && p->kw <= 8 && p->in_w >= 4) return launch_split_npl<1>(p, g);
+    if (p->stride_w == 2 && p->out_w % 2 == 0 && p->pad_left <= 1 && kwp % 2 == 0 && kwp <= 16 && p->in_w >= 4) return launch_split_npl<2>(p, g);
     if (kwp != p->kw) return -2; // (the padded K space is GATHER 2's; nothing else reads it)
-    return launch_split_bm<0>(p, g);
+    return launch_split_npl<0>(p, g);
 }
 
+static uint16_t bf16_rn(float x) { // round to nearest even (NaN kept a NaN)
+    uint32_t b;
+    memcpy(&b, &x, 4);
+    if ((b & 0x7fffffffu) > 0x7f800000u) return (uint16_t)((b >> 16) | 0x40u);
+    return (uint16_t)((b + 0x7fffu + ((b >> 16) & 1u)) >> 16);
+}
+static float bf16_val(uint16_t h) {
+    const uint32_t b = (uint32_t)h << 16;
+    float f;
+    memcpy(&f, &b, 4);
+    return f;
+}
 extern "C" size_t mhip_conv_f32_split_pack(int out_c, int in_c, int kh, int kw, int stride_w, const float *w, void *out) {
     if (out_c <= 0 || in_c <= 0 || kh <= 0 || kw <= 0) return 0;
     const int kwp = split_kwp(kw, stride_w);
@@ -405,21 +475,14 @@ extern "C" size_t mhip_conv_f32_split_pack(int out_c, int in_c, int kh, int kw, 
             for (int ky = 0; ky < kh; ky++)
                 for (int kx = 0; kx < kw; kx++) {
                     const float x = w[((size_t)(oc * (size_t)in_c + ic) * kh + ky) * kw + kx];
-                    uint32_t xb, r1b, r2b;
-                    memcpy(&xb, &x, 4);
-                    const uint32_t hb = xb & 0xffff0000u;
-                    float h, m;
-                    memcpy(&h, &hb, 4);
-                    const float r1 = x - h; // exact
-                    memcpy(&r1b, &r1, 4);
-                    const uint32_t mb = r1b & 0xffff0000u;
-                    memcpy(&m, &mb, 4);
-                    const float r2 = r1 - m; // exact, a bf16 value
-                    memcpy(&r2b, &r2, 4);
+                    const uint16_t h = bf16_rn(x);
+                    const float r1 = x - bf16_val(h); // exact
+                    const uint16_t m = bf16_rn(r1);
+                    const float r2 = r1 - bf16_val(m); // exact, a bf16 value
                     const size_t k = ((size_t)ic * kh + ky) * kwp + kx;
-                    o[(size_t)oc * kp + k] = (uint16_t)(xb >> 16);
-                    o[ocp * kp + (size_t)oc * kp + k] = (uint16_t)(r1b >> 16);
-                    o[2 * ocp * kp + (size_t)oc * kp + k] = (uint16_t)(r2b >> 16);
+                    o[(size_t)oc * kp + k] = h;
+                    o[ocp * kp + (size_t)oc * kp + k] = m;
+                    o[2 * ocp * kp + (size_t)oc * kp + k] = bf16_rn(r2);
                 }
     return bytes;
 }

@@ -120,7 +120,7 @@ static int launch_op(mars_model_ext_t *m, mars_op_t *op) {
             p.silu = op->silu_f32;
             {
                 const int mode = mhip_conv_f32_mode(-1);
-                p.use_mfma = mode == 3 ? 2 : (mode == 2 || (mode == 1 && !op->f32_exact));
+                p.use_mfma = mode == 3 ? 3 : mode == 4 ? 2 : (mode == 2 || (mode == 1 && !op->f32_exact));
             }
             return mhip_conv_f32(&p);
         }
@@ -572,9 +572,9 @@ static int tune_raw(const char *key, int value, int *get) {
             *tab[i].v = value;
             return 0;
         }
-    if (!strcmp(key, "f32_mfma")) { /* 0 exact everywhere, 1 matrix cores where provably safe (default), 2 everywhere, 3 everywhere + split bf16 */
+    if (!strcmp(key, "f32_mfma")) { /* 0 exact everywhere, 1 f32 matrix cores where provably safe (default), 2 everywhere, 3 / 4 bf16 matrix cores on split operands, three / six piece products */
         if (get) { *get = mhip_conv_f32_mode(-1); return 0; }
-        if (value < 0 || value > 3) return -1;
+        if (value < 0 || value > 4) return -1;
         mhip_conv_f32_mode(value);
         return 0;
     }

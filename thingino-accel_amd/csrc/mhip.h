@@ -144,16 +144,17 @@ typedef struct {
     int use_mfma; /* 0: reference summation order, bit-identical; 1: implicit GEMM on v_mfma_f32_16x16x4_f32 (fused
                      rounding per tap: inside the 1e-4 tolerance of the float32 models, not bit-equal); 2: implicit GEMM on
                      v_mfma_f32_16x16x32_bf16 with every operand split into three bf16 pieces, six piece products per
-                     product (conv_f32_split.hip: same tolerance class, 2.7x the f32 matrix peak) */
+                     product (conv_f32_split.hip: errors of the size of an f32 rounding); 3: the same with two pieces
+                     and three piece products ("bf16x3": relative error per product <= 2^-16, same tolerance class) */
 } mhip_conv_f32_t;
 int mhip_conv_f32(const mhip_conv_f32_t *p);
 /* Bytes of, and (out != NULL) the content of, the weight image conv_f32_split reads: three planes (hi, mid, lo) of bf16
  * [oc_pad][k_pad] -- oc_pad = roundup128(out_c), k_pad = roundup64(K') + 64, zero filled -- with w = hi + mid + lo exactly
- * (truncation split).  K' = in_c * kh * kw, or in_c * kh * (kw + 1) for stride_w == 2 with an odd kw (one zero column
+ * (hi = bf16(w), mid = bf16(w - hi), round to nearest; use_mfma == 3 reads the first two planes).  K' = in_c * kh * kw, or in_c * kh * (kw + 1) for stride_w == 2 with an odd kw (one zero column
  * appended to every kernel row: taps come in pairs there). */
 size_t mhip_conv_f32_split_pack(int out_c, int in_c, int kh, int kw, int stride_w, const float *w, void *out);
-/* policy knob: 0 never the matrix cores, 1 (default) wherever the host proves it safe, 2 everywhere, 3 everywhere on the
- * bf16 matrix cores with split operands.  set < 0 only
+/* policy knob: 0 never the matrix cores, 1 (default) wherever the host proves it safe, 2 everywhere, 3 / 4 everywhere on the
+ * bf16 matrix cores with operands split in two / three (three / six piece products).  set < 0 only
  * reads; returns the mode in force (first call reads MARS_HIP_F32_MFMA) */
 int mhip_conv_f32_mode(int set);
 
