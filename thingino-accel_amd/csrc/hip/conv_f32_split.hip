@@ -118,7 +118,7 @@ struct split_args_t {
 
 // BM = output channels per workgroup (128 | 64 | 32); waves: WM along channels x WN along pixels, WM * WN == 8
 template <int BM, int WM, int WN, int GATHER, int NPL>
-__global__ __launch_bounds__(S_NT) void conv_f32_split(const mhip_conv_f32_t p, const split_args_t g) {
+__global__ __launch_bounds__(S_NT, BM == 32 && NPL == 2 ? 4 : 2) void conv_f32_split(const mhip_conv_f32_t p, const split_args_t g) {
     constexpr int TM = BM / WM, TN = S_BN / WN; // wave tile
     constexpr int MI = TM / 16, NI = TN / 16;   // MFMA tiles per wave
     constexpr int APLANE = BM * 64, BPLANE = S_BN * 64;
@@ -132,9 +132,11 @@ __global__ __launch_bounds__(S_NT) void conv_f32_split(const mhip_conv_f32_t p, 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wv % WM, wn = wv / WM;
-    const unsigned pt = blockIdx.x % g.npt, ot = blockIdx.x / g.npt;
-    const unsigned p0 = pt * S_BN;
-    const int oc0 = (int)ot * BM;
+    // persistent over pixel tiles: this workgroup keeps its channel tile (blockIdx.y) and walks pixel tiles blockIdx.x,
+    // + gridDim.x, ...  The K pipeline runs THROUGH the tile boundary (the last two steps of a tile fetch steps 0 and 1 of the
+    // next), so a tile's stores and the next tile's first loads overlap -- layers with few K steps (the stem: 4) otherwise
+    // pay two exposed memory latencies and a store drain per 256 pixels
+    const int oc0 = (int)blockIdx.y * BM;
     const unsigned hw = (unsigned)(p.out_h * p.out_w);
     const int K = g.K, kwp = g.kwp;
     const int taps = p.kh * kwp;
@@ -147,16 +149,17 @@ __global__ __launch_bounds__(S_NT) void conv_f32_split(const mhip_conv_f32_t p, 
     const int pl_ = tid % (S_BN / PPL);                           // pixel group inside the tile
     const int tg = __builtin_amdgcn_readfirstlane(tid / (S_BN / PPL)); // tap group (wave-uniform): taps tg * TPL .. of the step
     unsigned vbase;     // byte offset of the window origin (channel 0) of the lane's FIRST pixel; "negative" values wrap
-    unsigned rowbits = 0, colbits = 0; // kernel rows inside the image; (tap column, element) pairs inside the image
+    unsigned rowbits, colbits; // kernel rows inside the image; (tap column, element) pairs inside the image
     int ix0;
-    {
-        const unsigned px = p0 + (unsigned)(pl_ * PPL);
-        const bool valid = px < g.total_pix; // (GATHER 1 / 2: out_w % PPL == 0, so the lane's pixels share row, frame and validity)
+    auto setup = [&](unsigned pt) __attribute__((always_inline)) { // the fetch side's view of pixel tile pt (beyond the last: nothing valid)
+        const unsigned px = pt * S_BN + (unsigned)(pl_ * PPL);
+        const bool valid = pt < g.npt && px < g.total_pix; // (GATHER 1 / 2: out_w % PPL == 0, so the lane's pixels share row, frame and validity)
         const unsigned f = sdiv(valid ? px : 0u, g.dhw), rem = (valid ? px : 0u) - f * hw;
         const int oy = (int)sdiv(rem, g.dow), ox = (int)rem - oy * p.out_w;
         const int iy0 = oy * p.stride_h - p.pad_top;
         ix0 = ox * p.stride_w - p.pad_left;
         vbase = (unsigned)(f * (unsigned)p.in_stride) + (unsigned)((iy0 * p.in_w + ix0) * 4);
+        rowbits = 0; colbits = 0;
         if (valid)
             for (int ky = 0; ky < p.kh; ky++)
                 if ((unsigned)(iy0 + ky) < (unsigned)p.in_h) rowbits |= 1u << ky;
@@ -172,7 +175,8 @@ __global__ __launch_bounds__(S_NT) void conv_f32_split(const mhip_conv_f32_t p, 
                 for (int i = 0; i < 4; i++)
                     if (kx + (i & 1) < p.kw && (unsigned)(ix0 + 2 * (i >> 1) + kx + (i & 1)) < (unsigned)p.in_w) colbits |= 1u << ((kx >> 1) * 4 + i);
         }
-    }
+    };
+    setup(blockIdx.x);
     // weights: row oc0 + tid / ATPR of every plane, taps (tid % ATPR) * AE .. + AE - 1 of the step
     const int arow = tid / ATPR, akc = (tid % ATPR) * AE;
     const int8_t *wrow = (const int8_t *)p.w_split + ((size_t)(oc0 + arow) * g.kp + akc) * 2;
@@ -294,19 +298,19 @@ __global__ __launch_bounds__(S_NT) void conv_f32_split(const mhip_conv_f32_t p, 
 
     // accumulators start at the bias: lane holds channels 4 * (lane / 16) + j of an MFMA tile, pixel lane % 16
     const int fr = lane & 15, fc = lane >> 4;
-    v4f acc[MI][NI];
+    v4f acc[MI][NI], bias4[MI];
 #pragma unroll
     for (int a = 0; a < MI; a++) {
-        v4f b = {0.f, 0.f, 0.f, 0.f};
+        bias4[a] = (v4f){0.f, 0.f, 0.f, 0.f};
         if (p.bias) {
 #pragma unroll
             for (int j = 0; j < 4; j++) {
                 const int oc = oc0 + wm * TM + a * 16 + fc * 4 + j;
-                b[j] = oc < p.out_c ? p.bias[oc] : 0.f;
+                bias4[a][j] = oc < p.out_c ? p.bias[oc] : 0.f;
             }
         }
 #pragma unroll
-        for (int c = 0; c < NI; c++) acc[a][c] = b;
+        for (int c = 0; c < NI; c++) acc[a][c] = bias4[a];
     }
 
     // one K step: the MFMAs of LDS stage `buf`, and the operands in (breg, areg) split into the other stage (last read in the
@@ -374,32 +378,40 @@ __global__ __launch_bounds__(S_NT) void conv_f32_split(const mhip_conv_f32_t p, 
     // nks is even (the weight planes' rows are padded to 64 taps): two steps per iteration, no exit in between -- with a
     // `break` after the first step the compiler lost count of the loads in flight at the loop's merge points and waited
     // vmcnt(0..3) right behind every fetch, i.e. for the loads it had just issued
-    for (int ks = 0; ks < nks; ks += 2) {
-        // the scheduler fence keeps a fetch's six loads AHEAD of the step's MFMAs: left alone, the compiler sinks them (with their
-        // scalar address arithmetic) to the end of the step, 400 cycles before the next step needs them -- a memory latency
-        // exposed per step (vmcnt(1..3) in the middle of the MFMAs)
-        fetch(ks + 2, bregs[0], aregs[0], metas[0], smetas[0]); // (past the last step: taps beyond K load zeros, the weight rows' padding is zero)
-        __builtin_amdgcn_sched_barrier(0);
-        step(0, bregs[1], aregs[1], metas[1], smetas[1]);
-        fetch(ks + 3, bregs[1], aregs[1], metas[1], smetas[1]);
-        __builtin_amdgcn_sched_barrier(0);
-        step(1, bregs[0], aregs[0], metas[0], smetas[0]);
-    }
-    // store: 16 lanes write 16 consecutive floats of one channel row
+    for (unsigned pt = blockIdx.x; pt < g.npt; pt += gridDim.x) {
+        for (int ks = 0; ks < nks; ks += 2) {
+            int kq = ks + 2;
+            if (kq >= nks) { kq = 0; setup(pt + gridDim.x); } // the last two steps of a tile fetch the first two of the next
+            // the scheduler fence keeps a fetch's six loads AHEAD of the step's MFMAs: left alone, the compiler sinks them (with
+            // their scalar address arithmetic) to the end of the step, 400 cycles before the next step needs them -- a memory
+            // latency exposed per step (vmcnt(1..3) in the middle of the MFMAs)
+            fetch(kq, bregs[0], aregs[0], metas[0], smetas[0]);
+            __builtin_amdgcn_sched_barrier(0);
+            step(0, bregs[1], aregs[1], metas[1], smetas[1]);
+            fetch(kq + 1, bregs[1], aregs[1], metas[1], smetas[1]);
+            __builtin_amdgcn_sched_barrier(0);
+            step(1, bregs[0], aregs[0], metas[0], smetas[0]);
+        }
+        // store: 16 lanes write 16 consecutive floats of one channel row
+        const unsigned p0 = pt * S_BN;
 #pragma unroll
-    for (int c = 0; c < NI; c++) {
-        const unsigned px = p0 + (unsigned)(wn * TN + c * 16 + fr);
-        if (px >= g.total_pix) continue;
-        const unsigned f = sdiv(px, g.dhw), rem = px - f * hw;
-        float *out = (float *)((char *)p.out + (size_t)f * p.out_stride);
+        for (int c = 0; c < NI; c++) {
+            const unsigned px = p0 + (unsigned)(wn * TN + c * 16 + fr);
+            if (px < g.total_pix) {
+                const unsigned f = sdiv(px, g.dhw), rem = px - f * hw;
+                float *out = (float *)((char *)p.out + (size_t)f * p.out_stride);
 #pragma unroll
-        for (int a = 0; a < MI; a++)
+                for (int a = 0; a < MI; a++)
 #pragma unroll
-            for (int j = 0; j < 4; j++) {
-                const int oc = oc0 + wm * TM + a * 16 + fc * 4 + j;
-                if (SPLIT_ABL & 32) asm volatile("" ::"v"(acc[a][c][j]));
-                else if (oc < p.out_c) out[(size_t)oc * hw + rem] = p.silu && !(SPLIT_ABL & 16) ? (NPL == 2 ? silu_fast(acc[a][c][j]) : silu_split(acc[a][c][j])) : acc[a][c][j];
+                    for (int j = 0; j < 4; j++) {
+                        const int oc = oc0 + wm * TM + a * 16 + fc * 4 + j;
+                        if (SPLIT_ABL & 32) asm volatile("" ::"v"(acc[a][c][j]));
+                        else if (oc < p.out_c) out[(size_t)oc * hw + rem] = p.silu && !(SPLIT_ABL & 16) ? (NPL == 2 ? silu_fast(acc[a][c][j]) : silu_split(acc[a][c][j])) : acc[a][c][j];
+                    }
             }
+#pragma unroll
+            for (int a = 0; a < MI; a++) acc[a][c] = bias4[a];
+        }
     }
 }
 
@@ -410,18 +422,30 @@ template <int BM, int WM, int WN, int GATHER, int NPL>
 static int launch_split(const mhip_conv_f32_t *p, split_args_t g) {
     auto kern = conv_f32_split<BM, WM, WN, GATHER, NPL>;
     const size_t ldsb = 2 * NPL * (size_t)(BM * 64 + S_BN * 64);
-    static bool attr = false;
-    if (!attr && hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsb) != hipSuccess)
-        return mhip_check(hipErrorUnknown, "conv_f32_split LDS attribute");
-    attr = true;
+    static int slots = 0; // workgroups the device holds at once (per instantiation)
+    if (!slots) {
+        hipDeviceProp_t prop;
+        int dev = 0, occ = 0;
+        if (hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsb) != hipSuccess ||
+            hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess ||
+            hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, kern, S_NT, ldsb) != hipSuccess)
+            return mhip_check(hipErrorUnknown, "conv_f32_split occupancy query");
+        slots = (occ > 0 ? occ : 1) * prop.multiProcessorCount;
+    }
     const unsigned noc = (unsigned)((p->out_c + BM - 1) / BM);
-    if ((unsigned long long)g.npt * noc > 0x7fffffffull) return -2;
-    hipLaunchKernelGGL(kern, dim3(g.npt * noc), dim3(S_NT), ldsb, mhip_stream_native(), *p, g);
+    if (noc > 65535u) return -2;
+    // pixel tiles per workgroup: as even as the slots allow (every workgroup walks ceil(npt / gx) tiles or one fewer)
+    unsigned gx = (unsigned)slots / noc;
+    if (gx < 1) gx = 1;
+    if (gx > g.npt) gx = g.npt;
+    const unsigned per = (g.npt + gx - 1) / gx;
+    gx = (g.npt + per - 1) / per;
+    hipLaunchKernelGGL(kern, dim3(gx, noc), dim3(S_NT), ldsb, mhip_stream_native(), *p, g);
     return mhip_check(hipGetLastError(), "conv_f32_split");
 }
 template <int GATHER, int NPL>
 static int launch_split_bm(const mhip_conv_f32_t *p, const split_args_t &g) {
-    if (p->out_c > 64) return launch_split<128, 2, 4, GATHER, NPL>(p, g);
+    if (p->out_c > 64 && NPL == 2) return launch_split<128, 2, 4, GATHER, 2>(p, g); // (three planes: the 128-row tile spills)
     if (p->out_c > 32) return launch_split<64, 1, 8, GATHER, NPL>(p, g);
     return launch_split<32, 1, 8, GATHER, NPL>(p, g);
 }

@@ -5,5 +5,5 @@
 for n in ${@:-0 1 2 4 8 6 14 15 16 32 48 63}; do
   if [ $n = 0 ]; then L=thingino-accel_amd/lib/libnna_mars.so; else L=thingino-accel_amd/lib/diag/lib_abl_split_$n.so; fi
   echo "== SPLIT_ABL=$n"
-  LIB=$L timeout -k 10 120 python3 tools/layer_time.py --f32 --no-oracle D40 L15 --cfg f32_mfma=3 | grep f32_mfma
+  LIB=$L timeout -k 10 120 python3 tools/layer_time.py --f32 --no-oracle ${LAYERS:-D40 L15} --cfg f32_mfma=3 | grep f32_mfma
 done

@@ -24,6 +24,7 @@ import marsfile  # noqa: E402
 import marsrt as M  # noqa: E402
 
 LAYERS = {  # yolov5s twin at 640 x 640: h, w, in_c, out_c, k, stride, fused Add
+    "L0": (640, 640, 3, 32, 6, 2, False),
     "L3": (320, 320, 32, 64, 3, 2, False),
     "L15": (160, 160, 32, 32, 3, 1, True),
     "L23": (160, 160, 64, 128, 3, 2, False),
