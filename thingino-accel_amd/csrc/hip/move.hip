@@ -272,6 +272,7 @@ __global__ __launch_bounds__(MV_THREADS) void concat_kernel(const int8_t *in, si
     const int8_t *s = in + (size_t)blockIdx.y * is + pix * in_c + c;
     int8_t *d = out + (size_t)blockIdx.y * os + pix * out_c + ch_off + c;
     if (VEC == 16) *(v4i *)d = *(const v4i *)s;
+    else if (VEC == 4) *(int *)d = *(const int *)s;
     else d[0] = s[0];
 }
 
@@ -282,8 +283,15 @@ extern "C" int mhip_concat_slice(const int8_t *in, size_t in_stride, int8_t *out
     if (npix == 0 || in_c == 0) return 0;
     bool v16 = (in_c % 16 == 0) && (out_c % 16 == 0) && (ch_off % 16 == 0) &&
                ((((uintptr_t)in | (uintptr_t)out | in_stride | out_stride) & 15) == 0);
+    // (the float32 twins' "channels" are map rows of 20 / 40 / 80 / 160 BYTES -- the reference's concat is byte logic over
+    // shape[3] whatever the dtype: dwords, not single bytes, for those)
+    const bool v4 = (in_c % 4 == 0) && (out_c % 4 == 0) && (ch_off % 4 == 0) &&
+                    ((((uintptr_t)in | (uintptr_t)out | in_stride | out_stride) & 3) == 0);
     if (v16)
         hipLaunchKernelGGL((concat_kernel<16>), mv_grid(npix * (in_c / 16), frames), dim3(MV_THREADS), 0,
+                           mhip_stream_native(), in, in_stride, out, out_stride, npix, in_c, out_c, ch_off);
+    else if (v4)
+        hipLaunchKernelGGL((concat_kernel<4>), mv_grid(npix * (in_c / 4), frames), dim3(MV_THREADS), 0,
                            mhip_stream_native(), in, in_stride, out, out_stride, npix, in_c, out_c, ch_off);
     else
         hipLaunchKernelGGL((concat_kernel<1>), mv_grid(npix * in_c, frames), dim3(MV_THREADS), 0,
@@ -308,6 +316,7 @@ __global__ __launch_bounds__(MV_THREADS) void upsample_kernel(const int8_t *in, 
     const int8_t *s = in + (size_t)blockIdx.y * is + ((size_t)iy * in_w + ix) * ch + c;
     int8_t *d = out + (size_t)blockIdx.y * os + pix * pstride + choff + c;
     if (VEC == 16) *(v4i *)d = *(const v4i *)s;
+    else if (VEC == 4) *(int *)d = *(const int *)s;
     else d[0] = s[0];
 }
 
@@ -322,8 +331,13 @@ extern "C" int mhip_upsample_i8(const int8_t *in, size_t in_stride, int8_t *out,
     size_t total = (size_t)out_h * out_w * ch;
     if (total == 0) return 0;
     bool v16 = (ch % 16 == 0) && ((((uintptr_t)in | (uintptr_t)out | in_stride | out_stride | pstride | choff) & 15) == 0);
+    const bool v4 = (ch % 4 == 0) && ((((uintptr_t)in | (uintptr_t)out | in_stride | out_stride | pstride | choff) & 3) == 0);
     if (v16)
         hipLaunchKernelGGL((upsample_kernel<16>), mv_grid(total / 16, frames), dim3(MV_THREADS), 0,
+                           mhip_stream_native(), in, in_stride, out, out_stride, in_h, in_w, ch, out_h, out_w,
+                           scale_h, scale_w, pstride, choff);
+    else if (v4)
+        hipLaunchKernelGGL((upsample_kernel<4>), mv_grid(total / 4, frames), dim3(MV_THREADS), 0,
                            mhip_stream_native(), in, in_stride, out, out_stride, in_h, in_w, ch, out_h, out_w,
                            scale_h, scale_w, pstride, choff);
     else
