@@ -713,6 +713,66 @@ def test_residual_add_folded_into_conv(gpu, orc, order, ic, hw):
         assert np.array_equal(outs[1][f], want)
 
 
+@pytest.mark.parametrize("order", ["conv_first", "conv_second"])
+@pytest.mark.parametrize("ic,hw", [(16, 24), (48, 20)])
+def test_residual_add_folded_into_conv_f32(gpu, orc, order, ic, hw):
+    """the float32 form (round 4): x -> conv1x1 -> SIGMOID -> MUL -> t1 -> conv3x3 -> SIGMOID -> MUL -> t2; out = Add(t1, t2).
+    The fused plan evaluates both SiLU chains and the Add in the convolutions' epilogues (5 launches fewer).  In the
+    reference's summation order (f32_mfma = 0) fused and unfused plans are BIT-IDENTICAL to the oracle; on the bf16 matrix
+    cores (modes 3 / 4) the fused plan stays within 1e-4 * max(1, |b|)."""
+    rng = np.random.default_rng(ic * 100 + hw)
+    G = marsfile.Graph()
+    F, N = marsfile.F32, marsfile.NCHW
+
+    def act():
+        return G.tensor([1, ic, hw, hw], dtype=F, fmt=N)
+
+    def conv_silu(x, k):
+        a, g, o = act(), act(), act()
+        amp = 1.7 / (k * k * ic) ** 0.5
+        w = G.tensor([ic, ic, k, k], dtype=F, fmt=marsfile.OIHW, data=((rng.random((ic, ic, k, k), dtype=np.float32) * 2 - 1) * amp).astype(np.float32))
+        b = G.tensor([ic], dtype=F, fmt=marsfile.D1, data=((rng.random(ic, dtype=np.float32) * 2 - 1) * 0.1).astype(np.float32))
+        G.conv(x, a, w, b, (k, k), (1, 1))
+        G.layer(marsfile.SIGMOID, [a], [g])
+        G.layer(marsfile.MUL, [a, g], [o])
+        return o
+
+    x = act()
+    t1 = conv_silu(x, 1)
+    t2 = conv_silu(t1, 3)
+    o = act()
+    G.layer(marsfile.ADD, [t2, t1] if order == "conv_first" else [t1, t2], [o])
+    d = G.serialise([x], [o])
+    B = 3
+    xs = [(rng.random(ic * hw * hw, dtype=np.float32) * 2 - 1).astype(np.float32).view(np.uint8) for _ in range(B)]
+    want = []
+    for f in range(B):
+        g, rc = run_oracle(orc, d, xs[f])
+        assert rc == 0
+        want.append(g.tensor(o).copy())
+        g.close()
+    try:
+        nops = {}
+        for mode in (0, 3, 4):
+            gpu.set_tuning("f32_mfma", mode)
+            for fusion in (0, 1):
+                m = gpu.Model(d, batch=B, fusion=fusion)
+                for f in range(B):
+                    m.input_view(0)[f] = xs[f]
+                m.run()
+                got = m.output_view(0).copy()
+                nops[fusion] = len(m.ops())
+                m.close()
+                for f in range(B):
+                    if mode == 0:
+                        assert np.array_equal(got[f], want[f]), "mode 0 fusion %d frame %d" % (fusion, f)
+                    else:
+                        assert close_f32(got[f], want[f]).all(), "mode %d fusion %d frame %d" % (mode, fusion, f)
+            assert nops[1] == nops[0] - 5  # two SIGMOID + MUL pairs and the Add are gone
+    finally:
+        gpu.set_tuning("f32_mfma", 1)
+
+
 def test_deferred_load_and_arena_copy(gpu):
     """what every rank but 0 does in the multi-GPU job: load DESCRIPTORS only (weights blob zeroed,
     MARS_HIP_LOAD_DEFER_WEIGHTS), receive rank 0's packed parameter arena byte for byte (here: a device-to-device

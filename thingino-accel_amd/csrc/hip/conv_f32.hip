@@ -64,7 +64,9 @@ __global__ __launch_bounds__(256) void conv_f32_kernel(const mhip_conv_f32_t p) 
             }
         }
     }
-    out[((size_t)oc * p.out_h + oy) * p.out_w + ox] = p.silu ? silu_f32(acc) : acc;
+    const size_t oi = ((size_t)oc * p.out_h + oy) * p.out_w + ox;
+    const float r = p.silu ? silu_f32(acc) : acc;
+    out[oi] = p.add ? r + ((const float *)((const char *)p.add + (size_t)f * p.add_stride))[oi] : r;
 }
 
 // ---------------------------------------------------------------------------------
@@ -207,12 +209,16 @@ __global__ __launch_bounds__(256) void conv_f32_mfma(const mhip_conv_f32_t p, co
         if (px >= total_pix) continue;
         const unsigned f = fdivf(px, dhw), rem = px - f * hw;
         float *out = (float *)((char *)p.out + (size_t)f * p.out_stride);
+        const float *addp = p.add ? (const float *)((const char *)p.add + (size_t)f * p.add_stride) : nullptr;
 #pragma unroll
         for (int a = 0; a < 2; a++)
 #pragma unroll
             for (int j = 0; j < 4; j++) {
                 const int oc = oc0 + wm * 32 + a * 16 + (lane >> 4) * 4 + j;
-                if (oc < p.out_c) out[(size_t)oc * hw + rem] = p.silu ? silu_f32(acc[a][c][j]) : acc[a][c][j];
+                if (oc < p.out_c) {
+                    const float r = p.silu ? silu_f32(acc[a][c][j]) : acc[a][c][j];
+                    out[(size_t)oc * hw + rem] = addp ? r + addp[(size_t)oc * hw + rem] : r;
+                }
             }
     }
 }

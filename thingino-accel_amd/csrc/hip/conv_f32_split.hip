@@ -400,13 +400,17 @@ __global__ __launch_bounds__(S_NT, BM == 32 && NPL == 2 ? 4 : 2) void conv_f32_s
             if (px < g.total_pix) {
                 const unsigned f = sdiv(px, g.dhw), rem = px - f * hw;
                 float *out = (float *)((char *)p.out + (size_t)f * p.out_stride);
+                const float *addp = p.add ? (const float *)((const char *)p.add + (size_t)f * p.add_stride) : nullptr;
 #pragma unroll
                 for (int a = 0; a < MI; a++)
 #pragma unroll
                     for (int j = 0; j < 4; j++) {
                         const int oc = oc0 + wm * TM + a * 16 + fc * 4 + j;
                         if (SPLIT_ABL & 32) asm volatile("" ::"v"(acc[a][c][j]));
-                        else if (oc < p.out_c) out[(size_t)oc * hw + rem] = p.silu && !(SPLIT_ABL & 16) ? (NPL == 2 ? silu_fast(acc[a][c][j]) : silu_split(acc[a][c][j])) : acc[a][c][j];
+                        else if (oc < p.out_c) {
+                            const float r = p.silu && !(SPLIT_ABL & 16) ? (NPL == 2 ? silu_fast(acc[a][c][j]) : silu_split(acc[a][c][j])) : acc[a][c][j];
+                            out[(size_t)oc * hw + rem] = addp ? r + addp[(size_t)oc * hw + rem] : r;
+                        }
                     }
             }
 #pragma unroll

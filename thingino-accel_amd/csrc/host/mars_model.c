@@ -170,6 +170,7 @@ mars_error_t build_plan(mars_model_ext_t *m) {
         fuse_silu(m);
         fuse_silu_f32(m);
         fuse_add(m);
+        fuse_add_f32(m);
         if (!m->no_vconcat) virtual_concat(m);
         elide_concat(m);
         fuse_pool_chains(m);

@@ -784,6 +784,65 @@ void fuse_add(mars_model_ext_t *m) {
     free(writers);
 }
 
+/* The float32 form: Add(conv_f32 result, x) (reference mars_runtime.c:807-816: out[i] = a[i] + b[i]) evaluated where the
+ * convolution stores -- one float add behind the (fused) SiLU, the same float the separate layer computes from the same two
+ * floats, so every kernel form stays what it was (the exact-order kernel bit-identical).  Saves a write and two reads of
+ * the tensor per bottleneck (7 launches, 7 % of the float32 twin's step). */
+void fuse_add_f32(mars_model_ext_t *m) {
+    const int nt = (int)m->pub.header.num_tensors;
+    int *readers = (int *)calloc((size_t)nt + 1, sizeof(int));
+    int *writers = (int *)calloc((size_t)nt + 1, sizeof(int));
+    if (!readers || !writers) { free(readers); free(writers); return; }
+    for (int i = 0; i < m->n_ops; i++) {
+        for (int k = 0; k < m->ops[i].n_in; k++)
+            if (m->ops[i].t_in[k] >= 0) readers[m->ops[i].t_in[k]]++;
+        if (m->ops[i].t_out >= 0) writers[m->ops[i].t_out]++;
+    }
+    for (int j = 0; j < m->n_ops; j++) {
+        mars_op_t *ad = &m->ops[j];
+        if (ad->kind != OP_BINARY_F32 || ad->is_mul || ad->n_in != 2) continue;
+        for (int side = 0; side < 2; side++) {
+            const int A = ad->t_in[side], X = ad->t_in[1 - side], O = ad->t_out;
+            if (A < 0 || X < 0 || O < 0 || A == X || O == X || O == A) continue;
+            if (readers[A] != 1 || writers[A] != 1 || m->mt[A].io_in || m->mt[A].io_out || m->mt[A].is_weight) continue;
+            if (m->mt[X].is_weight || m->mt[O].is_weight || writers[O] != 1) continue;
+            int i = -1;
+            for (int k = 0; k < j; k++)
+                if (m->ops[k].t_out == A) i = k;
+            if (i < 0) continue;
+            mars_op_t *c = &m->ops[i];
+            if (c->kind != OP_CONV_F32 || c->add_t || c->n_in != 1) continue;
+            if (ad->n != (size_t)c->out_h * c->out_w * c->out_c) continue;
+            if (c->t_in[0] == O) continue; /* add(conv(X), Y) -> X: sequential in the reference, a race when fused */
+            int clash = 0;
+            for (int k = i; k <= j && !clash; k++) {
+                const mars_op_t *o = &m->ops[k];
+                if (o->t_out == X) clash = 1; /* x must be complete before the convolution runs */
+                if (k > i && k < j) {
+                    if (o->t_out == O) clash = 1;
+                    for (int q = 0; q < o->n_in; q++)
+                        if (o->t_in[q] == O) clash = 1;
+                }
+            }
+            if (clash) continue;
+            c->t_out = O;
+            c->add_t = X + 1;
+            c->t_in[c->n_in++] = X;
+            c->bytes += 4.0 * (double)ad->n;
+            m->mt[A].needed = 0;
+            ad->kind = -1;
+            readers[A] = 0;
+            break;
+        }
+    }
+    int w = 0;
+    for (int i = 0; i < m->n_ops; i++)
+        if (m->ops[i].kind != -1) m->ops[w++] = m->ops[i];
+    m->n_ops = w;
+    free(readers);
+    free(writers);
+}
+
 /* Fused C3 bottleneck: conv1x1 + SiLU (A) whose only reader is the k x k convolution B right behind it (B usually
  * carries the folded residual Add of A's input) -> B evaluates A on its staged input patch (conv_i8_patch<PRE>); A's
  * output tensor is never written.  Same bytes: B sees, at every in-image pixel of its window, exactly the int8 value A

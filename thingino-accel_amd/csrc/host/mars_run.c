@@ -118,6 +118,7 @@ static int launch_op(mars_model_ext_t *m, mars_op_t *op) {
             p.out_h = op->out_h; p.out_w = op->out_w; p.out_c = op->out_c;
             p.kh = op->kh; p.kw = op->kw; p.stride_h = op->sh; p.stride_w = op->sw; p.pad_top = op->pt; p.pad_left = op->pl;
             p.silu = op->silu_f32;
+            if (op->add_t) { p.add = (const float *)tdev(m, op->add_t - 1); p.add_stride = tstride(m, op->add_t - 1); }
             {
                 const int mode = mhip_conv_f32_mode(-1);
                 p.use_mfma = mode == 3 ? 3 : mode == 4 ? 2 : (mode == 2 || (mode == 1 && !op->f32_exact));

@@ -141,6 +141,8 @@ typedef struct {
     int in_h, in_w, in_c, out_h, out_w, out_c;
     int kh, kw, stride_h, stride_w, pad_top, pad_left;
     int silu;     /* fused conv -> SIGMOID -> MUL chain (float forms): out = v * (1 / (1 + expf(-v))), libm-exact expf */
+    const float *add; size_t add_stride; /* optional fused residual Add (reference mars_runtime.c:807-816, the float ADD): out = result + add[same index],
+                                            one float add after the SiLU -- the same float the separate layer computes */
     int use_mfma; /* 0: reference summation order, bit-identical; 1: implicit GEMM on v_mfma_f32_16x16x4_f32 (fused
                      rounding per tap: inside the 1e-4 tolerance of the float32 models, not bit-equal); 2: implicit GEMM on
                      v_mfma_f32_16x16x32_bf16 with every operand split into three bf16 pieces, six piece products per
