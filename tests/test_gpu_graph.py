@@ -6,6 +6,8 @@ import json
 import os
 import struct
 
+import ctypes as C
+
 import numpy as np
 import pytest
 
@@ -771,6 +773,81 @@ def test_residual_add_folded_into_conv_f32(gpu, orc, order, ic, hw):
             assert nops[1] == nops[0] - 5  # two SIGMOID + MUL pairs and the Add are gone
     finally:
         gpu.set_tuning("f32_mfma", 1)
+
+
+F32_SPLIT_SHAPES = [
+    # h, w, in_c, out_c, k, stride, pad, batch, silu       which path of conv_f32_split (round 4)
+    (7, 9, 3, 5, 3, 1, "same", 3, True),       # odd map width: one dword per tap (GATHER 0), a 32-channel tile 5 channels full
+    (16, 20, 8, 40, 3, 1, "same", 5, True),    # stride 1, 16-byte gathers (4 pixels x 1 tap), 64-channel tile
+    (17, 18, 4, 130, 3, 2, "same", 2, False),  # stride 2, odd output width: not a split shape -> falls back to conv_f32_mfma
+    (32, 32, 16, 128, 3, 2, "same", 4, True),  # stride 2, kernel rows padded to 4 taps, 2 pixels x 2 taps per load, 128-channel tile
+    (48, 48, 8, 16, 3, 1, "same", 64, True),   # 576 pixel tiles on 512 slots: every workgroup walks two tiles (the K pipeline
+                                               # runs through the tile boundary), the last ones one
+    (64, 64, 3, 32, 6, 2, "same", 9, True),    # the stem's geometry: 6 x 6, stride 2, 3 channels
+    (12, 12, 24, 200, 1, 1, "same", 7, False), # 1 x 1, two 128-channel tiles (the second 72 channels full), K = 24 < one step
+    (20, 24, 6, 12, 3, 1, "valid", 3, True),   # no padding: no tap ever starts left of the image
+    (9, 16, 5, 7, 5, 1, "same", 2, True),      # 5 x 5, pad 2: more than one column left of the image -> GATHER 0
+]
+
+
+@pytest.mark.parametrize("shape", F32_SPLIT_SHAPES, ids=lambda v: "x".join(str(q) for q in v))
+def test_conv_f32_split_shapes(gpu, orc, shape):
+    """one float32 convolution (+ fused SIGMOID / MUL) on the bf16 matrix cores with split operands, modes 3 (two pieces,
+    three products) and 4 (three pieces, six products), over the gather forms, tile sizes, ragged channel counts, tile
+    counts above and below the persistent grid, and a shape the kernel declines; every frame of the batch against the
+    oracle within 1e-4 * max(1, |b|), and mode 0 bit-identical (the same plan through the reference-order kernel)"""
+    h, w, ic, oc, k, st, pad, B, silu = shape
+    rng = np.random.default_rng(h * 1000 + w * 10 + k)
+    G = marsfile.Graph()
+    F, N = marsfile.F32, marsfile.NCHW
+    if pad == "same":
+        oh, ow = (h + st - 1) // st, (w + st - 1) // st
+    else:
+        oh, ow = (h - k) // st + 1, (w - k) // st + 1
+    x = G.tensor([1, ic, h, w], dtype=F, fmt=N)
+    a = G.tensor([1, oc, oh, ow], dtype=F, fmt=N)
+    amp = 1.7 / (k * k * ic) ** 0.5
+    wt = G.tensor([oc, ic, k, k], dtype=F, fmt=marsfile.OIHW, data=((rng.random((oc, ic, k, k), dtype=np.float32) * 2 - 1) * amp).astype(np.float32))
+    b = G.tensor([oc], dtype=F, fmt=marsfile.D1, data=((rng.random(oc, dtype=np.float32) * 2 - 1) * 0.1).astype(np.float32))
+    G.conv(x, a, wt, b, (k, k), (st, st), pad=marsfile.PAD_SAME if pad == "same" else marsfile.PAD_VALID)
+    out = a
+    if silu:
+        g_, o_ = G.tensor([1, oc, oh, ow], dtype=F, fmt=N), G.tensor([1, oc, oh, ow], dtype=F, fmt=N)
+        G.layer(marsfile.SIGMOID, [a], [g_])
+        G.layer(marsfile.MUL, [a, g_], [o_])
+        out = o_
+    d = G.serialise([x], [out])
+    xs = [(rng.random(ic * h * w, dtype=np.float32) * 2 - 1).astype(np.float32).view(np.uint8) for _ in range(min(B, 4))]
+    want = []
+    for q in xs:
+        g, rc = run_oracle(orc, d, q)
+        assert rc == 0
+        want.append(g.tensor(out).copy())
+        g.close()
+    try:
+        gpu.set_tuning("dual_stream_min_batch", 0)  # one launch over the whole batch: the 64-frame case must walk two tiles per workgroup
+        for mode in (3, 4, 0):
+            gpu.set_tuning("f32_mfma", mode)
+            m = gpu.Model(d, batch=B)
+            for f in range(B):
+                m.input_view(0)[f] = xs[f % len(xs)]
+            count = gpu.lib().mhip_conv_f32_split_launches
+            count.restype = C.c_ulong
+            n0 = count()
+            m.run()
+            declined = st == 2 and ow % 2 == 1  # (the one shape above the split kernel does not take)
+            assert count() - n0 == (0 if mode == 0 or declined else 1), "mode %d: conv_f32_split launched %d time(s)" % (mode, count() - n0)
+            got = m.output_view(0).copy()
+            m.close()
+            for f in range(B):
+                if mode == 0:
+                    assert np.array_equal(got[f], want[f % len(xs)]), "mode 0 frame %d" % f
+                else:
+                    ok = close_f32(got[f], want[f % len(xs)])
+                    assert ok.all(), "mode %d frame %d: %d of %d out of tolerance" % (mode, f, int((~ok).sum()), ok.size)
+    finally:
+        gpu.set_tuning("f32_mfma", 1)
+        gpu.set_tuning("dual_stream_min_batch", 64)
 
 
 def test_deferred_load_and_arena_copy(gpu):

@@ -419,6 +419,9 @@ __global__ __launch_bounds__(S_NT, BM == 32 && NPL == 2 ? 4 : 2) void conv_f32_s
     }
 }
 
+static unsigned long g_split_launches = 0; // launches of conv_f32_split since load (tests: did a shape take this kernel or the fallback?)
+extern "C" unsigned long mhip_conv_f32_split_launches(void) { return g_split_launches; }
+
 // kernel row length in the packed K space: an odd kernel width under stride 2 gets one zero column (taps come in pairs there)
 static int split_kwp(int kw, int stride_w) { return stride_w == 2 && kw > 1 && (kw & 1) ? kw + 1 : kw; }
 
@@ -445,6 +448,7 @@ static int launch_split(const mhip_conv_f32_t *p, split_args_t g) {
     const unsigned per = (g.npt + gx - 1) / gx;
     gx = (g.npt + per - 1) / per;
     hipLaunchKernelGGL(kern, dim3(gx, noc), dim3(S_NT), ldsb, mhip_stream_native(), *p, g);
+    g_split_launches++;
     return mhip_check(hipGetLastError(), "conv_f32_split");
 }
 template <int GATHER, int NPL>

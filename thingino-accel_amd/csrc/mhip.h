@@ -155,6 +155,7 @@ int mhip_conv_f32(const mhip_conv_f32_t *p);
  * (hi = bf16(w), mid = bf16(w - hi), round to nearest; use_mfma == 3 reads the first two planes).  K' = in_c * kh * kw, or in_c * kh * (kw + 1) for stride_w == 2 with an odd kw (one zero column
  * appended to every kernel row: taps come in pairs there). */
 size_t mhip_conv_f32_split_pack(int out_c, int in_c, int kh, int kw, int stride_w, const float *w, void *out);
+unsigned long mhip_conv_f32_split_launches(void); /* launches of conv_f32_split since load (diagnostic) */
 /* policy knob: 0 never the matrix cores, 1 (default) wherever the host proves it safe, 2 everywhere, 3 / 4 everywhere on the
  * bf16 matrix cores with operands split in two / three (three / six piece products).  set < 0 only
  * reads; returns the mode in force (first call reads MARS_HIP_F32_MFMA) */
