@@ -3,6 +3,8 @@
 //   mars_probe_copy_rate_gbs  what a plain device-to-device copy reaches on this box: the practical HBM ceiling
 //   mars_probe_clock_mhz      the shader clock right now, beside whatever the other streams of the process are running
 #include <hip/hip_runtime.h>
+#include <stdio.h>
+#include <stdlib.h>
 #include <stdint.h>
 #include <string.h>
 
@@ -80,6 +82,7 @@ extern "C" double mars_probe_copy_rate_gbs(size_t bytes, int reps) {
             if (ok && hipEventRecord(e1, st) == hipSuccess && hipEventSynchronize(e1) == hipSuccess && hipEventElapsedTime(&ms, e0, e1) == hipSuccess &&
                 ms > 0.f) {
                 const double r = 2.0 * (double)bytes * reps / ((double)ms * 1e-3) / 1e9;
+                if (getenv("MARS_PROBE_VERBOSE")) fprintf(stderr, "copy probe: %-70s %7.1f GB/s\n", names[form], r);
                 if (r > best) { best = r; g_copy_form = names[form]; }
             }
         }
