@@ -30,7 +30,7 @@
 // wave, read back by the same lane after the wave's own counted wait (wave-private: no barrier).  (Ordinary loads hidden
 // from the compiler in inline asm were tried first: it may copy an asm statement's destination registers at once, before
 // the data has landed -- it did, in the 4-row instantiation.)
-#ifdef PATCH_STAMPS // diagnostic build only (scratch/stamps.sh): where a tile's cycles go, summed over all waves
+#ifdef PATCH_STAMPS // diagnostic build only (tools/stamps_build.sh patch, tools/patch_stamps.py): where a tile's cycles go, summed over all waves
 __device__ unsigned long long patch_stamp_sums[8];
 extern "C" int mhip_patch_stamps(unsigned long long *out, int reset) {
     if (out && hipMemcpyFromSymbol(out, HIP_SYMBOL(patch_stamp_sums), sizeof(patch_stamp_sums)) != hipSuccess) return -1;
@@ -476,7 +476,7 @@ struct patch_geom_t {
     size_t lds;
 };
 static inline const tune_t &tune() { return conv_i8_tune_state(); }
-// LDS budget of one workgroup.  Measured (scratch/patch_time.py, yolov5s shapes, batch 256): workgroups per CU matter
+// LDS budget of one workgroup.  Measured (tools/layer_time.py, yolov5s shapes, batch 256): workgroups per CU matter
 // more than ring depth -- three workgroups with two patch buffers beat two with four (3x3 32->32 @160: 194 vs 225 us) -- and
 // beyond one patch in flight per workgroup nothing is gained.  The 32-channel-tile instantiations fit three waves per SIMD
 // (<= 168 registers): they get a third of the CU; the 64-channel tiles (200+ registers: two waves per SIMD) half of it.
