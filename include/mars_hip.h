@@ -81,7 +81,10 @@ mars_error_t mars_hip_set_fusion(mars_model_t *model, int level);
  * (force one launch variant wherever a layer has it); "f32_mfma" (float32 convolutions: 0 = the reference's summation
  * order everywhere, bit-identical; 1 = default: the f32 matrix cores -- fused rounding per tap, inside the 1e-4
  * tolerance of the float32 models -- for every convolution from which no byte-wise MAXPOOL over float bytes is
- * reachable; 2 = matrix cores everywhere); "graph_max_batch" (default 8: at batches up to this the plan is captured into a
+ * reachable; 2 = those matrix cores everywhere; 3 / 4 = everywhere on the bf16 matrix cores with every operand split,
+ * exactly, into two / three bf16 pieces and three / six piece products per product -- same tolerance class, 2.7x the rate:
+ * what bench.py --dtype f32 runs is 3); "rows" (default 1: the patch-staged deep-K kernel conv_i8_rows where it is ahead);
+ * "few_wgs" (default 256: launches with fewer workgroups than this take the small-launch variant); "graph_max_batch" (default 8: at batches up to this the plan is captured into a
  * HIP graph after its first run and replayed with one call -- single frames are launch-bound; 0 = never);
  * "small_batch" (default 1: a launch whose large-batch tiling yields fewer workgroups than the device has CUs takes
  * smaller tiles -- what single frames want; 0 = the large-batch policy everywhere); "rgb_direct" (default 1: the RGB stem
