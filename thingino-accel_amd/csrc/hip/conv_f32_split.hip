@@ -1,33 +1,38 @@
 // conv_f32_split.hip -- float32 convolution (NCHW / OIHW, reference src/mars/mxu_conv.c:673-710) on the bf16 matrix cores
-// by operand splitting.  Round 4, verdict item 3; mhip_conv_f32_t.use_mfma == 2, tuning "f32_mfma" = 3.
+// by operand splitting.  Round 4, verdict item 3; mhip_conv_f32_t.use_mfma == 3 / 2 = tuning "f32_mfma" 3 / 4.
 //
 // The f32-input MFMA (conv_f32.hip, v_mfma_f32_16x16x4_f32) runs at the f32 VECTOR rate, 1/16 of the bf16 matrix rate, and
-// gfx950 has no xf32: config 5 sat at 0.37 of a 157 TFLOP/s ceiling.  Here every float is cut, exactly, into three bf16
-// pieces by truncation,  x = hi + mid + lo  (hi = top 16 bits of x, mid = top 16 bits of x - hi, lo = x - hi - mid: 8 + 8 + 8
-// significant bits, every subtraction exact), and a product a * b is summed from the six piece products that carry more than
-// 2^-24 of it,  a.hi b.hi + (a.hi b.mid + a.mid b.hi) + (a.mid b.mid + a.hi b.lo + a.lo b.hi)  -- each exact in f32, added
-// into f32 accumulators by v_mfma_f32_16x16x32_bf16: six MFMAs at 16x the f32 rate = 2.7x the f32 matrix peak, with the
-// per-product error (the three dropped terms) below 2^-23 relative -- the size of one f32 rounding, inside north_star's 1e-4
-// tolerance, not bit-equal (like conv_f32_mfma; the exact-order kernel stays where a byte-wise consumer follows).
+// gfx950 has no xf32: config 5 sat at 0.37 of a 157 TFLOP/s ceiling.  Here every float is cut, exactly, into bf16 pieces by
+// round-to-nearest,  hi = bf16(x), mid = bf16(x - hi), lo = x - hi - mid  (every subtraction exact: x - hi has at most 16
+// significant bits, x - hi - mid at most 8), and a product a * b is summed from piece products, each exact in f32, added into
+// f32 accumulators by v_mfma_f32_16x16x32_bf16:
+//   NPL = 2 (use_mfma 3): two pieces, THREE products  a.hi b.hi + a.hi b.mid + a.mid b.hi   -- relative error per product <= 2^-16,
+//                         either sign; 8e-7 worst relative error on the config-5 twin's outputs; the benchmark's mode;
+//   NPL = 3 (use_mfma 2): three pieces, SIX products  ... + a.mid b.mid + a.hi b.lo + a.lo b.hi -- what is dropped is below 2^-23
+//                         relative, the size of one f32 rounding.
+// Inside north_star's 1e-4 tolerance, not bit-equal (like conv_f32_mfma; the exact-order kernel stays where a byte-wise
+// consumer follows).  Peak for the roofline: 2.5 PFLOP/s / 3 (or / 6) of float32 work.
 //
 // Implicit GEMM  D[oc][pixel] = bias[oc] + sum_k W[oc][k] X[k][pixel],  k = (ic, ky, kx) in the reference's order.  Workgroup =
-// 512 threads = 8 waves; tile = BM output channels x 256 pixels (all frames flattened), K step = 32 taps.
-//  * weights: cut into their three planes ONCE, on the host at load time (mhip_conv_f32_split_pack: [plane][oc_pad][k_pad]
-//    bf16); a step's tile is three 16-byte copies per thread;
-//  * input: gathered through registers, split there (the vector instructions hide in the MFMAs' issue shadow) and written as
-//    K-contiguous bf16 rows -- the MFMA's fragment layout -- into the three planes of the LDS tile.  What bounded the first
-//    version was the gather itself: one dword per lane and tap = 128 wave-loads per step through the texture addresser, ~12
-//    vector instructions per element (440 per wave and step against 96 MFMAs).  So: 16-BYTE loads.  Stride 1 (GATHER 1): a
-//    lane owns 4 consecutive pixels of a map row and loads them for one tap in one instruction; stride 2 (GATHER 2): a lane
-//    owns 2 pixels and a load brings taps (kx, kx + 1) of both -- kernel rows are padded to an even length there (one zero
-//    weight column).  A tap left of the image (pad 1) loads one element further right and shifts; columns outside the image
-//    are masked by a per-lane bit table, rows outside by an out-of-range offset the buffer unit turns into zeros.  GATHER 0
-//    (any other geometry): one dword per tap.
+// 512 threads = 8 waves; tile = BM output channels x 256 pixels (all frames flattened), K step = 32 taps.  PERSISTENT over
+// pixel tiles (grid = what the device holds x channel tiles): the K pipeline runs through the tile boundary, so a tile's
+// stores overlap the next tile's first loads.
+//  * weights: cut into their planes ONCE, on the host at load time (mhip_conv_f32_split_pack: [plane][oc_pad][k_pad] bf16);
+//    a step's tile is one 16-byte copy per thread and plane;
+//  * input: gathered through registers with 16-BYTE loads, split there and written as K-contiguous bf16 rows -- the MFMA's
+//    fragment layout -- into the planes of the LDS tile.  Stride 1 (GATHER 1): a lane owns 4 consecutive pixels of a map row
+//    and loads them for one tap in one instruction; stride 2 (GATHER 2): a lane owns 2 pixels and a load brings taps (kx,
+//    kx + 1) of both -- kernel rows are padded to an even length there (one zero weight column).  A tap left of the image
+//    (pad 1) loads one element further right and shifts; columns outside the image are masked by a per-lane bit table, rows
+//    outside by an out-of-range offset the buffer unit turns into zeros.  GATHER 0 (any other geometry): one dword per tap.
+//    A fetch ONLY issues loads (a scheduler fence follows it; left alone the compiler sinks the loads to the end of the step);
+//    shifts and masks are applied by the commit one step later from a per-lane `meta` word;
 //  * LDS: A rows as in the int8 kernels (64-byte rows, chunk swizzle).  B rows (pixels) are dealt over four 64-row blocks
-//    (pixel r -> block r % 4, row r / 4) with the 16-byte chunk XOR-ed by (block ^ row / 4 % 4): the 4-pixel-per-lane
-//    writes, the pixel-per-lane writes and the 16-pixel fragment reads are all bank-conflict free.
+//    (pixel r -> block r % 4, row r / 4) with the 16-byte chunk XOR-ed by (block ^ row / 4 % 4), laid out so that the
+//    4-pixel-per-lane writes and the 16-pixel fragment reads spread over the banks (SQ counters: 22 % of the LDS cycles are
+//    still conflicts -- LDS is busy a fifth of the time, not the bound);
 //  * two stages, two register sets: step ks + 2's loads are in flight while step ks multiplies and step ks + 1's operands
-//    are split and written (sched_group_barrier interleaves them with the MFMAs).
+//    are split and written (sched_group_barrier interleaves them with the MFMAs: two vector instructions fit in an MFMA's shadow).
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdlib.h>
