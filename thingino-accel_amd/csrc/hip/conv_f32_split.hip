@@ -51,6 +51,25 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 #define S_BN 256  // pixels per workgroup
 #define S_BK 32   // taps per K step = one v_mfma_f32_16x16x32_bf16
 #define S_NT 512
+#ifdef SPLIT_STAMPS // diagnostic build (tools/stamps_build.sh splitstamps; read with tools/split_stamps.py): where a K step goes
+__device__ unsigned long long split_stamp_sums[8];
+extern "C" int mhip_split_stamps(unsigned long long *out, int reset) {
+    unsigned long long z[8] = {0};
+    if (out && hipMemcpyFromSymbol(out, HIP_SYMBOL(split_stamp_sums), sizeof z) != hipSuccess) return -1;
+    if (reset && hipMemcpyToSymbol(HIP_SYMBOL(split_stamp_sums), z, sizeof z) != hipSuccess) return -1;
+    return 0;
+}
+#define STAMP(i)                                                                  \
+    do {                                                                          \
+        __builtin_amdgcn_sched_barrier(0);                                        \
+        const unsigned long long t_ = __builtin_readcyclecounter();              \
+        st_acc[i] += t_ - st_last;                                                \
+        st_last = t_;                                                             \
+        __builtin_amdgcn_sched_barrier(0);                                        \
+    } while (0)
+#else
+#define STAMP(i) do { } while (0)
+#endif
 #ifndef SPLIT_ABL // timing-only ablations (tools/stamps_build.sh split N; wrong results): 1 no MFMAs, 2 no gather loads, 4 no
 #define SPLIT_ABL 0 // split / LDS writes of the input, 8 no fragment reads, 16 plain stores (no SiLU), 32 no stores
 #endif
@@ -318,6 +337,9 @@ __global__ __launch_bounds__(S_NT, BM == 32 && NPL == 2 ? 4 : 2) void conv_f32_s
         for (int c = 0; c < NI; c++) acc[a][c] = bias4[a];
     }
 
+#ifdef SPLIT_STAMPS
+    unsigned long long st_acc[4] = {0, 0, 0, 0}, st_last = 0, st_steps = 0;
+#endif
     // one K step: the MFMAs of LDS stage `buf`, and the operands in (breg, areg) split into the other stage (last read in the
     // previous step, every wave is past that step's barrier; after the last step it receives stale registers nobody reads --
     // unconditional, so that it shares the MFMAs' basic block and the scheduler can interleave the two)
@@ -370,9 +392,11 @@ __global__ __launch_bounds__(S_NT, BM == 32 && NPL == 2 ? 4 : 2) void conv_f32_s
         // vmcnt(0) as well, i.e. for the loads of step ks + 2 issued a moment ago -- a full memory latency per K step (5600
         // cycles per step whatever the MFMA count: 899 / 761 / 729 us with 6 / 4 / 3 piece products); the compiler's own
         // counted vmcnt wait sits where those registers are first used, one step later
+        STAMP(1); // the step's body: fragment reads, MFMAs, split + LDS writes of the next step
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
+        STAMP(2); // own LDS writes landing + the wait for the other waves
     };
 
     const int nks = g.nks;
@@ -383,18 +407,28 @@ __global__ __launch_bounds__(S_NT, BM == 32 && NPL == 2 ? 4 : 2) void conv_f32_s
     // nks is even (the weight planes' rows are padded to 64 taps): two steps per iteration, no exit in between -- with a
     // `break` after the first step the compiler lost count of the loads in flight at the loop's merge points and waited
     // vmcnt(0..3) right behind every fetch, i.e. for the loads it had just issued
+#ifdef SPLIT_STAMPS
+    st_last = __builtin_readcyclecounter();
+#endif
     for (unsigned pt = blockIdx.x; pt < g.npt; pt += gridDim.x) {
+#ifdef SPLIT_STAMPS
+        st_steps += (unsigned long long)nks;
+#endif
         for (int ks = 0; ks < nks; ks += 2) {
             int kq = ks + 2;
             if (kq >= nks) { kq = 0; setup(pt + gridDim.x); } // the last two steps of a tile fetch the first two of the next
             // the scheduler fence keeps a fetch's six loads AHEAD of the step's MFMAs: left alone, the compiler sinks them (with
             // their scalar address arithmetic) to the end of the step, 400 cycles before the next step needs them -- a memory
             // latency exposed per step (vmcnt(1..3) in the middle of the MFMAs)
+            STAMP(3); // loop overhead, and the tile epilogue when a tile ended
             fetch(kq, bregs[0], aregs[0], metas[0], smetas[0]);
             __builtin_amdgcn_sched_barrier(0);
+            STAMP(0); // the fetch: address arithmetic and six load issues
             step(0, bregs[1], aregs[1], metas[1], smetas[1]);
+            STAMP(3);
             fetch(kq + 1, bregs[1], aregs[1], metas[1], smetas[1]);
             __builtin_amdgcn_sched_barrier(0);
+            STAMP(0);
             step(1, bregs[0], aregs[0], metas[0], smetas[0]);
         }
         // store: 16 lanes write 16 consecutive floats of one channel row
@@ -422,6 +456,12 @@ __global__ __launch_bounds__(S_NT, BM == 32 && NPL == 2 ? 4 : 2) void conv_f32_s
             for (int a = 0; a < MI; a++) acc[a][c] = bias4[a];
         }
     }
+#ifdef SPLIT_STAMPS
+    if (lane == 0) {
+        for (int i = 0; i < 4; i++) atomicAdd(&split_stamp_sums[i], st_acc[i]);
+        atomicAdd(&split_stamp_sums[4], st_steps);
+    }
+#endif
 }
 
 static unsigned long g_split_launches = 0; // launches of conv_f32_split since load (tests: did a shape take this kernel or the fallback?)
