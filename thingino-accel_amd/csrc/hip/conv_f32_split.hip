@@ -320,19 +320,16 @@ __global__ __launch_bounds__(S_NT, BM == 32 && NPL == 2 ? 4 : 2) void conv_f32_s
         }
     };
 
-    // accumulators start at the bias: lane holds channels 4 * (lane / 16) + j of an MFMA tile, pixel lane % 16
+    // accumulators start at the bias.  The MFMA takes the PIXELS as its A operand and the weights as B (D = X W^T), so a lane holds
+    // pixels 4 * (lane / 16) + j of an MFMA tile for channel lane % 16: four consecutive floats of a channel row -- one 16-byte
+    // store (the other way round a tile was 4 dword stores per lane: 64 store instructions per lane and 256-pixel tile)
     const int fr = lane & 15, fc = lane >> 4;
     v4f acc[MI][NI], bias4[MI];
 #pragma unroll
     for (int a = 0; a < MI; a++) {
-        bias4[a] = (v4f){0.f, 0.f, 0.f, 0.f};
-        if (p.bias) {
-#pragma unroll
-            for (int j = 0; j < 4; j++) {
-                const int oc = oc0 + wm * TM + a * 16 + fc * 4 + j;
-                bias4[a][j] = oc < p.out_c ? p.bias[oc] : 0.f;
-            }
-        }
+        const int oc = oc0 + wm * TM + a * 16 + fr;
+        const float b = p.bias && oc < p.out_c ? p.bias[oc] : 0.f;
+        bias4[a] = (v4f){b, b, b, b};
 #pragma unroll
         for (int c = 0; c < NI; c++) acc[a][c] = bias4[a];
     }
@@ -373,13 +370,13 @@ __global__ __launch_bounds__(S_NT, BM == 32 && NPL == 2 ? 4 : 2) void conv_f32_s
 #pragma unroll
             for (int c = 0; c < NI; c++) {
                 if (NPL == 3) {
-                    acc[a][c] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[NPL - 1][a], bf[0][c], acc[a][c], 0, 0, 0); // lo * hi
-                    acc[a][c] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[0][a], bf[NPL - 1][c], acc[a][c], 0, 0, 0); // hi * lo
-                    acc[a][c] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[1][a], bf[1][c], acc[a][c], 0, 0, 0);       // mid * mid
+                    acc[a][c] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bf[0][c], af[NPL - 1][a], acc[a][c], 0, 0, 0); // lo * hi
+                    acc[a][c] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bf[NPL - 1][c], af[0][a], acc[a][c], 0, 0, 0); // hi * lo
+                    acc[a][c] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bf[1][c], af[1][a], acc[a][c], 0, 0, 0);       // mid * mid
                 }
-                acc[a][c] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[0][a], bf[1][c], acc[a][c], 0, 0, 0); // hi * mid
-                acc[a][c] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[1][a], bf[0][c], acc[a][c], 0, 0, 0); // mid * hi
-                acc[a][c] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[0][a], bf[0][c], acc[a][c], 0, 0, 0); // hi * hi
+                acc[a][c] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bf[1][c], af[0][a], acc[a][c], 0, 0, 0); // hi * mid
+                acc[a][c] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bf[0][c], af[1][a], acc[a][c], 0, 0, 0); // mid * hi
+                acc[a][c] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bf[0][c], af[0][a], acc[a][c], 0, 0, 0); // hi * hi
             }
         commit(buf ^ 1, breg, areg, meta, smeta);
 #pragma unroll
@@ -431,26 +428,50 @@ __global__ __launch_bounds__(S_NT, BM == 32 && NPL == 2 ? 4 : 2) void conv_f32_s
             STAMP(0);
             step(1, bregs[0], aregs[0], metas[0], smetas[0]);
         }
-        // store: 16 lanes write 16 consecutive floats of one channel row
+        // store: a lane writes its 4 consecutive pixels of one channel row (16 bytes when the map size allows: hw % 4 == 0 keeps
+        // the four in one frame and the address aligned), 4 lanes = 64 contiguous bytes, 16 channel rows per instruction
         const unsigned p0 = pt * S_BN;
+        const bool vec4 = (hw & 3u) == 0u;
 #pragma unroll
         for (int c = 0; c < NI; c++) {
-            const unsigned px = p0 + (unsigned)(wn * TN + c * 16 + fr);
-            if (px < g.total_pix) {
-                const unsigned f = sdiv(px, g.dhw), rem = px - f * hw;
-                float *out = (float *)((char *)p.out + (size_t)f * p.out_stride);
-                const float *addp = p.add ? (const float *)((const char *)p.add + (size_t)f * p.add_stride) : nullptr;
+            const unsigned px = p0 + (unsigned)(wn * TN + c * 16 + fc * 4);
+            if (vec4) {
+                if (px < g.total_pix) { // (total_pix % 4 == 0 here: all four pixels or none)
+                    const unsigned f = sdiv(px, g.dhw), rem = px - f * hw;
+                    float *out = (float *)((char *)p.out + (size_t)f * p.out_stride);
+                    const float *addp = p.add ? (const float *)((const char *)p.add + (size_t)f * p.add_stride) : nullptr;
 #pragma unroll
-                for (int a = 0; a < MI; a++)
+                    for (int a = 0; a < MI; a++) {
+                        const int oc = oc0 + wm * TM + a * 16 + fr;
+                        if (SPLIT_ABL & 32) asm volatile("" ::"v"(acc[a][c]));
+                        else if (oc < p.out_c) {
+                            v4f r = acc[a][c];
+                            if (p.silu && !(SPLIT_ABL & 16)) {
 #pragma unroll
-                    for (int j = 0; j < 4; j++) {
-                        const int oc = oc0 + wm * TM + a * 16 + fc * 4 + j;
+                                for (int j = 0; j < 4; j++) r[j] = NPL == 2 ? silu_fast(r[j]) : silu_split(r[j]);
+                            }
+                            if (addp) r += *(const v4f *)(addp + (size_t)oc * hw + rem);
+                            *(v4f *)(out + (size_t)oc * hw + rem) = r;
+                        }
+                    }
+                }
+            } else {
+#pragma unroll
+                for (int j = 0; j < 4; j++) {
+                    if (px + j >= g.total_pix) continue;
+                    const unsigned f = sdiv(px + j, g.dhw), rem = px + j - f * hw;
+                    float *out = (float *)((char *)p.out + (size_t)f * p.out_stride);
+                    const float *addp = p.add ? (const float *)((const char *)p.add + (size_t)f * p.add_stride) : nullptr;
+#pragma unroll
+                    for (int a = 0; a < MI; a++) {
+                        const int oc = oc0 + wm * TM + a * 16 + fr;
                         if (SPLIT_ABL & 32) asm volatile("" ::"v"(acc[a][c][j]));
                         else if (oc < p.out_c) {
                             const float r = p.silu && !(SPLIT_ABL & 16) ? (NPL == 2 ? silu_fast(acc[a][c][j]) : silu_split(acc[a][c][j])) : acc[a][c][j];
                             out[(size_t)oc * hw + rem] = addp ? r + addp[(size_t)oc * hw + rem] : r;
                         }
                     }
+                }
             }
 #pragma unroll
             for (int a = 0; a < MI; a++) acc[a][c] = bias4[a];
