@@ -71,7 +71,7 @@ extern "C" int mhip_split_stamps(unsigned long long *out, int reset) {
 #define STAMP(i) do { } while (0)
 #endif
 #ifndef SPLIT_ABL // timing-only ablations (tools/stamps_build.sh split N; wrong results): 1 no MFMAs, 2 no gather loads, 4 no
-#define SPLIT_ABL 0 // split / LDS writes of the input, 8 no fragment reads, 16 plain stores (no SiLU), 32 no stores
+#define SPLIT_ABL 0 // split / LDS writes of the input, 8 no fragment reads, 16 plain stores (no SiLU), 32 no stores, 64 aligned gathers
 #endif
 
 __device__ __forceinline__ float silu_split(float v) { // as conv_f32.hip: the exporter's SiLU with the reference's roundings
@@ -234,7 +234,8 @@ __global__ __launch_bounds__(S_NT, BM == 32 && NPL == 2 ? 4 : 2) void conv_f32_s
             } else {
                 const bool lsh = ix0 + kx < 0; // the load would start left of the image (pad 1, first group of a row): start one
                                                // element later and shift -- the element shifted in is masked below anyway
-                const unsigned vo = rowok ? vbase + (unsigned)soff + (lsh ? 4u : 0u) : 0xffffffffu;
+                unsigned vo = rowok ? vbase + (unsigned)soff + (lsh ? 4u : 0u) : 0xffffffffu;
+                if (SPLIT_ABL & 64) vo &= ~15u; // ablation: every gather 16-byte aligned (wrong data): what do the unaligned ones cost?
                 if (SPLIT_ABL & 2) breg[j] = (v4i){(int)vo, (int)vo + 1, (int)vo + 2, (int)vo + 3};
                 else breg[j] = __builtin_bit_cast(v4i, __builtin_amdgcn_raw_buffer_load_b128(xrs, vo, 0, 0));
                 const unsigned bits = (colbits >> ((GATHER == 2 ? (kx >> 1) : kx) * 4)) & 15u;
