@@ -535,7 +535,10 @@ def main():
             # 128 per GPU): the same total as 4 GPUs x 256, i.e. strong scaling from there
             "scaling": "strong" if total_batch else "weak",
             "vs_baseline": None,
-            "dtype": "f32" if f32 else "int8",
+            # the arithmetic the convolutions run in: modes 3 / 4 multiply exact bf16 pieces of the float32 operands on the bf16 matrix
+            # cores and accumulate in f32 (DESIGN.md section 5 "f32 path, round 4"); results inside north_star's 1e-4, checked below
+            "dtype": ("f32 (bf16x3: operands split exactly into two bf16 pieces, three piece products, f32 accumulate)" if args.f32_mode == 3
+                      else "f32 (bf16x6: three bf16 pieces, six piece products, f32 accumulate)" if args.f32_mode == 4 else "f32") if f32 else "int8",
             "data": "synthetic",
             "config": {"workload": ("synthetic yolov5s_float32.mars twin (mars_synth_model width_x16=%d, seed 1, float32), %dx%d f32 "
                                     "NCHW frames, batch %d per GPU, graph only, f32_mfma mode %d" %
