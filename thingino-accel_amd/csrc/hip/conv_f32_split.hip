@@ -131,7 +131,7 @@ __device__ __forceinline__ void splitn(const float (&x)[N], int (&hi)[N / 2], in
 }
 
 struct split_args_t {
-    unsigned total_pix, npt, in_bytes;
+    unsigned total_pix, npt, per, in_bytes; // pixels, pixel tiles, tiles per workgroup
     int K;       // taps in the packed K space (kernel rows padded to kwp)
     int kp;      // row length of the weight planes (bf16 elements): K rounded up to 64, + 64 of slack (the loop fetches two steps ahead)
     int nks;     // K steps: roundup64(K) / 32 (even)
@@ -200,7 +200,7 @@ __global__ __launch_bounds__(S_NT, BM == 32 && NPL == 2 ? 4 : 2) void conv_f32_s
                     if (kx + (i & 1) < p.kw && (unsigned)(ix0 + 2 * (i >> 1) + kx + (i & 1)) < (unsigned)p.in_w) colbits |= 1u << ((kx >> 1) * 4 + i);
         }
     };
-    setup(blockIdx.x);
+    setup(blockIdx.x * g.per);
     // weights: row oc0 + tid / ATPR of every plane, taps (tid % ATPR) * AE .. + AE - 1 of the step
     const int arow = tid / ATPR, akc = (tid % ATPR) * AE;
     const int8_t *wrow = (const int8_t *)p.w_split + ((size_t)(oc0 + arow) * g.kp + akc) * 2;
@@ -408,13 +408,16 @@ __global__ __launch_bounds__(S_NT, BM == 32 && NPL == 2 ? 4 : 2) void conv_f32_s
 #ifdef SPLIT_STAMPS
     st_last = __builtin_readcyclecounter();
 #endif
-    for (unsigned pt = blockIdx.x; pt < g.npt; pt += gridDim.x) {
+    // a workgroup walks a RUN of consecutive tiles: the halo rows (and, under stride 2, most of a tile's rows) it shares with the
+    // next tile are then in its own XCD's L2 -- strided over the grid, neighbouring tiles ran on different XCDs at the same time
+    const unsigned pt_end = (blockIdx.x + 1) * g.per < g.npt ? (blockIdx.x + 1) * g.per : g.npt;
+    for (unsigned pt = blockIdx.x * g.per; pt < pt_end; pt++) {
 #ifdef SPLIT_STAMPS
         st_steps += (unsigned long long)nks;
 #endif
         for (int ks = 0; ks < nks; ks += 2) {
             int kq = ks + 2;
-            if (kq >= nks) { kq = 0; setup(pt + gridDim.x); } // the last two steps of a tile fetch the first two of the next
+            if (kq >= nks) { kq = 0; setup(pt + 1 < pt_end ? pt + 1 : g.npt); } // the last two steps of a tile fetch the first two of the next
             // the scheduler fence keeps a fetch's six loads AHEAD of the step's MFMAs: left alone, the compiler sinks them (with
             // their scalar address arithmetic) to the end of the step, 400 cycles before the next step needs them -- a memory
             // latency exposed per step (vmcnt(1..3) in the middle of the MFMAs)
@@ -514,6 +517,7 @@ static int launch_split(const mhip_conv_f32_t *p, split_args_t g) {
     if (gx > g.npt) gx = g.npt;
     const unsigned per = (g.npt + gx - 1) / gx;
     gx = (g.npt + per - 1) / per;
+    g.per = per;
     hipLaunchKernelGGL(kern, dim3(gx, noc), dim3(S_NT), ldsb, mhip_stream_native(), *p, g);
     g_split_launches++;
     return mhip_check(hipGetLastError(), "conv_f32_split");
