@@ -227,6 +227,29 @@ def reference_detections(ref_outs, scales, thresh=0.45):
     return tail.nms(tail.parse_output(pred, len(pred) // 85, np.float32(scales[0])), thresh)
 
 
+def self_launch(n):
+    """`python bench.py --gpus N` with no launcher: N child processes of this (GPU-untouched) one, one per GPU, with the
+    environment torch.distributed.run would give them (thingino-accel_amd/dist.py: spawn_ranks); rank 0's single JSON line
+    is relayed, a failing rank fails the job, and a line whose n_gpus is not N is refused.  Returns the exit code."""
+    D = load_dist_helpers()
+    argv = [a for a in sys.argv[1:] if a != "--self-launch"]
+    # one rank on one GPU still takes the multi-process path (RCCL group, arena broadcast, barriers, MAX over ranks)
+    rc, out, codes = D.spawn_ranks(n, [sys.executable, os.path.abspath(__file__)] + argv, extra_env={"BENCH_FORCE_DIST": "1"})
+    if rc != 0:
+        print("bench: the %d-rank job failed (exit codes per rank: %r)" % (n, codes), file=sys.stderr)
+        return rc
+    lines = [l for l in out.splitlines() if l.startswith("{")]
+    try:
+        d = json.loads(lines[-1]) if len(lines) == 1 else None
+    except ValueError:
+        d = None
+    if d is None or d.get("n_gpus") != n or (d.get("config", {}).get("rccl") or {}).get("ranks_in_group") != n:
+        print("bench: rank 0 did not report one line for %d GPUs (got %r)" % (n, out[-400:]), file=sys.stderr)
+        return 1
+    print(lines[0], flush=True)
+    return 0
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -271,10 +294,20 @@ def main():
     ap.add_argument("--event-steps", type=int, default=1,
                     help="timed steps (the last ones) whose launches are bracketed by HIP events for the roofline; "
                          "each event pair costs a queue barrier, so not every step carries them")
+    ap.add_argument("--self-launch", action="store_true",
+                    help="start the --gpus N ranks as child processes of this one even at N=1 (what `--gpus N` with N>1 does "
+                         "by itself when no launcher has set WORLD_SIZE): rehearses the N>1 entry point on one GPU")
     args = ap.parse_args()
 
-    rank = int(os.environ.get("RANK", "0"))
+    # ---- N ranks: either a launcher started us (torch.distributed.run sets WORLD_SIZE; it must equal --gpus), or this
+    # process -- which has not imported torch nor made a HIP call -- starts one fresh child per GPU and relays rank 0's line
+    if "WORLD_SIZE" not in os.environ and (args.gpus > 1 or args.self_launch):
+        sys.exit(self_launch(args.gpus))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        raise SystemExit("bench: --gpus %d but the launcher started %d ranks (WORLD_SIZE): refusing to report a line whose "
+                         "n_gpus is not the --gpus asked for" % (args.gpus, world))
+    rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     dist = None
     # frames per GPU: explicit total > config 4 at eight GPUs > --batch per GPU

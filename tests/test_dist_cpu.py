@@ -98,3 +98,58 @@ def test_sharding_helpers():
     m = _load("marsrt", "thingino-accel_amd/marsrt.py").synth_model(tiny=True, input_hw=16)
     s = D.strip_weights(m)
     assert len(s) == len(m) and s != m and D.descriptor_bytes(s) == D.descriptor_bytes(m)
+
+
+# ---- the job launcher behind `bench.py --gpus N` (dist.spawn_ranks): environment, relay, failure handling -------------
+
+_CHILD = r"""
+import os, sys, time
+r, w = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+assert os.environ["LOCAL_RANK"] == str(r) and os.environ["MASTER_ADDR"] == "127.0.0.1" and int(os.environ["MASTER_PORT"]) > 0
+mode = sys.argv[1]
+if mode == "fail" and r == 1:
+    sys.exit(7)
+if mode == "fail" and r != 1:
+    time.sleep(60)  # must be stopped by the launcher, not waited for
+if mode == "hang":
+    time.sleep(60)
+print('{"rank": %d, "world": %d, "port": %s, "x": "%s"}' % (r, w, os.environ["MASTER_PORT"], os.environ.get("EXTRA", "")))
+"""
+
+
+def test_spawn_ranks_env_relay_and_failure():
+    import json
+    import sys
+    import time
+    D = _load("mdist", "thingino-accel_amd/dist.py")
+    rc, out, codes = D.spawn_ranks(3, [sys.executable, "-c", _CHILD, "ok"], extra_env={"EXTRA": "e"})
+    assert rc == 0 and codes == [0, 0, 0]
+    d = json.loads(out)  # rank 0's stdout only: the other ranks' lines went to stderr
+    assert d["rank"] == 0 and d["world"] == 3 and d["x"] == "e" and d["port"] > 0
+    t0 = time.time()
+    rc, out, codes = D.spawn_ranks(3, [sys.executable, "-c", _CHILD, "fail"])
+    assert rc == 7 and codes[1] == 7 and out == "" and time.time() - t0 < 30  # ranks 0 and 2 were terminated, not joined
+    assert all(c is not None for c in codes)
+    t0 = time.time()
+    rc, out, codes = D.spawn_ranks(2, [sys.executable, "-c", _CHILD, "hang"], timeout=1.0)
+    assert rc != 0 and time.time() - t0 < 30
+    with pytest.raises(ValueError):
+        D.spawn_ranks(0, [sys.executable, "-c", "pass"])
+    e = D.rank_env(2, 8, 1234, base={})
+    assert e["RANK"] == "2" and e["LOCAL_RANK"] == "2" and e["WORLD_SIZE"] == "8" and e["HSA_ENABLE_IPC_MODE_LEGACY"] == "0"
+
+
+def test_bench_entry_point_refuses_a_rank_count_it_was_not_asked_for():
+    """`bench.py --gpus N`: under a launcher WORLD_SIZE must equal N; without one it starts N ranks itself -- here (no GPU)
+    they fail at device selection, and the parent must fail too, printing no JSON line"""
+    import subprocess
+    import sys
+    bench = os.path.join(ROOT, "bench.py")
+    r = subprocess.run([sys.executable, bench, "--gpus", "1"], env=dict(os.environ, WORLD_SIZE="2", RANK="0"),
+                       capture_output=True, text=True, timeout=60)
+    assert r.returncode != 0 and "WORLD_SIZE" in r.stderr and r.stdout == ""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    env["HIP_VISIBLE_DEVICES"] = ""  # also on a GPU box: the ranks find no device
+    r = subprocess.run([sys.executable, bench, "--gpus", "2", "--steps", "1", "--warmup", "0"], env=env,
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode != 0 and r.stdout == "" and "2-rank job failed" in r.stderr

@@ -93,3 +93,23 @@ def test_bench_multi_rank_path_with_one_rank():
 def test_bench_total_batch_flag():
     d = run_bench("--no-cpu-baseline", "--total-batch", "6")
     assert d["config"]["frames_per_gpu"] == 6 and d["config"]["frames_total"] == 6 and d["scaling"] == "strong"
+
+
+def test_bench_starts_its_own_ranks():
+    """`bench.py --gpus N` with no launcher starts N ranks itself (dist.spawn_ranks: fresh children of a parent that never
+    touched the GPU) and relays rank 0's line; with one GPU here, `--self-launch` takes that entry point for N = 1: the
+    child runs the whole multi-process path and the line's rank count is the RCCL group's."""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--self-launch", "--steps", "3", "--warmup", "1",
+                          "--batch", "4", "--hw", "160", "--width", "4", "--no-cpu-baseline", "--sustain-s", "0"],
+                         capture_output=True, text=True, timeout=600, env=env)
+    assert out.returncode == 0, out.stderr[-2000:]
+    assert out.stdout.count("\n") == 1 and out.stdout.startswith("{")
+    d = json.loads(out.stdout)
+    assert d["n_gpus"] == 1 and d["config"]["rccl"]["ranks_in_group"] == d["n_gpus"] and d["config"]["rccl"]["backend"] == "nccl"
+    assert d["config"]["ranks"] == 1 and d["value"] > 0
+    # a rank count the box cannot serve fails the job instead of reporting fewer GPUs than asked for
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0",
+                          "--batch", "2", "--hw", "160", "--width", "4", "--no-cpu-baseline", "--sustain-s", "0", "--timed-only"],
+                         capture_output=True, text=True, timeout=600, env=env)
+    assert out.returncode != 0 and out.stdout == ""

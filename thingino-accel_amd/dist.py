@@ -74,3 +74,74 @@ def gather_rows(dist, rows, device="cpu"):
     outs = [torch.empty_like(t) for _ in range(dist.get_world_size())]
     dist.all_gather(outs, t)
     return np.concatenate([o.cpu().numpy() for o in outs])
+
+
+def free_port():
+    import socket
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def rank_env(rank, world, port, base=None):
+    """the environment of rank `rank` of a one-node job: what `torch.distributed.run` would have set"""
+    import os
+    env = dict(os.environ if base is None else base)
+    env.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), LOCAL_WORLD_SIZE=str(world),
+               MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # RCCL needs dmabuf IPC on these hosts
+    return env
+
+
+def spawn_ranks(world, cmd, extra_env=None, timeout=None, poll_s=0.05):
+    """One FRESH child process per rank (`cmd` = argv list, the same for every rank), started by a parent that has not
+    touched the GPU (children are spawned, never exec'd over a process that owns a HIP context).  Rank 0's stdout is
+    captured and returned, the other ranks' stdout goes to this process's stderr, every rank's stderr is inherited.
+    If any rank exits non-zero (or the job outlives `timeout` seconds) the ranks still running are terminated -- by the
+    exact PIDs started here -- and the job fails.  Returns (return code, rank 0's stdout as str, per-rank codes)."""
+    import subprocess
+    import sys
+    import time
+    if world < 1:
+        raise ValueError("world size %r" % (world,))
+    port = free_port()
+    procs = []
+    for r in range(world):
+        env = rank_env(r, world, port)
+        env.update(extra_env or {})
+        procs.append(subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE if r == 0 else sys.stderr, text=True))
+    out0 = []
+    import threading
+    rd = threading.Thread(target=lambda: out0.append(procs[0].stdout.read()), daemon=True)  # drain the pipe while it runs
+    rd.start()
+    t0, failed = time.time(), None
+    while True:
+        codes = [p.poll() for p in procs]
+        bad = [(r, c) for r, c in enumerate(codes) if c not in (None, 0)]
+        if bad:
+            failed = "rank %d exited with code %d" % bad[0]
+            break
+        if all(c == 0 for c in codes):
+            break
+        if timeout is not None and time.time() - t0 > timeout:
+            failed = "job exceeded %.0f s" % timeout
+            break
+        time.sleep(poll_s)
+    if failed:
+        for p in procs:
+            if p.poll() is None:
+                p.terminate()
+        t1 = time.time()
+        for p in procs:
+            try:
+                p.wait(max(0.1, 10 - (time.time() - t1)))
+            except subprocess.TimeoutExpired:
+                p.kill()
+                p.wait()
+        print("spawn_ranks: %s; the other ranks were stopped" % failed, file=sys.stderr)
+    rd.join(5)
+    codes = [p.returncode for p in procs]
+    rc = 0 if not failed else next((c for c in codes if c not in (0, None) and c > 0), 1)
+    return rc, (out0[0] if out0 else ""), codes
