@@ -53,6 +53,48 @@ CONV_F32_CASES = [
 ]
 
 
+# Shape families the GPU tests use to FORCE particular launch forms (tests/test_gpu_kernels.py): SAME-padded NHWC layers at
+# sizes the reference's scalar C finishes in under a second.  Listed here -- not inside the GPU tests -- so that
+# tests/golden/make_golden.py pins every one of them to the reference's own output (golden.json "conv_i8_family") and
+# tests/test_oracle.py checks the restatement against it on the CPU: a GPU kernel and the restatement can then not share a bug
+# on these shapes.  name -> (seed, [(in_h, in_w, in_c, out_c, kh, kw, stride)]).
+CONV_I8_FAMILIES = {
+    "big": (4, [(40, 40, 64, 128, 3, 3, 2), (20, 20, 256, 256, 1, 1, 1), (23, 17, 128, 64, 3, 3, 1), (16, 16, 512, 255, 1, 1, 1),
+                (64, 64, 32, 32, 1, 1, 1), (48, 48, 3, 32, 6, 6, 2)]),
+    "stem": (6, [(37, 53, 3, 32, 6, 6, 2), (70, 41, 3, 16, 3, 3, 1), (9, 3, 3, 32, 3, 3, 1), (33, 6, 3, 48, 6, 6, 2), (18, 50, 1, 32, 5, 5, 2),
+                 (11, 13, 4, 64, 3, 3, 1), (21, 35, 2, 16, 6, 6, 2), (130, 131, 3, 32, 6, 6, 2),
+                 (16, 128, 3, 32, 7, 7, 4), (40, 90, 2, 48, 8, 8, 3)]),  # the last two: patches wider than the staged kernel holds
+    "walk": (5, [(64, 64, 32, 32, 1, 1, 1), (40, 40, 64, 128, 3, 3, 2), (37, 29, 128, 64, 1, 1, 1), (23, 17, 128, 64, 3, 3, 1),
+                 (33, 31, 256, 256, 1, 1, 1), (50, 50, 64, 64, 1, 1, 1), (80, 80, 16, 48, 3, 3, 1),
+                 # ragged channel runs (unaligned rows, 8+4+2+1-byte tail stores): the 255-channel heads and odd widths
+                 (16, 16, 512, 255, 1, 1, 1), (21, 19, 64, 81, 1, 1, 1), (20, 20, 32, 7, 3, 3, 1), (17, 23, 128, 131, 1, 1, 1)]),
+    "wres": (9, [(64, 64, 32, 32, 1, 1, 1), (40, 40, 64, 128, 3, 3, 2), (37, 29, 128, 64, 1, 1, 1), (23, 17, 128, 64, 3, 3, 1),
+                 (33, 31, 256, 256, 1, 1, 1), (50, 50, 64, 64, 1, 1, 1), (16, 16, 512, 255, 1, 1, 1), (21, 19, 64, 81, 1, 1, 1),
+                 (20, 20, 32, 7, 3, 3, 1), (17, 23, 128, 131, 1, 1, 1)]),
+    "wide": (7, [(40, 40, 128, 128, 3, 3, 1), (23, 17, 256, 256, 3, 3, 1), (33, 31, 128, 256, 1, 1, 1), (20, 20, 512, 255, 1, 1, 1),
+                 (19, 21, 64, 128, 3, 3, 2), (16, 16, 1024, 128, 1, 1, 1), (21, 19, 128, 128, 3, 3, 2), (9, 11, 256, 128, 5, 5, 1)]),
+    # conv_i8_rows (launch variant 20) takes 3x3 stride-1 layers on 20- / 40-wide maps with in_c a multiple of 128 and an even
+    # number of 64-channel chunks; every shape below is one it accepts (a launch counter in the test proves it ran)
+    "rows": (9, [(40, 40, 128, 128, 3, 3, 1), (20, 20, 256, 256, 3, 3, 1), (23, 40, 128, 256, 3, 3, 1), (9, 20, 512, 128, 3, 3, 1),
+                 (7, 40, 256, 128, 3, 3, 1), (31, 20, 128, 128, 3, 3, 1)]),
+    "patch": (6, [(48, 48, 64, 64, 3, 3, 1), (64, 64, 32, 64, 3, 3, 2), (47, 45, 32, 32, 3, 3, 1), (61, 63, 64, 32, 3, 3, 2),
+                  (32, 48, 32, 48, 5, 5, 1), (40, 32, 64, 16, 3, 1, 1), (64, 64, 32, 32, 1, 3, 2), (33, 31, 64, 128, 3, 3, 1)]),
+}
+
+
+def family_cases(name):
+    """the CONV_I8_CASES-style tuples of one family: NHWC, SAME-style padding (the split the GPU tests have always used), bias,
+    weight scale shrinking with K so that the int8 outputs spread over the whole range"""
+    seed, shapes = CONV_I8_FAMILIES[name]
+    out = []
+    for i, (h, w, ic, oc, kh, kw, s) in enumerate(shapes):
+        oh, ow = (h + s - 1) // s, (w + s - 1) // s
+        ph = max((oh - 1) * s + kh - h, 0) // 2
+        pw = max((ow - 1) * s + kw - w, 0) // 2
+        out.append(("%s%d" % (name, i), 1, h, w, ic, oc, kh, kw, s, s, ph, pw, oh, ow, 0.03, 0.003 / (kh * kw * ic) ** 0.5 * 8, 0.05, True))
+    return seed, out
+
+
 def conv_i8_inputs(case, seed=1):
     (name, nhwc, in_h, in_w, in_c, out_c, kh, kw, sh, sw, pt, pl, out_h, out_w, in_s, w_s, out_s, has_b) = case
     x = i8(seed * 7919 + 1, in_h * in_w * in_c)

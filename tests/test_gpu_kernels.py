@@ -16,6 +16,19 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 GOLD = json.load(open(os.path.join(HERE, "golden", "golden.json")))
 
 
+def check_family(gpu, orc, name, note=None):
+    """every case of a shape family (cases.CONV_I8_FAMILIES) under the launch policy currently forced: against the oracle
+    (element-wise, so a failure says how many bytes differ) AND against the digest the reference itself produced for the same
+    inputs (golden.json "conv_i8_family", tests/golden/make_golden.py): the restatement is not the only witness"""
+    seed, cs = cases.family_cases(name)
+    for case in cs:
+        a = cases.conv_i8_call(gpu.conv2d_int8, case, seed)
+        b = cases.conv_i8_call(orc.conv2d_int8, case, seed)
+        assert np.array_equal(a, b), (case[0], note, int((a != b).sum()))
+        assert len(np.unique(a)) > 32  # not a saturated / all-zero comparison
+        assert cases.digest(a) == GOLD["conv_i8_family"][case[0]], (case[0], note)
+
+
 @pytest.mark.parametrize("case", cases.CONV_I8_CASES, ids=lambda c: c[0])
 def test_conv_i8_bit_exact(gpu, orc, case):
     got = cases.conv_i8_call(gpu.conv2d_int8, case)
@@ -38,37 +51,14 @@ def test_conv_f32(gpu, orc, case):
 
 def test_conv_i8_larger_shapes(gpu, orc):
     """yolov5s-shaped layers at sizes the oracle still finishes quickly: M tails, all N tiles"""
-    shapes = [  # in_h, in_w, in_c, out_c, k, s
-        (40, 40, 64, 128, 3, 2), (20, 20, 256, 256, 1, 1), (23, 17, 128, 64, 3, 1), (16, 16, 512, 255, 1, 1),
-        (64, 64, 32, 32, 1, 1), (48, 48, 3, 32, 6, 2)]
-    for i, (h, w, ic, oc, k, s) in enumerate(shapes):
-        oh, ow = (h + s - 1) // s, (w + s - 1) // s
-        ph = max((oh - 1) * s + k - h, 0) // 2
-        pw = max((ow - 1) * s + k - w, 0) // 2
-        case = ("big%d" % i, 1, h, w, ic, oc, k, k, s, s, ph, pw, oh, ow, 0.03, 0.003 / (k * k * ic) ** 0.5 * 8, 0.05, True)
-        a = cases.conv_i8_call(gpu.conv2d_int8, case, 4)
-        b = cases.conv_i8_call(orc.conv2d_int8, case, 4)
-        assert np.array_equal(a, b), case[0]
-        assert len(np.unique(a)) > 32  # not a saturated / all-zero comparison
+    check_family(gpu, orc, "big")
 
 
 def test_conv_i8_stem_edges(gpu, orc):
     """the small-channel (RGB stem) kernel: tiles hanging over every image edge (its edge units load at a clamped
     column and shift), widths below one 4-pixel unit and 1 / 2 / 4 channels (the per-byte path), several tiles per
     workgroup, strides 1 and 2"""
-    shapes = [  # in_h, in_w, in_c, out_c, k, s
-        (37, 53, 3, 32, 6, 2), (70, 41, 3, 16, 3, 1), (9, 3, 3, 32, 3, 1), (33, 6, 3, 48, 6, 2), (18, 50, 1, 32, 5, 2),
-        (11, 13, 4, 64, 3, 1), (21, 35, 2, 16, 6, 2), (130, 131, 3, 32, 6, 2),
-        (16, 128, 3, 32, 7, 4), (40, 90, 2, 48, 8, 3)]  # patches wider than the staged kernel holds: the gather kernel on the same packing
-    for i, (h, w, ic, oc, k, s) in enumerate(shapes):
-        oh, ow = (h + s - 1) // s, (w + s - 1) // s
-        ph = max((oh - 1) * s + k - h, 0) // 2
-        pw = max((ow - 1) * s + k - w, 0) // 2
-        case = ("stem%d" % i, 1, h, w, ic, oc, k, k, s, s, ph, pw, oh, ow, 0.03, 0.003 / (k * k * ic) ** 0.5 * 8, 0.05, True)
-        a = cases.conv_i8_call(gpu.conv2d_int8, case, 6)
-        b = cases.conv_i8_call(orc.conv2d_int8, case, 6)
-        assert np.array_equal(a, b), (case[0], int((a != b).sum()))
-        assert len(np.unique(a)) > 32
+    check_family(gpu, orc, "stem")
 
 
 @pytest.mark.parametrize("slots,stages", [(1, 2), (3, 2), (5, 2), (0, 2)])  # (the three-stage walker was pruned in round 4)
@@ -76,26 +66,13 @@ def test_conv_i8_persistent_tile_walk(gpu, orc, slots, stages):
     """the persistent kernel walking SEVERAL pixel tiles per workgroup (cross-tile prefetch, counted vmcnt
     across the epilogue's buffer stores): force few workgroups so that small inputs exercise it; both ring
     depths; K loops of 1, 2, 4, 9 and 18 steps; pixel counts that are not a multiple of the tile"""
-    shapes = [  # in_h, in_w, in_c, out_c, k, s
-        (64, 64, 32, 32, 1, 1), (40, 40, 64, 128, 3, 2), (37, 29, 128, 64, 1, 1), (23, 17, 128, 64, 3, 1),
-        (33, 31, 256, 256, 1, 1), (50, 50, 64, 64, 1, 1), (80, 80, 16, 48, 3, 1),
-        # ragged channel runs (unaligned rows, 8+4+2+1-byte tail stores): the 255-channel heads and odd widths
-        (16, 16, 512, 255, 1, 1), (21, 19, 64, 81, 1, 1), (20, 20, 32, 7, 3, 1), (17, 23, 128, 131, 1, 1)]
     try:
         gpu.set_tuning("persist", 1)
         gpu.set_tuning("persist_maxk", 1 << 20)
         gpu.set_tuning("persist_slots", slots)
         gpu.set_tuning("persist_stages", stages)
         gpu.set_tuning("variant", 2 if stages == 2 else 6)  # the tile-walking form wherever a layer has it
-        for i, (h, w, ic, oc, k, s) in enumerate(shapes):
-            oh, ow = (h + s - 1) // s, (w + s - 1) // s
-            ph = max((oh - 1) * s + k - h, 0) // 2
-            pw = max((ow - 1) * s + k - w, 0) // 2
-            case = ("walk%d" % i, 1, h, w, ic, oc, k, k, s, s, ph, pw, oh, ow, 0.03, 0.003 / (k * k * ic) ** 0.5 * 8, 0.05, True)
-            a = cases.conv_i8_call(gpu.conv2d_int8, case, 5)
-            b = cases.conv_i8_call(orc.conv2d_int8, case, 5)
-            assert np.array_equal(a, b), (case[0], int((a != b).sum()))
-            assert len(np.unique(a)) > 32
+        check_family(gpu, orc, "walk", (slots, stages))
         # a whole graph (fused SiLU LUT epilogues, zero-copy concat slices, strided outputs), several frames
         import marsfile
         from conftest import lcg_frame
@@ -126,22 +103,10 @@ def test_conv_i8_tile_walk_resident_weights(gpu, orc, slots, variant):
     """variants 14 / 15: the tile walker with the weights of its channel tile fetched once and kept in LDS (the ring
     carries pixel tiles only); few workgroups so that every one walks several tiles; K loops of 1..18 steps; ragged
     rows; then a whole graph, whose never-materialised concat inputs take the same form"""
-    shapes = [  # in_h, in_w, in_c, out_c, k, s
-        (64, 64, 32, 32, 1, 1), (40, 40, 64, 128, 3, 2), (37, 29, 128, 64, 1, 1), (23, 17, 128, 64, 3, 1),
-        (33, 31, 256, 256, 1, 1), (50, 50, 64, 64, 1, 1), (16, 16, 512, 255, 1, 1), (21, 19, 64, 81, 1, 1),
-        (20, 20, 32, 7, 3, 1), (17, 23, 128, 131, 1, 1)]
     try:
         gpu.set_tuning("persist_slots", slots)
         gpu.set_tuning("variant", variant)
-        for i, (h, w, ic, oc, k, s) in enumerate(shapes):
-            oh, ow = (h + s - 1) // s, (w + s - 1) // s
-            ph = max((oh - 1) * s + k - h, 0) // 2
-            pw = max((ow - 1) * s + k - w, 0) // 2
-            case = ("wres%d" % i, 1, h, w, ic, oc, k, k, s, s, ph, pw, oh, ow, 0.03, 0.003 / (k * k * ic) ** 0.5 * 8, 0.05, True)
-            a = cases.conv_i8_call(gpu.conv2d_int8, case, 9)
-            b = cases.conv_i8_call(orc.conv2d_int8, case, 9)
-            assert np.array_equal(a, b), (case[0], int((a != b).sum()))
-            assert len(np.unique(a)) > 32
+        check_family(gpu, orc, "wres", (slots, variant))
         import marsfile
         from conftest import lcg_frame
         d = gpu.synth_model(width_x16=4, input_hw=96, seed=22)
@@ -172,21 +137,10 @@ def test_conv_i8_wide_one_tile_forms(gpu, orc, variant, slots):
     ragged (255) rows.  (Variants 16, 17 and 20 -- patch-staged input with streamed weights, the two-team strip kernel, the
     persistent 128-byte-step tile -- were measured in round 2, never chosen by the policy or the tuner on a BASELINE
     workload, and removed in round 3: DESIGN.md section 5.)"""
-    shapes = [  # in_h, in_w, in_c, out_c, k, s
-        (40, 40, 128, 128, 3, 1), (23, 17, 256, 256, 3, 1), (33, 31, 128, 256, 1, 1), (20, 20, 512, 255, 1, 1),
-        (19, 21, 64, 128, 3, 2), (16, 16, 1024, 128, 1, 1), (21, 19, 128, 128, 3, 2), (9, 11, 256, 128, 5, 1)]
     try:
         gpu.set_tuning("variant", variant)
         gpu.set_tuning("persist_slots", slots)
-        for i, (h, w, ic, oc, k, s) in enumerate(shapes):
-            oh, ow = (h + s - 1) // s, (w + s - 1) // s
-            ph = max((oh - 1) * s + k - h, 0) // 2
-            pw = max((ow - 1) * s + k - w, 0) // 2
-            case = ("wide%d" % i, 1, h, w, ic, oc, k, k, s, s, ph, pw, oh, ow, 0.03, 0.003 / (k * k * ic) ** 0.5 * 8, 0.05, True)
-            a = cases.conv_i8_call(gpu.conv2d_int8, case, 7)
-            b = cases.conv_i8_call(orc.conv2d_int8, case, 7)
-            assert np.array_equal(a, b), (case[0], int((a != b).sum()))
-            assert len(np.unique(a)) > 32
+        check_family(gpu, orc, "wide", variant)
     finally:
         gpu.set_tuning("variant", 0)
         gpu.set_tuning("persist_slots", 0)
@@ -195,25 +149,32 @@ def test_conv_i8_wide_one_tile_forms(gpu, orc, variant, slots):
 @pytest.mark.parametrize("slots", [0, 2, 5])
 def test_conv_i8_rows_persistent_deep(gpu, orc, slots):
     """variant 20 (round 4, conv_i8_rows): deep 3x3 stride-1 layers as one persistent 8-wave workgroup per CU over tiles of
-    256 consecutive pixels -- patch-staged input (64-channel chunks, double buffered), streamed weights in K-step blocks,
-    two accumulator sets with the previous tile's epilogue inside the next tile's K loop, hand-counted vmcnt.  Map widths
-    20 / 40 / 80 (the instantiated patch pitches), heights that make tiles straddle rows and FRAMES (the zero rows between
-    stacked frames), 128 / 256 / 512 input channels (2 / 4 / 8 chunks), 128 / 256 output channels, partial last tiles;
-    `slots` forces 2 or 5 workgroups so that each walks many tiles.  Direct calls (no table, one frame) and whole graphs
-    with the fused SiLU table and several frames."""
-    shapes = [  # in_h, in_w, in_c, out_c
-        (40, 40, 128, 128), (20, 20, 256, 256), (7, 80, 128, 128), (23, 40, 128, 256), (9, 20, 512, 128), (3, 40, 256, 128)]
+    256 consecutive pixels -- patch-staged input (64-channel chunks, two buffers), streamed weights in K-step blocks, the K
+    stream in pairs of steps with waves 4-7 one phase behind waves 0-3, the epilogue in line after a tile's last pair,
+    hand-counted vmcnt.  Map widths 20 / 40 (the instantiated patch pitches; the kernel declines others), heights that make
+    tiles straddle rows and FRAMES (the zero rows between stacked frames), 128 / 256 / 512 input channels (2 / 4 / 8 chunks),
+    128 / 256 output channels, partial last tiles; `slots` forces 2 or 5 workgroups so that each walks many tiles.  A launch
+    counter proves that every case took this kernel (a forced variant falls back silently where the geometry is declined).
+    Direct calls (no table, one frame) and whole graphs with the fused SiLU table and several frames."""
+    count = gpu.lib().mhip_conv_i8_rows_launches
+    count.restype = __import__("ctypes").c_ulong
     try:
         gpu.set_tuning("variant", 20)
         gpu.set_tuning("persist_slots", slots)
-        for i, (h, w, ic, oc) in enumerate(shapes):
-            case = ("rows%d" % i, 1, h, w, ic, oc, 3, 3, 1, 1, 1, 1, h, w, 0.03, 0.003 / (9 * ic) ** 0.5 * 8, 0.05, True)
+        n0 = count()
+        check_family(gpu, orc, "rows", slots)
+        assert count() - n0 == len(cases.CONV_I8_FAMILIES["rows"][1])  # one launch per case: nothing fell back
+        # declined shapes keep working through the default policy: an 80-wide map, an odd chunk count, a short map whose
+        # tiles would hold too many frame boundaries
+        n0 = count()
+        for i, (h, w, ic, oc) in enumerate([(7, 80, 128, 128), (20, 20, 192, 128), (3, 40, 256, 128)]):
+            case = ("rowsx%d" % i, 1, h, w, ic, oc, 3, 3, 1, 1, 1, 1, h, w, 0.03, 0.003 / (9 * ic) ** 0.5 * 8, 0.05, True)
             a = cases.conv_i8_call(gpu.conv2d_int8, case, 9)
             b = cases.conv_i8_call(orc.conv2d_int8, case, 9)
             assert np.array_equal(a, b), (case[0], slots, int((a != b).sum()))
-            assert len(np.unique(a)) > 32
+        assert count() == n0
         import marsfile
-        for (h, w, ic, oc, frames) in [(20, 20, 256, 256, 7), (13, 40, 128, 128, 5), (5, 80, 128, 128, 3)]:
+        for (h, w, ic, oc, frames) in [(20, 20, 256, 256, 7), (13, 40, 128, 128, 5), (5, 80, 128, 128, 3)]:  # (the 80-wide one: default policy)
             G = marsfile.Graph()
             rng = np.random.default_rng(h * 100 + w)
             x = G.tensor([1, h, w, ic], scale=4 / 127)
@@ -251,24 +212,13 @@ def test_conv_i8_patch_staged(gpu, orc, variant, ring):
     ring (1 = one buffer, no prefetch; 3 / 4 = two / three patches in flight behind the one being computed, with an LDS
     budget that holds them), so that the hand-counted vector-memory waits are exercised at every depth, on interior tiles
     (buffer-addressed LDS-DMA) and edge tiles alike, with and without the wave-private residual staging of a folded Add"""
-    shapes = [  # in_h, in_w, in_c, out_c, kh, kw, s
-        (48, 48, 64, 64, 3, 3, 1), (64, 64, 32, 64, 3, 3, 2), (47, 45, 32, 32, 3, 3, 1), (61, 63, 64, 32, 3, 3, 2),
-        (32, 48, 32, 48, 5, 5, 1), (40, 32, 64, 16, 3, 1, 1), (64, 64, 32, 32, 1, 3, 2), (33, 31, 64, 128, 3, 3, 1)]
     try:
         gpu.set_tuning("variant", variant)
         gpu.set_tuning("patch_ring", ring)
         gpu.set_tuning("patch_lds_kb", 160 if ring > 2 else 80)
         for slots in (0, 3):
             gpu.set_tuning("persist_slots", slots)
-            for i, (h, w, ic, oc, kh, kw, s) in enumerate(shapes):
-                oh, ow = (h + s - 1) // s, (w + s - 1) // s
-                ph = max((oh - 1) * s + kh - h, 0) // 2
-                pw = max((ow - 1) * s + kw - w, 0) // 2
-                case = ("patch%d" % i, 1, h, w, ic, oc, kh, kw, s, s, ph, pw, oh, ow, 0.03, 0.003 / (kh * kw * ic) ** 0.5 * 8, 0.05, True)
-                a = cases.conv_i8_call(gpu.conv2d_int8, case, 6)
-                b = cases.conv_i8_call(orc.conv2d_int8, case, 6)
-                assert np.array_equal(a, b), (case[0], slots, int((a != b).sum()))
-                assert len(np.unique(a)) > 32
+            check_family(gpu, orc, "patch", (variant, ring, slots))
         gpu.set_tuning("persist_slots", 0)
         import marsfile
         from conftest import lcg_frame

@@ -54,6 +54,15 @@ def test_conv_i8_golden(orc, case):
     assert cases.digest(cases.conv_i8_call(orc.conv2d_int8, case)) == GOLD["conv_i8"][case[0]]
 
 
+@pytest.mark.parametrize("fam", sorted(cases.CONV_I8_FAMILIES))
+def test_conv_i8_family_golden(orc, fam):
+    """the shape families the GPU tests force launch forms with: the restatement reproduces the digests the reference's own
+    conv2d_int8_nhwc_mxu produced for them (so on the GPU box kernel, restatement and reference are three witnesses)"""
+    seed, cs = cases.family_cases(fam)
+    for c in cs:
+        assert cases.digest(cases.conv_i8_call(orc.conv2d_int8, c, seed)) == GOLD["conv_i8_family"][c[0]], c[0]
+
+
 @pytest.mark.parametrize("case", cases.CONV_F32_CASES, ids=lambda c: c[0])
 def test_conv_f32_golden(orc, case):
     assert cases.digest(cases.conv_f32_call(orc.conv2d_f32, case)) == GOLD["conv_f32"][case[0]]
@@ -102,6 +111,16 @@ def test_conv_i8_vs_reference(orc, ref, case, seed):
     a = cases.conv_i8_call(orc.conv2d_int8, case, seed)
     b = cases.conv_i8_call(ref.conv2d_int8, case, seed)
     assert np.array_equal(a, b)
+
+
+@pytest.mark.parametrize("fam", sorted(cases.CONV_I8_FAMILIES))
+def test_conv_i8_family_vs_reference(orc, ref, fam):
+    """... and element-wise against the live reference, at a second seed the goldens do not hold"""
+    seed, cs = cases.family_cases(fam)
+    for c in cs:
+        a = cases.conv_i8_call(orc.conv2d_int8, c, seed + 100)
+        b = cases.conv_i8_call(ref.conv2d_int8, c, seed + 100)
+        assert np.array_equal(a, b), c[0]
 
 
 @pytest.mark.parametrize("case", cases.CONV_F32_CASES, ids=lambda c: c[0])

@@ -1,26 +1,40 @@
-// conv_i8_rows.hip -- the deep 3x3 stride-1 convolutions (in_c >= 128, 128-channel output tiles) as ONE persistent
-// 8-wave workgroup per CU that walks tiles of WHOLE MAP ROWS (reference src/mars/mxu_conv.c:713-757; same arithmetic
-// contract as conv_i8.hip).  Round 4, verdict item 1.  Launch variant 20.
+// conv_i8_rows.hip -- the deep 3x3 stride-1 convolutions (in_c a multiple of 128, 128-channel output tiles, 20- / 40-wide maps)
+// as ONE persistent 8-wave workgroup per CU that walks tiles of 256 consecutive map pixels (reference
+// src/mars/mxu_conv.c:713-757; same arithmetic contract as conv_i8.hip).  Round 4, verdict item 1.  Launch variant 20.
 //
 // Why another form.  The implicit-GEMM tile (conv_i8_mfma<256,128,3,1,8>) moves (256 + 128) x 64 bytes into LDS per K step
 // for 512 CU-cycles of matrix work = 48 B/clk/CU, and the L2 -> LDS path delivers 20-22 under every loop structure tried
-// (DESIGN.md section 6): 0.45 busy in the loop, 0.34 with the ~35 % of a launch that is per-tile fixed cost.  Here
-//   * the input is staged as a PATCH, 64 channels at a time (double buffered): each byte enters LDS once per tile instead
-//     of once per tap -- the nine taps of a K chunk are nine LDS addresses;
+// (DESIGN.md section 5 "Deep-K"): 0.45 busy in the loop, 0.34 with the ~35 % of a launch that is per-tile fixed cost.  Here
+//   * the input is staged as a PATCH, 64 channels at a time (two buffers: the chunk being multiplied and the next one): each
+//     byte enters LDS once per tile instead of once per tap -- the nine taps of a K chunk are nine LDS addresses;
 //   * a tile is 256 CONSECUTIVE pixels of the map in row-major order, frames stacked (6.4 rows of a 40-wide map, 12.8 of a
 //     20-wide one), so every MFMA column carries 16 real pixels whatever the map's size: round 1's 16 x 16 tiles covered
 //     69 % / 39 % of their pixels on the 40 x 40 / 20 x 20 maps of a 640 x 640 input.  The patch holds the rows the tile
 //     touches plus the halo; a tile may straddle two frames, the patch then holds the zero rows between them (rowtab: one
 //     entry per patch row = byte offset of that input row, or -1 = zeros);
 //   * the weights of a K step (128 x 64 bytes, pre-laid on the host in LDS image order: mhip_conv_i8_rows_pack) stream
-//     through a 9-slot ring (eight K steps in flight: ~1 us of DMA latency under load x 22 B/clk/CU = 50+ KB) as whole 128-byte lines: 8 KB + ~3 KB of patch per 512 CU-cycles = 22 B/clk/CU;
-//   * one workgroup per CU owns a run of tiles: index math, tables and the ring's prologue are paid once, and the
-//     EPILOGUE of tile i runs inside the K loop of tile i + 1 -- a second accumulator set (the last K step's MFMAs write
-//     their results straight into it), requantised / looked up / stored in eight slices of 8 values, placed BEFORE the
-//     step's MFMAs in waves 0-3 and AFTER them in waves 4-7, so that the two waves of a SIMD alternate vector and matrix
-//     work (MI355X_MICROARCH.md, "Two waves per SIMD", item 9).
-// vmcnt is counted by hand across LDS-DMA, buffer stores and the residual loads (in order on gfx9): a step waits for
-// everything up to its own weight tile, i.e. all but the operations issued after that tile's DMA.
+//     through a 9-slot ring (slot = tap), RW_AHEAD = 6 steps ahead of their readers, as whole 128-byte lines: one 1 KB
+//     `buffer_load ... lds` per wave and step; 8 KB + ~3 KB of patch per 512 CU-cycles = 22 B/clk/CU;
+//   * one workgroup per CU owns a run of tiles: index math, tables and the ring's prologue are paid once per run.
+// The shipped loop (what the code below does; the alternatives that were built and measured slower are in
+// profiles/r04_experiments.md section 1): the K stream runs in PAIRS of steps, two 64-channel chunks (18 steps) per loop
+// iteration; a pair is a READING phase (the pair's 16 fragment reads + its DMA issue) and a MULTIPLYING phase (32 MFMAs), one
+// raw s_barrier after each; waves 4-7 (the second wave of each SIMD) run ONE PHASE behind waves 0-3, so on every SIMD one
+// wave multiplies while its mate reads.  The epilogue of a tile runs IN LINE after the tile's last pair (all 64 values of a
+// lane requantised / looked up in place in the accumulator registers, four 16-byte buffer stores per lane).
+// vmcnt invariants (loads, LDS-DMA and stores retire in order against one counter on gfx9):
+//   * prologue: [patch pieces] W0..W5 issued; vmcnt(4) => patch, W0, W1 of this wave landed; barrier => everybody's.
+//   * reading phase of pair j issues [<= 2 patch pieces] W(2j+6) W(2j+7) and then waits vmcnt(4): at most 4 operations stay
+//     in flight -- the two weight blocks just issued and the two of pair j-1 (patch pieces, issued before the weights of
+//     their pair, are older than those and have landed).  So W(2j+2), W(2j+3) -- what pair j+1 reads -- are in LDS one
+//     barrier before any wave reads them.
+//   * behind a tile's epilogue the lane's 4 stores sit between the weight blocks in that in-order count.  Pair 0 of the next
+//     tile waits vmcnt(10) (in flight: W4 W5 | S S S S | [P P] W6 W7 -- the stores and everything younger), pair 1 waits
+//     vmcnt(8) (S S S S | [P P] W6 W7 | [P P] W8 W9 minus the two patch pieces that may not exist: 8 is exact when both
+//     pairs carry patch pieces and conservative -- waits for more -- when they do not), so the stores are never waited for
+//     in the K stream (waiting cost ~7 us per tile: every workgroup of the launch stores at the same moment).
+//   * a ring slot is rewritten one and a half pairs after its last reader's fragments were in registers (lgkmcnt(0) before
+//     the reading phase's barrier).
 #include "conv_i8_common.hpp"
 
 #define RW_NPX 256                 // pixels per tile
@@ -32,9 +46,6 @@
 #define RW_NDWMAX 6                // patch DMA instructions per wave and chunk, at most
 #define RW_FIXED (2048 + RW_RING * RW_STAGE) // LUT | bias | rowtab | ring
 
-#ifndef ROWS_OVERLAP
-#define ROWS_OVERLAP 0 // 1: the previous tile's epilogue runs inside the next tile's K loop (second accumulator set: 250+ registers)
-#endif
 #ifndef ROWS_ABL
 #define ROWS_ABL 0 // ablation builds (timing only, wrong bytes): bit 0 no patch DMA in the K stream, bit 1 no weight DMA,
                    // bit 2 no epilogue, bit 3 no MFMA, bit 4 / 5 trailing waves = odd waves / waves 2,3,6,7, bit 6 no vmcnt wait in the K stream, bit 7 no epilogue but live accumulators
@@ -67,34 +78,11 @@ struct rows_args_t {
     int C, nchunk;     // input channels, 64-channel chunks (>= 2)
     int prmax;         // patch rows (<= 64)
     int ndw;           // patch DMA instructions per wave and chunk
-    int pb;            // bytes of one patch buffer = ndw * 8 KB
     unsigned ntiles, noc, ngrp, nblk;
     unsigned npix;     // frames * H * W
     unsigned in_bytes, out_bytes, w_bytes;
     fastdiv_t dW, dH, dH2;
 };
-
-// s_waitcnt vmcnt(n) for a wave-uniform n in [LO, HI]: the immediate by a binary tree of scalar branches
-template <int LO, int HI>
-__device__ __forceinline__ void wait_vmcnt_range(int n) {
-    if constexpr (LO == HI) {
-        wait_vmcnt<LO>();
-    } else {
-        constexpr int MID = (LO + HI) / 2;
-        if (n <= MID) wait_vmcnt_range<LO, MID>(n);
-        else wait_vmcnt_range<MID + 1, HI>(n);
-    }
-}
-__device__ __forceinline__ void wait_vmcnt_dyn(int n) { wait_vmcnt_range<0, 31>(n > 31 ? 31 : n); }
-
-// the half-step table look-up of eight values, each in place (index register = destination register)
-__device__ __forceinline__ void lut8_inplace(int (&v)[8]) {
-    asm volatile("ds_read_i8 %0, %0 offset:256\n\tds_read_i8 %1, %1 offset:256\n\tds_read_i8 %2, %2 offset:256\n\tds_read_i8 %3, %3 offset:256\n\t"
-                 "ds_read_i8 %4, %4 offset:256\n\tds_read_i8 %5, %5 offset:256\n\tds_read_i8 %6, %6 offset:256\n\tds_read_i8 %7, %7 offset:256"
-                 : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]), "+v"(v[3]), "+v"(v[4]), "+v"(v[5]), "+v"(v[6]), "+v"(v[7])
-                 :
-                 : "memory");
-}
 
 // PWP = patch row pitch in pixels = roundup8(W + 2): a multiple of 8 keeps the bank swizzle (unit bit 1 ^= pixel bit 2)
 // invariant under the kernel-row offsets, which therefore sit in the ds_read's immediate; kernel columns 0..2 have
@@ -273,7 +261,7 @@ __global__ __launch_bounds__(512) void conv_i8_rows(const mhip_conv_i8_t p, cons
     // reads them.  A ring slot is rewritten one and a half pairs after its last reader's fragments were in registers.
     if (late) __builtin_amdgcn_s_barrier();
 #ifdef ROWS_STAMPS
-    unsigned long long s0 = 0, s1 = 0, s2 = 0, s3 = 0, s4 = 0, sum_wait = 0, sum_pre = 0, sum_mfma = 0, sum_post = 0, sum_steps = 0;
+    unsigned long long s0 = 0, s1 = 0, s2 = 0, s3 = 0, s4 = 0, sum_wait = 0, sum_pre = 0, sum_mfma = 0, sum_steps = 0;
 #endif
 
     for (unsigned t = t0; t < t1; t++) {
@@ -323,7 +311,7 @@ __global__ __launch_bounds__(512) void conv_i8_rows(const mhip_conv_i8_t p, cons
                 // weight DMAs in this in-order count: waiting them out cost ~7 us per tile (every workgroup of the launch stores at
                 // the same moment); the first two pairs of a tile therefore leave them in flight as well
                 if (pr == 0 && c2 == 0 && t > t0) wait_vmcnt<10>();      // W4 W5 | S S S S | [P P] W6 W7
-                else if (pr == 1 && c2 == 0 && t > t0) wait_vmcnt<8>();  // S S S S | [P P] W6 W7 | [P P] W8 W9
+                else if (pr == 1 && c2 == 0 && t > t0) wait_vmcnt<8>();  // S S S S | [P P] W6 W7 | [P P] W8 W9: 8 youngest stay (header)
                 else if (!(ROWS_ABL & 64)) wait_vmcnt<4>();
                 __builtin_amdgcn_sched_barrier(0);
                 __builtin_amdgcn_s_barrier();
@@ -380,7 +368,7 @@ __global__ __launch_bounds__(512) void conv_i8_rows(const mhip_conv_i8_t p, cons
     if (lane == 0) {
         const int o = late ? 8 : 0;
         atomicAdd(&rows_stamp_sums[o + 0], sum_wait); atomicAdd(&rows_stamp_sums[o + 1], sum_pre); atomicAdd(&rows_stamp_sums[o + 2], sum_mfma);
-        atomicAdd(&rows_stamp_sums[o + 3], sum_post); atomicAdd(&rows_stamp_sums[o + 4], sum_steps);
+        atomicAdd(&rows_stamp_sums[o + 4], sum_steps);
     }
 #endif
 }
@@ -410,8 +398,7 @@ static bool rows_geom(const mhip_conv_i8_t *p, rows_geom_t *g) {
     a.ndw = (int)((units + 511) / 512);
     if (a.ndw > rows_patch_pieces(g->pwp)) return false; // (short maps: more frame boundaries, i.e. zero rows, inside a tile)
     if (a.nchunk & 1) return false;                      // the K stream runs two chunks per loop iteration
-    a.pb = rows_patch_pieces(g->pwp) * 8 * 1024;
-    g->lds = RW_FIXED + 2 * (size_t)a.pb;
+    g->lds = RW_FIXED + 2 * (size_t)rows_patch_pieces(g->pwp) * 8 * 1024;
     if (g->lds > 160 * 1024) return false;
     const long npix = (long)p->frames * H * W;
     if (npix > 0x3fffffffL) return false;
@@ -455,9 +442,13 @@ static int launch_rows_t(const mhip_conv_i8_t *p, rows_geom_t &g) {
     return mhip_check(hipGetLastError(), "conv_i8_rows launch");
 }
 
+static unsigned long g_rows_launches = 0; // launches of conv_i8_rows since load (tests: did a forced variant 20 take this kernel?)
+extern "C" unsigned long mhip_conv_i8_rows_launches(void) { return g_rows_launches; }
+
 int conv_i8_launch_rows(const mhip_conv_i8_t *p) {
     rows_geom_t g;
     if (!p->w_rows || !rows_geom(p, &g)) return -1;
+    g_rows_launches++;
 #define ROWS(P) (p->lut ? launch_rows_t<P, true>(p, g) : launch_rows_t<P, false>(p, g))
     if (g.pwp == 24) return ROWS(24);
     if (g.pwp == 48) return ROWS(48);
@@ -467,11 +458,14 @@ int conv_i8_launch_rows(const mhip_conv_i8_t *p) {
 
 // Bytes of, and (out != NULL) the content of, the weight image conv_i8_rows streams: per (channel tile, 64-channel
 // chunk, tap) one 8 KB block = the LDS image of that K step's 128 x 64 weight bytes (rows in the packed order, the
-// 16-byte slots of a row swizzled as lds_off() reads them).  0 = not a shape that kernel takes (geometry only).
-extern "C" size_t mhip_conv_i8_rows_pack(int in_c, int kh, int kw, int stride_h, int stride_w, int oc_pad, int k64,
+// 16-byte slots of a row swizzled as lds_off() reads them).  0 = not a shape that kernel takes: the same tests as
+// rows_geom() -- an even number of 64-channel chunks, and (out_w != 0) one of the instantiated map widths -- so that a
+// second weight image is only reserved where the kernel can use it.  out_w = 0: the map width is not known (any).
+extern "C" size_t mhip_conv_i8_rows_pack(int in_c, int kh, int kw, int stride_h, int stride_w, int oc_pad, int k64, int out_w,
                                          const int8_t *packed, int8_t *out) {
-    if (kh != 3 || kw != 3 || stride_h != 1 || stride_w != 1 || in_c < 128 || (in_c & 63) || oc_pad % RW_BN != 0 || k64 != 9 * in_c)
+    if (kh != 3 || kw != 3 || stride_h != 1 || stride_w != 1 || in_c < 128 || (in_c & 127) || oc_pad % RW_BN != 0 || k64 != 9 * in_c)
         return 0;
+    if (out_w != 0 && out_w != 20 && out_w != 40) return 0;
     const size_t bytes = (size_t)oc_pad * 9 * in_c;
     if (!out || !packed) return bytes;
     const int nchunk = in_c / 64, noc = oc_pad / RW_BN;

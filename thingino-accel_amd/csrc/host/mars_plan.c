@@ -312,13 +312,13 @@ static void plan_conv(mars_model_ext_t *m, int li) {
         }
     }
     if (!op->nchw && op->w2_off == NO_OFF) { /* deep 3x3 stride-1 layers: the weight image conv_i8_rows streams (same bytes, K-step blocks) */
-        const size_t n3 = mhip_conv_i8_rows_pack(in_c, kh, kw, sh, sw, op->oc_pad, (int)k64, NULL, NULL);
+        const size_t n3 = mhip_conv_i8_rows_pack(in_c, kh, kw, sh, sw, op->oc_pad, (int)k64, out_w, NULL, NULL);
         if (n3) {
             op->w2_off = arena_reserve(m, n3);
             if (op->w2_off == NO_OFF) return;
             op->w2_rows = 1;
             if (!m->deferred)
-                mhip_conv_i8_rows_pack(in_c, kh, kw, sh, sw, op->oc_pad, (int)k64, (const int8_t *)m->arena_host + op->w_off,
+                mhip_conv_i8_rows_pack(in_c, kh, kw, sh, sw, op->oc_pad, (int)k64, out_w, (const int8_t *)m->arena_host + op->w_off,
                                        (int8_t *)m->arena_host + op->w2_off);
         }
     }

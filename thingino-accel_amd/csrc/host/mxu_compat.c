@@ -69,7 +69,7 @@ static void conv_i8_host(int nchw, const signed char *input, int in_h, int in_w,
     const size_t in_b = (size_t)in_h * in_w * in_c, out_b = (size_t)out_h * out_w * out_c;
     const size_t w_b = (size_t)oc_pad * k64, scr_b = nchw ? (size_t)in_h * in_w * c_pad : 0;
     /* deep 3x3 stride-1 shapes: also the K-step image conv_i8_rows streams (launch variant 20; 0 bytes otherwise) */
-    const size_t w3_b = nchw ? 0 : mhip_conv_i8_rows_pack(in_c, kh, kw, stride_h, stride_w, oc_pad, (int)k64, NULL, NULL);
+    const size_t w3_b = nchw ? 0 : mhip_conv_i8_rows_pack(in_c, kh, kw, stride_h, stride_w, oc_pad, (int)k64, out_w, NULL, NULL);
     int8_t *hw3 = w3_b ? (int8_t *)malloc(w3_b) : NULL;
     int8_t *hw = (int8_t *)malloc(w_b);
     int32_t *hb = (int32_t *)calloc((size_t)oc_pad, 4);
@@ -86,7 +86,7 @@ static void conv_i8_host(int nchw, const signed char *input, int in_h, int in_w,
         int rc = mhip_h2d_async(din, input, in_b);
         if (!rc) rc = mhip_h2d_async(dw, hw, w_b);
         if (!rc && w3_b) {
-            mhip_conv_i8_rows_pack(in_c, kh, kw, stride_h, stride_w, oc_pad, (int)k64, hw, hw3);
+            mhip_conv_i8_rows_pack(in_c, kh, kw, stride_h, stride_w, oc_pad, (int)k64, out_w, hw, hw3);
             rc = mhip_h2d_async(dw3, hw3, w3_b);
         }
         if (!rc) rc = mhip_h2d_async(db, hb, (size_t)oc_pad * 4);

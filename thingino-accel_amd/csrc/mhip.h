@@ -110,9 +110,11 @@ int mhip_conv_i8_oc_row(int oc, int oc_pad);
 int mhip_conv_i8_pre_ok(const mhip_conv_i8_t *p);
 size_t mhip_conv_i8_rgb_pack(int in_c, int kh, int kw, int stride_h, int stride_w, int pad_left, int oc_pad, int k64,
                              const int8_t *packed, int8_t *out);
-/* Bytes of, and (out != NULL) the content of, conv_i8_rows' weight image (deep 3x3 stride-1 layers); 0 = not such a shape */
-size_t mhip_conv_i8_rows_pack(int in_c, int kh, int kw, int stride_h, int stride_w, int oc_pad, int k64,
+/* Bytes of, and (out != NULL) the content of, conv_i8_rows' weight image (deep 3x3 stride-1 layers); 0 = not a shape that
+ * kernel takes (out_w = the map width, 0 = unknown / any) */
+size_t mhip_conv_i8_rows_pack(int in_c, int kh, int kw, int stride_h, int stride_w, int oc_pad, int k64, int out_w,
                               const int8_t *packed, int8_t *out);
+unsigned long mhip_conv_i8_rows_launches(void); /* launches of conv_i8_rows since load (diagnostic) */
 /* is the float->int conversion of acc*cs provably in range for every int32 accumulator? */
 int mhip_conv_i8_is_safe(float cs);
 /* may the half-step LUT be used for this combined scale?  (no int32 accumulator may requantise to +-0x3EFFFFFF) */
