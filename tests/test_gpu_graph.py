@@ -850,6 +850,92 @@ def test_conv_f32_split_shapes(gpu, orc, shape):
         gpu.set_tuning("dual_stream_min_batch", 64)
 
 
+F32_PATCH_SHAPES = [
+    # h, w, in_c, out_c, k, stride, batch, silu, add          conv_f32_patch (round 5): which geometry
+    (20, 20, 32, 16, 3, 1, 3, True, False),    # whole-row tiles that run on into the next frame; 32-channel tile half full; 4 dummy units
+    (12, 40, 64, 72, 3, 1, 5, True, True),     # 40-wide map, 128-channel tile 72 channels full, fused residual Add
+    (24, 160, 32, 64, 3, 1, 2, False, False),  # wide map: 32-column strips (2-D tiles), 64-channel tile
+    (40, 40, 32, 130, 3, 2, 3, True, False),   # stride 2 (de-interleaved patch columns), two 128-channel tiles (the second 2 channels full)
+    (32, 160, 64, 32, 3, 2, 2, True, False),   # stride 2 onto an 80-wide map: 16-column strips, 34 patch rows
+    (16, 24, 32, 20, 5, 1, 4, False, False),   # 5 x 5, pad 2: 25 taps per chunk
+    (9, 20, 96, 128, 3, 1, 37, True, True),    # short frames: several frame boundaries per tile; 12 chunks; 27 tiles
+    (80, 80, 64, 64, 3, 1, 9, True, False),    # 225 tiles: every workgroup walks a run of tiles (the ring runs through tile boundaries)
+]
+
+
+@pytest.mark.parametrize("shape", F32_PATCH_SHAPES, ids=lambda v: "x".join(str(q) for q in v))
+def test_conv_f32_patch_shapes(gpu, orc, shape):
+    """one float32 k x k convolution (+ fused SIGMOID / MUL, + fused residual Add) through conv_f32_patch (mode 3: the input patch of a
+    pixel tile staged and split once, csrc/hip/conv_f32_patch.hip): every frame of the batch against the oracle within
+    1e-4 * max(1, |b|); the launch counter proves the kernel ran (and that mode 4 / mode 0 do not take it).  Run twice: one
+    workgroup per CU (the default), and `persist_slots` = 3, so that three workgroups walk ALL tiles (runs of many tiles: the
+    patch ring, the weight pipeline and the row tables carried through tile boundaries)."""
+    h, w, ic, oc, k, st, B, silu, add = shape
+    rng = np.random.default_rng(h * 1000 + w * 10 + k + st)
+    G = marsfile.Graph()
+    F, N = marsfile.F32, marsfile.NCHW
+    oh, ow = (h + st - 1) // st, (w + st - 1) // st
+    x = G.tensor([1, ic, h, w], dtype=F, fmt=N)
+    a = G.tensor([1, oc, oh, ow], dtype=F, fmt=N)
+    amp = 1.7 / (k * k * ic) ** 0.5
+    wt = G.tensor([oc, ic, k, k], dtype=F, fmt=marsfile.OIHW, data=((rng.random((oc, ic, k, k), dtype=np.float32) * 2 - 1) * amp).astype(np.float32))
+    b = G.tensor([oc], dtype=F, fmt=marsfile.D1, data=((rng.random(oc, dtype=np.float32) * 2 - 1) * 0.1).astype(np.float32))
+    G.conv(x, a, wt, b, (k, k), (st, st), pad=marsfile.PAD_SAME)
+    out = a
+    if silu:
+        g_, o_ = G.tensor([1, oc, oh, ow], dtype=F, fmt=N), G.tensor([1, oc, oh, ow], dtype=F, fmt=N)
+        G.layer(marsfile.SIGMOID, [a], [g_])
+        G.layer(marsfile.MUL, [a, g_], [o_])
+        out = o_
+    ins = [x]
+    if add:  # the C3 shortcut: Add(conv-chain result, another tensor of the same shape) folded into the convolution's epilogue
+        r_ = G.tensor([1, oc, oh, ow], dtype=F, fmt=N)
+        s_ = G.tensor([1, oc, oh, ow], dtype=F, fmt=N)
+        G.layer(marsfile.ADD, [out, r_], [s_])
+        ins.append(r_)
+        out = s_
+    d = G.serialise(ins, [out])
+    nx = min(B, 4)
+    xs = [(rng.random(ic * h * w, dtype=np.float32) * 2 - 1).astype(np.float32) for _ in range(nx)]
+    rs = [(rng.random(oc * oh * ow, dtype=np.float32) * 2 - 1).astype(np.float32) for _ in range(nx)]
+    want = []
+    for q, r in zip(xs, rs):
+        g = orc.Graph(d)
+        g.set_input(0, q.tobytes())
+        if add:
+            g.set_input(1, r.tobytes())
+        assert g.run() == 0
+        want.append(g.tensor(out).copy())
+        g.close()
+    count = gpu.lib().mhip_conv_f32_patch_launches
+    count.restype = C.c_ulong
+    try:
+        gpu.set_tuning("dual_stream_min_batch", 0)
+        for mode, slots in ((3, 0), (3, 3), (4, 0), (0, 0)):
+            gpu.set_tuning("f32_mfma", mode)
+            gpu.set_tuning("persist_slots", slots)
+            m = gpu.Model(d, batch=B)
+            for f in range(B):
+                m.input_view(0)[f] = xs[f % nx].view(np.uint8)
+                if add:
+                    m.input_view(1)[f] = rs[f % nx].view(np.uint8)
+            n0 = count()
+            m.run()
+            assert count() - n0 == (1 if mode == 3 else 0), "mode %d: conv_f32_patch launched %d time(s)" % (mode, count() - n0)
+            got = m.output_view(0).copy()
+            m.close()
+            for f in range(B):
+                if mode == 0:
+                    assert np.array_equal(got[f], want[f % nx]), "mode 0 frame %d" % f
+                else:
+                    ok = close_f32(got[f], want[f % nx])
+                    assert ok.all(), "mode %d slots %d frame %d: %d of %d out of tolerance" % (mode, slots, f, int((~ok).sum()), ok.size)
+    finally:
+        gpu.set_tuning("f32_mfma", 1)
+        gpu.set_tuning("persist_slots", 0)
+        gpu.set_tuning("dual_stream_min_batch", 64)
+
+
 def test_deferred_load_and_arena_copy(gpu):
     """what every rank but 0 does in the multi-GPU job: load DESCRIPTORS only (weights blob zeroed,
     MARS_HIP_LOAD_DEFER_WEIGHTS), receive rank 0's packed parameter arena byte for byte (here: a device-to-device

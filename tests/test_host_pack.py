@@ -24,19 +24,20 @@ def test_conv_f32_split_pack_is_an_exact_split(out_c, in_c, kh, kw, stride):
     L = marsrt.lib()
     f = L.mhip_conv_f32_split_pack
     f.restype = C.c_size_t
-    f.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
+    f.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
     rng = np.random.default_rng(out_c * 100 + kw)
     w = ((rng.random((out_c, in_c, kh, kw), dtype=np.float32) * 2 - 1) * np.float32(10.0) ** rng.integers(-6, 3, (out_c, 1, 1, 1))).astype(np.float32)
     w[0, 0, 0, 0] = 0.0
     w[-1, -1, -1, -1] = np.float32(1.0) + np.float32(2.0) ** -23  # needs all three pieces
-    n = f(out_c, in_c, kh, kw, stride, None, None)
+    n = f(out_c, in_c, kh, kw, stride, 3, None, None)
+    assert f(out_c, in_c, kh, kw, stride, 2, None, None) == n // 3 * 2  # mode 3 reads two planes: only those are packed for it
     kwp = kw + 1 if (stride == 2 and kw > 1 and kw % 2) else kw
     K = in_c * kh * kwp
     kp = (K + 63) // 64 * 64 + 64
     ocp = (out_c + 127) // 128 * 128
     assert n == 3 * ocp * kp * 2
     buf = np.zeros(n // 2, dtype=np.uint16)
-    assert f(out_c, in_c, kh, kw, stride, w.ctypes.data, buf.ctypes.data) == n
+    assert f(out_c, in_c, kh, kw, stride, 3, w.ctypes.data, buf.ctypes.data) == n
     planes = buf.reshape(3, ocp, kp)
     hi, mid, lo = (bf16_to_f32(planes[i]) for i in range(3))
     got = np.zeros((out_c, in_c, kh, kwp), dtype=np.float64)
@@ -48,3 +49,182 @@ def test_conv_f32_split_pack_is_an_exact_split(out_c, in_c, kh, kw, stride):
         assert not pl[out_c:].any() and not pl[:, K:].any()             # padding rows and taps
     two = hi[:out_c, :K].reshape(out_c, in_c, kh, kwp)[..., :kw].astype(np.float64) + mid[:out_c, :K].reshape(out_c, in_c, kh, kwp)[..., :kw].astype(np.float64)
     assert (np.abs(w.astype(np.float64) - two) <= np.abs(w.astype(np.float64)) * 2.0 ** -16).all()
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# conv_f32_patch (csrc/hip/conv_f32_patch.hip): everything index-shaped in that kernel is host code -- the layer geometry
+# (strip order, patch rows / pitch), the unit table, the chunk schedule, the weights' K order.  The emulation below walks the
+# kernel's control flow (prologue, per-step patch action, ring slots, the four units of a step, tile -> pixel mapping) in numpy
+# with those tables and must reproduce a direct convolution; a slot read before its chunk was committed, a row outside the
+# patch or a wrong tap offset shows as a wrong sum.
+
+GEOM_FIELDS = ("s kh kw pad C nchunk U SW nstrips H_in W_in H_out W_out HV PR PWP PWH dx slotpix nsteps ngrp nitems BM kp oc_pad "
+               "tab_ints ndummy woff poff lds_bytes").split()
+
+
+def patch_geom(L, out_c, in_c, kh, kw, s, pad, in_h, in_w, out_h, out_w):
+    f = L.mhip_conv_f32_patch_geom
+    f.restype = C.c_int
+    f.argtypes = [C.c_int] * 10 + [C.c_void_p, C.c_int]
+    v = np.zeros(64, dtype=np.int32)
+    n = f(out_c, in_c, kh, kw, s, pad, in_h, in_w, out_h, out_w, v.ctypes.data, 64)
+    return dict(zip(GEOM_FIELDS, (int(x) for x in v[:n]))) if n else None
+
+
+def patch_pack(L, w, s, pad, in_h, in_w, out_h, out_w):
+    out_c, in_c, kh, kw = w.shape
+    f = L.mhip_conv_f32_patch_pack
+    f.restype = C.c_size_t
+    f.argtypes = [C.c_int] * 10 + [C.c_void_p, C.c_void_p]
+    n = f(out_c, in_c, kh, kw, s, pad, in_h, in_w, out_h, out_w, None, None)
+    buf = np.zeros(n, dtype=np.uint8)
+    assert f(out_c, in_c, kh, kw, s, pad, in_h, in_w, out_h, out_w, w.ctypes.data, buf.ctypes.data) == n
+    return buf
+
+
+def direct_conv(x, w, s, pad, out_h, out_w):
+    frames, C_, H, W = x.shape
+    out_c, _, kh, kw = w.shape
+    xp = np.zeros((frames, C_, H + 2 * pad + 8, W + 2 * pad + 8), dtype=np.float64)
+    xp[:, :, pad:pad + H, pad:pad + W] = x
+    out = np.zeros((frames, out_c, out_h, out_w), dtype=np.float64)
+    for ky in range(kh):
+        for kx in range(kw):
+            win = xp[:, :, ky:ky + (out_h - 1) * s + 1:s, kx:kx + (out_w - 1) * s + 1:s]
+            out += np.einsum("fchw,oc->fohw", win, w[:, :, ky, kx].astype(np.float64))
+    return out
+
+
+def emulate_patch_kernel(g, tabs, wk, x, frames, t_first, t_end):
+    """the workgroup that walks tiles [t_first, t_end): returns {tile: acc[256, oc_rows]} following conv_f32_patch's control flow"""
+    s, pad, PWP, PWH, SW, HV = g["s"], g["pad"], g["PWP"], g["PWH"], g["SW"], g["HV"]
+    nchunk, nsteps, slotpix = g["nchunk"], g["nsteps"], g["slotpix"]
+    dutab, sched = tabs[:nsteps * 4].reshape(nsteps, 4), tabs[nsteps * 4:nsteps * 5]
+    total = frames * g["H_out"] * g["W_out"]
+    ntiles = (total + 255) // 256
+    nsegs = frames * g["nstrips"]
+    slots = np.full((2 * slotpix, 8), np.nan)  # NaN = never written: a read of it poisons the sum
+    cmap = (lambda v: (v >> 1) + (v & 1) * PWH) if s == 2 else (lambda v: v)
+
+    def tile_v0(t):
+        R0 = (t * 256) // SW
+        seg0 = R0 // g["H_out"]
+        return seg0 * HV + (R0 - seg0 * g["H_out"]) * s
+
+    def rowtab(t):
+        rows = []
+        for r in range(g["PR"]):
+            V = tile_v0(t) + r
+            seg, iy = V // HV, V % HV - pad
+            f, st = seg // g["nstrips"], seg % g["nstrips"]
+            ok = t < ntiles and seg < nsegs and 0 <= iy < g["H_in"]
+            rows.append(((f, iy) if ok else None, st * SW * s - pad - g["dx"]))
+        return rows
+
+    tables = {}
+
+    def fetch(t, chunk):
+        vals = np.zeros((g["nitems"], 4, 8))
+        for it in range(g["nitems"]):
+            ir, igq = divmod(it, g["ngrp"])
+            src, xal = tables[t & 1][ir]
+            xx = xal + 4 * igq
+            if src is not None and 0 <= xx < g["W_in"]:
+                f, iy = src
+                vals[it] = x[f, chunk * 8:chunk * 8 + 8, iy, xx:xx + 4].T
+        return vals
+
+    def commit(slot, vals):
+        for it in range(g["nitems"]):
+            ir, igq = divmod(it, g["ngrp"])
+            for i in range(4):
+                slots[slot * slotpix + ir * PWP + cmap(4 * igq + i)] = vals[it, i]
+
+    # prologue
+    tables[t_first & 1] = rowtab(t_first)
+    breg = fetch(t_first, 0)
+    for i in range(nsteps):
+        if sched[i] > nchunk:
+            cc = sched[i] - 1 - nchunk
+            commit(cc & 1, breg)
+            breg = fetch(t_first, cc + 1)
+    out = {}
+    for t in range(t_first, t_end):
+        V0 = tile_v0(t)
+        q = t * 256 + np.arange(256)
+        R, xs = q // SW, q % SW
+        seg, y = R // g["H_out"], R % g["H_out"]
+        pbase = np.where(q < total, (seg * HV + y * s - V0) * PWP + xs, 0)
+        acc = np.zeros((256, wk.shape[0]))
+        for ks in range(nsteps):
+            if ks == 0:
+                tables[(t + 1) & 1] = rowtab(t + 1)
+            if sched[ks]:
+                cc = sched[ks] - 1
+                commit(cc & 1, breg)
+                nx = cc + 1
+                breg = fetch(t + 1, nx - nchunk) if nx >= nchunk else fetch(t, nx)
+            for fc in range(4):
+                e = dutab[ks, fc]
+                if e < 0:
+                    continue  # dummy unit: zeros
+                P = pbase + e
+                assert (P >= 0).all() and (P < 2 * slotpix).all()
+                xv = slots[P]  # [256, 8]
+                acc += xv @ wk[:, (ks * 4 + fc) * 8:(ks * 4 + fc) * 8 + 8].T
+        out[t] = (q, acc)
+    return out
+
+
+@pytest.mark.parametrize("shape", [
+    # out_c, in_c, k, s, pad, in_h, in_w, frames
+    (16, 32, 3, 1, 1, 20, 20, 3),    # whole-row tiles running on into the next frame (the 20-wide maps)
+    (24, 64, 3, 1, 1, 12, 40, 2),    # 40-wide
+    (8, 32, 3, 1, 1, 24, 160, 1),    # wide map: 2-D tiles out of 32-column strips
+    (8, 32, 3, 2, 1, 40, 40, 2),     # stride 2: de-interleaved patch columns, 20-wide output
+    (8, 64, 3, 2, 1, 32, 160, 1),    # stride 2, 80-wide output: 16-column strips
+    (8, 32, 5, 1, 2, 16, 24, 2),     # 25 taps
+    (8, 32, 6, 2, 2, 32, 32, 1),     # the stem's kernel geometry on 32 channels
+    (40, 96, 3, 1, 1, 9, 20, 5),     # short frames: several frame boundaries inside one tile; 12 chunks
+])
+def test_conv_f32_patch_tables_reproduce_a_direct_convolution(shape):
+    out_c, in_c, k, s, pad, in_h, in_w, frames = shape
+    out_h, out_w = (in_h + s - 1) // s, (in_w + s - 1) // s
+    L = marsrt.lib()
+    g = patch_geom(L, out_c, in_c, k, k, s, pad, in_h, in_w, out_h, out_w)
+    assert g is not None, "the kernel must take this shape"
+    assert g["nsteps"] % 2 == 0 and g["nitems"] <= 512 and g["lds_bytes"] <= 160 * 1024 and g["PWP"] % 8 == 0 and g["slotpix"] % 8 == 0
+    rng = np.random.default_rng(k * 1000 + in_c + s)
+    w = (rng.random((out_c, in_c, k, k), dtype=np.float32) - np.float32(0.5)).astype(np.float32)
+    x = rng.random((frames, in_c, in_h, in_w), dtype=np.float32).astype(np.float64)
+    img = patch_pack(L, w, s, pad, in_h, in_w, out_h, out_w)
+    tabb = (g["tab_ints"] * 4 + 255) & ~255
+    tabs = img[:g["tab_ints"] * 4].view(np.int32)
+    planes = img[tabb:].view(np.uint16).reshape(2, g["oc_pad"], g["kp"])
+    wk = (bf16_to_f32(planes[0]).astype(np.float64) + bf16_to_f32(planes[1]).astype(np.float64))[:out_c]
+    # the two planes hold w to 2^-16 relative, in the kernel's K order (checked through the convolution below); padding is zero
+    assert not planes[:, out_c:].any() and not planes[:, :, g["nchunk"] * g["U"] * 8:].any()
+    want = direct_conv(x, w, s, pad, out_h, out_w)
+    total = frames * out_h * out_w
+    ntiles = (total + 255) // 256
+    runs = [(0, ntiles)] if ntiles < 3 else [(0, ntiles), (1, 3), (ntiles - 1, ntiles)]  # different first tiles: the prologue's state
+    for t0, t1 in runs:
+        res = emulate_patch_kernel(g, tabs, wk, x, frames, t0, t1)
+        for t, (q, acc) in res.items():
+            ok = q < total
+            R, xs = q // g["SW"], q % g["SW"]
+            seg, y = R // out_h, R % out_h
+            f, st = seg // g["nstrips"], seg % g["nstrips"]
+            ref = want[f[ok], :, y[ok], st[ok] * g["SW"] + xs[ok]]
+            got = acc[ok]
+            assert not np.isnan(got).any(), "tile %d read a slot before its chunk was committed" % t
+            assert np.abs(got - ref).max() <= 1e-3 * max(1.0, np.abs(ref).max()), (shape, t)
+
+
+def test_conv_f32_patch_declines_what_it_cannot_take():
+    L = marsrt.lib()
+    assert patch_geom(L, 32, 3, 6, 6, 2, 2, 64, 64, 32, 32) is None      # the RGB stem: 3 channels
+    assert patch_geom(L, 32, 64, 1, 1, 1, 0, 40, 40, 40, 40) is None     # 1 x 1: one tap
+    assert patch_geom(L, 32, 16, 3, 3, 1, 1, 40, 40, 40, 40) is None     # fewer than four chunks
+    assert patch_geom(L, 32, 64, 3, 3, 1, 1, 21, 21, 21, 21) is None     # map width not a multiple of 4
+    assert patch_geom(L, 32, 64, 3, 3, 3, 1, 40, 40, 14, 14) is None     # stride 3

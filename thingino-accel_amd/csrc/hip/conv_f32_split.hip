@@ -565,11 +565,11 @@ static float bf16_val(uint16_t h) {
     memcpy(&f, &b, 4);
     return f;
 }
-extern "C" size_t mhip_conv_f32_split_pack(int out_c, int in_c, int kh, int kw, int stride_w, const float *w, void *out) {
-    if (out_c <= 0 || in_c <= 0 || kh <= 0 || kw <= 0) return 0;
+extern "C" size_t mhip_conv_f32_split_pack(int out_c, int in_c, int kh, int kw, int stride_w, int planes, const float *w, void *out) {
+    if (out_c <= 0 || in_c <= 0 || kh <= 0 || kw <= 0 || planes < 2 || planes > 3) return 0;
     const int kwp = split_kwp(kw, stride_w);
     const size_t K = (size_t)in_c * kh * kwp, kp = (K + 63) / 64 * 64 + 64, ocp = ((size_t)out_c + 127) / 128 * 128;
-    const size_t bytes = 3 * ocp * kp * 2;
+    const size_t bytes = (size_t)planes * ocp * kp * 2;
     if (!w || !out) return bytes;
     uint16_t *o = (uint16_t *)out;
     memset(o, 0, bytes);
@@ -579,13 +579,14 @@ extern "C" size_t mhip_conv_f32_split_pack(int out_c, int in_c, int kh, int kw, 
                 for (int kx = 0; kx < kw; kx++) {
                     const float x = w[((size_t)(oc * (size_t)in_c + ic) * kh + ky) * kw + kx];
                     const uint16_t h = bf16_rn(x);
-                    const float r1 = x - bf16_val(h); // exact
+                    const float hv = bf16_val(h);
+                    const float r1 = hv - hv == 0.0f ? x - hv : 0.0f; // exact; hi not finite (|x| >= 2^128 - 2^119, inf, NaN): no residual
                     const uint16_t m = bf16_rn(r1);
                     const float r2 = r1 - bf16_val(m); // exact, a bf16 value
                     const size_t k = ((size_t)ic * kh + ky) * kwp + kx;
                     o[(size_t)oc * kp + k] = h;
                     o[ocp * kp + (size_t)oc * kp + k] = m;
-                    o[2 * ocp * kp + (size_t)oc * kp + k] = bf16_rn(r2);
+                    if (planes == 3) o[2 * ocp * kp + (size_t)oc * kp + k] = bf16_rn(r2);
                 }
     return bytes;
 }

@@ -73,6 +73,7 @@ typedef struct {
     size_t w2_off;   /* a second image of the weights, or NO_OFF: the RGB stem's as conv_i8_rgb keeps them in LDS
                         (mhip_conv_i8_rgb_pack), or (w2_rows) a deep 3x3 layer's as conv_i8_rows streams them (mhip_conv_i8_rows_pack) */
     int w2_rows;
+    size_t w3_off;   /* conv_f32: conv_f32_patch's image (unit table, schedule, two bf16 planes in its K order), or NO_OFF */
     size_t lut2_off; /* 512-entry half-step form of the fused LUT (4-instruction requantisation), or NO_OFF */
     size_t w_blob_off[2];     /* operands that live in the blob mirror */
     double macs, bytes;       /* algorithmic work per frame */

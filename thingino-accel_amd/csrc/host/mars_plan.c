@@ -150,7 +150,7 @@ static mars_op_t *new_op(mars_model_ext_t *m, int kind, int layer) {
     op->kind = kind;
     op->layer = layer;
     op->t_in[0] = op->t_in[1] = op->t_in[2] = op->t_in[3] = op->t_out = -1;
-    op->w_off = op->b_off = op->lut_off = op->lut2_off = op->s_off = op->w2_off = NO_OFF;
+    op->w_off = op->b_off = op->lut_off = op->lut2_off = op->s_off = op->w2_off = op->w3_off = NO_OFF;
     op->w_blob_off[0] = op->w_blob_off[1] = NO_OFF;
     op->prof_kind = 4;
     return op;
@@ -264,13 +264,31 @@ static void plan_conv(mars_model_ext_t *m, int li) {
         op->w_off = arena_reserve(m, wcount * 4);
         if (op->w_off == NO_OFF) return;
         if (!m->deferred) blob_read(m, (size_t)w->data_offset, wcount * 4, m->arena_host + op->w_off);
-        { /* the same weights cut into three bf16 planes for the split-operand matrix-core kernel (conv_f32_split.hip, f32_mfma = 3) */
-            const size_t n2 = mhip_conv_f32_split_pack(out_c, in_c, kh, kw, sw, NULL, NULL);
-            if (n2) {
-                op->w2_off = arena_reserve(m, n2);
-                if (op->w2_off == NO_OFF) return;
+        /* The bf16 images of the weights the split-operand matrix-core kernels read, for the f32_mfma mode in force AT LOAD (set it
+         * before loading; a model switched to mode 3 / 4 later runs its convolutions on the f32 matrix cores instead): mode 3 =
+         * conv_f32_patch's image where the shape is one it takes (k x k layers; unit table + two planes in its K order), else two
+         * planes for conv_f32_split; mode 4 = three planes for conv_f32_split; modes 0 - 2 read neither (no dead planes in
+         * the arena, its upload and its multi-GPU broadcast). */
+        {
+            const int mode = mhip_conv_f32_mode(-1);
+            size_t n3 = 0;
+            if (mode == 3 && sh == sw && pt == pl)
+                n3 = mhip_conv_f32_patch_pack(out_c, in_c, kh, kw, sw, pl, in_h, in_w, out_h, out_w, NULL, NULL);
+            if (n3) {
+                op->w3_off = arena_reserve(m, n3);
+                if (op->w3_off == NO_OFF) return;
                 if (!m->deferred)
-                    mhip_conv_f32_split_pack(out_c, in_c, kh, kw, sw, (const float *)(m->arena_host + op->w_off), m->arena_host + op->w2_off);
+                    mhip_conv_f32_patch_pack(out_c, in_c, kh, kw, sw, pl, in_h, in_w, out_h, out_w, (const float *)(m->arena_host + op->w_off),
+                                             m->arena_host + op->w3_off);
+            } else if (mode >= 3) {
+                const int planes = mode == 3 ? 2 : 3;
+                const size_t n2 = mhip_conv_f32_split_pack(out_c, in_c, kh, kw, sw, planes, NULL, NULL);
+                if (n2) {
+                    op->w2_off = arena_reserve(m, n2);
+                    if (op->w2_off == NO_OFF) return;
+                    if (!m->deferred)
+                        mhip_conv_f32_split_pack(out_c, in_c, kh, kw, sw, planes, (const float *)(m->arena_host + op->w_off), m->arena_host + op->w2_off);
+                }
             }
         }
         if (tb >= 0) {

@@ -112,6 +112,7 @@ static int launch_op(mars_model_ext_t *m, mars_op_t *op) {
             p.out = (float *)tdev(m, op->t_out); p.out_stride = tstride(m, op->t_out);
             p.w = (const float *)(A + op->w_off);
             p.w_split = op->w2_off != NO_OFF ? (const void *)(A + op->w2_off) : NULL;
+            p.w_patch = op->w3_off != NO_OFF ? (const void *)(A + op->w3_off) : NULL;
             p.bias = op->b_off != NO_OFF ? (const float *)(A + op->b_off) : NULL;
             p.frames = B;
             p.in_h = op->in_h; p.in_w = op->in_w; p.in_c = op->in_c;

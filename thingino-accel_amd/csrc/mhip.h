@@ -138,7 +138,9 @@ typedef struct {
     const float *in;  size_t in_stride;
     float *out;       size_t out_stride;
     const float *w;   const float *bias;
-    const void *w_split; /* optional: the weights cut into three bf16 planes (mhip_conv_f32_split_pack): conv_f32_split needs it */
+    const void *w_split; /* optional: the weights cut into bf16 planes (mhip_conv_f32_split_pack): conv_f32_split needs it */
+    const void *w_patch; /* optional: unit table, schedule and the weights' two bf16 planes in conv_f32_patch's K order
+                            (mhip_conv_f32_patch_pack): k x k layers take that kernel under use_mfma == 3 when it is there */
     int frames;
     int in_h, in_w, in_c, out_h, out_w, out_c;
     int kh, kw, stride_h, stride_w, pad_top, pad_left;
@@ -152,12 +154,21 @@ typedef struct {
                      and three piece products ("bf16x3": relative error per product <= 2^-16, same tolerance class) */
 } mhip_conv_f32_t;
 int mhip_conv_f32(const mhip_conv_f32_t *p);
-/* Bytes of, and (out != NULL) the content of, the weight image conv_f32_split reads: three planes (hi, mid, lo) of bf16
+/* Bytes of, and (out != NULL) the content of, the weight image conv_f32_split reads: `planes` (2: hi, mid; 3: hi, mid, lo) planes of bf16
  * [oc_pad][k_pad] -- oc_pad = roundup128(out_c), k_pad = roundup64(K') + 64, zero filled -- with w = hi + mid + lo exactly
  * (hi = bf16(w), mid = bf16(w - hi), round to nearest; use_mfma == 3 reads the first two planes).  K' = in_c * kh * kw, or in_c * kh * (kw + 1) for stride_w == 2 with an odd kw (one zero column
  * appended to every kernel row: taps come in pairs there). */
-size_t mhip_conv_f32_split_pack(int out_c, int in_c, int kh, int kw, int stride_w, const float *w, void *out);
+size_t mhip_conv_f32_split_pack(int out_c, int in_c, int kh, int kw, int stride_w, int planes, const float *w, void *out);
 unsigned long mhip_conv_f32_split_launches(void); /* launches of conv_f32_split since load (diagnostic) */
+/* conv_f32_patch (conv_f32_patch.hip: the input patch of a pixel tile staged and split once, k x k layers with >= 8 taps, stride
+ * 1 / 2, in_c a multiple of 8 and >= 32, map widths multiples of 4).  Bytes of, and (w, out != NULL) the content of, its image:
+ * [nsteps][4] unit offsets, [nsteps] chunk schedule, two bf16 planes [oc_pad][kp] in its K order; 0 = not such a shape */
+size_t mhip_conv_f32_patch_pack(int out_c, int in_c, int kh, int kw, int stride, int pad, int in_h, int in_w, int out_h, int out_w,
+                                const float *w, void *out);
+/* the layer geometry that kernel derives, as ints (tests, tools): see conv_f32_patch.hip; returns the count, 0 = not such a shape */
+int mhip_conv_f32_patch_geom(int out_c, int in_c, int kh, int kw, int stride, int pad, int in_h, int in_w, int out_h, int out_w,
+                             int *outv, int cap);
+unsigned long mhip_conv_f32_patch_launches(void); /* launches of conv_f32_patch since load (diagnostic) */
 /* policy knob: 0 never the matrix cores, 1 (default) wherever the host proves it safe, 2 everywhere, 3 / 4 everywhere on the
  * bf16 matrix cores with operands split in two / three (three / six piece products).  set < 0 only
  * reads; returns the mode in force (first call reads MARS_HIP_F32_MFMA) */
