@@ -59,7 +59,7 @@ def test_conv_f32_split_pack_is_an_exact_split(out_c, in_c, kh, kw, stride):
 # patch or a wrong tap offset shows as a wrong sum.
 
 GEOM_FIELDS = ("s kh kw pad C nchunk U SW nstrips H_in W_in H_out W_out HV PR PWP PWH dx slotpix nsteps ngrp nitems BM kp oc_pad "
-               "tab_ints ndummy woff poff lds_bytes").split()
+               "tab_ints ndummy cpi woff poff lds_bytes").split()
 
 
 def patch_geom(L, out_c, in_c, kh, kw, s, pad, in_h, in_w, out_h, out_w):
@@ -123,22 +123,29 @@ def emulate_patch_kernel(g, tabs, wk, x, frames, t_first, t_end):
 
     tables = {}
 
+    cpi = g["cpi"]
+    nsub = 8 // cpi  # items per (row, 4-column group): each fetches cpi of the chunk's 8 channels
+    assert g["nitems"] == g["PR"] * g["ngrp"] * nsub
+
     def fetch(t, chunk):
-        vals = np.zeros((g["nitems"], 4, 8))
+        vals = np.zeros((g["nitems"], 4, cpi))
         for it in range(g["nitems"]):
-            ir, igq = divmod(it, g["ngrp"])
+            cell, ich = divmod(it, nsub)
+            ir, igq = divmod(cell, g["ngrp"])
             src, xal = tables[t & 1][ir]
             xx = xal + 4 * igq
             if src is not None and 0 <= xx < g["W_in"]:
                 f, iy = src
-                vals[it] = x[f, chunk * 8:chunk * 8 + 8, iy, xx:xx + 4].T
+                c0 = chunk * 8 + ich * cpi
+                vals[it] = x[f, c0:c0 + cpi, iy, xx:xx + 4].T
         return vals
 
     def commit(slot, vals):
         for it in range(g["nitems"]):
-            ir, igq = divmod(it, g["ngrp"])
+            cell, ich = divmod(it, nsub)
+            ir, igq = divmod(cell, g["ngrp"])
             for i in range(4):
-                slots[slot * slotpix + ir * PWP + cmap(4 * igq + i)] = vals[it, i]
+                slots[slot * slotpix + ir * PWP + cmap(4 * igq + i), ich * cpi:(ich + 1) * cpi] = vals[it, i]
 
     # prologue
     tables[t_first & 1] = rowtab(t_first)
@@ -165,10 +172,11 @@ def emulate_patch_kernel(g, tabs, wk, x, frames, t_first, t_end):
                 nx = cc + 1
                 breg = fetch(t + 1, nx - nchunk) if nx >= nchunk else fetch(t, nx)
             for fc in range(4):
-                e = dutab[ks, fc]
+                e = dutab[ks, fc]  # byte offset into the patch ring (32 bytes per patch pixel), or -1
                 if e < 0:
                     continue  # dummy unit: zeros
-                P = pbase + e
+                assert e % 32 == 0
+                P = pbase + e // 32
                 assert (P >= 0).all() and (P < 2 * slotpix).all()
                 xv = slots[P]  # [256, 8]
                 acc += xv @ wk[:, (ks * 4 + fc) * 8:(ks * 4 + fc) * 8 + 8].T

@@ -12,8 +12,7 @@
 //     tiles that run on into the next frame, so every MFMA row holds a real pixel on every map size;
 //   * the tile's input PATCH (its rows and columns plus the halo) is fetched 8 channels (one CHUNK) at a time by 16-byte
 //     loads, ONCE, split ONCE into its two bf16 pieces (v_cvt_pk_bf16_f32 + exact residual) and written channels-last into LDS:
-//     a pixel's record is 32 bytes = [8 x hi | 8 x mid] (the halves swapped on every other group of 8 pixels: bank
-//     spreading).  The patch ring holds two chunks;
+//     a pixel's record is 32 bytes = [8 x hi | 8 x mid].  The patch ring holds two chunks;
 //   * the K stream is a sequence of UNITS (tap, chunk) = 8 K-elements = one 16-byte LDS read per pixel row; an MFMA K step
 //     (32 elements) is four consecutive units, each lane group (lane / 16) reading its own unit at patch pixel
 //     Pbase(pixel) + toff(unit): no im2col anywhere, the nine taps are nine LDS offsets.  Units run on across chunk
@@ -49,6 +48,32 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 #define P_PRCAP 96 // patch rows, at most
 #define P_MAGIC 0x35504650
 
+#ifdef FPATCH_STAMPS // diagnostic build (tools/stamps_build.sh fpatch; read with tools/fpatch_stamps.py): where a K step goes
+__device__ unsigned long long fpatch_stamp_sums[8];
+extern "C" int mhip_fpatch_stamps(unsigned long long *out, int reset) {
+    unsigned long long z[8] = {0};
+    if (out && hipMemcpyFromSymbol(out, HIP_SYMBOL(fpatch_stamp_sums), sizeof z) != hipSuccess) return -1;
+    if (reset && hipMemcpyToSymbol(HIP_SYMBOL(fpatch_stamp_sums), z, sizeof z) != hipSuccess) return -1;
+    return 0;
+}
+#define STAMP(i)                                                                  \
+    do {                                                                          \
+        __builtin_amdgcn_sched_barrier(0);                                        \
+        const unsigned long long t_ = __builtin_readcyclecounter();              \
+        st_acc[i] += t_ - st_last;                                                \
+        st_last = t_;                                                             \
+        __builtin_amdgcn_sched_barrier(0);                                        \
+    } while (0)
+#else
+#define STAMP(i) do { } while (0)
+#endif
+#ifndef FPATCH_PRIO // experiment: 1 = the staging phase runs at raised wave priority (its few instructions ahead of the mate's MFMAs)
+#define FPATCH_PRIO 0
+#endif
+#ifndef FPATCH_ABL // timing-only ablations (tools/stamps_build.sh fpabl N; wrong results): 1 no MFMAs, 2 no split / LDS writes of the
+#define FPATCH_ABL 0 // patch, 4 no patch loads, 8 no fragment reads
+#endif
+
 struct pdiv_t {
     unsigned m, s1, s2;
 };
@@ -80,10 +105,11 @@ struct fpatch_geom_t {
     int PR, PWP, PWH, dx;      // patch rows, row pitch (pixels, multiple of 8), half pitch (stride 2), column of tap 0 of strip column 0
     int slotpix;               // pixels per ring slot
     int nsteps;                // K steps per tile (even; dummy units pad the stream)
-    int ngrp, nitems;          // 4-column groups per patch row, fetch items per chunk (threads that fetch)
+    int ngrp, nitems;          // 4-column groups per patch row, fetch items per chunk (threads that fetch) = PR * ngrp * (8 / cpi)
     int BM, kp, oc_pad;        // channel tile, weight row length (bf16 elements), weight rows per plane
     int tab_ints;              // ints of the table block in front of the weight planes
     int ndummy;                // dummy units at the end of a tile's stream (table entry -1: multiply zeros)
+    int cpi;                   // channels per fetch item (8 | 4 | 2)
     int woff, poff, lds_bytes; // LDS byte offsets of the weight stages and the patch ring, total
     unsigned total_pix, ntiles, nsegs, in_bytes, per;
     pdiv_t dSW, dHo, dHV, dNS, dgrp;
@@ -95,16 +121,19 @@ __device__ __forceinline__ float psilu_fast(float v) { // as conv_f32_split's th
     return v * __builtin_amdgcn_rcpf(1.0f + e);
 }
 
-// eight floats (one pixel, 8 channels) -> 4 dwords of hi, 4 of mid.  hi = bf16(x) (round to nearest even), mid = bf16(x - hi); the
-// subtraction is exact.  Not finite (hi = +-inf or NaN, i.e. |x| >= 2^128 - 2^119 or x not finite): mid = 0, so that the product sums
+// N floats (one pixel, N consecutive channels) -> N / 2 dwords of hi, N / 2 of mid.  hi = bf16(x) (round to nearest even), mid = bf16(x - hi);
+// the subtraction is exact.  Not finite (hi = +-inf or NaN, i.e. |x| >= 2^128 - 2^119 or x not finite): mid = 0, so that the product sums
 // see the inf / NaN once instead of the NaN an inf - inf residual would be
-__device__ __forceinline__ void psplit8(const float (&x)[8], v4i &hi, v4i &mid) {
+template <int N>
+__device__ __forceinline__ void psplit(const float (&x)[N], int (&hi)[N / 2], int (&mid)[N / 2]) {
 #pragma unroll
-    for (int i = 0; i < 4; i++) {
+    for (int i = 0; i < N / 2; i++) {
         const f32x2 v = {x[2 * i], x[2 * i + 1]};
         const int h = __builtin_bit_cast(int, __builtin_convertvector(v, bf16x2));
         const float h0 = __int_as_float(h << 16), h1 = __int_as_float(h & (int)0xffff0000);
-        f32x2 r = {v[0] - h0, v[1] - h1};
+        f32x2 r; // two plain subtractions (left to itself the compiler packs them into a v_pk_add_f32 behind two register moves)
+        asm("v_sub_f32 %0, %1, %2" : "=v"(r[0]) : "v"(v[0]), "v"(h0));
+        asm("v_sub_f32 %0, %1, %2" : "=v"(r[1]) : "v"(v[1]), "v"(h1));
         r[0] = __builtin_isfinite(h0) ? r[0] : 0.0f;
         r[1] = __builtin_isfinite(h1) ? r[1] : 0.0f;
         hi[i] = h;
@@ -112,8 +141,10 @@ __device__ __forceinline__ void psplit8(const float (&x)[8], v4i &hi, v4i &mid) 
     }
 }
 
-// BM = output channels per workgroup; waves WM (channels) x WN (pixels), WM * WN == 8
-template <int BM, int WM, int WN>
+// BM = output channels per workgroup; waves WM (channels) x WN (pixels), WM * WN == 8; CPI = channels of a chunk per fetch item
+// (8 | 4 | 2: the fewer, the more threads share a chunk's loads, split and LDS writes -- the host picks the smallest that keeps the
+// items within the workgroup's 512 threads)
+template <int BM, int WM, int WN, int CPI, bool DUMMY>
 __global__ __launch_bounds__(P_NT, 2) void conv_f32_patch(const mhip_conv_f32_t p, const fpatch_geom_t g, const int *__restrict__ tabs,
                                                           const int8_t *__restrict__ wpl) {
     constexpr int TM = BM / WM, TN = P_BN / WN;
@@ -126,6 +157,7 @@ __global__ __launch_bounds__(P_NT, 2) void conv_f32_patch(const mhip_conv_f32_t 
     int *dutab = (int *)lds;                                 // [nsteps][4] patch-pixel offset of the step's four units (slot included)
     int *sched = dutab + g.nsteps * 4;                       // [nsteps] 0 | 1 + chunk to commit at the top of the step
     int2 *rowtab = (int2 *)(lds + g.woff - 2 * P_PRCAP * 8); // [2][P_PRCAP] (row byte offset | ~0, first column x_al)
+    const int zrec = g.woff - 2 * P_PRCAP * 8 - 64 - g.poff;  // a zero pixel record (relative to the patch ring): what dummy units read
     int8_t *wst = lds + g.woff;
     int8_t *patch = lds + g.poff;
 
@@ -139,16 +171,25 @@ __global__ __launch_bounds__(P_NT, 2) void conv_f32_patch(const mhip_conv_f32_t 
     const __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc((void *)p.in, 0, (int)g.in_bytes, 0x00020000);
 
     for (int i = tid; i < g.nsteps * 5; i += P_NT) dutab[i] = tabs[i]; // dutab and sched are contiguous in both places
+    if (tid < 16) ((int *)(patch + zrec))[tid] = 0;
 
-    // ---- this thread's fetch item: patch row `ir`, columns 4 * igq .. + 3, all 8 channels of a chunk
+    // ---- this thread's fetch item: patch row `ir`, columns 4 * igq .. + 3, channels ich * CPI .. + CPI - 1 of a chunk
+    constexpr int NSUB = 8 / CPI; // items per (row, column group)
     const bool has_item = tid < g.nitems;
-    const int ir = (int)pdiv((unsigned)tid, g.dgrp), igq = tid - ir * g.ngrp;
-    int pitem[4]; // patch pixel (inside a slot) of the item's four columns
+    const int icell = tid / NSUB, ich = tid % NSUB;
+    const int ir = (int)pdiv((unsigned)icell, g.dgrp), igq = icell - ir * g.ngrp;
+    // A pixel's record in the ring: 32 bytes = [8 x hi | 8 x mid] at pixel * 32, NO bank swizzle: the reader's address is then one
+    // add per fragment (patch pixel of the lane's row + the unit's offset, both pre-multiplied), the mid half an immediate offset;
+    // the two lane groups of a 16-byte read that meet in a bank (pixels 8 apart) cost LDS cycles the staging phase has, where the
+    // ~30 vector instructions per step the swizzle cost were what bounded it (the staging wave issues at half rate beside its
+    // mate's MFMAs: profiles/r05_experiments.md)
+    int8_t *aitem[4]; // LDS address (slot 0) of this item's share of the records of its four columns
 #pragma unroll
     for (int i = 0; i < 4; i++) {
         const int v = 4 * igq + i;
-        pitem[i] = ir * g.PWP + (g.s == 2 ? (v >> 1) + (v & 1) * g.PWH : v);
+        aitem[i] = patch + (ir * g.PWP + (g.s == 2 ? (v >> 1) + (v & 1) * g.PWH : v)) * 32 + ich * (CPI * 2);
     }
+    const int slot_bytes = g.slotpix * 32;
     // first virtual row of tile t
     auto tile_v0 = [&](unsigned t) __attribute__((always_inline)) {
         const unsigned R0 = pdiv(t * P_BN, g.dSW), seg0 = pdiv(R0, g.dHo);
@@ -164,33 +205,50 @@ __global__ __launch_bounds__(P_NT, 2) void conv_f32_patch(const mhip_conv_f32_t 
                                                         (int)st * g.SW * g.s - g.pad - g.dx);
         }
     };
-    v4i breg[8]; // the chunk in flight: channel j, 4 columns
-    auto fetch_patch = [&](unsigned t, int chunk) __attribute__((always_inline)) { // chunk of tile t (rowtab[t & 1] is in place)
-        unsigned vo = 0xffffffffu;
-        if (has_item) {
-            const int2 rt = rowtab[(t & 1) * P_PRCAP + ir];
-            const int x = rt.y + 4 * igq;
-            if (rt.x != -1 && x >= 0 && x < g.W_in) vo = (unsigned)rt.x + (unsigned)x * 4u;
-        }
-        unsigned so = (unsigned)chunk * 8u * plane_bytes;
+    v4i breg[CPI]; // the chunk in flight: channel ich * CPI + j, 4 columns
+    const int irc = ir < g.PR ? ir : 0;
+    int2 rt_cur = make_int2(-1, 0), rt_nxt = make_int2(-1, 0); // this thread's row-table entry for the tile being computed / the next one
+    auto fetch_patch = [&](bool next_tile, int chunk) __attribute__((always_inline)) { // chunk of the current or the next tile
+        // no divergent branch here: a select per lane (threads without an item, rows / columns outside the image: an offset
+        // the buffer unit's range check turns into zeros, no memory access), the chunk in the SCALAR offset; the row-table entry
+        // comes from registers (an LDS round trip in front of every fetch was 150+ cycles of the staging phase)
+        const int2 rt = next_tile ? rt_nxt : rt_cur;
+        const int x = rt.y + 4 * igq;
+        const bool ok = has_item && rt.x != -1 && x >= 0 && x < g.W_in;
+        const unsigned vo = ok ? (unsigned)rt.x + (unsigned)x * 4u : 0xffffffffu;
+        // (the item's channel group goes into the per-lane offset: it differs inside a wave)
+        const unsigned vc = ok ? vo + (unsigned)(ich * CPI) * plane_bytes : 0xffffffffu;
+        unsigned so = (unsigned)__builtin_amdgcn_readfirstlane((int)((unsigned)chunk * 8u * plane_bytes));
 #pragma unroll
-        for (int j = 0; j < 8; j++) {
-            breg[j] = __builtin_bit_cast(v4i, __builtin_amdgcn_raw_buffer_load_b128(xrs, vo, so, 0));
+        for (int j = 0; j < CPI; j++) {
+            if (FPATCH_ABL & 4) breg[j] = (v4i){(int)vc, (int)so, j, 0};
+            else breg[j] = __builtin_bit_cast(v4i, __builtin_amdgcn_raw_buffer_load_b128(xrs, vc, so, 0));
             so += plane_bytes;
         }
     };
     auto commit_patch = [&](int slot) __attribute__((always_inline)) {
-        if (has_item) {
+        if (FPATCH_ABL & 2) {
+#pragma unroll
+            for (int j = 0; j < CPI; j++) asm volatile("" ::"v"(breg[j]));
+        } else if (has_item) {
 #pragma unroll
             for (int i = 0; i < 4; i++) {
-                const float x[8] = {__int_as_float(breg[0][i]), __int_as_float(breg[1][i]), __int_as_float(breg[2][i]), __int_as_float(breg[3][i]),
-                                    __int_as_float(breg[4][i]), __int_as_float(breg[5][i]), __int_as_float(breg[6][i]), __int_as_float(breg[7][i])};
-                v4i hi, mid;
-                psplit8(x, hi, mid);
-                const int P = slot * g.slotpix + pitem[i];
-                const int a = P * 32 + (((P >> 3) & 1) << 4);
-                *(v4i *)(patch + a) = hi;
-                *(v4i *)(patch + (a ^ 16)) = mid;
+                float x[CPI];
+#pragma unroll
+                for (int j = 0; j < CPI; j++) x[j] = __int_as_float(breg[j][i]);
+                int hi[CPI / 2], mid[CPI / 2];
+                psplit<CPI>(x, hi, mid);
+                int8_t *a = aitem[i] + slot * slot_bytes;
+                if (CPI == 8) {
+                    *(v4i *)a = (v4i){hi[0], hi[1 % (CPI / 2)], hi[2 % (CPI / 2)], hi[3 % (CPI / 2)]};
+                    *(v4i *)(a + 16) = (v4i){mid[0], mid[1 % (CPI / 2)], mid[2 % (CPI / 2)], mid[3 % (CPI / 2)]};
+                } else if (CPI == 4) {
+                    *(int2 *)a = make_int2(hi[0], hi[1 % (CPI / 2)]);
+                    *(int2 *)(a + 16) = make_int2(mid[0], mid[1 % (CPI / 2)]);
+                } else {
+                    *(int *)a = hi[0];
+                    *(int *)(a + 16) = mid[0];
+                }
             }
         }
     };
@@ -221,7 +279,7 @@ __global__ __launch_bounds__(P_NT, 2) void conv_f32_patch(const mhip_conv_f32_t 
     };
 
     // ---- the compute side's view of a tile: patch pixel of tap (0, 0) of this lane's A rows, output offsets of its D rows
-    int pbase[NI];
+    const int8_t *pbase[NI]; // LDS address of the record of tap (0, 0), slot 0, of the lane's A rows
     unsigned ooff[NI]; // byte offset (frame + position inside a channel plane) of the lane's 4 result pixels, ~0 = none
     auto tile_setup = [&](unsigned t) __attribute__((always_inline)) {
         const int V0 = tile_v0(t);
@@ -231,7 +289,7 @@ __global__ __launch_bounds__(P_NT, 2) void conv_f32_patch(const mhip_conv_f32_t 
             const unsigned R = pdiv(q, g.dSW), xs = q - R * (unsigned)g.SW;
             const unsigned seg = pdiv(R, g.dHo), y = R - seg * (unsigned)g.H_out;
             const int prow = (int)(seg * (unsigned)g.HV + y * (unsigned)g.s) - V0;
-            pbase[n] = q < g.total_pix ? prow * g.PWP + (int)xs : 0;
+            pbase[n] = patch + (q < g.total_pix ? prow * g.PWP + (int)xs : 0) * 32;
             const unsigned q4 = t * P_BN + (unsigned)(wn * TN + n * 16 + fc * 4); // D: pixels 4 fc .. + 3 of tile n, channel fr
             const unsigned R4 = pdiv(q4, g.dSW), xs4 = q4 - R4 * (unsigned)g.SW;
             const unsigned seg4 = pdiv(R4, g.dHo), y4 = R4 - seg4 * (unsigned)g.H_out;
@@ -250,58 +308,66 @@ __global__ __launch_bounds__(P_NT, 2) void conv_f32_patch(const mhip_conv_f32_t 
         for (int c = 0; c < NI; c++) acc[a][c] = bias4[a];
     }
 
-    const int nsteps_m2 = g.nsteps - 2;
-    // one K step: the MFMAs of weight stage `buf` on the units of step t, and the weights in `areg` written into the other stage
-    auto step = [&](int t, int buf, const int (&areg)[2][AD]) __attribute__((always_inline)) {
+#ifdef FPATCH_STAMPS
+    unsigned long long st_acc[6] = {0, 0, 0, 0, 0, 0}, st_last = 0, st_steps = 0;
+#endif
+    // A K step is two PHASES with a barrier behind each, and the two waves of a SIMD (w, w + 4) run ONE PHASE APART (waves 4-7 take
+    // one extra barrier before the loop, waves 0-3 one after it): while one multiplies, its mate stages.
+    //   R(t): [the chunk commit the schedule names] -> weights of step t + 1 (registers -> the other stage) -> the fragments of step t
+    //         (unit table, patch, this stage's weights) into registers -> load issue (weights of step t + 3, the next chunk)
+    //   M(t): the step's 48 MFMAs, nothing else.
+    // First round 5 form: one barrier per step, every wave in the same phase: stamps put a step at body 1630 (the SIMD's 1536 matrix
+    // cycles) + commit 410 + load issue 370 + barrier 790 + rest 310 = 3500 cycles -- the matrix pipe idle half the time.
+    // LDS hazards under the offset: everything a phase R(t) WRITES (patch slot, stage (t + 1) & 1) was last read in an R(t - 1), which
+    // for either group ended at the barrier before this R(t) begins; everything it READS was written in an R(t - 1) or earlier.
+    bf16x8 xh[NI], xm[NI], wh[MI], wmid[MI];
+    auto read_frags = [&](int t, int buf, const int e) __attribute__((always_inline)) {
         const int8_t *ap = wst + buf * WSTAGE;
-        const int e = dutab[t * 4 + fc];
-        bf16x8 xh[NI], xm[NI], wh[MI], wmid[MI];
 #pragma unroll
         for (int c = 0; c < NI; c++) {
-            const int P = pbase[c] + (e < 0 ? 0 : e);
-            const int a = P * 32 + (((P >> 3) & 1) << 4);
-            xh[c] = __builtin_bit_cast(bf16x8, *(const v4i *)(patch + a));
-            xm[c] = __builtin_bit_cast(bf16x8, *(const v4i *)(patch + (a ^ 16)));
-        }
-        if (g.ndummy && t >= nsteps_m2) { // dummy units (the stream padded to an even number of steps) multiply ZEROS: their weights are
-                                          // zero, but 0 x inf would be a NaN the reference does not have (the float twins do hold infs)
-            const bool dm = e < 0;
-#pragma unroll
-            for (int c = 0; c < NI; c++) {
-                v4i h = __builtin_bit_cast(v4i, xh[c]), m = __builtin_bit_cast(v4i, xm[c]);
-#pragma unroll
-                for (int j = 0; j < 4; j++) { h[j] = dm ? 0 : h[j]; m[j] = dm ? 0 : m[j]; }
-                xh[c] = __builtin_bit_cast(bf16x8, h); xm[c] = __builtin_bit_cast(bf16x8, m);
-            }
+            const int8_t *a = pbase[c] + e; // e = the unit's offset in BYTES (slot included)
+            // dummy units (the stream padded to an even number of steps; table entry -1) read a ZERO record: their weights are zero,
+            // but 0 x inf would be a NaN the reference does not have (the float twins do hold infs)
+            if (DUMMY) a = e < 0 ? patch + zrec : a;
+            if (FPATCH_ABL & 8) { xh[c] = __builtin_bit_cast(bf16x8, (v4i){(int)(size_t)a, c, t, lane}); xm[c] = xh[c]; continue; }
+            xh[c] = __builtin_bit_cast(bf16x8, *(const v4i *)a);
+            xm[c] = __builtin_bit_cast(bf16x8, *(const v4i *)(a + 16));
         }
 #pragma unroll
         for (int a = 0; a < MI; a++) {
             const int o = pa_lds_off(wm * TM + a * 16 + fr, fc);
+            if (FPATCH_ABL & 8) { wh[a] = __builtin_bit_cast(bf16x8, (v4i){o, a, t, lane}); wmid[a] = wh[a]; continue; }
             wh[a] = __builtin_bit_cast(bf16x8, *(const v4i *)(ap + o));
             wmid[a] = __builtin_bit_cast(bf16x8, *(const v4i *)(ap + APLANE + o));
         }
+    };
+    auto phase_m = [&]() __attribute__((always_inline)) {
 #pragma unroll
         for (int a = 0; a < MI; a++)
 #pragma unroll
             for (int c = 0; c < NI; c++) { // pixels are the A operand: a lane ends with 4 consecutive pixels of one channel
+                if (FPATCH_ABL & 1) { asm volatile("" ::"v"(xm[c]), "v"(xh[c]), "v"(wh[a]), "v"(wmid[a])); continue; }
                 acc[a][c] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xm[c], wh[a], acc[a][c], 0, 0, 0);   // mid * hi
                 acc[a][c] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xh[c], wmid[a], acc[a][c], 0, 0, 0); // hi * mid
                 acc[a][c] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xh[c], wh[a], acc[a][c], 0, 0, 0);   // hi * hi
             }
-        commit_w(buf ^ 1, areg);
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); // LDS only: the loads in flight stay in flight
-        __builtin_amdgcn_s_barrier();
-        asm volatile("" ::: "memory");
     };
-    // top of step t: commit the chunk the schedule names (its loads were issued >= 2 steps ago), then fetch the next one
-    auto patch_action = [&](unsigned t_tile, int t) __attribute__((always_inline)) {
-        const int sc = __builtin_amdgcn_readfirstlane(sched[t]);
+    auto barrier_lds = [&]() __attribute__((always_inline)) { // this wave's LDS operations done (loads in flight stay in flight), then the barrier
+        __builtin_amdgcn_sched_barrier(0);
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+    };
+    // top of R(t): commit the chunk the schedule names (its loads were issued >= 2 steps ago); the next chunk's loads are issued AFTER
+    // the step's weight loads (vmcnt is in order: the weights, consumed one step later, must not queue behind them).  The schedule
+    // word and the unit offset of step t were read from LDS during R(t - 1) (tab_sc / tab_e): no LDS round trip in front of either
+    auto patch_commit = [&](int sc) __attribute__((always_inline)) {
+        if (sc) commit_patch((sc - 1) & (P_NB - 1));
+    };
+    auto patch_fetch = [&](int sc) __attribute__((always_inline)) {
         if (sc) {
-            const int cc = sc - 1; // chunk of this tile, or nchunk + chunk of the next
-            commit_patch(cc & (P_NB - 1));
-            const int nx = cc + 1;
-            if (nx >= g.nchunk) fetch_patch(t_tile + 1, nx - g.nchunk);
-            else fetch_patch(t_tile, nx);
+            const int nx = sc; // chunk after the one just committed: of this tile, or nchunk + chunk of the next
+            const bool nxt = nx >= g.nchunk;
+            fetch_patch(nxt, nxt ? nx - g.nchunk : nx);
         }
     };
 
@@ -310,39 +376,95 @@ __global__ __launch_bounds__(P_NT, 2) void conv_f32_patch(const mhip_conv_f32_t 
     const unsigned t_end = (blockIdx.x + 1) * g.per < g.ntiles ? (blockIdx.x + 1) * g.per : g.ntiles;
     fill_rowtab(t_first);
     __syncthreads();
+    rt_cur = rowtab[(t_first & 1) * P_PRCAP + irc];
     // the state every later tile starts in: what the PREVIOUS tile's steps would have done for this tile's first chunks (the
     // schedule entries that name chunk nchunk + c), in order -- chunk 0's loads, then per entry: commit, fetch the next
-    fetch_patch(t_first, 0);
+    fetch_patch(false, 0);
     for (int i = 0; i < g.nsteps; i++) {
         const int sc = __builtin_amdgcn_readfirstlane(sched[i]);
         if (sc > g.nchunk) {
             const int cc = sc - 1 - g.nchunk;
             commit_patch(cc & (P_NB - 1));
-            fetch_patch(t_first, cc + 1);
+            fetch_patch(false, cc + 1);
         }
     }
     fetch_w(0, aregs[0]);
     commit_w(0, aregs[0]);
     fetch_w(1, aregs[1]);
+    fetch_w(2, aregs[0]);
     __syncthreads();
 
     const int nsteps = g.nsteps;
+    const bool late = wv >= 4; // the second wave of its SIMD: one phase behind
+    int tab_e = dutab[fc], tab_sc = sched[0];
+    if (late) __builtin_amdgcn_s_barrier();
+#ifdef FPATCH_STAMPS
+    st_last = __builtin_readcyclecounter();
+#endif
     for (unsigned t = t_first; t < t_end; t++) {
+#ifdef FPATCH_STAMPS
+        st_steps += (unsigned long long)nsteps;
+#endif
         tile_setup(t);
         for (int ks = 0; ks < nsteps; ks += 2) {
-            int kq = ks + 2;
-            if (kq >= nsteps) kq = 0; // the last two steps of a tile fetch the weights of the next tile's first two
-            if (ks == 0) fill_rowtab(t + 1); // the other table held tile t - 1's rows: its last chunk was fetched during tile t - 1;
-                                             // this one is first read by a fetch at step >= 1 (nchunk >= 4), behind step 0's barrier
-            patch_action(t, ks);
-            fetch_w(kq, aregs[0]);
+            int kq = ks + 3; // weights are fetched three steps ahead (two register sets, two stages); they wrap into the next tile
+            if (kq >= nsteps) kq -= nsteps;
+            int kq1 = ks + 4;
+            if (kq1 >= nsteps) kq1 -= nsteps;
+            const int k2 = ks + 2 < nsteps ? ks + 2 : 0;
+            if (ks == 0) fill_rowtab(t + 1); // the other table held tile t - 1's rows: its last chunk was fetched during tile t - 1
+            STAMP(4); // loop overhead; tile setup and epilogue when a tile began
+            // ---- R(ks)
+            if (FPATCH_PRIO) __builtin_amdgcn_s_setprio(1);
+            {
+                const int e = tab_e, sc = __builtin_amdgcn_readfirstlane(tab_sc);
+                tab_e = dutab[(ks + 1) * 4 + fc]; // for R(ks + 1): in registers by this phase's barrier
+                tab_sc = sched[ks + 1];
+                patch_commit(sc);
+                STAMP(0); // the chunk commit (wait for its loads, split, LDS writes) when the schedule names one
+                commit_w(1, aregs[1]);
+                read_frags(ks, 0, e);
+                fetch_w(kq, aregs[1]);
+                patch_fetch(sc);
+            }
+            STAMP(1); // staging: next weights into LDS, fragment reads, load issue
+            if (FPATCH_PRIO) __builtin_amdgcn_s_setprio(0);
+            barrier_lds();
+            STAMP(3);
+            phase_m();
             __builtin_amdgcn_sched_barrier(0);
-            step(ks, 0, aregs[1]);
-            patch_action(t, ks + 1);
-            fetch_w(kq + 1, aregs[1]);
+            STAMP(2); // the MFMAs
+            __builtin_amdgcn_s_barrier();
             __builtin_amdgcn_sched_barrier(0);
-            step(ks + 1, 1, aregs[0]);
+            STAMP(3); // barriers
+            // ---- R(ks + 1)
+            if (FPATCH_PRIO) __builtin_amdgcn_s_setprio(1);
+            {
+                const int e = tab_e, sc = __builtin_amdgcn_readfirstlane(tab_sc);
+                tab_e = dutab[k2 * 4 + fc];
+                tab_sc = sched[k2];
+                // the next tile's row-table entry: written in an R(0) (waves 0 / 1), two barriers before any wave's R(1); the host's
+                // schedule has no fetch for the next tile before step 2
+                if (ks == 0) rt_nxt = rowtab[((t + 1) & 1) * P_PRCAP + irc];
+                patch_commit(sc);
+                STAMP(0);
+                commit_w(0, aregs[0]);
+                read_frags(ks + 1, 1, e);
+                fetch_w(kq1, aregs[0]);
+                patch_fetch(sc);
+            }
+            STAMP(1);
+            if (FPATCH_PRIO) __builtin_amdgcn_s_setprio(0);
+            barrier_lds();
+            STAMP(3);
+            phase_m();
+            __builtin_amdgcn_sched_barrier(0);
+            STAMP(2);
+            __builtin_amdgcn_s_barrier();
+            __builtin_amdgcn_sched_barrier(0);
+            STAMP(3);
         }
+        rt_cur = rt_nxt;
         // ---- store: a lane holds 4 consecutive pixels (one 16-byte store) of channel row fr of every MFMA tile
 #pragma unroll
         for (int c = 0; c < NI; c++) {
@@ -366,6 +488,13 @@ __global__ __launch_bounds__(P_NT, 2) void conv_f32_patch(const mhip_conv_f32_t 
             for (int a = 0; a < MI; a++) acc[a][c] = bias4[a];
         }
     }
+    if (!late) __builtin_amdgcn_s_barrier(); // pairs with the late waves' last one
+#ifdef FPATCH_STAMPS
+    if (lane == 0) {
+        for (int i = 0; i < 5; i++) atomicAdd(&fpatch_stamp_sums[i], st_acc[i]);
+        atomicAdd(&fpatch_stamp_sums[5], st_steps);
+    }
+#endif
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -402,6 +531,7 @@ static int fpatch_schedule(int nchunk, int U, int nsteps, int *sched /* [nsteps]
             const long rel = gch - nchunk; // chunk index relative to tile 1: may reach into tile 2 (>= nchunk)
             if (rel < 0 || rel >= 2L * nchunk || sched[c - nsteps]) return 0;
             sched[c - nsteps] = (int)rel + 1;
+            if (rel + 1 >= nchunk && c - nsteps < 2) return 0; // the kernel reads the next tile's row table in R(1): no fetch for it before step 2
         }
     }
     // the same commits, seen from tile 0, must be what tile 1 shows (periodicity): chunk g of tile 0 at step c <=> chunk g of tile 1 at c
@@ -431,7 +561,7 @@ static int fpatch_geom(const mhip_conv_f32_t *p, fpatch_geom_t *g, int frames) {
     g->kp = g->nsteps * 32 + 64; // (fetches run two steps ahead and wrap: the slack is never multiplied)
     g->tab_ints = g->nsteps * 5;
     // strip width: a divisor of out_w, multiple of 4; the one with the smallest patch (ties: the wider)
-    const int woff_base = (g->nsteps * 5 * 4 + 2 * P_PRCAP * 8 + 255) & ~255;
+    const int woff_base = (g->nsteps * 5 * 4 + 64 + 2 * P_PRCAP * 8 + 255) & ~255; // tables | zero record | row tables
     const int wbytes = 2 * 2 * g->BM * 64;
     int best = 0;
     for (int SW = 4; SW <= p->out_w; SW += 4) {
@@ -444,13 +574,15 @@ static int fpatch_geom(const mhip_conv_f32_t *p, fpatch_geom_t *g, int frames) {
         const int ncross = (NR + p->out_h - 2) / p->out_h;                    // strip / frame boundaries inside them, at most
         const int PR = (NR - 1) * s + p->kh + ncross * (p->kh - s > 0 ? p->kh - s : 0);
         if (PR > P_PRCAP) continue;
-        const int nitems = PR * (PWP / 4);
+        const int cells = PR * (PWP / 4);
+        const int cpi = cells * 4 <= P_NT ? 2 : (cells * 2 <= P_NT ? 4 : 8);
+        const int nitems = cells * (8 / cpi);
         const int slotpix = (PR * PWP + 7) & ~7;
         const int lds = woff_base + wbytes + P_NB * slotpix * 32;
         if (nitems > P_NT || lds > 160 * 1024) continue;
         if (!best || PR * PWP < g->PR * g->PWP || (PR * PWP == g->PR * g->PWP && SW > g->SW)) {
             best = 1;
-            g->SW = SW; g->dx = dx; g->PWP = PWP; g->PWH = PWP / 2; g->PR = PR; g->nitems = nitems; g->ngrp = PWP / 4; g->slotpix = slotpix;
+            g->SW = SW; g->dx = dx; g->PWP = PWP; g->PWH = PWP / 2; g->PR = PR; g->nitems = nitems; g->cpi = cpi; g->ngrp = PWP / 4; g->slotpix = slotpix;
             g->woff = woff_base; g->poff = woff_base + wbytes; g->lds_bytes = lds;
         }
     }
@@ -496,7 +628,7 @@ static void shape_of(mhip_conv_f32_t *p, int out_c, int in_c, int kh, int kw, in
     p->in_stride = (size_t)in_c * in_h * in_w * 4; p->out_stride = (size_t)out_c * out_h * out_w * 4; p->frames = 1;
 }
 
-// Bytes of, and (w, out != NULL) the content of, the image conv_f32_patch reads: [nsteps][4] unit offsets, [nsteps] schedule, then
+// Bytes of, and (w, out != NULL) the content of, the image conv_f32_patch reads: [nsteps][4] unit offsets (bytes into the patch ring, -1 = dummy), [nsteps] schedule, then
 // two planes (hi, mid) of bf16 [oc_pad][kp] in the kernel's K order: element 8 u + j of a row = channel 8 c + j, tap of unit u =
 // (chunk c, tap) (dummy units and the slack: zeros).  0 = not a shape this kernel takes.
 extern "C" size_t mhip_conv_f32_patch_pack(int out_c, int in_c, int kh, int kw, int stride, int pad, int in_h, int in_w, int out_h, int out_w,
@@ -512,7 +644,7 @@ extern "C" size_t mhip_conv_f32_patch_pack(int out_c, int in_c, int kh, int kw, 
     int *tabs = (int *)out;
     int units[4096];
     fpatch_units(g.nchunk, g.U, units, 4096);
-    for (int i = 0; i < g.nsteps * 4; i++) tabs[i] = units[i] < 0 ? -1 : fpatch_toff(&g, units[i], i - units[i] * g.U);
+    for (int i = 0; i < g.nsteps * 4; i++) tabs[i] = units[i] < 0 ? -1 : fpatch_toff(&g, units[i], i - units[i] * g.U) * 32; // bytes: 32 per patch pixel
     fpatch_schedule(g.nchunk, g.U, g.nsteps, tabs + g.nsteps * 4);
     uint16_t *hi = (uint16_t *)((char *)out + tabb), *mid = hi + (size_t)g.oc_pad * g.kp;
     for (int oc = 0; oc < out_c; oc++)
@@ -531,13 +663,13 @@ extern "C" size_t mhip_conv_f32_patch_pack(int out_c, int in_c, int kh, int kw, 
 }
 
 // the geometry as ints (tests / tools): s kh kw pad C nchunk U SW nstrips H_in W_in H_out W_out HV PR PWP PWH dx slotpix nsteps ngrp
-// nitems BM kp oc_pad tab_ints ndummy woff poff lds_bytes; returns how many were written (0 = not a shape this kernel takes)
+// nitems BM kp oc_pad tab_ints ndummy cpi woff poff lds_bytes; returns how many were written (0 = not a shape this kernel takes)
 extern "C" int mhip_conv_f32_patch_geom(int out_c, int in_c, int kh, int kw, int stride, int pad, int in_h, int in_w, int out_h, int out_w, int *outv, int cap) {
     mhip_conv_f32_t p;
     shape_of(&p, out_c, in_c, kh, kw, stride, pad, in_h, in_w, out_h, out_w);
     fpatch_geom_t g;
     if (out_c <= 0 || !fpatch_geom(&p, &g, 1)) return 0;
-    const int n = 30;
+    const int n = 31;
     if (cap < n) return 0;
     memcpy(outv, &g, n * sizeof(int));
     return n;
@@ -546,9 +678,9 @@ extern "C" int mhip_conv_f32_patch_geom(int out_c, int in_c, int kh, int kw, int
 static unsigned long g_patch_launches = 0;
 extern "C" unsigned long mhip_conv_f32_patch_launches(void) { return g_patch_launches; }
 
-template <int BM, int WM, int WN>
+template <int BM, int WM, int WN, int CPI, bool DUMMY>
 static int launch_patch(const mhip_conv_f32_t *p, fpatch_geom_t &g) {
-    auto kern = conv_f32_patch<BM, WM, WN>;
+    auto kern = conv_f32_patch<BM, WM, WN, CPI, DUMMY>;
     static int cus = 0;
     if (!cus) {
         hipDeviceProp_t prop;
@@ -581,7 +713,11 @@ int conv_f32_try_patch(const mhip_conv_f32_t *p) {
     fpatch_geom_t g;
     if (!fpatch_geom(p, &g, p->frames)) return -2;
     if (p->add && p->add_stride != p->out_stride) return -2;
-    if (g.BM == 128) return launch_patch<128, 2, 4>(p, g);
-    if (g.BM == 64) return launch_patch<64, 1, 8>(p, g);
-    return launch_patch<32, 1, 8>(p, g);
+#define FP_D(BM, WM, WN, CPI) (g.ndummy ? launch_patch<BM, WM, WN, CPI, true>(p, g) : launch_patch<BM, WM, WN, CPI, false>(p, g))
+#define FP_CPI(BM, WM, WN) (g.cpi == 8 ? FP_D(BM, WM, WN, 8) : g.cpi == 4 ? FP_D(BM, WM, WN, 4) : FP_D(BM, WM, WN, 2))
+    if (g.BM == 128) return FP_CPI(128, 2, 4);
+    if (g.BM == 64) return FP_CPI(64, 1, 8);
+    return FP_CPI(32, 1, 8);
+#undef FP_CPI
+#undef FP_D
 }
