@@ -59,7 +59,7 @@ def test_conv_f32_split_pack_is_an_exact_split(out_c, in_c, kh, kw, stride):
 # patch or a wrong tap offset shows as a wrong sum.
 
 GEOM_FIELDS = ("s kh kw pad C nchunk U SW nstrips H_in W_in H_out W_out HV PR PWP PWH dx slotpix nsteps ngrp nitems BM kp oc_pad "
-               "tab_ints ndummy cpi woff poff lds_bytes").split()
+               "tab_ints ndummy cpi bn woff poff lds_bytes").split()
 
 
 def patch_geom(L, out_c, in_c, kh, kw, s, pad, in_h, in_w, out_h, out_w):
@@ -100,14 +100,15 @@ def emulate_patch_kernel(g, tabs, wk, x, frames, t_first, t_end):
     s, pad, PWP, PWH, SW, HV = g["s"], g["pad"], g["PWP"], g["PWH"], g["SW"], g["HV"]
     nchunk, nsteps, slotpix = g["nchunk"], g["nsteps"], g["slotpix"]
     dutab, sched = tabs[:nsteps * 4].reshape(nsteps, 4), tabs[nsteps * 4:nsteps * 5]
+    BN = g["bn"]
     total = frames * g["H_out"] * g["W_out"]
-    ntiles = (total + 255) // 256
+    ntiles = (total + BN - 1) // BN
     nsegs = frames * g["nstrips"]
     slots = np.full((2 * slotpix, 8), np.nan)  # NaN = never written: a read of it poisons the sum
     cmap = (lambda v: (v >> 1) + (v & 1) * PWH) if s == 2 else (lambda v: v)
 
     def tile_v0(t):
-        R0 = (t * 256) // SW
+        R0 = (t * BN) // SW
         seg0 = R0 // g["H_out"]
         return seg0 * HV + (R0 - seg0 * g["H_out"]) * s
 
@@ -158,11 +159,11 @@ def emulate_patch_kernel(g, tabs, wk, x, frames, t_first, t_end):
     out = {}
     for t in range(t_first, t_end):
         V0 = tile_v0(t)
-        q = t * 256 + np.arange(256)
+        q = t * BN + np.arange(BN)
         R, xs = q // SW, q % SW
         seg, y = R // g["H_out"], R % g["H_out"]
         pbase = np.where(q < total, (seg * HV + y * s - V0) * PWP + xs, 0)
-        acc = np.zeros((256, wk.shape[0]))
+        acc = np.zeros((BN, wk.shape[0]))
         for ks in range(nsteps):
             if ks == 0:
                 tables[(t + 1) & 1] = rowtab(t + 1)
@@ -194,6 +195,8 @@ def emulate_patch_kernel(g, tabs, wk, x, frames, t_first, t_end):
     (8, 32, 5, 1, 2, 16, 24, 2),     # 25 taps
     (8, 32, 6, 2, 2, 32, 32, 1),     # the stem's kernel geometry on 32 channels
     (40, 96, 3, 1, 1, 9, 20, 5),     # short frames: several frame boundaries inside one tile; 12 chunks
+    (200, 64, 3, 1, 1, 16, 40, 3),   # two 128-channel tiles: 256-pixel tiles (the cases above with <= 64 channels take 512-pixel tiles)
+    (64, 32, 3, 2, 1, 64, 320, 1),   # the twin's second layer's geometry: a 512-pixel tile's patch does not fit, 256 it is
 ])
 def test_conv_f32_patch_tables_reproduce_a_direct_convolution(shape):
     out_c, in_c, k, s, pad, in_h, in_w, frames = shape
@@ -201,6 +204,7 @@ def test_conv_f32_patch_tables_reproduce_a_direct_convolution(shape):
     L = marsrt.lib()
     g = patch_geom(L, out_c, in_c, k, k, s, pad, in_h, in_w, out_h, out_w)
     assert g is not None, "the kernel must take this shape"
+    assert g["bn"] == (512 if out_c <= 64 and s == 1 else 256)  # (stride 2: the 512-pixel tile's patch exceeds the fetch items / LDS)
     assert g["nsteps"] % 2 == 0 and g["nitems"] <= 512 and g["lds_bytes"] <= 160 * 1024 and g["PWP"] % 8 == 0 and g["slotpix"] % 8 == 0
     rng = np.random.default_rng(k * 1000 + in_c + s)
     w = (rng.random((out_c, in_c, k, k), dtype=np.float32) - np.float32(0.5)).astype(np.float32)
@@ -214,7 +218,7 @@ def test_conv_f32_patch_tables_reproduce_a_direct_convolution(shape):
     assert not planes[:, out_c:].any() and not planes[:, :, g["nchunk"] * g["U"] * 8:].any()
     want = direct_conv(x, w, s, pad, out_h, out_w)
     total = frames * out_h * out_w
-    ntiles = (total + 255) // 256
+    ntiles = (total + g["bn"] - 1) // g["bn"]
     runs = [(0, ntiles)] if ntiles < 3 else [(0, ntiles), (1, 3), (ntiles - 1, ntiles)]  # different first tiles: the prologue's state
     for t0, t1 in runs:
         res = emulate_patch_kernel(g, tabs, wk, x, frames, t0, t1)

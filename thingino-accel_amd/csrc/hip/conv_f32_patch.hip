@@ -42,7 +42,6 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 
-#define P_BN 256   // pixels per tile
 #define P_NT 512   // threads per workgroup
 #define P_NB 2     // patch ring slots (chunks)
 #define P_PRCAP 96 // patch rows, at most
@@ -110,6 +109,7 @@ struct fpatch_geom_t {
     int tab_ints;              // ints of the table block in front of the weight planes
     int ndummy;                // dummy units at the end of a tile's stream (table entry -1: multiply zeros)
     int cpi;                   // channels per fetch item (8 | 4 | 2)
+    int bn;                    // pixels per tile (256 | 512)
     int woff, poff, lds_bytes; // LDS byte offsets of the weight stages and the patch ring, total
     unsigned total_pix, ntiles, nsegs, in_bytes, per;
     pdiv_t dSW, dHo, dHV, dNS, dgrp;
@@ -144,7 +144,9 @@ __device__ __forceinline__ void psplit(const float (&x)[N], int (&hi)[N / 2], in
 // BM = output channels per workgroup; waves WM (channels) x WN (pixels), WM * WN == 8; CPI = channels of a chunk per fetch item
 // (8 | 4 | 2: the fewer, the more threads share a chunk's loads, split and LDS writes -- the host picks the smallest that keeps the
 // items within the workgroup's 512 threads)
-template <int BM, int WM, int WN, int CPI, bool DUMMY>
+// P_BN = pixels per tile: 256, or 512 under the 64- / 32-channel tiles (a wave then has the 48 / 24 MFMAs per step that make a
+// barrier interval worth its fixed cost; with 256 pixels those layers ran 24 / 12 per step and were bound by the step skeleton)
+template <int BM, int WM, int WN, int CPI, bool DUMMY, int P_BN>
 __global__ __launch_bounds__(P_NT, 2) void conv_f32_patch(const mhip_conv_f32_t p, const fpatch_geom_t g, const int *__restrict__ tabs,
                                                           const int8_t *__restrict__ wpl) {
     constexpr int TM = BM / WM, TN = P_BN / WN;
@@ -564,6 +566,7 @@ static int fpatch_geom(const mhip_conv_f32_t *p, fpatch_geom_t *g, int frames) {
     const int woff_base = (g->nsteps * 5 * 4 + 64 + 2 * P_PRCAP * 8 + 255) & ~255; // tables | zero record | row tables
     const int wbytes = 2 * 2 * g->BM * 64;
     int best = 0;
+    for (int P_BN = g->BM <= 64 ? 512 : 256; P_BN >= 256 && !best; P_BN -= 256) // (the larger tile where its patch fits)
     for (int SW = 4; SW <= p->out_w; SW += 4) {
         if (p->out_w % SW) continue;
         const int x0 = -p->pad_left;                     // input column of tap 0 of strip column 0 (strip 0)
@@ -583,7 +586,7 @@ static int fpatch_geom(const mhip_conv_f32_t *p, fpatch_geom_t *g, int frames) {
         if (!best || PR * PWP < g->PR * g->PWP || (PR * PWP == g->PR * g->PWP && SW > g->SW)) {
             best = 1;
             g->SW = SW; g->dx = dx; g->PWP = PWP; g->PWH = PWP / 2; g->PR = PR; g->nitems = nitems; g->cpi = cpi; g->ngrp = PWP / 4; g->slotpix = slotpix;
-            g->woff = woff_base; g->poff = woff_base + wbytes; g->lds_bytes = lds;
+            g->woff = woff_base; g->poff = woff_base + wbytes; g->lds_bytes = lds; g->bn = P_BN;
         }
     }
     if (!best) return 0;
@@ -592,9 +595,9 @@ static int fpatch_geom(const mhip_conv_f32_t *p, fpatch_geom_t *g, int frames) {
     if (g->nsteps > 1024 || !fpatch_schedule(g->nchunk, g->U, g->nsteps, sched)) return 0;
     const long total = (long)frames * p->out_h * p->out_w;
     const size_t in_bytes = (size_t)(frames - 1) * p->in_stride + (size_t)p->in_c * p->in_h * p->in_w * 4;
-    if (total > 0x7fffffffL - P_BN || in_bytes > 0xfffffff0ull || (size_t)frames * p->out_stride > 0xfffffff0ull) return 0;
+    if (total > 0x7fffffffL - g->bn || in_bytes > 0xfffffff0ull || (size_t)frames * p->out_stride > 0xfffffff0ull) return 0;
     g->total_pix = (unsigned)total;
-    g->ntiles = (unsigned)((total + P_BN - 1) / P_BN);
+    g->ntiles = (unsigned)((total + g->bn - 1) / g->bn);
     g->nsegs = (unsigned)(frames * g->nstrips);
     g->in_bytes = (unsigned)in_bytes;
     g->dSW = make_pdiv((unsigned)g->SW); g->dHo = make_pdiv((unsigned)g->H_out); g->dHV = make_pdiv((unsigned)g->HV);
@@ -663,13 +666,13 @@ extern "C" size_t mhip_conv_f32_patch_pack(int out_c, int in_c, int kh, int kw, 
 }
 
 // the geometry as ints (tests / tools): s kh kw pad C nchunk U SW nstrips H_in W_in H_out W_out HV PR PWP PWH dx slotpix nsteps ngrp
-// nitems BM kp oc_pad tab_ints ndummy cpi woff poff lds_bytes; returns how many were written (0 = not a shape this kernel takes)
+// nitems BM kp oc_pad tab_ints ndummy cpi bn woff poff lds_bytes; returns how many were written (0 = not a shape this kernel takes)
 extern "C" int mhip_conv_f32_patch_geom(int out_c, int in_c, int kh, int kw, int stride, int pad, int in_h, int in_w, int out_h, int out_w, int *outv, int cap) {
     mhip_conv_f32_t p;
     shape_of(&p, out_c, in_c, kh, kw, stride, pad, in_h, in_w, out_h, out_w);
     fpatch_geom_t g;
     if (out_c <= 0 || !fpatch_geom(&p, &g, 1)) return 0;
-    const int n = 31;
+    const int n = 32;
     if (cap < n) return 0;
     memcpy(outv, &g, n * sizeof(int));
     return n;
@@ -678,9 +681,9 @@ extern "C" int mhip_conv_f32_patch_geom(int out_c, int in_c, int kh, int kw, int
 static unsigned long g_patch_launches = 0;
 extern "C" unsigned long mhip_conv_f32_patch_launches(void) { return g_patch_launches; }
 
-template <int BM, int WM, int WN, int CPI, bool DUMMY>
+template <int BM, int WM, int WN, int CPI, bool DUMMY, int BN>
 static int launch_patch(const mhip_conv_f32_t *p, fpatch_geom_t &g) {
-    auto kern = conv_f32_patch<BM, WM, WN, CPI, DUMMY>;
+    auto kern = conv_f32_patch<BM, WM, WN, CPI, DUMMY, BN>;
     static int cus = 0;
     if (!cus) {
         hipDeviceProp_t prop;
@@ -713,11 +716,11 @@ int conv_f32_try_patch(const mhip_conv_f32_t *p) {
     fpatch_geom_t g;
     if (!fpatch_geom(p, &g, p->frames)) return -2;
     if (p->add && p->add_stride != p->out_stride) return -2;
-#define FP_D(BM, WM, WN, CPI) (g.ndummy ? launch_patch<BM, WM, WN, CPI, true>(p, g) : launch_patch<BM, WM, WN, CPI, false>(p, g))
-#define FP_CPI(BM, WM, WN) (g.cpi == 8 ? FP_D(BM, WM, WN, 8) : g.cpi == 4 ? FP_D(BM, WM, WN, 4) : FP_D(BM, WM, WN, 2))
-    if (g.BM == 128) return FP_CPI(128, 2, 4);
-    if (g.BM == 64) return FP_CPI(64, 1, 8);
-    return FP_CPI(32, 1, 8);
+#define FP_D(BM, WM, WN, CPI, BN) (g.ndummy ? launch_patch<BM, WM, WN, CPI, true, BN>(p, g) : launch_patch<BM, WM, WN, CPI, false, BN>(p, g))
+#define FP_CPI(BM, WM, WN, BN) (g.cpi == 8 ? FP_D(BM, WM, WN, 8, BN) : g.cpi == 4 ? FP_D(BM, WM, WN, 4, BN) : FP_D(BM, WM, WN, 2, BN))
+    if (g.BM == 128) return FP_CPI(128, 2, 4, 256);
+    if (g.BM == 64) return g.bn == 512 ? FP_CPI(64, 1, 8, 512) : FP_CPI(64, 1, 8, 256);
+    return g.bn == 512 ? FP_CPI(32, 1, 8, 512) : FP_CPI(32, 1, 8, 256);
 #undef FP_CPI
 #undef FP_D
 }
