@@ -152,6 +152,7 @@ MARS_INTERNAL void fuse_silu_f32(mars_model_ext_t *m);
 MARS_INTERNAL void elide_concat(mars_model_ext_t *m);
 MARS_INTERNAL void fuse_add(mars_model_ext_t *m);
 MARS_INTERNAL void fuse_add_f32(mars_model_ext_t *m);
+MARS_INTERNAL void trim_concat(mars_model_ext_t *m);
 MARS_INTERNAL void fuse_bottleneck(mars_model_ext_t *m);
 MARS_INTERNAL void virtual_concat(mars_model_ext_t *m);
 MARS_INTERNAL void pair_convs(mars_model_ext_t *m);

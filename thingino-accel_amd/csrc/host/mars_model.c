@@ -173,6 +173,7 @@ mars_error_t build_plan(mars_model_ext_t *m) {
         fuse_add_f32(m);
         if (!m->no_vconcat) virtual_concat(m);
         elide_concat(m);
+        trim_concat(m);
         fuse_pool_chains(m);
         pair_convs(m);
         if (m->fusion >= 2 && !m->no_bottleneck) fuse_bottleneck(m); /* opt-in (level 2); after pairing: a paired launch stays a pair */

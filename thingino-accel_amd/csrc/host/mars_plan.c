@@ -730,6 +730,32 @@ void elide_concat(mars_model_ext_t *m) {
     free(writers);
 }
 
+/* Dead stores of a CONCAT.  The reference copies input k's "pixels" (runs of shape[3] BYTES, whatever the dtype) to byte
+ * p * out_c + off_k of the output, one input after the other (mars_runtime.c:977-996).  When shape[3] of an input EQUALS the
+ * output's (the NCHW-tagged float twins: every tensor's shape[3] is the map width), a slice is one contiguous run of
+ * npix * out_c bytes starting at off_k, and the next input's run, starting out_c bytes later, overwrites all of it but its first
+ * off_j - off_k bytes before anything can read them.  Such a slice copies only the pixels that hold surviving bytes (the partly
+ * surviving last one whole: the later slice, launched after it on the same stream, rewrites the rest) -- the tensor's final bytes
+ * are the reference's.  On the float yolov5 twins this halves the concat traffic (2.7 -> 1.4 ms per batch of 256). */
+void trim_concat(mars_model_ext_t *m) {
+    for (int i = 0; i < m->n_ops; i++) {
+        mars_op_t *k = &m->ops[i];
+        if (k->kind != OP_CONCAT_SLICE || k->in_c != k->out_c || k->out_c <= 0) continue;
+        const size_t npix = (size_t)k->out_h * k->out_w;
+        for (int q = i + 1; q < m->n_ops && m->ops[q].layer == k->layer; q++) {
+            const mars_op_t *j = &m->ops[q];
+            if (j->kind != OP_CONCAT_SLICE || j->t_out != k->t_out || j->in_c != j->out_c || j->out_c != k->out_c) continue;
+            if ((size_t)j->out_h * j->out_w != npix || j->ch_off < k->ch_off) continue;
+            const size_t live = (size_t)(j->ch_off - k->ch_off), live_pix = (live + (size_t)k->out_c - 1) / (size_t)k->out_c;
+            if (live_pix < (size_t)k->out_h * k->out_w) {
+                k->out_h = 1;
+                k->out_w = (int)live_pix; /* 0: nothing of this slice survives (the launcher skips an empty copy) */
+                k->bytes = 2.0 * (double)live_pix * k->in_c;
+            }
+        }
+    }
+}
+
 /* Residual Add folded into the convolution that produces one of its operands (the bottleneck shortcut of C3):
  * out = Add(conv_result, x) is evaluated in the convolution's epilogue with the reference's float steps
  * (mars_runtime.c ADD branch: (a*sa + b*sb) * (1/so) + 0.5f, truncated, saturated), reading x where the output
