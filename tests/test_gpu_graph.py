@@ -836,7 +836,8 @@ def test_conv_f32_split_shapes(gpu, orc, shape):
             n0 = count()
             m.run()
             declined = st == 2 and ow % 2 == 1  # (the one shape above the split kernel does not take)
-            assert count() - n0 == (0 if mode == 0 or declined else 1), "mode %d: conv_f32_split launched %d time(s)" % (mode, count() - n0)
+            stem = mode == 3 and ic == 3 and k == 6  # round 5: in mode 3 the stem's geometry goes to conv_f32_stem (test_conv_f32_stem_shapes)
+            assert count() - n0 == (0 if mode == 0 or declined or stem else 1), "mode %d: conv_f32_split launched %d time(s)" % (mode, count() - n0)
             got = m.output_view(0).copy()
             m.close()
             for f in range(B):
@@ -930,6 +931,75 @@ def test_conv_f32_patch_shapes(gpu, orc, shape):
                 else:
                     ok = close_f32(got[f], want[f % nx])
                     assert ok.all(), "mode %d slots %d frame %d: %d of %d out of tolerance" % (mode, slots, f, int((~ok).sum()), ok.size)
+    finally:
+        gpu.set_tuning("f32_mfma", 1)
+        gpu.set_tuning("persist_slots", 0)
+        gpu.set_tuning("dual_stream_min_batch", 64)
+
+
+F32_STEM_SHAPES = [
+    # h, w, in_c, out_c, k, pad-as-SAME, batch, silu        conv_f32_stem (round 5)
+    (64, 64, 3, 32, 6, 9, True),     # the twins' first layer at 64 x 64: 2 x 1 tiles per frame, 9 frames
+    (128, 192, 3, 32, 6, 5, True),   # 4 x 3 tiles per frame: interior tiles and every edge
+    (32, 64, 3, 20, 6, 3, False),    # 20 of the 32 channel rows
+    (96, 64, 1, 32, 6, 4, True),     # one channel
+    (96, 64, 3, 32, 4, 2, True),     # 4 x 4 under SAME padding has pad 1: odd, declined (conv_f32_split takes it)
+    (64, 128, 4, 16, 6, 7, True),    # four channels (every slot real)
+    (32, 64, 2, 32, 8, 2, True),     # 8 x 8 would be 32 units: declined (conv_f32_split takes it)
+]
+
+
+@pytest.mark.parametrize("shape", F32_STEM_SHAPES, ids=lambda v: "x".join(str(q) for q in v))
+def test_conv_f32_stem_shapes(gpu, orc, shape):
+    """the float twins' first layer (few channels, even kernel, stride 2) through conv_f32_stem (mode 3: pair records in LDS, weights
+    in registers, one barrier per tile; csrc/hip/conv_f32_stem.hip): every frame against the oracle within 1e-4 * max(1, |b|), with
+    one workgroup per CU and with `persist_slots` = 3 (three workgroups walk all tiles: the two patch slots alternate through long
+    runs); the launch counter proves which kernel ran."""
+    h, w, ic, oc, k, B, silu = shape
+    rng = np.random.default_rng(h * 1000 + w * 10 + k + ic)
+    G = marsfile.Graph()
+    F, N = marsfile.F32, marsfile.NCHW
+    oh, ow = h // 2, w // 2
+    x = G.tensor([1, ic, h, w], dtype=F, fmt=N)
+    a = G.tensor([1, oc, oh, ow], dtype=F, fmt=N)
+    amp = 1.7 / (k * k * ic) ** 0.5
+    wt = G.tensor([oc, ic, k, k], dtype=F, fmt=marsfile.OIHW, data=((rng.random((oc, ic, k, k), dtype=np.float32) * 2 - 1) * amp).astype(np.float32))
+    b = G.tensor([oc], dtype=F, fmt=marsfile.D1, data=((rng.random(oc, dtype=np.float32) * 2 - 1) * 0.1).astype(np.float32))
+    G.conv(x, a, wt, b, (k, k), (2, 2), pad=marsfile.PAD_SAME)
+    out = a
+    if silu:
+        g_, o_ = G.tensor([1, oc, oh, ow], dtype=F, fmt=N), G.tensor([1, oc, oh, ow], dtype=F, fmt=N)
+        G.layer(marsfile.SIGMOID, [a], [g_])
+        G.layer(marsfile.MUL, [a, g_], [o_])
+        out = o_
+    d = G.serialise([x], [out])
+    nx = min(B, 3)
+    xs = [(rng.random(ic * h * w, dtype=np.float32) * 2 - 1).astype(np.float32) for _ in range(nx)]
+    want = []
+    for q in xs:
+        g, rc = run_oracle(orc, d, q.view(np.uint8))
+        assert rc == 0
+        want.append(g.tensor(out).copy())
+        g.close()
+    count = gpu.lib().mhip_conv_f32_stem_launches
+    count.restype = C.c_ulong
+    takes = k * k // 2 <= 20 and ((k - 2) // 2) % 2 == 0  # (an even pad keeps the column pairs aligned)
+    try:
+        gpu.set_tuning("dual_stream_min_batch", 0)
+        for mode, slots in ((3, 0), (3, 3), (4, 0)):
+            gpu.set_tuning("f32_mfma", mode)
+            gpu.set_tuning("persist_slots", slots)
+            m = gpu.Model(d, batch=B)
+            for f in range(B):
+                m.input_view(0)[f] = xs[f % nx].view(np.uint8)
+            n0 = count()
+            m.run()
+            assert count() - n0 == (1 if mode == 3 and takes else 0), "mode %d: conv_f32_stem launched %d time(s)" % (mode, count() - n0)
+            got = m.output_view(0).copy()
+            m.close()
+            for f in range(B):
+                ok = close_f32(got[f], want[f % nx])
+                assert ok.all(), "mode %d slots %d frame %d: %d of %d out of tolerance" % (mode, slots, f, int((~ok).sum()), ok.size)
     finally:
         gpu.set_tuning("f32_mfma", 1)
         gpu.set_tuning("persist_slots", 0)

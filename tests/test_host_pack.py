@@ -240,3 +240,32 @@ def test_conv_f32_patch_declines_what_it_cannot_take():
     assert patch_geom(L, 32, 16, 3, 3, 1, 1, 40, 40, 40, 40) is None     # fewer than four chunks
     assert patch_geom(L, 32, 64, 3, 3, 1, 1, 21, 21, 21, 21) is None     # map width not a multiple of 4
     assert patch_geom(L, 32, 64, 3, 3, 3, 1, 40, 40, 14, 14) is None     # stride 3
+
+
+def test_conv_f32_stem_pack_order():
+    """mhip_conv_f32_stem_pack: two bf16 planes [32][20 units][8]; element par * 4 + ch of unit ky * (kw / 2) + j is
+    w[oc][ch][ky][2 j + par], hi + mid == w to 2^-16 relative, every other position zero; shapes the kernel declines give 0"""
+    L = marsrt.lib()
+    f = L.mhip_conv_f32_stem_pack
+    f.restype = C.c_size_t
+    f.argtypes = [C.c_int] * 10 + [C.c_void_p, C.c_void_p]
+    out_c, in_c, k = 20, 3, 6
+    rng = np.random.default_rng(5)
+    w = (rng.random((out_c, in_c, k, k), dtype=np.float32) - np.float32(0.5)).astype(np.float32)
+    n = f(out_c, in_c, k, k, 2, 2, 64, 64, 32, 32, None, None)
+    assert n == 2 * 32 * 20 * 8 * 2
+    buf = np.zeros(n // 2, dtype=np.uint16)
+    assert f(out_c, in_c, k, k, 2, 2, 64, 64, 32, 32, w.ctypes.data, buf.ctypes.data) == n
+    planes = buf.reshape(2, 32, 20, 2, 4)  # plane, channel row, unit, column parity, channel slot
+    got = bf16_to_f32(planes[0]).astype(np.float64) + bf16_to_f32(planes[1]).astype(np.float64)
+    for ky in range(k):
+        for kx in range(k):
+            u = ky * (k // 2) + kx // 2
+            ref = w[:, :, ky, kx].astype(np.float64)
+            assert np.abs(got[:out_c, u, kx & 1, :in_c] - ref).max() <= np.abs(ref).max() * 2.0 ** -16
+    assert not got[out_c:].any() and not got[:, 18:].any() and not got[..., in_c:].any()
+    assert f(33, 3, 6, 6, 2, 2, 64, 64, 32, 32, None, None) == 0     # more than 32 output channels
+    assert f(32, 3, 6, 6, 2, 2, 72, 64, 36, 32, None, None) == 0     # output height not a multiple of 16
+    assert f(32, 3, 8, 8, 2, 2, 64, 64, 32, 32, None, None) == 0     # 32 units
+    assert f(32, 3, 3, 3, 2, 1, 64, 64, 32, 32, None, None) == 0     # odd kernel width / odd pad
+    assert f(32, 8, 6, 6, 2, 2, 64, 64, 32, 32, None, None) == 0     # more than 4 input channels

@@ -225,6 +225,7 @@ __global__ __launch_bounds__(256) void conv_f32_mfma(const mhip_conv_f32_t p, co
 
 int conv_f32_try_split(const mhip_conv_f32_t *p); // conv_f32_split.hip: -2 = not a shape it takes
 int conv_f32_try_patch(const mhip_conv_f32_t *p); // conv_f32_patch.hip: -2 = not a shape it takes (or no image packed)
+int conv_f32_try_stem(const mhip_conv_f32_t *p);  // conv_f32_stem.hip: likewise
 
 static int g_f32_mode = -1; // -1: environment not read yet
 extern "C" int mhip_conv_f32_mode(int set) { // set >= 0: new mode; returns the mode in force
@@ -245,7 +246,9 @@ extern "C" int mhip_conv_f32(const mhip_conv_f32_t *p) {
     if (p->out_c > 65535 || p->frames > 65535) return -1;
     const long hw = (long)p->out_h * p->out_w, total = hw * p->frames, K = (long)p->in_c * p->kh * p->kw;
     if (p->use_mfma >= 2) { // the bf16 matrix cores on split operands (conv_f32_split.hip): 2 = six piece products, 3 = three
-        int rc = conv_f32_try_patch(p); // k x k layers, three piece products: the patch-staged form (round 5)
+        int rc = conv_f32_try_stem(p); // the 3-channel first layer, three piece products (round 5)
+        if (rc != -2) return rc;
+        rc = conv_f32_try_patch(p); // k x k layers, three piece products: the patch-staged form (round 5)
         if (rc != -2) return rc;
         rc = p->w_split ? conv_f32_try_split(p) : -2;
         if (rc != -2) return rc;

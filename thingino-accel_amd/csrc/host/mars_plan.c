@@ -272,14 +272,23 @@ static void plan_conv(mars_model_ext_t *m, int li) {
         {
             const int mode = mhip_conv_f32_mode(-1);
             size_t n3 = 0;
-            if (mode == 3 && sh == sw && pt == pl)
-                n3 = mhip_conv_f32_patch_pack(out_c, in_c, kh, kw, sw, pl, in_h, in_w, out_h, out_w, NULL, NULL);
+            int stem = 0;
+            if (mode == 3 && sh == sw && pt == pl) {
+                n3 = mhip_conv_f32_stem_pack(out_c, in_c, kh, kw, sw, pl, in_h, in_w, out_h, out_w, NULL, NULL);
+                stem = n3 != 0;
+                if (!n3) n3 = mhip_conv_f32_patch_pack(out_c, in_c, kh, kw, sw, pl, in_h, in_w, out_h, out_w, NULL, NULL);
+            }
             if (n3) {
                 op->w3_off = arena_reserve(m, n3);
                 if (op->w3_off == NO_OFF) return;
-                if (!m->deferred)
-                    mhip_conv_f32_patch_pack(out_c, in_c, kh, kw, sw, pl, in_h, in_w, out_h, out_w, (const float *)(m->arena_host + op->w_off),
-                                             m->arena_host + op->w3_off);
+                if (!m->deferred) {
+                    if (stem)
+                        mhip_conv_f32_stem_pack(out_c, in_c, kh, kw, sw, pl, in_h, in_w, out_h, out_w, (const float *)(m->arena_host + op->w_off),
+                                                m->arena_host + op->w3_off);
+                    else
+                        mhip_conv_f32_patch_pack(out_c, in_c, kh, kw, sw, pl, in_h, in_w, out_h, out_w, (const float *)(m->arena_host + op->w_off),
+                                                 m->arena_host + op->w3_off);
+                }
             } else if (mode >= 3) {
                 const int planes = mode == 3 ? 2 : 3;
                 const size_t n2 = mhip_conv_f32_split_pack(out_c, in_c, kh, kw, sw, planes, NULL, NULL);

@@ -169,6 +169,13 @@ size_t mhip_conv_f32_patch_pack(int out_c, int in_c, int kh, int kw, int stride,
 int mhip_conv_f32_patch_geom(int out_c, int in_c, int kh, int kw, int stride, int pad, int in_h, int in_w, int out_h, int out_w,
                              int *outv, int cap);
 unsigned long mhip_conv_f32_patch_launches(void); /* launches of conv_f32_patch since load (diagnostic) */
+/* conv_f32_stem (conv_f32_stem.hip: the float twins' first layer -- in_c <= 4, out_c <= 32, even kernel width, stride 2, output maps
+ * multiples of 16 x 32): bytes of, and (w, out != NULL) the content of, the weight image it loads into registers (two bf16 planes
+ * [32][20 units][8]); 0 = not such a shape.  The image travels in mhip_conv_f32_t.w_patch like conv_f32_patch's (a shape is taken by at
+ * most one of the two kernels). */
+size_t mhip_conv_f32_stem_pack(int out_c, int in_c, int kh, int kw, int stride, int pad, int in_h, int in_w, int out_h, int out_w,
+                               const float *w, void *out);
+unsigned long mhip_conv_f32_stem_launches(void);
 /* policy knob: 0 never the matrix cores, 1 (default) wherever the host proves it safe, 2 everywhere, 3 / 4 everywhere on the
  * bf16 matrix cores with operands split in two / three (three / six piece products).  set < 0 only
  * reads; returns the mode in force (first call reads MARS_HIP_F32_MFMA) */
