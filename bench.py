@@ -280,10 +280,12 @@ def main():
                     help="check run, not the benchmark workload: the twin with per-convolution scales (every fused table "
                          "differs); the CPU-baseline leg then compares its frames bit for bit as usual")
     ap.add_argument("--no-tail", action="store_true", help="graph only, skip decode+NMS")
-    ap.add_argument("--io", choices=["resident", "pipelined"], default="resident",
+    ap.add_argument("--io", choices=["resident", "pipelined", "camera"], default="resident",
                     help="pipelined: after the timed (resident) region every rank also runs its batches through mars_hip_pipe_* "
                          "(pinned host frames in, detections out) and the line carries `pipelined_io` (MAX over ranks); at N=1 "
-                         "the default run measures this anyway")
+                         "the default run measures this anyway.  camera (N=1): additionally the reference demo's whole loop "
+                         "(src/mars/mars_yolo_test.c:132-214) -- uint8 RGB 1280x720 frames in pinned host memory -> letterbox / px-128 on "
+                         "the device -> graph -> decode + NMS -> detections back, pipelined (mars_hip_pipe_* in camera mode): `camera_io`")
     ap.add_argument("--sustain-s", type=float, default=3.0, help="seconds of back-to-back steps of the sustained leg (0 = skip)")
     ap.add_argument("--ops", type=str, default="", help="write a per-launch table (last timed step) to this file")
     ap.add_argument("--autotune", action="store_true",
@@ -498,6 +500,46 @@ def main():
             model.pipe_close()
             pipe_rates[key] = world * (nb + 3) * args.batch / dtp
 
+    # ---- camera leg (--io camera): the demo's loop.  Frames: 1280 x 720 uint8 RGB (a camera's native size; the front-end shrinks
+    # them to the graph's 640 x 640 exactly as the reference's load_image() does) from pinned host memory, every batch.
+    camera = None
+    if args.io == "camera" and world == 1 and not f32 and not args.no_tail and not args.timed_only:
+        from conftest import lcg_frame
+        cw, chh = 1280, 720
+        model.pipe_open(download_outputs=False, detect=True, det_outputs=outputs, thresh=0.45, camera=(cw, chh))
+        shots = [lcg_frame(0xCA3E0000 + k, cw * chh * 3) for k in range(8)]
+        for k in range(4):  # fill the four staging slots once (a camera would DMA into them), untimed
+            v = model.pipe_input_view(0)
+            for f in range(args.batch):
+                v[f] = shots[(f + k) % 8]
+            model.pipe_submit()
+            if k >= 2:
+                model.pipe_wait(copy=False)
+        for _ in range(2):
+            model.pipe_wait(copy=False)
+        nb, pre_ms = 12, []
+        barrier()
+        t1 = time.perf_counter()
+        for k in range(3):
+            model.pipe_submit()
+        for _ in range(nb):
+            model.pipe_wait(copy=False)
+            pre_ms.append(float(M.lib().mars_hip_pipe_camera_ms(model.p)))
+            model.pipe_submit()
+        for _ in range(3):
+            model.pipe_wait(copy=False)
+        dtc = time.perf_counter() - t1
+        model.pipe_close()
+        pre = float(np.median([x for x in pre_ms if x > 0])) if any(x > 0 for x in pre_ms) else None
+        pre_bytes = args.batch * (cw * chh * 3 + in_bytes)  # every camera byte read once + every graph-input byte written once
+        camera = {"images_per_s": (nb + 3) * args.batch / dtc, "frame": "%dx%d uint8 RGB, pinned host memory" % (cw, chh),
+                  "host_to_device_bytes_per_batch": args.batch * cw * chh * 3, "returns": "detections",
+                  "timing": "%d batches submitted AND drained inside the window, three in flight" % (nb + 3),
+                  "preproc_kernel": {"ms_per_batch": pre, "algorithmic_bytes": pre_bytes,
+                                     "achieved_gbs": pre_bytes / (pre * 1e-3) / 1e9 if pre else None,
+                                     "frac_of_hbm_peak": pre_bytes / (pre * 1e-3) / 8e12 if pre else None,
+                                     "how": "HIP events around letterbox_tiled_kernel on the upload stream (mars_hip_pipe_camera_ms), median"}}
+
     result = None
     if rank == 0 and args.ops:
         import ctypes as C
@@ -529,7 +571,8 @@ def main():
         # summed durations; the matrix-roof view of the same launches is reported next to it.  f32: 4-byte activations but
         # a 32x lower matrix peak (157.3 TF, v_mfma_f32_16x16x4_f32): ridge 20 flop/B against ~65 flop/B -> the roof is MFMA.
         roof = {"bound": "mfma" if f32 else "hbm",
-                "kernel": (("conv_f32_split (v_mfma_f32_16x16x32_bf16, %d per product)" % (3 if args.f32_mode == 3 else 6) if args.f32_mode >= 3 else "conv_f32_mfma / conv_f32_kernel") if f32 else "conv_i8_*") + " (%d launches per step)" % n_conv,
+                "kernel": (("conv_f32_patch / conv_f32_stem (k x k layers: input patch staged and split once) + conv_f32_split (1 x 1 layers); v_mfma_f32_16x16x32_bf16, 3 per product" if args.f32_mode == 3
+                            else "conv_f32_split (v_mfma_f32_16x16x32_bf16, 6 per product)" if args.f32_mode == 4 else "conv_f32_mfma / conv_f32_kernel") if f32 else "conv_i8_*") + " (%d launches per step)" % n_conv,
                 "achieved": achieved if f32 else hbm_gbs, "peak": peak if f32 else 8000.0, "unit": "TFLOP/s" if f32 else "GB/s",
                 "frac": (achieved / peak) if f32 else hbm_gbs / 8000.0,
                 "traffic": traffic, "traffic_source": traffic_src,
@@ -598,6 +641,8 @@ def main():
             if world == 1:
                 result["pipelined_detections_images_per_s"] = pipe_rates.get("detections")
                 result["pipelined_raw_outputs_images_per_s"] = pipe_rates.get("raw_outputs")
+        if camera is not None:
+            result["camera_io"] = camera
         if multi:
             result["config"]["rccl"] = rccl_info
         if world == 1 and not args.timed_only:
@@ -665,10 +710,16 @@ def main():
             model.download()
             if f32:  # north_star: within 1e-4 on the float32 models
                 worst = 0.0
+                heads = []  # is the comparison informative?  finite share and magnitude of every head, on both sides
                 for f in range(len(ref_outs)):
                     for i in range(len(out_ids)):
                         a = model.output_view(i)[f].view(np.float32).astype(np.float64)
                         b = ref_outs[f][i].view(np.float32).astype(np.float64)
+                        fin = np.isfinite(a) & np.isfinite(b)
+                        sane = fin & (np.abs(b) < 1e6)
+                        heads.append({"head": i, "finite_fraction_gpu": float(np.isfinite(a).mean()), "finite_fraction_reference": float(np.isfinite(b).mean()),
+                                      "max_abs_reference": float(np.abs(b[fin]).max()) if fin.any() else None,
+                                      "worst_relative_error_where_finite_and_below_1e6": float((np.abs(a - b)[sane] / np.maximum(1.0, np.abs(b)[sane])).max()) if sane.any() else None})
                         if (np.isnan(a) != np.isnan(b)).any() or (np.isinf(a) != np.isinf(b)).any():
                             worst = float("inf")  # a NaN / inf on one side only is a failure, not a value np.nanmax may drop
                         bad = ~((np.isnan(a) & np.isnan(b)) | (a == b))
@@ -677,6 +728,7 @@ def main():
                             worst = float("inf") if np.isnan(err).any() else max(worst, float(err.max()))
                 base["gpu_matches_within_1e-4"] = bool(worst <= 1e-4)
                 base["worst_relative_error"] = worst
+                base["heads"] = heads
                 same = worst == 0.0
             else:
                 same = all(np.array_equal(ref_outs[f][i], model.output_view(i)[f])

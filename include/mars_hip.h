@@ -173,6 +173,12 @@ typedef struct {
     int det_outputs[4];     /* detect: output indices forming the prediction list, as for mars_hip_detect */
     int n_det_outputs;
     float nms_thresh;
+    int camera_w, camera_h; /* both > 0: CAMERA mode.  Graph input 0 (int8, 3 channels) is fed from uint8 RGB frames of camera_w x
+                             * camera_h: mars_hip_pipe_input(model, 0) is then a pinned buffer of [batch][camera_h][camera_w][3] bytes,
+                             * and a submit uploads it and runs the letterbox / px - 128 front-end (the reference's load_image(),
+                             * src/mars/mars_yolo_test.c:40-77, as mars_hip_preprocess does it) on the upload stream, into the
+                             * slot's graph input -- the demo's whole loop (:132-214: load_image -> run -> parse_output -> nms),
+                             * three batches in flight.  0 / 0: the graph inputs themselves are uploaded (as before). */
 } mars_hip_pipe_opts_t;
 mars_error_t mars_hip_pipe_open(mars_model_t *model, const mars_hip_pipe_opts_t *opts);
 /* pinned host buffer ([batch][frame bytes]) to fill for the NEXT submit; changes after every submit */
@@ -187,6 +193,8 @@ mars_error_t mars_hip_pipe_submit(mars_model_t *model);
  * are overwritten by the submit after that. */
 mars_error_t mars_hip_pipe_wait(mars_model_t *model, const void **outputs, const mars_det_t **dets, const int **counts);
 void mars_hip_pipe_close(mars_model_t *model);
+/* camera mode: device time (ms) of the image front-end kernel of the batch mars_hip_pipe_wait() handed out last; < 0 = not available */
+float mars_hip_pipe_camera_ms(mars_model_t *model);
 
 /* --------------------------------------------------- synthetic .mars writer */
 /* Well-formed graphs (NHWC activations, OHWI int8 weights, int32 bias; or
@@ -218,6 +226,10 @@ int mars_yolo_letterbox(const unsigned char *rgb, int w, int h, int tw, int th, 
  * (mars_yolo_test.c:157-165); follow with mars_hip_run_device().  Input must be int8 with 3 channels. */
 mars_error_t mars_hip_preprocess(mars_model_t *model, int input_index, const unsigned char *rgb_frames, int w, int h,
                                  int first_frame, int frames);
+/* The same front-end on frames that are ALREADY in device memory (a capture card writing into HBM, or a caller's own upload):
+ * rgb_dev = frames x [h][w][3] bytes, contiguous; enqueued on the library's current stream, no synchronisation. */
+mars_error_t mars_hip_preprocess_device(mars_model_t *model, int input_index, const void *rgb_dev, int w, int h,
+                                        int first_frame, int frames);
 
 #ifdef __cplusplus
 }

@@ -161,6 +161,11 @@ SYNTH = [
     ("v5n_64_nchw", dict(width_x16=4, input_hw=64, nchw_int8=True, seed=4)),
     ("tiny_32_f32", dict(tiny=True, input_hw=32, float32=True, seed=5)),
     ("v5n_64_f32", dict(width_x16=4, input_hw=64, float32=True, seed=6)),   # config 5 topology (yolov5 f32), small
+    # the same topology at a size where EVERY map width is a multiple of 4 (64 ... 4), as at config 5's 640 x 640 (160 ... 20): the
+    # reference's CONCAT copies runs of shape[3] = W BYTES at byte offsets that are multiples of W (mars_runtime.c:977-996), so with
+    # W % 4 != 0 (the 2-wide map of the 64 x 64 twin, the 10- / 5-wide ones of a 160 x 160 twin) floats are cut between bytes and
+    # 1e38-sized values appear; with W % 4 == 0 whole floats move and every tensor stays O(0.1) -- the WELL-CONDITIONED float twin
+    ("v5n_128_f32", dict(width_x16=4, input_hw=128, float32=True, seed=9)),
     # per-convolution scales: no two fused tables (or folded-Add factors) are equal, so a launch that picks up a
     # neighbour's table shows (the plain twins share one scale per tensor kind and once hid exactly that in a pair)
     ("v5n_64_vs", dict(width_x16=4, input_hw=64, seed=7, vary_scales=True)),

@@ -113,3 +113,12 @@ def test_bench_starts_its_own_ranks():
                           "--batch", "2", "--hw", "160", "--width", "4", "--no-cpu-baseline", "--sustain-s", "0", "--timed-only"],
                          capture_output=True, text=True, timeout=600, env=env)
     assert out.returncode != 0 and out.stdout == ""
+
+
+def test_bench_camera_leg():
+    """--io camera: the reference demo's whole loop (RGB camera frames -> front-end -> graph -> decode + NMS -> detections), pipelined"""
+    d = run_bench("--no-cpu-baseline", "--io", "camera", "--sustain-s", "0")
+    c = d["camera_io"]
+    assert c["images_per_s"] > 0 and "1280x720" in c["frame"] and c["host_to_device_bytes_per_batch"] == 4 * 1280 * 720 * 3
+    k = c["preproc_kernel"]
+    assert k["ms_per_batch"] > 0 and k["achieved_gbs"] > 0 and 0 < k["frac_of_hbm_peak"] < 1

@@ -73,3 +73,37 @@ def test_preprocess_into_model_input(gpu, orc):
     with pytest.raises(gpu.MarsError):
         m.preprocess(frames, first_frame=1)  # frames beyond the batch
     m.close()
+
+
+def test_camera_pipe_equals_preprocess_run_detect(gpu):
+    """mars_hip_pipe_* in camera mode (RGB frames up, front-end on the device, graph, tail, detections back; three batches in
+    flight) returns, batch for batch, what mars_hip_preprocess + run + detect give for the same frames"""
+    import marsfile
+    from conftest import lcg_frame
+    d = gpu.synth_model(width_x16=4, input_hw=128, seed=31)
+    hdr, tensors, _ = marsfile.parse(d)
+    B, cw, ch = 3, 200, 152
+    outputs = tuple(range(len(hdr["outputs"])))
+    frames = [[lcg_frame(0xCA300 + 10 * k + f, cw * ch * 3).reshape(ch, cw, 3) for f in range(B)] for k in range(5)]
+    m = gpu.Model(d, batch=B)
+    want = []
+    for k in range(5):
+        m.preprocess(np.stack(frames[k]))
+        m.run_device()
+        want.append([x.tobytes() for x in m.detect(outputs=outputs, thresh=0.45)])
+    m.pipe_open(download_outputs=False, detect=True, det_outputs=outputs, thresh=0.45, camera=(cw, ch))
+    got = []
+    for k in range(5):
+        v = m.pipe_input_view(0)
+        assert v.shape == (B, cw * ch * 3)
+        for f in range(B):
+            v[f] = frames[k][f].reshape(-1)
+        m.pipe_submit()
+        if k >= 2:
+            got.append([x.tobytes() for x in m.pipe_wait()[1]])
+            assert gpu.lib().mars_hip_pipe_camera_ms(m.p) > 0
+    for _ in range(2):
+        got.append([x.tobytes() for x in m.pipe_wait()[1]])
+    m.pipe_close()
+    m.close()
+    assert got == want and sum(len(b) for w_ in want for b in w_) > 0

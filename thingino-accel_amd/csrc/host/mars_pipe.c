@@ -13,6 +13,9 @@
  *     aux stream       decode + NMS(k)          |  (upload -> graph -> tail -> download -> slot free)
  *     download stream  D2H(k-1)
  *
+ * Camera mode (opts.camera_w / camera_h): what is uploaded for input 0 is the camera's uint8 RGB frames, and the image front-end
+ * (letterbox resize + px - 128, mars_preproc.c) runs behind the copy on the upload stream: the reference demo's whole loop.
+ *
  * What travels back is the caller's choice: the raw graph outputs (as mars_run leaves them), the detections of the
  * decode + NMS tail (24 KB per frame at most instead of 2.1 MB of head tensors), or both.
  */
@@ -32,11 +35,13 @@
 typedef struct {
     uint8_t *in_host[MARS_MAX_IO], *in_dev[MARS_MAX_IO];
     uint8_t *out_host[MARS_MAX_IO], *out_dev[MARS_MAX_IO], *out_dense[MARS_MAX_IO];
+    uint8_t *rgb_dev; /* camera mode: the uploaded RGB frames of input 0 (in_host[0] is their pinned source) */
     mars_det_t *det_host;
     int *cnt_host;
     void *det_dev;
     int *cnt_dev;
     void *ev_up, *ev_graph, *ev_tail, *ev_down;
+    void *ev_pre0, *ev_pre1; /* camera mode: around the front-end kernel (timing events: mars_hip_pipe_camera_ms) */
     int used; /* the slot has been submitted before: its events are meaningful */
 } pipe_slot_t;
 
@@ -64,6 +69,7 @@ static void slot_free(pipe_slot_t *s) {
         if (s->out_dev[i]) mhip_free(s->out_dev[i]);
         if (s->out_dense[i]) mhip_free(s->out_dense[i]);
     }
+    if (s->rgb_dev) mhip_free(s->rgb_dev);
     if (s->det_host) mhip_host_free(s->det_host);
     if (s->cnt_host) mhip_host_free(s->cnt_host);
     if (s->det_dev) mhip_free(s->det_dev);
@@ -72,6 +78,8 @@ static void slot_free(pipe_slot_t *s) {
     if (s->ev_graph) mhip_event_destroy(s->ev_graph);
     if (s->ev_tail) mhip_event_destroy(s->ev_tail);
     if (s->ev_down) mhip_event_destroy(s->ev_down);
+    if (s->ev_pre0) mhip_event_destroy(s->ev_pre0);
+    if (s->ev_pre1) mhip_event_destroy(s->ev_pre1);
     memset(s, 0, sizeof(*s));
 }
 
@@ -104,6 +112,8 @@ mars_error_t mars_hip_pipe_open(mars_model_t *model, const mars_hip_pipe_opts_t 
     if (!m->act_dev || !m->arena_dev) return MARS_ERR_NNA_INIT_FAILED;
     if (!opts->download_outputs && !opts->detect) return MARS_ERR_INVALID_LAYER; /* nothing would come back */
     if (opts->detect && (opts->n_det_outputs <= 0 || opts->n_det_outputs > 4)) return MARS_ERR_INVALID_TENSOR;
+    const int camera = opts->camera_w > 0 && opts->camera_h > 0;
+    if ((opts->camera_w > 0) != (opts->camera_h > 0) || opts->camera_w < 0 || opts->camera_h < 0) return MARS_ERR_INVALID_FILE;
     if (model->header.num_inputs > MARS_MAX_IO || model->header.num_outputs > MARS_MAX_IO) return MARS_ERR_INVALID_FILE;
     mars_hip_pipe_close(model);
     if (mhip_sync()) return MARS_ERR_LAYER_FAILED;
@@ -127,10 +137,13 @@ mars_error_t mars_hip_pipe_open(mars_model_t *model, const mars_hip_pipe_opts_t 
         for (uint32_t i = 0; i < model->header.num_inputs && err == MARS_OK; i++) {
             mtensor_t *t = io_tensor(m, 0, (int)i);
             if (!t) continue;
-            sl->in_host[i] = (uint8_t *)mhip_host_alloc(t->bytes > 0 ? t->bytes * B : 64);
+            const size_t cam_b = (i == 0 && camera) ? (size_t)opts->camera_w * opts->camera_h * 3 * B : 0;
+            const size_t host_b = cam_b ? cam_b : (t->bytes > 0 ? t->bytes * B : 64);
+            sl->in_host[i] = (uint8_t *)mhip_host_alloc(host_b);
             sl->in_dev[i] = (uint8_t *)mhip_malloc(t->stride * B + 256);
-            if (!sl->in_host[i] || !sl->in_dev[i]) { err = MARS_ERR_ALLOC_FAILED; break; }
-            memset(sl->in_host[i], 0, t->bytes * B);
+            if (cam_b) sl->rgb_dev = (uint8_t *)mhip_malloc(cam_b);
+            if (!sl->in_host[i] || !sl->in_dev[i] || (cam_b && !sl->rgb_dev)) { err = MARS_ERR_ALLOC_FAILED; break; }
+            memset(sl->in_host[i], 0, host_b);
             if (mhip_memset_async(sl->in_dev[i], 0, t->stride * B + 256)) err = MARS_ERR_ALLOC_FAILED;
         }
         for (uint32_t i = 0; i < model->header.num_outputs && err == MARS_OK; i++) {
@@ -160,6 +173,18 @@ mars_error_t mars_hip_pipe_open(mars_model_t *model, const mars_hip_pipe_opts_t 
         sl->ev_tail = mhip_event_create_sync();
         sl->ev_down = mhip_event_create();
         if (!sl->ev_up || !sl->ev_graph || !sl->ev_tail || !sl->ev_down) err = MARS_ERR_ALLOC_FAILED;
+        if (camera) {
+            sl->ev_pre0 = mhip_event_create();
+            sl->ev_pre1 = mhip_event_create();
+            if (!sl->ev_pre0 || !sl->ev_pre1) err = MARS_ERR_ALLOC_FAILED;
+        }
+    }
+    if (err == MARS_OK && camera) { /* the front-end's gather tables: built and uploaded now, not behind the first submit */
+        mtensor_t *t0 = io_tensor(m, 0, 0);
+        const mars_tensor_t *d0 = &model->tensors[model->header.input_tensor_ids[0]].desc;
+        const int nhwc = d0->format == MARS_FORMAT_NHWC;
+        const int th = nhwc ? d0->shape[1] : d0->shape[2], tw = nhwc ? d0->shape[2] : d0->shape[3], ch = nhwc ? d0->shape[3] : d0->shape[1];
+        if (!t0 || ch != 3 || d0->dtype != MARS_DTYPE_INT8 || mars_preproc_prepare(opts->camera_w, opts->camera_h, tw, th)) err = MARS_ERR_INVALID_TENSOR;
     }
     if (err == MARS_OK && opts->detect) /* decode tables: built and uploaded once, before anything is in flight */
         err = mars_detect_prepare(m, opts->det_outputs, opts->n_det_outputs);
@@ -187,9 +212,20 @@ mars_error_t mars_hip_pipe_submit(mars_model_t *model) {
     /* ---- upload stream: the slot's device inputs were last read by the graph of its previous use */
     mhip_select_stream(2);
     if (sl->used) rc = mhip_stream_wait(2, sl->ev_graph);
+    const int camera = pp->opts.camera_w > 0;
     for (uint32_t i = 0; i < model->header.num_inputs && !rc; i++) {
         mtensor_t *t = io_tensor(m, 0, (int)i);
         if (!t || !t->bytes) continue;
+        if (i == 0 && camera) { /* RGB frames up, then the front-end on the same stream into this slot's graph input */
+            uint8_t *own = t->dev;
+            rc = mhip_h2d_async(sl->rgb_dev, sl->in_host[0], (size_t)pp->opts.camera_w * pp->opts.camera_h * 3 * B);
+            t->dev = sl->in_dev[0];
+            if (!rc) rc = mhip_event_record(sl->ev_pre0);
+            if (!rc && mars_hip_preprocess_device(model, 0, sl->rgb_dev, pp->opts.camera_w, pp->opts.camera_h, 0, (int)B) != MARS_OK) rc = -1;
+            if (!rc) rc = mhip_event_record(sl->ev_pre1);
+            t->dev = own;
+            continue;
+        }
         rc = mhip_h2d_2d_async(sl->in_dev[i], t->stride, sl->in_host[i], t->bytes, t->bytes, B);
     }
     if (!rc) rc = mhip_event_record(sl->ev_up);
@@ -248,6 +284,17 @@ mars_error_t mars_hip_pipe_submit(mars_model_t *model) {
     pp->head = (pp->head + 1) % PIPE_SLOTS;
     pp->inflight++;
     return MARS_OK;
+}
+
+/* camera mode: device time of the front-end kernel (letterbox + px - 128 of one batch) of the batch most recently handed out by
+ * mars_hip_pipe_wait(), in milliseconds; < 0 = not available */
+float mars_hip_pipe_camera_ms(mars_model_t *model) {
+    if (!model) return -1.f;
+    mars_pipe_t *pp = (mars_pipe_t *)((mars_model_ext_t *)model)->pipe;
+    if (!pp || pp->opts.camera_w <= 0) return -1.f;
+    const pipe_slot_t *sl = &pp->slot[(pp->tail + PIPE_SLOTS - 1) % PIPE_SLOTS];
+    if (!sl->used || !sl->ev_pre0 || !sl->ev_pre1) return -1.f;
+    return mhip_event_elapsed_ms(sl->ev_pre0, sl->ev_pre1);
 }
 
 mars_error_t mars_hip_pipe_wait(mars_model_t *model, const void **outputs, const mars_det_t **dets, const int **counts) {

@@ -286,12 +286,16 @@ int mars_yolo_letterbox(const unsigned char *rgb, int w, int h, int tw, int th, 
     return rc ? -1 : 0;
 }
 
-/* camera batch: `frames` RGB frames of w x h (host, contiguous) -> frames [first_frame, first_frame + frames) of
- * graph input `input_index` on the device, in the layout the input tensor's format tag asks for
- * (mars_yolo_test.c:157-165).  The frames are staged through one device buffer; no host-side pixel work. */
-mars_error_t mars_hip_preprocess(mars_model_t *model, int input_index, const unsigned char *rgb_frames, int w, int h,
-                                 int first_frame, int frames) {
-    if (!model || !rgb_frames || w <= 0 || h <= 0 || frames <= 0 || first_frame < 0) return MARS_ERR_INVALID_FILE;
+/* build (and cache) the gather tables of a geometry ahead of the first frame: the pipelined camera path calls it when the pipe opens */
+int mars_preproc_prepare(int w, int h, int tw, int th) {
+    geom_t *g;
+    return geometry(w, h, tw, th, &g);
+}
+
+/* geometry + target checks shared by the host and the device form */
+static mars_error_t preproc_target(mars_model_t *model, int input_index, int w, int h, int first_frame, int frames, geom_t **g,
+                                   int8_t **dst, size_t *dst_stride, int *nhwc_out) {
+    if (!model || w <= 0 || h <= 0 || frames <= 0 || first_frame < 0) return MARS_ERR_INVALID_FILE;
     mars_model_ext_t *m = (mars_model_ext_t *)model;
     if (!m->act_dev || !mhip_ready()) return MARS_ERR_NNA_INIT_FAILED;
     if (input_index < 0 || (uint32_t)input_index >= model->header.num_inputs || first_frame + frames > m->batch)
@@ -306,16 +310,45 @@ mars_error_t mars_hip_preprocess(mars_model_t *model, int input_index, const uns
     if (ch != 3 || t->dtype != MARS_DTYPE_INT8 || tw <= 0 || th <= 0 || !m->mt[ti].dev ||
         m->mt[ti].stride < (size_t)tw * th * 3)
         return MARS_ERR_INVALID_TENSOR;
+    if (geometry(w, h, tw, th, g)) return MARS_ERR_LAYER_FAILED;
+    *dst = (int8_t *)m->mt[ti].dev + (size_t)first_frame * m->mt[ti].stride;
+    *dst_stride = m->mt[ti].stride;
+    *nhwc_out = nhwc;
+    return MARS_OK;
+}
+
+/* camera batch: `frames` RGB frames of w x h (host, contiguous) -> frames [first_frame, first_frame + frames) of
+ * graph input `input_index` on the device, in the layout the input tensor's format tag asks for
+ * (mars_yolo_test.c:157-165).  The frames are staged through one device buffer; no host-side pixel work. */
+mars_error_t mars_hip_preprocess(mars_model_t *model, int input_index, const unsigned char *rgb_frames, int w, int h,
+                                 int first_frame, int frames) {
+    if (!rgb_frames) return MARS_ERR_INVALID_FILE;
     geom_t *g;
-    if (geometry(w, h, tw, th, &g)) return MARS_ERR_LAYER_FAILED;
+    int8_t *dst;
+    size_t dst_stride;
+    int nhwc;
+    const mars_error_t e = preproc_target(model, input_index, w, h, first_frame, frames, &g, &dst, &dst_stride, &nhwc);
+    if (e != MARS_OK) return e;
     const size_t in_b = (size_t)w * h * 3;
     uint8_t *d = (uint8_t *)mhip_malloc(in_b * (size_t)frames);
     if (!d) return MARS_ERR_ALLOC_FAILED;
     int rc = mhip_h2d_async(d, rgb_frames, in_b * (size_t)frames);
-    if (!rc)
-        rc = run_letterbox(g, d, in_b, (int8_t *)m->mt[ti].dev + (size_t)first_frame * m->mt[ti].stride, m->mt[ti].stride,
-                           frames, nhwc);
+    if (!rc) rc = run_letterbox(g, d, in_b, dst, dst_stride, frames, nhwc);
     if (mhip_sync()) rc = -1;
     mhip_free(d);
     return rc ? MARS_ERR_LAYER_FAILED : MARS_OK;
+}
+
+/* the same with the frames already in device memory: enqueued on the current stream, not synchronised (the pipelined camera
+ * path of mars_pipe.c, or a caller whose capture hardware writes into HBM) */
+mars_error_t mars_hip_preprocess_device(mars_model_t *model, int input_index, const void *rgb_dev, int w, int h,
+                                        int first_frame, int frames) {
+    if (!rgb_dev) return MARS_ERR_INVALID_FILE;
+    geom_t *g;
+    int8_t *dst;
+    size_t dst_stride;
+    int nhwc;
+    const mars_error_t e = preproc_target(model, input_index, w, h, first_frame, frames, &g, &dst, &dst_stride, &nhwc);
+    if (e != MARS_OK) return e;
+    return run_letterbox(g, (const uint8_t *)rgb_dev, (size_t)w * h * 3, dst, dst_stride, frames, nhwc) ? MARS_ERR_LAYER_FAILED : MARS_OK;
 }

@@ -82,7 +82,7 @@ class SynthOpts(C.Structure):
 
 class PipeOpts(C.Structure):
     _fields_ = [("download_outputs", C.c_int), ("detect", C.c_int), ("det_outputs", C.c_int * 4), ("n_det_outputs", C.c_int),
-                ("nms_thresh", C.c_float)]
+                ("nms_thresh", C.c_float), ("camera_w", C.c_int), ("camera_h", C.c_int)]
 
 
 assert C.sizeof(MarsHeader) == 76 and C.sizeof(MarsTensorDesc) == 124
@@ -114,8 +114,8 @@ EXPORTS = {
                    "mars_hip_set_profiling", "mars_hip_num_ops", "mars_hip_op_info", "mars_hip_stream",
                    "mars_hip_load_memory_ex", "mars_hip_param_arena", "mars_yolo_parse_output", "mars_yolo_nms",
                    "mars_hip_detect", "mars_hip_detect_device", "mars_synth_model", "mars_hip_set_tuning", "mars_hip_autotune", "mars_yolo_letterbox",
-                   "mars_hip_preprocess", "mars_hip_tensor_frame_bytes", "mars_hip_tensor_byte_size", "mars_hip_pipe_open",
-                   "mars_hip_pipe_input", "mars_hip_pipe_submit", "mars_hip_pipe_wait", "mars_hip_pipe_close", "mars_hip_set_output_mode",
+                   "mars_hip_preprocess", "mars_hip_preprocess_device", "mars_hip_tensor_frame_bytes", "mars_hip_tensor_byte_size", "mars_hip_pipe_open",
+                   "mars_hip_pipe_input", "mars_hip_pipe_submit", "mars_hip_pipe_wait", "mars_hip_pipe_close", "mars_hip_pipe_camera_ms", "mars_hip_set_output_mode",
                    "mars_hip_get_tuning", "mars_hip_model_set_tuning", "mars_hip_model_get_tuning"],
     "mars_compile.h": ["mars_compile_onnx", "mars_compile_file", "mars_compile_last_error"],
 }
@@ -168,6 +168,8 @@ def lib():
     L.mars_hip_pipe_input.restype = C.c_void_p
     L.mars_hip_pipe_input.argtypes = [P(MarsModel), C.c_int]
     L.mars_hip_pipe_submit.argtypes = [P(MarsModel)]
+    L.mars_hip_pipe_camera_ms.restype = C.c_float
+    L.mars_hip_pipe_camera_ms.argtypes = [P(MarsModel)]
     L.mars_hip_pipe_wait.argtypes = [P(MarsModel), P(C.c_void_p), P(C.c_void_p), P(C.c_void_p)]
     L.mars_hip_pipe_close.argtypes = [P(MarsModel)]
     L.mars_hip_pipe_close.restype = None
@@ -184,6 +186,7 @@ def lib():
     L.mars_hip_autotune.argtypes = [P(MarsModel), C.c_int]
     L.mars_yolo_letterbox.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]
     L.mars_hip_preprocess.argtypes = [P(MarsModel), C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int]
+    L.mars_hip_preprocess_device.argtypes = [P(MarsModel), C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int]
     L.mars_hip_set_profiling.argtypes = [P(MarsModel), C.c_int]
     L.mars_hip_set_profiling.restype = None
     L.mars_hip_tensor_device.restype = C.c_void_p
@@ -430,18 +433,25 @@ class Model:
             raise MarsError(rc, "mars_hip_detect_device")
 
     # -- pipelined host I/O (mars_hip_pipe_*)
-    def pipe_open(self, download_outputs=True, detect=False, det_outputs=(0,), thresh=0.45):
+    def pipe_open(self, download_outputs=True, detect=False, det_outputs=(0,), thresh=0.45, camera=None):
+        """camera = (w, h): input 0 is fed from uint8 RGB camera frames, the letterbox front-end runs on the device behind the upload"""
+        cw, ch = camera if camera else (0, 0)
         o = PipeOpts(int(download_outputs), int(detect), (C.c_int * 4)(*(list(det_outputs) + [0] * (4 - len(det_outputs)))),
-                     len(det_outputs) if detect else 0, thresh)
+                     len(det_outputs) if detect else 0, thresh, int(cw), int(ch))
         rc = lib().mars_hip_pipe_open(self.p, C.byref(o))
         if rc != MARS_OK:
             raise MarsError(rc, "mars_hip_pipe_open")
         self._pipe = (bool(download_outputs), bool(detect))
+        self._pipe_camera = (int(cw), int(ch)) if camera else None
 
     def pipe_input_view(self, i=0):
-        """uint8 view [batch, frame_bytes] of the staging buffer the NEXT pipe_submit() uploads"""
+        """uint8 view [batch, frame_bytes] of the staging buffer the NEXT pipe_submit() uploads (camera mode, input 0:
+        [batch, h * w * 3] RGB bytes)"""
         ptr = lib().mars_hip_pipe_input(self.p, i)
-        n = lib().mars_hip_tensor_frame_bytes(self.p, self.header.input_tensor_ids[i]) * self.batch
+        if i == 0 and getattr(self, "_pipe_camera", None):
+            n = self._pipe_camera[0] * self._pipe_camera[1] * 3 * self.batch
+        else:
+            n = lib().mars_hip_tensor_frame_bytes(self.p, self.header.input_tensor_ids[i]) * self.batch
         return np.ctypeslib.as_array(C.cast(ptr, C.POINTER(C.c_uint8)), shape=(n,)).reshape(self.batch, -1)
 
     def pipe_submit(self):
