@@ -40,6 +40,8 @@ def main():
     ap.add_argument("--width", type=int, default=8)
     ap.add_argument("--hw", type=int, default=640)
     ap.add_argument("--batch", type=int, default=256)
+    ap.add_argument("--family", default="conv_i8", help="kernel-name prefix of the dominant family (conv_i8 | conv_f32)")
+    ap.add_argument("--dtype", default="int8")
     a = ap.parse_args()
     rd, nrd = read(a.fetch, "FETCH_SIZE")
     wr, nwr = read(a.write, "WRITE_SIZE")
@@ -49,13 +51,13 @@ def main():
         rows.append({"kernel": k, "launches": launches, "launches_per_step": launches / a.executions,
                      "read_bytes_per_step": 2.0 * rd.get(k, 0) * 1024 / a.executions,
                      "write_bytes_per_step": wr.get(k, 0) * 1024 / a.executions})
-    conv = [r for r in rows if r["kernel"].startswith("conv_i8")]
+    conv = [r for r in rows if r["kernel"].startswith(a.family)]
     import importlib.util
     spec = importlib.util.spec_from_file_location("bench", os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "bench.py"))
     bench = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(bench)
     out = {"note": a.note, "kernel_source_sha16": bench.kernel_source_sha16(),
-           "config": {"width": a.width, "hw": a.hw, "batch": a.batch}, "executions": a.executions, "fetch_size_doubled": True, "kernels": rows,
+           "config": {"width": a.width, "hw": a.hw, "batch": a.batch}, "dtype": a.dtype, "family": a.family, "executions": a.executions, "fetch_size_doubled": True, "kernels": rows,
            "conv_i8": {"launches_per_step": sum(r["launches_per_step"] for r in conv),
                        "read_bytes_per_step": sum(r["read_bytes_per_step"] for r in conv),
                        "write_bytes_per_step": sum(r["write_bytes_per_step"] for r in conv)},
@@ -67,7 +69,7 @@ def main():
     for r in rows:
         print("%-44s %6.1f launches/step  read %8.1f MB  write %8.1f MB" % (r["kernel"][:44], r["launches_per_step"],
               r["read_bytes_per_step"] / 1e6, r["write_bytes_per_step"] / 1e6))
-    print("conv_i8 per step: read %.3f GB write %.3f GB" % (out["conv_i8"]["read_bytes_per_step"] / 1e9, out["conv_i8"]["write_bytes_per_step"] / 1e9))
+    print("%s per step: read %.3f GB write %.3f GB" % (a.family, out["conv_i8"]["read_bytes_per_step"] / 1e9, out["conv_i8"]["write_bytes_per_step"] / 1e9))
 
 
 if __name__ == "__main__":
