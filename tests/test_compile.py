@@ -377,6 +377,29 @@ def test_malformed_input_is_refused(marsrt):
             pass
 
 
+def test_weights_with_few_dims_or_no_inline_payload_compile_like_the_reference(marsrt):
+    """the payload check guards the allocation of the --nhwc re-order of quantised weights, nothing else.  A weight with
+    three dims (kh / kw then default to 3, as in the reference's `dims.get(2).unwrap_or(3)`) and an initializer without an inline
+    payload (external data: the reference reads raw_data only and gets an empty blob) compile wherever that re-order does not run;
+    under --nhwc a payload shorter than the o x i x 3 x 3 bytes the re-order walks is refused instead of asking for memory."""
+    x, y = [ox.value_info("x", [1, 3, 8, 8])], [ox.value_info("y", [1, 2, 8, 8])]
+    w3 = ox.tensor("w", np.ones((2, 3, 3), np.float32))  # Conv1d-style: [O, I, K]
+    d = marsrt.compile_onnx(ox.model([ox.node("Conv", ["x", "w"], ["y"])], [w3], x, y))
+    hdr, T, L = marsfile.parse(d)
+    wt = [t for t in T if t["size"]][0]
+    assert list(wt["shape"][:4]) == [2, 3, 3, 3] and wt["size"] == 18  # the 18 values present, quantised; dims as the reference writes them
+    d = marsrt.compile_onnx(ox.model([ox.node("Conv", ["x", "w"], ["y"])], [w3], x, y), float32=True)
+    assert [t for t in marsfile.parse(d)[1] if t["size"]][0]["size"] == 72
+    ext = ox.tensor("w", None, dims=[2, 3, 3, 3], dtype=ox.FLOAT)  # no raw_data, no typed field
+    d = marsrt.compile_onnx(ox.model([ox.node("Conv", ["x", "w"], ["y"])], [ext], x, y), float32=True)
+    assert len(marsfile.parse(d)[2]) == 1
+    with pytest.raises(ValueError, match="shorter than its dims"):
+        marsrt.compile_onnx(ox.model([ox.node("Conv", ["x", "w"], ["y"])], [w3], x, y), nhwc=True)
+    big = ox.tensor("w", None, dims=[1 << 12, 1 << 12, 3, 3], dtype=ox.INT8)  # 150 M elements declared, none present
+    with pytest.raises(ValueError, match="shorter than its dims"):
+        marsrt.compile_onnx(ox.model([ox.node("Conv", ["x", "w"], ["y"])], [big], x, y), nhwc=True)
+
+
 def test_long_names_are_cut_to_59_bytes(marsrt):
     long = "n" * 100
     m = ox.model([ox.node("Relu", ["x"], [long])], [], [ox.value_info("x", [1, 3, 4, 4])], [ox.value_info(long, [1, 3, 4, 4])])

@@ -761,9 +761,12 @@ struct compiler_t {
         uint32_t oc = (uint32_t)at_or(wt->dims, 0, 1), ic = (uint32_t)at_or(wt->dims, 1, 1);
         uint32_t kh = (uint32_t)at_or(wt->dims, 2, 3), kw = (uint32_t)at_or(wt->dims, 3, 3);
         if ((uint64_t)oc * ic * kh * kw > ((uint64_t)1 << 28)) bail("Conv weight dims out of range"); /* the --nhwc re-order allocates that many bytes */
-        /* ... and only for weights that are really there: the declared element count must be covered by the initializer's payload
-         * (1 byte per int8 element, 2 / 4 per half / float), or a few-KB file could ask for 256 MB per node */
-        if ((uint64_t)oc * ic * kh * kw > (uint64_t)wt->data.size()) bail("Conv weight initializer shorter than its dims");
+        /* ... and, where that allocation happens (quantised weights under --nhwc), only for weights that are really there: the element
+         * count the re-order walks must be covered by the initializer's payload, or a few-KB file could ask for 256 MB per node
+         * (ADVICE r3).  Elsewhere the payload is copied as it is, as the reference does -- weights with fewer than four dims (kh / kw
+         * then default to 3) and initializers without an inline payload (external data) compile like there */
+        if (quantize && nhwc && (uint64_t)oc * ic * kh * kw > (uint64_t)wt->data.size())
+            bail("Conv weight initializer shorter than its dims");
 
         std::vector<uint8_t> wdata;
         float w_scale = 1.0f;
