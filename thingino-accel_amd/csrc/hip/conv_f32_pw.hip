@@ -87,7 +87,9 @@ __global__ __launch_bounds__(PW_NT, 2) void conv_f32_pw(const mhip_conv_f32_t p,
     constexpr int NPG = BN / 4;             // 4-pixel groups of a tile
     constexpr int CPI = 32 * NPG / PW_NT;   // channels per thread and step: 4 (BN 256) | 8 (BN 512)
     constexpr int NCS = 32 / CPI;           // channel sub-groups
-    constexpr int SLOT = 4 * BN * 32;       // [4 channel groups][BN pixels][32 bytes]
+    constexpr int PP = BN * 32 + 32;        // pitch of a channel-group plane: + 32 bytes, so that the four planes start in four different
+                                            // quarters of the 128-byte bank period (see the lane mapping below)
+    constexpr int SLOT = 4 * PP;            // [4 channel groups][BN pixels][32 bytes]
     extern __shared__ __attribute__((aligned(16))) int8_t lds[];
     int8_t *wst = lds;              // two weight stages
     int8_t *xs = lds + 2 * WSTAGE;  // two input slots
@@ -102,8 +104,13 @@ __global__ __launch_bounds__(PW_NT, 2) void conv_f32_pw(const mhip_conv_f32_t p,
     const __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc((void *)p.in, 0, (int)g.in_bytes, 0x00020000);
 
     // ---- this thread's share of a step's input: pixels 4 ipg .. + 3 of the tile, channels ics * CPI .. + CPI - 1 of the step's 32
-    const int ipg = tid % NPG, ics = tid / NPG;
-    int8_t *xdst = xs + (((ics * CPI) >> 3) * BN + 4 * ipg) * 32 + ((ics * CPI) & 7) * 2; // record of pixel 4 ipg in its channel group
+    // Lane mapping: the channel sub-group varies FASTEST.  A lane's four pixels are four consecutive 32-byte records, so for a given
+    // pixel slot every lane of a wave writes at the same offset inside the 128-byte bank period -- with the pixel group fastest the
+    // eight LDS writes of a step were 16-way bank conflicts (first form of this kernel: 6000 cycles per step).  With the sub-group
+    // fastest, 8 consecutive lanes write the 8 different 8-byte pieces of (4 planes x 32-byte period quarters x 2 halves): 2-way.  The
+    // loads stay coalesced: the lanes of one load instruction that share a channel cover 128 contiguous bytes.
+    const int ics = tid % NCS, ipg = tid / NCS;
+    int8_t *xdst = xs + ((ics * CPI) >> 3) * PP + 4 * ipg * 32 + ((ics * CPI) & 7) * 2; // record of pixel 4 ipg in its channel group
     v4i bregs[2][CPI]; // two sets: the loads of step t + 2 are in flight while step t + 1's are split (two steps of latency)
     unsigned xoff; // byte offset of (frame, channel 0, position) of the lane's 4 pixels of the tile being fetched; ~0 = none
     auto fetch_setup = [&](unsigned t) __attribute__((always_inline)) {
@@ -112,11 +119,14 @@ __global__ __launch_bounds__(PW_NT, 2) void conv_f32_pw(const mhip_conv_f32_t p,
         xoff = t < g.ntiles && q < g.total_pix ? f * (unsigned)p.in_stride + pos * 4u : 0xffffffffu;
     };
     auto fetch_x = [&](int ks, v4i (&breg)[CPI]) __attribute__((always_inline)) { // step ks of the tile fetch_setup named
+        // (the channel goes into the PER-LANE offset: the sub-group differs inside a wave, and a scalar offset that is not
+        // wave-uniform makes the compiler serialise the load over its distinct values)
         const int c0 = ks * 32 + ics * CPI;
+        unsigned vo = xoff == 0xffffffffu ? 0xffffffffu : xoff + (unsigned)c0 * plane_bytes;
 #pragma unroll
         for (int j = 0; j < CPI; j++) {
-            const unsigned vo = c0 + j < g.C ? xoff : 0xffffffffu; // (beyond the last channel: zeros, like the weights there)
-            breg[j] = __builtin_bit_cast(v4i, __builtin_amdgcn_raw_buffer_load_b128(xrs, vo, (unsigned)(c0 + j) * plane_bytes, 0));
+            breg[j] = __builtin_bit_cast(v4i, __builtin_amdgcn_raw_buffer_load_b128(xrs, c0 + j < g.C ? vo : 0xffffffffu, 0, 0));
+            vo = vo == 0xffffffffu ? vo : vo + plane_bytes; // (beyond the last channel: zeros, like the weights there)
         }
     };
     auto commit_x = [&](int slot, const v4i (&breg)[CPI]) __attribute__((always_inline)) {
@@ -166,7 +176,7 @@ __global__ __launch_bounds__(PW_NT, 2) void conv_f32_pw(const mhip_conv_f32_t p,
     // ---- A rows (pixels) of this lane: the same LDS addresses for every tile
     const int8_t *pbase[NI];
 #pragma unroll
-    for (int n = 0; n < NI; n++) pbase[n] = xs + (fc * BN + wn * TN + n * 16 + fr) * 32;
+    for (int n = 0; n < NI; n++) pbase[n] = xs + fc * PP + (wn * TN + n * 16 + fr) * 32;
     unsigned ooff[NI];
     auto tile_setup = [&](unsigned t) __attribute__((always_inline)) {
 #pragma unroll
@@ -330,7 +340,7 @@ extern "C" unsigned long mhip_conv_f32_pw_launches(void) { return g_pw_launches;
 template <int BM, int WM, int WN, int BN>
 static int launch_pw(const mhip_conv_f32_t *p, pw_args_t &g) {
     auto kern = conv_f32_pw<BM, WM, WN, BN>;
-    const size_t ldsb = 2 * 2 * (size_t)BM * 64 + 2 * 4 * (size_t)BN * 32;
+    const size_t ldsb = 2 * 2 * (size_t)BM * 64 + 2 * 4 * ((size_t)BN * 32 + 32);
     static int cus = 0;
     if (!cus) {
         hipDeviceProp_t prop;
