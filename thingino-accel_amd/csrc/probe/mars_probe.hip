@@ -14,7 +14,7 @@
 // UNROLL independent 16-byte loads in flight per lane before the first store; the same with non-temporal loads and stores
 // (the data is touched once: no reason to keep it in L2 / the Infinity Cache).
 template <int UNROLL, bool NT>
-__global__ __launch_bounds__(256) void copy_probe(const uint4 *__restrict__ src, uint4 *__restrict__ dst, size_t n16) {
+__global__ __launch_bounds__(1024) void copy_probe(const uint4 *__restrict__ src, uint4 *__restrict__ dst, size_t n16) {
     const size_t stride = (size_t)gridDim.x * blockDim.x;
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     for (; i + (UNROLL - 1) * stride < n16; i += UNROLL * stride) {
@@ -60,10 +60,17 @@ extern "C" double mars_probe_copy_rate_gbs(size_t bytes, int reps) {
     if (hipStreamCreateWithFlags(&st, hipStreamNonBlocking) == hipSuccess && hipMalloc(&a, bytes) == hipSuccess && hipMalloc(&b, bytes) == hipSuccess &&
         hipEventCreate(&e0) == hipSuccess && hipEventCreate(&e1) == hipSuccess && hipMemsetAsync(a, 1, bytes, st) == hipSuccess &&
         hipMemcpyAsync(b, a, bytes, hipMemcpyDeviceToDevice, st) == hipSuccess) { // warm: first touch of both buffers
+        // Round 5: the runtime's blit is OpenCL C compiled at run time (the source sits in libamdhip64.so:
+        // `__amd_rocclr_copyBuffer`): `while (&dst[id] < end) { dst[id] = src[id]; id += next_chunk; }` on ulong2 -- one 16-byte load and
+        // store per lane and iteration, nothing unrolled; what differs from forms 1-5 can only be its launch geometry, so forms 6-11
+        // sweep that loop over workgroup sizes and grid sizes.
         static const char *names[] = {"hipMemcpyAsync", "kernel: 16 B/lane, 1 in flight, 8 workgroups/CU", "kernel: 16 B/lane, 4 in flight, 8 workgroups/CU",
                                       "kernel: 16 B/lane, 8 in flight, 4 workgroups/CU", "kernel: 16 B/lane, 4 in flight, non-temporal, 8 workgroups/CU",
-                                      "kernel: 16 B/lane, 8 in flight, non-temporal, 4 workgroups/CU"};
-        for (int form = 0; form < 6; form++) {
+                                      "kernel: 16 B/lane, 8 in flight, non-temporal, 4 workgroups/CU",
+                                      "kernel: 16 B/lane, 1 in flight, 1024-thread workgroups, 2/CU", "kernel: 16 B/lane, 1 in flight, 512-thread workgroups, 4/CU",
+                                      "kernel: 16 B/lane, 1 in flight, 256-thread workgroups, 16/CU", "kernel: 16 B/lane, 1 in flight, 256-thread workgroups, 32/CU",
+                                      "kernel: 16 B/lane, 2 in flight, 512-thread workgroups, 4/CU", "kernel: 16 B/lane, 1 in flight, 64-thread workgroups, 32/CU"};
+        for (int form = 0; form < 12; form++) {
             bool ok = hipEventRecord(e0, st) == hipSuccess;
             for (int i = 0; i < reps && ok; i++) {
                 const uint4 *s = (const uint4 *)a;
@@ -75,7 +82,13 @@ extern "C" double mars_probe_copy_rate_gbs(size_t bytes, int reps) {
                 case 2: hipLaunchKernelGGL((copy_probe<4, false>), dim3(cus * 8), dim3(256), 0, st, s, d, n); break;
                 case 3: hipLaunchKernelGGL((copy_probe<8, false>), dim3(cus * 4), dim3(256), 0, st, s, d, n); break;
                 case 4: hipLaunchKernelGGL((copy_probe<4, true>), dim3(cus * 8), dim3(256), 0, st, s, d, n); break;
-                default: hipLaunchKernelGGL((copy_probe<8, true>), dim3(cus * 4), dim3(256), 0, st, s, d, n); break;
+                case 5: hipLaunchKernelGGL((copy_probe<8, true>), dim3(cus * 4), dim3(256), 0, st, s, d, n); break;
+                case 6: hipLaunchKernelGGL((copy_probe<1, false>), dim3(cus * 2), dim3(1024), 0, st, s, d, n); break;
+                case 7: hipLaunchKernelGGL((copy_probe<1, false>), dim3(cus * 4), dim3(512), 0, st, s, d, n); break;
+                case 8: hipLaunchKernelGGL((copy_probe<1, false>), dim3(cus * 16), dim3(256), 0, st, s, d, n); break;
+                case 9: hipLaunchKernelGGL((copy_probe<1, false>), dim3(cus * 32), dim3(256), 0, st, s, d, n); break;
+                case 10: hipLaunchKernelGGL((copy_probe<2, false>), dim3(cus * 4), dim3(512), 0, st, s, d, n); break;
+                default: hipLaunchKernelGGL((copy_probe<1, false>), dim3(cus * 32), dim3(64), 0, st, s, d, n); break;
                 }
             }
             float ms = 0.f;
