@@ -989,6 +989,123 @@ def test_conv_f32_patch_shapes(gpu, orc, shape):
         gpu.set_tuning("dual_stream_min_batch", 64)
 
 
+F32_REC_CHAINS = [
+    # h, w, c0, producer (out_c, k, stride), consumer (out_c, k, stride), batch, residual   conv -> k x k conv with the tensor between them in record format
+    (20, 20, 64, (32, 1, 1), (16, 3, 1), 3, None),       # a C3 bottleneck's pair on a 20-wide map (whole-row tiles), 4 chunks, 4 dummy units
+    (12, 40, 64, (64, 1, 1), (64, 3, 1), 5, "x"),        # ... with the shortcut: Add(cv2(cv1(x)), x) folded into the second convolution
+    (40, 40, 128, (128, 1, 1), (128, 3, 1), 4, "x"),     # the 40 x 40 bottleneck of the twins: 128-channel tiles on both sides, 16 chunks, four ring slots
+    (24, 160, 48, (32, 1, 1), (64, 3, 1), 2, None),      # wide map: 2-D tiles out of 32-column strips
+    (40, 40, 48, (32, 1, 1), (130, 3, 2), 3, None),      # stride-2 reader (de-interleaved patch columns), two 128-channel tiles
+    (32, 160, 16, (64, 3, 2), (32, 3, 2), 2, None),      # the writer is a stride-2 3 x 3 on 16 channels (conv_f32_split's paired gather), the reader stride 2 on the 80-wide map
+    (16, 24, 40, (32, 1, 1), (24, 5, 1), 4, "r"),        # 5 x 5 reader, residual from a third tensor
+    (9, 20, 96, (96, 1, 1), (128, 3, 1), 37, "r"),       # short frames: frame boundaries inside a tile; 12 chunks (two ring slots: 12 % 4 == 0 -> four); 27 tiles
+    (80, 80, 64, (64, 1, 1), (64, 3, 1), 9, "x"),        # 113 tiles of 512 pixels: every workgroup walks a run of tiles
+    (64, 64, 3, (32, 6, 2), (64, 3, 2), 9, None),        # the twins' first two layers: conv_f32_stem writes the records, layer 3 reads them
+    (128, 160, 3, (24, 6, 2), (40, 3, 2), 3, None),      # ... 24 of the stem's 32 channels (3 chunks -> the reader declines: fewer than 4) -- stays NCHW floats
+]
+
+
+@pytest.mark.parametrize("shape", F32_REC_CHAINS, ids=lambda v: "x".join(str(q) for q in v).replace(" ", ""))
+def test_conv_f32_record_pairs(gpu, orc, shape):
+    """two float32 convolutions in a row (each + SIGMOID / MUL), the second k x k: under f32_mfma = 3 the planner keeps the tensor
+    between them in RECORD format (mars_plan.c rec_pairs: the first writes the two bf16 pieces channels-last, the second fills its patch
+    ring by LDS-DMA -- conv_f32_prec).  Every frame of the batch against the oracle within 1e-4 * max(1, |b|); the launch counters prove
+    which kernels ran; the tensor between them reads back (mars_hip_read_tensor converts) as the oracle's floats to 2^-15; at fusion
+    level 0 and in the other modes nothing is in record format and the results are the same."""
+    h, w, c0, (c1, k1, s1), (c2, k2, s2), B, res = shape
+    rng = np.random.default_rng(h * 1000 + w * 10 + c1 + c2)
+    G = marsfile.Graph()
+    F, N = marsfile.F32, marsfile.NCHW
+
+    def conv_silu(xin, ic, ih, iw, oc, k, st):
+        oh, ow = (ih + st - 1) // st, (iw + st - 1) // st
+        a = G.tensor([1, oc, oh, ow], dtype=F, fmt=N)
+        amp = 1.7 / (k * k * ic) ** 0.5
+        wt = G.tensor([oc, ic, k, k], dtype=F, fmt=marsfile.OIHW, data=((rng.random((oc, ic, k, k), dtype=np.float32) * 2 - 1) * amp).astype(np.float32))
+        b = G.tensor([oc], dtype=F, fmt=marsfile.D1, data=((rng.random(oc, dtype=np.float32) * 2 - 1) * 0.1).astype(np.float32))
+        G.conv(xin, a, wt, b, (k, k), (st, st), pad=marsfile.PAD_SAME)
+        g_, o_ = G.tensor([1, oc, oh, ow], dtype=F, fmt=N), G.tensor([1, oc, oh, ow], dtype=F, fmt=N)
+        G.layer(marsfile.SIGMOID, [a], [g_])
+        G.layer(marsfile.MUL, [a, g_], [o_])
+        return o_, oh, ow
+
+    x = G.tensor([1, c0, h, w], dtype=F, fmt=N)
+    t1, h1, w1 = conv_silu(x, c0, h, w, c1, k1, s1)
+    t2, h2, w2 = conv_silu(t1, c1, h1, w1, c2, k2, s2)
+    ins, out = [x], t2
+    if res == "x":
+        assert (c2, h2, w2) == (c0, h, w)
+        out = G.tensor([1, c2, h2, w2], dtype=F, fmt=N)
+        G.layer(marsfile.ADD, [t2, x], [out])
+    elif res == "r":
+        r_ = G.tensor([1, c2, h2, w2], dtype=F, fmt=N)
+        out = G.tensor([1, c2, h2, w2], dtype=F, fmt=N)
+        G.layer(marsfile.ADD, [t2, r_], [out])
+        ins.append(r_)
+    d = G.serialise(ins, [out])
+    nx = min(B, 4)
+    xs = [(rng.random(c0 * h * w, dtype=np.float32) * 2 - 1).astype(np.float32) for _ in range(nx)]
+    rs = [(rng.random(c2 * h2 * w2, dtype=np.float32) * 2 - 1).astype(np.float32) for _ in range(nx)]
+    want, mid = [], []
+    for q, r in zip(xs, rs):
+        g = orc.Graph(d)
+        g.set_input(0, q.tobytes())
+        if res == "r":
+            g.set_input(1, r.tobytes())
+        assert g.run() == 0
+        want.append(g.tensor(out).copy())
+        mid.append(g.tensor(t1).copy())
+        g.close()
+    L = gpu.lib()
+    counts = {}
+    for name in ("prec", "patch", "split", "stem"):
+        counts[name] = getattr(L, "mhip_conv_f32_%s_launches" % name)
+        counts[name].restype = C.c_ulong
+    geom2 = L.mhip_conv_f32_patch_geom2
+    geom2.restype = C.c_int
+    geom2.argtypes = [C.c_int] * 11 + [C.c_void_p, C.c_int]
+    gv = np.zeros(64, dtype=np.int32)
+    pad2 = (k2 - 1) // 2 if s2 == 1 else max(0, ((h2 - 1) * s2 + k2 - h1)) // 2  # SAME, as the planner derives it (top = left)
+    expect_patch = geom2(c2, c1, k2, k2, s2, pad2, h1, w1, h2, w2, 0, gv.ctypes.data, 64) != 0
+    expect_rec = geom2(c2, c1, k2, k2, s2, pad2, h1, w1, h2, w2, 1, gv.ctypes.data, 64) != 0  # (four ring slots must fit: not the large stride-2 patches)
+    try:
+        gpu.set_tuning("dual_stream_min_batch", 0)
+        for mode, slots, fusion in ((3, 0, 1), (3, 3, 1), (3, 0, 0), (4, 0, 1), (0, 0, 1)):
+            gpu.set_tuning("f32_mfma", mode)
+            gpu.set_tuning("persist_slots", slots)
+            m = gpu.Model(d, batch=B, fusion=fusion)
+            for f in range(B):
+                m.input_view(0)[f] = xs[f % nx].view(np.uint8)
+                if res == "r":
+                    m.input_view(1)[f] = rs[f % nx].view(np.uint8)
+            n0 = {k_: c() for k_, c in counts.items()}
+            m.run()
+            dn = {k_: c() - n0[k_] for k_, c in counts.items()}
+            rec = mode == 3 and fusion == 1 and expect_rec
+            assert dn["prec"] == (1 if rec else 0), (mode, slots, fusion, dn)
+            if mode == 3:
+                assert dn["patch"] == (0 if rec or not expect_patch else 1), (mode, fusion, dn)
+                assert dn["split"] + dn["stem"] + dn["patch"] + dn["prec"] == 2, dn
+            got = m.output_view(0).copy()
+            if fusion == 1:  # the tensor between the two (the first MUL's output): NCHW floats whatever its device format is
+                for f in (0, B - 1):
+                    t = np.frombuffer(m.read_tensor(t1, f), dtype=np.float32)
+                    w_ = mid[f % nx].view(np.float32)
+                    tol = 2.0 ** -15 if rec else 1e-4
+                    assert (np.abs(t.astype(np.float64) - w_) <= np.maximum(1e-4, tol * np.abs(w_))).all(), "mode %d: tensor between the convolutions, frame %d" % (mode, f)
+            m.close()
+            for f in range(B):
+                if mode == 0:
+                    assert np.array_equal(got[f], want[f % nx]), "mode 0 frame %d" % f
+                else:
+                    ok = close_f32(got[f], want[f % nx])
+                    assert ok.all(), "mode %d slots %d fusion %d frame %d: %d of %d out of tolerance" % (mode, slots, fusion, f, int((~ok).sum()), ok.size)
+    finally:
+        gpu.set_tuning("f32_mfma", 1)
+        gpu.set_tuning("persist_slots", 0)
+        gpu.set_tuning("dual_stream_min_batch", 64)
+
+
 F32_STEM_SHAPES = [
     # h, w, in_c, out_c, k, pad-as-SAME, batch, silu        conv_f32_stem (round 5)
     (64, 64, 3, 32, 6, 9, True),     # the twins' first layer at 64 x 64: 2 x 1 tiles per frame, 9 frames

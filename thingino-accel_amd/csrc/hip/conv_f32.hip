@@ -256,7 +256,7 @@ extern "C" int mhip_conv_f32(const mhip_conv_f32_t *p) {
         if (rc != -2) return rc;
         rc = conv_f32_try_patch(p); // k x k layers, three piece products: the patch-staged form (round 5)
         if (rc != -2) return rc;
-        if (g_f32_pw) { // 1 x 1 layers in the two-phase form: built and bit-checked in round 5, SLOWER than conv_f32_split (its LDS
+        if (g_f32_pw && !p->in_rec && !p->out_rec) { // 1 x 1 layers in the two-phase form: built and bit-checked in round 5, SLOWER than conv_f32_split (its LDS
                         // writes are 16-way bank conflicts by construction: profiles/r05_experiments.md), so opt-in ("f32_pw" = 1)
             rc = conv_f32_try_pw(p);
             if (rc != -2) return rc;
@@ -264,6 +264,8 @@ extern "C" int mhip_conv_f32(const mhip_conv_f32_t *p) {
         rc = p->w_split ? conv_f32_try_split(p) : -2;
         if (rc != -2) return rc;
     }
+    // record-format tensors exist between two of the kernels above only (the planner's pairing: mars_plan.c); nothing below reads or writes them
+    if (p->in_rec || p->out_rec) return mhip_check(hipErrorInvalidValue, "conv_f32: record-format operand and no kernel for it");
     if (p->use_mfma && total <= 0x7fffffffL - F_BN && K <= 0x7fffffffL - F_BK) {
         const unsigned npt = (unsigned)((total + F_BN - 1) / F_BN), noc = (unsigned)((p->out_c + F_BM - 1) / F_BM);
         if ((unsigned long long)npt * noc <= 0x7fffffffull) {

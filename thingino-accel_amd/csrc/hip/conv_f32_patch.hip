@@ -70,7 +70,7 @@ extern "C" int mhip_fpatch_stamps(unsigned long long *out, int reset) {
 #define FPATCH_PRIO 0
 #endif
 #ifndef FPATCH_ABL // timing-only ablations (tools/stamps_build.sh fpabl N; wrong results): 1 no MFMAs, 2 no split / LDS writes of the
-#define FPATCH_ABL 0 // patch, 4 no patch loads, 8 no fragment reads
+#define FPATCH_ABL 0 // patch, 4 no patch loads, 8 no fragment reads; conv_f32_prec: 16 no DMA waits, 32 no patch DMA
 #endif
 
 struct pdiv_t {
@@ -111,8 +111,9 @@ struct fpatch_geom_t {
     int cpi;                   // channels per fetch item (8 | 4 | 2)
     int bn;                    // pixels per tile (256 | 512)
     int woff, poff, lds_bytes; // LDS byte offsets of the weight stages and the patch ring, total
-    unsigned total_pix, ntiles, nsegs, in_bytes, per;
-    pdiv_t dSW, dHo, dHV, dNS, dgrp;
+    int nb, rec, ndma;         // patch ring slots (2; 2 | 4 for record input); input in record format; 1 KB LDS-DMA blocks per slot
+    unsigned total_pix, ntiles, nsegs, in_bytes, per, out_bytes;
+    pdiv_t dSW, dHo, dHV, dNS, dgrp, dPWP;
 };
 
 __device__ __forceinline__ int pa_lds_off(int row, int chunk) { return row * 64 + ((chunk ^ ((row >> 1) & 2)) << 4); }
@@ -526,6 +527,370 @@ __global__ __launch_bounds__(P_NT, 2) void conv_f32_patch(const mhip_conv_f32_t 
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
+// conv_f32_prec: the same convolution when the INPUT ARRIVES AS RECORDS (mhip_conv_f32_t.in_rec): the producing convolution
+// (conv_f32_split / conv_f32_stem with out_rec) has already cut its results into the two bf16 pieces and written them channels-last,
+// [in_c / 8 chunks][H][W] records of 32 bytes = [8 x hi | 8 x mid] -- exactly what conv_f32_patch's staging phase builds in LDS.  The
+// planner uses the format for a tensor whose only reader is one such convolution (a C3 bottleneck's 1 x 1 -> 3 x 3, stem -> layer 3).
+// What that removes from a K step's staging phase (profiles/r05_experiments.md: the staging phase, ~75 + ~130 vector instructions
+// issued at half rate beside the SIMD mate's MFMAs, is what bounds conv_f32_patch): the patch loads into registers, the split, the
+// LDS writes -- a chunk's slot is now filled by LDS-DMA (buffer_load ... lds, 1 KB per wave instruction, zero fill outside the
+// image by the buffer's range check), and so are the weight stages (four of them: a step's planes are requested three steps ahead).
+// Nothing the compiler counts is loaded inside the K loop, so every wait is counted by hand: a wave knows how many vector-memory
+// instructions it has issued after the DMA it needs (they retire in order), kept as scalar "ages" (yw*: the pending weight stages,
+// yp*: the pending chunks, a FIFO).  Phases, barriers, MFMA order, tile walk, epilogue: conv_f32_patch's.
+// s_waitcnt vmcnt(n) for a wave-uniform run-time n, rounded DOWN to one of three immediates (any smaller count is correct too, only
+// slower): HI = everything but what one step issues at most (its chunk DMA and two weight loads) may stay in flight -- the usual case, a
+// chunk is needed steps after its DMA; 2 = the chunk was issued in this very step, only the weight loads behind it; else everything.
+// (A binary tree down to the exact immediate cost ~450 cycles per wait: twelve scalar branches.)
+template <int HI>
+__device__ __forceinline__ void pwait_vm(int n) {
+    if (n >= HI) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(HI) : "memory");
+    else if (n >= 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+}
+// One LDS-DMA instruction: lane l's 16 bytes at buffer offset voff + soff land at LDS byte lds_wave_base + 16 l (zeros when the offset is
+// outside the buffer).  Inline assembly, not the builtin: the compiler then neither counts it (every wait for these is hand-counted
+// anyway) nor guards its address register -- with the builtin it put an s_waitcnt vmcnt(0) in front of the next write to the VGPR that
+// had held a DMA's offset, i.e. once per K step.  M0 = the LDS base: nothing else in this kernel uses it.
+__device__ __forceinline__ void pdma16(__amdgpu_buffer_rsrc_t rs, unsigned voff, unsigned soff, const void *lds_wave_base) {
+    const unsigned l = (unsigned)(size_t)(const __attribute__((address_space(3))) void *)lds_wave_base;
+    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds" ::"s"(l), "v"(voff), "s"(rs), "s"(soff) : "memory");
+}
+
+// NDW = LDS-DMA instructions per wave and chunk (ceil(slot KB / 8), rounded up to 2 | 3 | 4 | 6 | 8)
+template <int BM, int WM, int WN, bool DUMMY, int P_BN, int NDW>
+__global__ __launch_bounds__(P_NT, 2) void conv_f32_prec(const mhip_conv_f32_t p, const fpatch_geom_t g, const int *__restrict__ tabs,
+                                                         const int8_t *__restrict__ wpl) {
+    constexpr int TM = BM / WM, TN = P_BN / WN;
+    constexpr int MI = TM / 16, NI = TN / 16;
+    constexpr int APLANE = BM * 64, WSTAGE = 2 * APLANE;
+    constexpr int AE = BM * 32 / P_NT;     // weight elements per thread, plane and step: 8 | 4 | 2
+    constexpr int ATPR = 32 / AE, AD = AE / 2;
+    extern __shared__ __attribute__((aligned(16))) int8_t lds[];
+    int *dutab = (int *)lds;
+    int *sched = dutab + g.nsteps * 4; // low half: 1 + chunk whose DMA this step issues; bit 16: a chunk is first read in the next step
+    int2 *rowtab = (int2 *)(lds + g.woff - 2 * P_PRCAP * 8);
+    const int zrec = g.woff - 2 * P_PRCAP * 8 - 64 - g.poff;
+    int8_t *wst = lds + g.woff;
+    int8_t *patch = lds + g.poff;
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wv % WM, wn = wv / WM;
+    const int fr = lane & 15, fc = lane >> 4;
+    const int oc0 = (int)blockIdx.y * BM;
+    const unsigned hw = (unsigned)(g.H_out * g.W_out);
+    const unsigned chunk_bytes = (unsigned)(g.H_in * g.W_in) * 32u;
+    const __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc((void *)p.in, 0, (int)g.in_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t ors = __builtin_amdgcn_make_buffer_rsrc((void *)p.out, 0, (int)g.out_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t ars = __builtin_amdgcn_make_buffer_rsrc((void *)(p.add ? (const void *)p.add : (const void *)p.out), 0, (int)g.out_bytes, 0x00020000);
+
+    for (int i = tid; i < g.nsteps * 5; i += P_NT) dutab[i] = tabs[i];
+    if (tid < 16) ((int *)(patch + zrec))[tid] = 0;
+
+    // ---- weights: through registers, as conv_f32_patch (row oc0 + tid / ATPR of both planes, elements (tid % ATPR) * AE .. of the step; two
+    // register sets, two LDS stages, fetched three steps ahead).  By LDS-DMA too (the first form of this kernel, four stages): a
+    // 128-channel stage is 16 KB per step and the DMA path fills LDS at ~27 B/clk/CU (probe, round 4) -- 600 cycles of it per step beside
+    // the patch's, every wait for either grew long (stamps: patch issue 620, DMA waits 510, barriers 1270 cycles per step on D40)
+    const int arow = tid / ATPR, akc = (tid % ATPR) * AE;
+    const int8_t *wrow = wpl + ((size_t)(oc0 + arow) * g.kp + akc) * 2;
+    const size_t wplane_b = (size_t)g.oc_pad * g.kp * 2;
+    int aregs[2][2][AD];
+    auto fetch_w = [&](int ks, int (&areg)[2][AD]) __attribute__((always_inline)) {
+#pragma unroll
+        for (int pl = 0; pl < 2; pl++) {
+            const int8_t *src = wrow + pl * wplane_b + (size_t)ks * 64;
+            if (AE == 8) { const v4i t = *(const v4i *)src; areg[pl][0] = t[0]; areg[pl][1 % AD] = t[1]; areg[pl][2 % AD] = t[2]; areg[pl][3 % AD] = t[3]; }
+            else if (AE == 4) { const int2 t = *(const int2 *)src; areg[pl][0] = t.x; areg[pl][1 % AD] = t.y; }
+            else areg[pl][0] = *(const int *)src;
+        }
+    };
+    auto commit_w = [&](int buf, const int (&areg)[2][AD]) __attribute__((always_inline)) {
+        int8_t *st = wst + buf * WSTAGE;
+        const int aoff = pa_lds_off(arow, akc >> 3) + (akc & 7) * 2;
+#pragma unroll
+        for (int pl = 0; pl < 2; pl++) {
+            if (AE == 8) *(v4i *)(st + pl * APLANE + aoff) = (v4i){areg[pl][0], areg[pl][1 % AD], areg[pl][2 % AD], areg[pl][3 % AD]};
+            else if (AE == 4) *(int2 *)(st + pl * APLANE + aoff) = make_int2(areg[pl][0], areg[pl][1 % AD]);
+            else *(int *)(st + pl * APLANE + aoff) = areg[pl][0];
+        }
+    };
+
+    // ---- patch: instruction j of this wave fills block j * 8 + wv of a slot = patch positions (j * 8 + wv) * 32 + lane / 2, the lane's
+    // half record (lane & 1: hi | mid).  The lane's byte offsets for the tile whose chunks are being issued live in registers (vo[]):
+    // recomputed -- position -> (patch row, column), the row's offset from the tile's row table -- when the issue stream moves on to
+    // the next tile, once per tile.  (Read from the row table at every issue, the LDS round trip beside the other waves' fragment
+    // reads cost ~1500 cycles per issue: stamps.)
+    const int ndw = g.ndma > wv ? (g.ndma - wv + 7) >> 3 : 0;
+    auto tile_v0 = [&](unsigned t) __attribute__((always_inline)) {
+        const unsigned R0 = pdiv(t * P_BN, g.dSW), seg0 = pdiv(R0, g.dHo);
+        return (int)(seg0 * (unsigned)g.HV + (R0 - seg0 * (unsigned)g.H_out) * (unsigned)g.s);
+    };
+    auto fill_rowtab = [&](unsigned t) __attribute__((always_inline)) {
+        if (tid < g.PR) {
+            const unsigned V = (unsigned)tile_v0(t) + (unsigned)tid;
+            const unsigned seg = pdiv(V, g.dHV), f = pdiv(seg, g.dNS), st = seg - f * (unsigned)g.nstrips;
+            const int iy = (int)(V - seg * (unsigned)g.HV) - g.pad;
+            const bool ok = t < g.ntiles && seg < g.nsegs && iy >= 0 && iy < g.H_in;
+            rowtab[(t & 1) * P_PRCAP + tid] = make_int2(ok ? (int)(f * (unsigned)p.in_stride + (unsigned)(iy * g.W_in) * 32u) : -1,
+                                                        (int)st * g.SW * g.s - g.pad - g.dx);
+        }
+    };
+    unsigned vo[NDW];
+    auto tile_vo = [&](unsigned t) __attribute__((always_inline)) {
+        const int2 *rtab = rowtab + (t & 1u) * P_PRCAP;
+#pragma unroll
+        for (int j = 0; j < NDW; j++)
+            if (j < ndw) {
+                const unsigned pos = (unsigned)((j * 8 + wv) * 32 + (lane >> 1));
+                const unsigned r = pdiv(pos, g.dPWP);
+                const int cp = (int)(pos - r * (unsigned)g.PWP);
+                const int v = g.s == 2 ? (cp < g.PWH ? 2 * cp : 2 * (cp - g.PWH) + 1) : cp;
+                const bool in = (int)r < g.PR;
+                const int2 rt = rtab[in ? r : 0u];
+                const int x = rt.y + v;
+                const bool ok = in && rt.x != -1 && x >= 0 && x < g.W_in;
+                vo[j] = ok ? (unsigned)rt.x + (unsigned)x * 32u + (unsigned)(lane & 1) * 16u : 0xffffffffu;
+            }
+    };
+    // chunk `rel` of tile t (rel >= nchunk: chunk rel - nchunk of tile t + 1)
+    const int slot_bytes = g.slotpix * 32;
+    auto issue_patch = [&](unsigned t, int rel) __attribute__((always_inline)) {
+        const bool nxt = rel >= g.nchunk;
+        const int c = nxt ? rel - g.nchunk : rel;
+        if (rel == g.nchunk) tile_vo(t + 1); // the stream moves on to the next tile (its row table: written in an R(0); the schedule has no DMA for it before step 2)
+        int8_t *dst = patch + (c & (g.nb - 1)) * slot_bytes + wv * 1024;
+        const unsigned so = (unsigned)c * chunk_bytes;
+#pragma unroll
+        for (int j = 0; j < NDW; j++)
+            if (j < ndw && !(FPATCH_ABL & 32)) pdma16(xrs, vo[j], so, dst + j * 8192);
+    };
+
+    // ---- the compute side (as conv_f32_patch)
+    // (registers: the 128-channel instantiation has none to spare -- a value that lives through the K loop unused (the output offsets, the
+    // bias) is recomputed / re-read where it is needed; a spilled register's reload in front of the K loop makes the compiler wait
+    // vmcnt(0) -- i.e. for every DMA in flight -- at the loop's first counted wait, in every step)
+    const int8_t *pbase[NI];
+    auto tile_setup = [&](unsigned t) __attribute__((always_inline)) {
+        const int V0 = tile_v0(t);
+#pragma unroll
+        for (int n = 0; n < NI; n++) {
+            const unsigned q = t * P_BN + (unsigned)(wn * TN + n * 16 + fr);
+            const unsigned R = pdiv(q, g.dSW), xs = q - R * (unsigned)g.SW;
+            const unsigned seg = pdiv(R, g.dHo), y = R - seg * (unsigned)g.H_out;
+            const int prow = (int)(seg * (unsigned)g.HV + y * (unsigned)g.s) - V0;
+            pbase[n] = patch + (q < g.total_pix ? prow * g.PWP + (int)xs : 0) * 32;
+        }
+    };
+    auto out_off = [&](unsigned t, int n) __attribute__((always_inline)) { // byte offset (frame + position inside a channel plane) of the lane's 4 result pixels of MFMA tile n, ~0 = none
+        const unsigned q4 = t * P_BN + (unsigned)(wn * TN + n * 16 + fc * 4);
+        const unsigned R4 = pdiv(q4, g.dSW), xs4 = q4 - R4 * (unsigned)g.SW;
+        const unsigned seg4 = pdiv(R4, g.dHo), y4 = R4 - seg4 * (unsigned)g.H_out;
+        const unsigned f4 = pdiv(seg4, g.dNS), st4 = seg4 - f4 * (unsigned)g.nstrips;
+        return q4 < g.total_pix ? f4 * (unsigned)p.out_stride + (y4 * (unsigned)g.W_out + st4 * (unsigned)g.SW + xs4) * 4u : 0xffffffffu;
+    };
+    v4f acc[MI][NI];
+    float *sbias = (float *)(lds + g.woff - 2 * P_PRCAP * 8 - 64 - 512); // [BM] (the host leaves 512 bytes in front of the zero record)
+    if (tid < BM) sbias[tid] = p.bias && oc0 + tid < p.out_c ? p.bias[oc0 + tid] : 0.f;
+#pragma unroll
+    for (int a = 0; a < MI; a++) {
+        const int oc = oc0 + wm * TM + a * 16 + fr;
+        const float b = p.bias && oc < p.out_c ? p.bias[oc] : 0.f;
+#pragma unroll
+        for (int c = 0; c < NI; c++) acc[a][c] = (v4f){b, b, b, b};
+    }
+    bf16x8 xh[NI], xm[NI], wh[MI], wmid[MI];
+    auto read_frags = [&](int stage, const int e) __attribute__((always_inline)) {
+        const int8_t *ap = wst + stage * WSTAGE;
+#pragma unroll
+        for (int c = 0; c < NI; c++) {
+            const int8_t *a = pbase[c] + e;
+            if (DUMMY) a = e < 0 ? patch + zrec : a;
+            xh[c] = __builtin_bit_cast(bf16x8, *(const v4i *)a);
+            xm[c] = __builtin_bit_cast(bf16x8, *(const v4i *)(a + 16));
+        }
+#pragma unroll
+        for (int a = 0; a < MI; a++) {
+            const int o = pa_lds_off(wm * TM + a * 16 + fr, fc);
+            wh[a] = __builtin_bit_cast(bf16x8, *(const v4i *)(ap + o));
+            wmid[a] = __builtin_bit_cast(bf16x8, *(const v4i *)(ap + APLANE + o));
+        }
+    };
+    auto phase_m = [&]() __attribute__((always_inline)) {
+#pragma unroll
+        for (int a = 0; a < MI; a++)
+#pragma unroll
+            for (int c = 0; c < NI; c++) {
+                acc[a][c] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xm[c], wh[a], acc[a][c], 0, 0, 0);   // mid * hi
+                acc[a][c] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xh[c], wmid[a], acc[a][c], 0, 0, 0); // hi * mid
+                acc[a][c] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xh[c], wh[a], acc[a][c], 0, 0, 0);   // hi * hi
+            }
+    };
+    auto barrier_lds = [&]() __attribute__((always_inline)) {
+        __builtin_amdgcn_sched_barrier(0);
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+    };
+    auto barrier_raw = [&]() __attribute__((always_inline)) {
+        __builtin_amdgcn_sched_barrier(0);
+        asm volatile("s_barrier" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+    };
+
+    // ---- prologue: tables, the row table and DMA offsets of the first tile, what the previous tile's steps would have issued for
+    // it (the schedule entries that name a chunk of the NEXT tile), the first three weight stages; everything landed
+    const unsigned t_first = blockIdx.x * g.per;
+    const unsigned t_end = (blockIdx.x + 1) * g.per < g.ntiles ? (blockIdx.x + 1) * g.per : g.ntiles;
+    fill_rowtab(t_first);
+    __syncthreads();
+    const int nsteps = g.nsteps;
+    int npend = 0;
+    tile_vo(t_first);
+    for (int i = 0; i < nsteps; i++) {
+        const int sc = __builtin_amdgcn_readfirstlane(sched[i]) & 0xffff;
+        if (sc > g.nchunk) {
+            issue_patch(t_first, sc - 1 - g.nchunk);
+            npend++;
+        }
+    }
+    npend--; // chunk 0 is read in step 0: waited for here, not by a step's wait
+    fetch_w(0, aregs[0]);
+    commit_w(0, aregs[0]);
+    fetch_w(1, aregs[1]);
+    fetch_w(2, aregs[0]);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+
+    // ages: vector-memory instructions this wave has issued after the DMA of each pending chunk (oldest first).  EVERY such instruction
+    // counts, the compiler's too: two weight loads per step, the epilogue's loads and stores
+    int yp0 = 0, yp1 = 0, yp2 = 0, yp3 = 0;
+    const bool late = wv >= 4;
+    int tab_e = dutab[fc], tab_w = sched[0];
+    if (late) barrier_raw();
+#ifdef FPATCH_STAMPS // (tools/stamps_build.sh fpatch; tools/fpatch_stamps.py --chain): 0 weights (LDS write, next loads), 1 patch DMA issue, 2 fragment reads, 3 MFMAs, 4 DMA waits, 5 barriers, 6 rest
+    unsigned long long st_acc[7] = {0, 0, 0, 0, 0, 0, 0}, st_last = __builtin_readcyclecounter(), st_steps = 0;
+#endif
+    // one staging phase R(ks) -- LDS stage BUF for its reads, the weight registers AREG (step ks + 1's, fetched two steps ago) -- and the
+    // rest of the step.  Macros, not lambdas: the ages must stay scalar registers (captured by reference in a lambda they went to
+    // scratch memory, as vector values)
+#define PREC_PHASE_R(KS, BUF, AREG, K1, KQ)                                                                                            \
+    {                                                                                                                                  \
+        const int e = tab_e, w = __builtin_amdgcn_readfirstlane(tab_w), sc = w & 0xffff;                                               \
+        tab_e = dutab[(K1) * 4 + fc];                                                                                                  \
+        tab_w = sched[(K1)];                                                                                                           \
+        STAMP(6);                                                                                                                      \
+        commit_w((BUF) ^ 1, AREG);                                                                                                     \
+        STAMP(0);                                                                                                                      \
+        /* the chunk's DMA goes BEFORE this step's weight loads: the compiler's wait for those (vmcnt(2), a step later) then finds    \
+           the DMA among the older instructions it completes anyway, not among the two it leaves in flight -- a full step to land.    \
+           (The next tile's row table: written in an R(0); the schedule has no DMA for the next tile before step 2.) */                \
+        if (sc) {                                                                                                                      \
+            issue_patch(t, sc - 1);                                                                                                    \
+            yp0 += ndw; yp1 += ndw; yp2 += ndw; yp3 += ndw;                                                                            \
+            if (npend == 0) yp0 = 0;                                                                                                   \
+            else if (npend == 1) yp1 = 0;                                                                                              \
+            else if (npend == 2) yp2 = 0;                                                                                              \
+            else yp3 = 0;                                                                                                              \
+            npend++;                                                                                                                   \
+        }                                                                                                                              \
+        fetch_w((KQ), AREG);                                                                                                           \
+        yp0 += 2; yp1 += 2; yp2 += 2; yp3 += 2;                                                                                        \
+        STAMP(1);                                                                                                                      \
+        read_frags((BUF), e);                                                                                                          \
+        PREC_STAMP_LGKM;                                                                                                               \
+        STAMP(2);                                                                                                                      \
+        /* a chunk the NEXT step reads for the first time must have landed, in every wave, by the barrier in front of that step's     \
+           first reader (waves 0-3's R(ks + 1)): this wave's share is waited for before that barrier -- the one behind this phase     \
+           for waves 4-7, the one behind the MFMAs for waves 0-3 */                                                                    \
+        int nwait = -1;                                                                                                                \
+        if (w >> 16) {                                                                                                                 \
+            nwait = yp0;                                                                                                               \
+            yp0 = yp1; yp1 = yp2; yp2 = yp3;                                                                                           \
+            npend--;                                                                                                                   \
+        }                                                                                                                              \
+        if (late && nwait >= 0 && !(FPATCH_ABL & 16)) pwait_vm<NDW + 2>(nwait);                                                                 \
+        STAMP(4);                                                                                                                      \
+        barrier_lds();                                                                                                                 \
+        STAMP(5);                                                                                                                      \
+        phase_m();                                                                                                                     \
+        __builtin_amdgcn_sched_barrier(0);                                                                                             \
+        STAMP(3);                                                                                                                      \
+        if (!late && nwait >= 0 && !(FPATCH_ABL & 16)) pwait_vm<NDW + 2>(nwait);                                                                \
+        STAMP(4);                                                                                                                      \
+        barrier_raw();                                                                                                                 \
+        STAMP(5);                                                                                                                      \
+    }
+#ifdef FPATCH_STAMPS
+#define PREC_STAMP_LGKM asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory")
+#else
+#define PREC_STAMP_LGKM do { } while (0)
+#endif
+    for (unsigned t = t_first; t < t_end; t++) {
+#ifdef FPATCH_STAMPS
+        st_steps += (unsigned long long)nsteps;
+#endif
+        tile_setup(t);
+        for (int ks = 0; ks < nsteps; ks += 2) {
+            int kq = ks + 3; // weights are fetched three steps ahead (two register sets, two stages); they wrap into the next tile
+            if (kq >= nsteps) kq -= nsteps;
+            int kq1 = ks + 4;
+            if (kq1 >= nsteps) kq1 -= nsteps;
+            const int k2 = ks + 2 < nsteps ? ks + 2 : 0;
+            if (ks == 0) fill_rowtab(t + 1);
+            PREC_PHASE_R(ks, 0, aregs[1], ks + 1, kq)
+            PREC_PHASE_R(ks + 1, 1, aregs[0], k2, kq1)
+        }
+#undef PREC_PHASE_R
+        // ---- store: a lane holds 4 consecutive pixels (16 bytes) of channel row fr of every MFMA tile.  Buffer loads / stores whose
+        // offset is out of range for the lanes without a result: no branch, so every wave issues exactly MI * NI stores (and as many
+        // loads of a fused Add's operand) per tile -- the ages stay exact -- and nothing the compiler loads is read behind a branch
+        // (a loaded register whose only reader may be skipped stays "pending" for the compiler: it then put an s_waitcnt vmcnt(0) in
+        // front of the K loop's first write to that register, in every step)
+        {
+            unsigned oo[NI];
+#pragma unroll
+            for (int c = 0; c < NI; c++) oo[c] = out_off(t, c);
+            auto vso = [&](int a, int c) __attribute__((always_inline)) {
+                const int oc = oc0 + wm * TM + a * 16 + fr;
+                return oo[c] != 0xffffffffu && oc < p.out_c ? oo[c] + (unsigned)oc * hw * 4u : 0xffffffffu;
+            };
+            v4f addv[MI][NI];
+            if (p.add) {
+#pragma unroll
+                for (int c = 0; c < NI; c++)
+#pragma unroll
+                    for (int a = 0; a < MI; a++) addv[a][c] = __builtin_bit_cast(v4f, __builtin_amdgcn_raw_buffer_load_b128(ars, vso(a, c), 0, 0));
+            }
+#pragma unroll
+            for (int c = 0; c < NI; c++)
+#pragma unroll
+                for (int a = 0; a < MI; a++) {
+                    v4f r = acc[a][c];
+                    if (p.silu) {
+#pragma unroll
+                        for (int j = 0; j < 4; j++) r[j] = psilu_fast(r[j]);
+                    }
+                    if (p.add) r += addv[a][c];
+                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(v4i, r), ors, vso(a, c), 0, 0);
+                    const float b = sbias[wm * TM + a * 16 + fr];
+                    acc[a][c] = (v4f){b, b, b, b};
+                    __builtin_amdgcn_sched_barrier(0); // one result at a time: interleaved, the SiLU temporaries of all of them cost 40 registers
+                }
+            const int nst = MI * NI * (p.add ? 2 : 1);
+            yp0 += nst; yp1 += nst; yp2 += nst; yp3 += nst;
+        }
+    }
+    if (!late) barrier_raw(); // pairs with the late waves' last one
+#ifdef FPATCH_STAMPS
+    if (lane == 0) {
+        for (int i = 0; i < 7; i++) atomicAdd(&fpatch_stamp_sums[i], st_acc[i]);
+        atomicAdd(&fpatch_stamp_sums[7], st_steps);
+    }
+#endif
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // no LDS-DMA of this wave may land after the workgroup's LDS is handed on
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
 // host side: geometry, unit table, schedule, weight image
 
 // the K stream of one tile: units in (chunk, tap) order, padded with dummy units (-1) to an even number of 4-unit steps
@@ -540,8 +905,10 @@ static int fpatch_units(int nchunk, int U, int *units /* [nsteps * 4] chunk of e
 // commit step (inside a tile's step numbering, chunk indices continuing into the next tile) of every chunk: chunk g is written
 // at the top of the step after the last one that reads chunk g - 2 (same slot), at least 2 steps after chunk g - 1 (whose commit
 // issued g's loads), and at least one step before g's first reader.  Returns 0 if no such schedule exists.
-static int fpatch_schedule(int nchunk, int U, int nsteps, int *sched /* [nsteps] */) {
-    const int NB = P_NB;
+// rec (record-format input, conv_f32_prec): an entry is the step whose staging phase ISSUES the chunk's LDS-DMA into its slot (no
+// register staging: consecutive chunks may follow one step apart), NB = 2 | 4 slots; bit 16 of a step's word = "a chunk is read
+// for the first time in the NEXT step" (the wave waits for it before it leaves this one).
+static int fpatch_schedule(int nchunk, int U, int nsteps, int *sched /* [nsteps] */, int NB = P_NB, int rec = 0) {
     if (nchunk < NB || nchunk % NB) return 0;
     // first / last reading step of chunk c of the tile (global: + nsteps per tile)
     auto first_read = [&](long gch) { const long t = gch / nchunk, c = gch % nchunk; return t * nsteps + (c * U) / 4; };
@@ -552,22 +919,27 @@ static int fpatch_schedule(int nchunk, int U, int nsteps, int *sched /* [nsteps]
     long prev = -1;
     for (long gch = NB; gch < 3L * nchunk + NB; gch++) {
         long c = last_read(gch - NB) + 1;
-        if (c < prev + 2) c = prev + 2;
+        if (c < prev + (rec ? 1 : 2)) c = prev + (rec ? 1 : 2);
         if (c > first_read(gch) - 1) return 0;
         prev = c;
         if (c >= nsteps && c < 2L * nsteps) {
             const long rel = gch - nchunk; // chunk index relative to tile 1: may reach into tile 2 (>= nchunk)
             if (rel < 0 || rel >= 2L * nchunk || sched[c - nsteps]) return 0;
             sched[c - nsteps] = (int)rel + 1;
-            if (rel + 1 >= nchunk && c - nsteps < 2) return 0; // the kernel reads the next tile's row table in R(1): no fetch for it before step 2
+            if ((rec ? rel : rel + 1) >= nchunk && c - nsteps < 2) return 0; // the kernel reads the next tile's row table in R(1): no fetch for it before step 2
         }
     }
+    if (rec)
+        for (int c = 0; c < nchunk; c++) {
+            const int fr = (int)first_read(c);
+            sched[(fr + nsteps - 1) % nsteps] |= 1 << 16;
+        }
     // the same commits, seen from tile 0, must be what tile 1 shows (periodicity): chunk g of tile 0 at step c <=> chunk g of tile 1 at c
     // (holds because first/last_read are tile-periodic and the prologue's state equals the steady state's: checked by the emulation test)
     return 1;
 }
 
-static int fpatch_geom(const mhip_conv_f32_t *p, fpatch_geom_t *g, int frames) {
+static int fpatch_geom(const mhip_conv_f32_t *p, fpatch_geom_t *g, int frames, int rec = 0) {
     memset(g, 0, sizeof(*g));
     const int s = p->stride_w;
     if (p->stride_h != s || (s != 1 && s != 2) || p->pad_top != p->pad_left || p->pad_top < 0 || p->pad_top > 3) return 0;
@@ -588,9 +960,10 @@ static int fpatch_geom(const mhip_conv_f32_t *p, fpatch_geom_t *g, int frames) {
     g->ndummy = g->nsteps * 4 - g->nchunk * g->U;
     g->kp = g->nsteps * 32 + 64; // (fetches run two steps ahead and wrap: the slack is never multiplied)
     g->tab_ints = g->nsteps * 5;
+    g->rec = rec; g->nb = P_NB;
     // strip width: a divisor of out_w, multiple of 4; the one with the smallest patch (ties: the wider)
-    const int woff_base = (g->nsteps * 5 * 4 + 64 + 2 * P_PRCAP * 8 + 255) & ~255; // tables | zero record | row tables
-    const int wbytes = 2 * 2 * g->BM * 64;
+    const int woff_base = (g->nsteps * 5 * 4 + 512 + 64 + 2 * P_PRCAP * 8 + 255) & ~255; // tables | bias (record form) | zero record | row tables
+    const int wbytes = 2 * 2 * g->BM * 64; // two weight stages: hi + mid planes of a K step
     int best = 0;
     for (int P_BN = g->BM <= 64 ? 512 : 256; P_BN >= 256 && !best; P_BN -= 256) // (the larger tile where its patch fits)
     for (int SW = 4; SW <= p->out_w; SW += 4) {
@@ -606,9 +979,10 @@ static int fpatch_geom(const mhip_conv_f32_t *p, fpatch_geom_t *g, int frames) {
         const int cells = PR * (PWP / 4);
         const int cpi = cells * 4 <= P_NT ? 2 : (cells * 2 <= P_NT ? 4 : 8);
         const int nitems = cells * (8 / cpi);
-        const int slotpix = (PR * PWP + 7) & ~7;
+        const int slotpix = (PR * PWP + 31) & ~31; // whole 1 KB blocks (the record form fills a slot by LDS-DMA, 1 KB per wave instruction)
         const int lds = woff_base + wbytes + P_NB * slotpix * 32;
         if (nitems > P_NT || lds > 160 * 1024) continue;
+        if (rec && slotpix / 32 > 64) continue; // (8 waves x 8 DMA instructions per chunk)
         if (!best || PR * PWP < g->PR * g->PWP || (PR * PWP == g->PR * g->PWP && SW > g->SW)) {
             best = 1;
             g->SW = SW; g->dx = dx; g->PWP = PWP; g->PWH = PWP / 2; g->PR = PR; g->nitems = nitems; g->cpi = cpi; g->ngrp = PWP / 4; g->slotpix = slotpix;
@@ -617,8 +991,19 @@ static int fpatch_geom(const mhip_conv_f32_t *p, fpatch_geom_t *g, int frames) {
     }
     if (!best) return 0;
     g->nstrips = p->out_w / g->SW;
+    g->ndma = g->slotpix / 32;
+    if (rec) {
+        // four slots where they fit: a chunk's DMA is then issued two chunk periods earlier (one workgroup per CU by registers:
+        // nothing else hides a DMA's latency)
+        const int lds4 = g->lds_bytes + 2 * g->slotpix * 32;
+        const bool four = g->nchunk % 4 == 0 && lds4 <= 160 * 1024;
+        if (four) { g->nb = 4; g->lds_bytes = lds4; }
+        else return 0; // two slots: a chunk's DMA would be issued one chunk period before its first reader -- measured SLOWER than the
+                       // register-staged form on the stride-2 layers whose patch leaves no room for four (3 x 3 s2 128 -> 256 @80: 1226 vs 1067 us)
+        if (g->nsteps < 4 || (size_t)2 * g->oc_pad * g->kp * 2 > 0x7ffffff0ull) return 0;
+    }
     int sched[1024];
-    if (g->nsteps > 1024 || !fpatch_schedule(g->nchunk, g->U, g->nsteps, sched)) return 0;
+    if (g->nsteps > 1024 || !fpatch_schedule(g->nchunk, g->U, g->nsteps, sched, g->nb, rec)) return 0;
     const long total = (long)frames * p->out_h * p->out_w;
     const size_t in_bytes = (size_t)(frames - 1) * p->in_stride + (size_t)p->in_c * p->in_h * p->in_w * 4;
     if (total > 0x7fffffffL - g->bn || in_bytes > 0xfffffff0ull || (size_t)frames * p->out_stride > 0xfffffff0ull) return 0;
@@ -626,15 +1011,16 @@ static int fpatch_geom(const mhip_conv_f32_t *p, fpatch_geom_t *g, int frames) {
     g->ntiles = (unsigned)((total + g->bn - 1) / g->bn);
     g->nsegs = (unsigned)(frames * g->nstrips);
     g->in_bytes = (unsigned)in_bytes;
+    g->out_bytes = (unsigned)((size_t)(frames - 1) * p->out_stride + (size_t)p->out_c * p->out_h * p->out_w * 4);
     g->dSW = make_pdiv((unsigned)g->SW); g->dHo = make_pdiv((unsigned)g->H_out); g->dHV = make_pdiv((unsigned)g->HV);
-    g->dNS = make_pdiv((unsigned)g->nstrips); g->dgrp = make_pdiv((unsigned)g->ngrp);
+    g->dNS = make_pdiv((unsigned)g->nstrips); g->dgrp = make_pdiv((unsigned)g->ngrp); g->dPWP = make_pdiv((unsigned)g->PWP);
     return 1;
 }
 
 // patch-pixel offset of unit (chunk c, tap) of the K stream: ring slot + tap position (stride 2: de-interleaved columns)
 static int fpatch_toff(const fpatch_geom_t *g, int c, int tap) {
     const int ky = tap / g->kw, kx = tap - ky * g->kw, v = g->dx + kx;
-    return (c % P_NB) * g->slotpix + ky * g->PWP + (g->s == 2 ? (v >> 1) + (v & 1) * g->PWH : v);
+    return (c % g->nb) * g->slotpix + ky * g->PWP + (g->s == 2 ? (v >> 1) + (v & 1) * g->PWH : v);
 }
 
 static uint16_t pbf16_rn(float x) {
@@ -660,12 +1046,13 @@ static void shape_of(mhip_conv_f32_t *p, int out_c, int in_c, int kh, int kw, in
 // Bytes of, and (w, out != NULL) the content of, the image conv_f32_patch reads: [nsteps][4] unit offsets (bytes into the patch ring, -1 = dummy), [nsteps] schedule, then
 // two planes (hi, mid) of bf16 [oc_pad][kp] in the kernel's K order: element 8 u + j of a row = channel 8 c + j, tap of unit u =
 // (chunk c, tap) (dummy units and the slack: zeros).  0 = not a shape this kernel takes.
-extern "C" size_t mhip_conv_f32_patch_pack(int out_c, int in_c, int kh, int kw, int stride, int pad, int in_h, int in_w, int out_h, int out_w,
-                                           const float *w, void *out) {
+// rec != 0: the image of the record-input form (conv_f32_prec): the ring may have four slots, the schedule names DMA issue steps.
+extern "C" size_t mhip_conv_f32_patch_pack2(int out_c, int in_c, int kh, int kw, int stride, int pad, int in_h, int in_w, int out_h, int out_w,
+                                            int rec, const float *w, void *out) {
     mhip_conv_f32_t p;
     shape_of(&p, out_c, in_c, kh, kw, stride, pad, in_h, in_w, out_h, out_w);
     fpatch_geom_t g;
-    if (out_c <= 0 || !fpatch_geom(&p, &g, 1)) return 0;
+    if (out_c <= 0 || !fpatch_geom(&p, &g, 1, rec != 0)) return 0;
     const size_t tabb = ((size_t)g.tab_ints * 4 + 255) & ~(size_t)255, planeb = (size_t)g.oc_pad * g.kp * 2;
     const size_t bytes = tabb + 2 * planeb;
     if (!w || !out) return bytes;
@@ -674,7 +1061,7 @@ extern "C" size_t mhip_conv_f32_patch_pack(int out_c, int in_c, int kh, int kw, 
     int units[4096];
     fpatch_units(g.nchunk, g.U, units, 4096);
     for (int i = 0; i < g.nsteps * 4; i++) tabs[i] = units[i] < 0 ? -1 : fpatch_toff(&g, units[i], i - units[i] * g.U) * 32; // bytes: 32 per patch pixel
-    fpatch_schedule(g.nchunk, g.U, g.nsteps, tabs + g.nsteps * 4);
+    fpatch_schedule(g.nchunk, g.U, g.nsteps, tabs + g.nsteps * 4, g.nb, g.rec);
     uint16_t *hi = (uint16_t *)((char *)out + tabb), *mid = hi + (size_t)g.oc_pad * g.kp;
     for (int oc = 0; oc < out_c; oc++)
         for (int u = 0; u < g.nchunk * g.U; u++) {
@@ -691,21 +1078,31 @@ extern "C" size_t mhip_conv_f32_patch_pack(int out_c, int in_c, int kh, int kw, 
     return bytes;
 }
 
+extern "C" size_t mhip_conv_f32_patch_pack(int out_c, int in_c, int kh, int kw, int stride, int pad, int in_h, int in_w, int out_h, int out_w,
+                                           const float *w, void *out) {
+    return mhip_conv_f32_patch_pack2(out_c, in_c, kh, kw, stride, pad, in_h, in_w, out_h, out_w, 0, w, out);
+}
+
 // the geometry as ints (tests / tools): s kh kw pad C nchunk U SW nstrips H_in W_in H_out W_out HV PR PWP PWH dx slotpix nsteps ngrp
-// nitems BM kp oc_pad tab_ints ndummy cpi bn woff poff lds_bytes; returns how many were written (0 = not a shape this kernel takes)
-extern "C" int mhip_conv_f32_patch_geom(int out_c, int in_c, int kh, int kw, int stride, int pad, int in_h, int in_w, int out_h, int out_w, int *outv, int cap) {
+// nitems BM kp oc_pad tab_ints ndummy cpi bn woff poff lds_bytes nb rec ndma; returns how many were written (0 = not a shape this kernel takes)
+extern "C" int mhip_conv_f32_patch_geom2(int out_c, int in_c, int kh, int kw, int stride, int pad, int in_h, int in_w, int out_h, int out_w, int rec,
+                                         int *outv, int cap) {
     mhip_conv_f32_t p;
     shape_of(&p, out_c, in_c, kh, kw, stride, pad, in_h, in_w, out_h, out_w);
     fpatch_geom_t g;
-    if (out_c <= 0 || !fpatch_geom(&p, &g, 1)) return 0;
-    const int n = 32;
+    if (out_c <= 0 || !fpatch_geom(&p, &g, 1, rec != 0)) return 0;
+    const int n = 35;
     if (cap < n) return 0;
     memcpy(outv, &g, n * sizeof(int));
     return n;
 }
+extern "C" int mhip_conv_f32_patch_geom(int out_c, int in_c, int kh, int kw, int stride, int pad, int in_h, int in_w, int out_h, int out_w, int *outv, int cap) {
+    return mhip_conv_f32_patch_geom2(out_c, in_c, kh, kw, stride, pad, in_h, in_w, out_h, out_w, 0, outv, cap);
+}
 
-static unsigned long g_patch_launches = 0;
+static unsigned long g_patch_launches = 0, g_prec_launches = 0;
 extern "C" unsigned long mhip_conv_f32_patch_launches(void) { return g_patch_launches; }
+extern "C" unsigned long mhip_conv_f32_prec_launches(void) { return g_prec_launches; }
 
 template <int BM, int WM, int WN, int CPI, bool DUMMY, int BN>
 static int launch_patch(const mhip_conv_f32_t *p, fpatch_geom_t &g) {
@@ -736,12 +1133,52 @@ static int launch_patch(const mhip_conv_f32_t *p, fpatch_geom_t &g) {
     return mhip_check(hipGetLastError(), "conv_f32_patch");
 }
 
-// -2: not a shape this kernel takes (the caller goes on to conv_f32_split), else the launch result
+template <int BM, int WM, int WN, bool DUMMY, int BN, int NDW>
+static int launch_prec(const mhip_conv_f32_t *p, fpatch_geom_t &g) {
+    auto kern = conv_f32_prec<BM, WM, WN, DUMMY, BN, NDW>;
+    static int cus = 0;
+    if (!cus) {
+        hipDeviceProp_t prop;
+        int dev = 0;
+        if (hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess ||
+            hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess)
+            return mhip_check(hipErrorUnknown, "conv_f32_prec attribute");
+        cus = prop.multiProcessorCount;
+    }
+    const unsigned noc = (unsigned)((p->out_c + BM - 1) / BM);
+    if (noc > 65535u) return -2;
+    int slots = 0;
+    mhip_conv_i8_tune_get("persist_slots", &slots);
+    unsigned gx = (unsigned)(slots > 0 ? slots : cus) / noc; // one 8-wave workgroup per CU (registers)
+    if (gx < 1) gx = 1;
+    if (gx > g.ntiles) gx = g.ntiles;
+    const unsigned per = (g.ntiles + gx - 1) / gx;
+    gx = (g.ntiles + per - 1) / per;
+    g.per = per;
+    const size_t tabb = ((size_t)g.tab_ints * 4 + 255) & ~(size_t)255;
+    hipLaunchKernelGGL(kern, dim3(gx, noc), dim3(P_NT), (size_t)g.lds_bytes, mhip_stream_native(), *p, g, (const int *)p->w_patch,
+                       (const int8_t *)p->w_patch + tabb);
+    g_prec_launches++;
+    return mhip_check(hipGetLastError(), "conv_f32_prec");
+}
+
+// -2: not a shape this kernel takes (the caller goes on to conv_f32_split), else the launch result.  in_rec: the input is in record
+// format and the image (w_patch) was packed for that form (mhip_conv_f32_patch_pack2 with rec = 1) -- the planner's pairing
 int conv_f32_try_patch(const mhip_conv_f32_t *p) {
-    if (!p->w_patch || p->use_mfma != 3) return -2;
+    if (!p->w_patch || p->use_mfma != 3 || p->out_rec) return -2;
     fpatch_geom_t g;
-    if (!fpatch_geom(p, &g, p->frames)) return -2;
+    if (!fpatch_geom(p, &g, p->frames, p->in_rec != 0)) return -2;
     if (p->add && p->add_stride != p->out_stride) return -2;
+    if (p->in_rec) {
+        const int ndw = (g.ndma + 7) / 8;
+#define FR_N(BM, WM, WN, D, BN) (ndw <= 2 ? launch_prec<BM, WM, WN, D, BN, 2>(p, g) : ndw <= 3 ? launch_prec<BM, WM, WN, D, BN, 3>(p, g) : ndw <= 4 ? launch_prec<BM, WM, WN, D, BN, 4>(p, g) : ndw <= 6 ? launch_prec<BM, WM, WN, D, BN, 6>(p, g) : launch_prec<BM, WM, WN, D, BN, 8>(p, g))
+#define FR_D(BM, WM, WN, BN) (g.ndummy ? FR_N(BM, WM, WN, true, BN) : FR_N(BM, WM, WN, false, BN))
+        if (g.BM == 128) return FR_D(128, 2, 4, 256);
+        if (g.BM == 64) return g.bn == 512 ? FR_D(64, 1, 8, 512) : FR_D(64, 1, 8, 256);
+        return g.bn == 512 ? FR_D(32, 1, 8, 512) : FR_D(32, 1, 8, 256);
+#undef FR_D
+#undef FR_N
+    }
 #define FP_D(BM, WM, WN, CPI, BN) (g.ndummy ? launch_patch<BM, WM, WN, CPI, true, BN>(p, g) : launch_patch<BM, WM, WN, CPI, false, BN>(p, g))
 #define FP_CPI(BM, WM, WN, BN) (g.cpi == 8 ? FP_D(BM, WM, WN, 8, BN) : g.cpi == 4 ? FP_D(BM, WM, WN, 4, BN) : FP_D(BM, WM, WN, 2, BN))
     if (g.BM == 128) return FP_CPI(128, 2, 4, 256);

@@ -141,8 +141,11 @@ struct split_args_t {
 };
 
 // BM = output channels per workgroup (128 | 64 | 32); waves: WM along channels x WN along pixels, WM * WN == 8
-template <int BM, int WM, int WN, int GATHER, int NPL>
-__global__ __launch_bounds__(S_NT, BM == 32 && NPL == 2 ? 4 : 2) void conv_f32_split(const mhip_conv_f32_t p, const split_args_t g) {
+// RECOUT (mhip_conv_f32_t.out_rec, two pieces only): the results leave as RECORDS -- [out_c / 8][H][W] x 32 bytes = [8 x bf16 hi | 8 x bf16 mid] of
+// 8 consecutive channels of one pixel -- for the one k x k convolution that reads them (conv_f32_prec in conv_f32_patch.hip: its staging
+// phase is then plain LDS-DMA).  The MFMA operands change places (D = W X^T), so a lane ends with 4 consecutive CHANNELS of one pixel.
+template <int BM, int WM, int WN, int GATHER, int NPL, bool RECOUT = false>
+__global__ __launch_bounds__(S_NT, BM == 32 && NPL == 2 && !RECOUT ? 4 : 2) void conv_f32_split(const mhip_conv_f32_t p, const split_args_t g) {
     constexpr int TM = BM / WM, TN = S_BN / WN; // wave tile
     constexpr int MI = TM / 16, NI = TN / 16;   // MFMA tiles per wave
     constexpr int APLANE = BM * 64, BPLANE = S_BN * 64;
@@ -328,9 +331,17 @@ __global__ __launch_bounds__(S_NT, BM == 32 && NPL == 2 ? 4 : 2) void conv_f32_s
     v4f acc[MI][NI], bias4[MI];
 #pragma unroll
     for (int a = 0; a < MI; a++) {
-        const int oc = oc0 + wm * TM + a * 16 + fr;
-        const float b = p.bias && oc < p.out_c ? p.bias[oc] : 0.f;
-        bias4[a] = (v4f){b, b, b, b};
+        if (RECOUT) { // the lane's four channels: 4 * fc .. + 3 of channel tile a
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                const int oc = oc0 + wm * TM + a * 16 + fc * 4 + j;
+                bias4[a][j] = p.bias && oc < p.out_c ? p.bias[oc] : 0.f;
+            }
+        } else {
+            const int oc = oc0 + wm * TM + a * 16 + fr;
+            const float b = p.bias && oc < p.out_c ? p.bias[oc] : 0.f;
+            bias4[a] = (v4f){b, b, b, b};
+        }
 #pragma unroll
         for (int c = 0; c < NI; c++) acc[a][c] = bias4[a];
     }
@@ -374,6 +385,12 @@ __global__ __launch_bounds__(S_NT, BM == 32 && NPL == 2 ? 4 : 2) void conv_f32_s
                     acc[a][c] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bf[0][c], af[NPL - 1][a], acc[a][c], 0, 0, 0); // lo * hi
                     acc[a][c] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bf[NPL - 1][c], af[0][a], acc[a][c], 0, 0, 0); // hi * lo
                     acc[a][c] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bf[1][c], af[1][a], acc[a][c], 0, 0, 0);       // mid * mid
+                }
+                if (RECOUT) { // (NPL == 2) weights are the A operand: rows = channels
+                    acc[a][c] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[0][a], bf[1][c], acc[a][c], 0, 0, 0);
+                    acc[a][c] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[1][a], bf[0][c], acc[a][c], 0, 0, 0);
+                    acc[a][c] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[0][a], bf[0][c], acc[a][c], 0, 0, 0);
+                    continue;
                 }
                 acc[a][c] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bf[1][c], af[0][a], acc[a][c], 0, 0, 0); // hi * mid
                 acc[a][c] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bf[0][c], af[1][a], acc[a][c], 0, 0, 0); // mid * hi
@@ -436,6 +453,38 @@ __global__ __launch_bounds__(S_NT, BM == 32 && NPL == 2 ? 4 : 2) void conv_f32_s
         // the four in one frame and the address aligned), 4 lanes = 64 contiguous bytes, 16 channel rows per instruction
         const unsigned p0 = pt * S_BN;
         const bool vec4 = (hw & 3u) == 0u;
+        if (RECOUT) {
+            // a lane holds channels 4 fc .. + 3 (of channel tile a) of pixel fr (of pixel tile c): its two hi dwords and two mid dwords.
+            // v_permlane16_swap between lane rows fc, fc ^ 1 (every lane takes part: before any branch): the even row ends with the
+            // mid pieces of all 8 channels of the record, the odd row with the hi pieces -- one 16-byte store per lane, 32 contiguous
+            // bytes per pixel, 512 per chunk and instruction
+#pragma unroll
+            for (int c = 0; c < NI; c++) {
+                const unsigned px = p0 + (unsigned)(wn * TN + c * 16 + fr);
+                const bool pok = px < g.total_pix;
+                const unsigned f = sdiv(pok ? px : 0u, g.dhw), rem = (pok ? px : 0u) - f * hw;
+                char *ob = (char *)p.out + (size_t)f * p.out_stride + (size_t)rem * 32u + ((fc & 1) ? 0u : 16u);
+#pragma unroll
+                for (int a = 0; a < MI; a++) {
+                    float x[4];
+#pragma unroll
+                    for (int j = 0; j < 4; j++) x[j] = p.silu ? silu_fast(acc[a][c][j]) : acc[a][c][j];
+                    int hi[2], mid[2], lo_[2];
+                    splitn<4, 2>(x, hi, mid, lo_);
+#pragma unroll
+                    for (int i = 0; i < 2; i++) { // no residual of a non-finite hi (as the weights' packer and conv_f32_patch's split)
+                        const float h0 = __int_as_float(hi[i] << 16), h1 = __int_as_float(hi[i] & (int)0xffff0000);
+                        mid[i] = (__builtin_isfinite(h0) ? mid[i] & 0xffff : 0) | (__builtin_isfinite(h1) ? mid[i] & (int)0xffff0000 : 0);
+                    }
+                    const auto s0 = __builtin_amdgcn_permlane16_swap((unsigned)mid[0], (unsigned)hi[0], false, false);
+                    const auto s1 = __builtin_amdgcn_permlane16_swap((unsigned)mid[1], (unsigned)hi[1], false, false);
+                    const int chunk = (oc0 + wm * TM + a * 16) / 8 + (fc >> 1);
+                    if (pok && chunk * 8 < p.out_c) *(v4i *)(ob + (size_t)chunk * hw * 32u) = (v4i){(int)s0[0], (int)s1[0], (int)s0[1], (int)s1[1]};
+                    acc[a][c] = bias4[a];
+                }
+            }
+            continue;
+        }
 #pragma unroll
         for (int c = 0; c < NI; c++) {
             const unsigned px = p0 + (unsigned)(wn * TN + c * 16 + fc * 4);
@@ -495,9 +544,9 @@ extern "C" unsigned long mhip_conv_f32_split_launches(void) { return g_split_lau
 // kernel row length in the packed K space: an odd kernel width under stride 2 gets one zero column (taps come in pairs there)
 static int split_kwp(int kw, int stride_w) { return stride_w == 2 && kw > 1 && (kw & 1) ? kw + 1 : kw; }
 
-template <int BM, int WM, int WN, int GATHER, int NPL>
+template <int BM, int WM, int WN, int GATHER, int NPL, bool RECOUT = false>
 static int launch_split(const mhip_conv_f32_t *p, split_args_t g) {
-    auto kern = conv_f32_split<BM, WM, WN, GATHER, NPL>;
+    auto kern = conv_f32_split<BM, WM, WN, GATHER, NPL, RECOUT>;
     const size_t ldsb = 2 * NPL * (size_t)(BM * 64 + S_BN * 64);
     static int slots = 0; // workgroups the device holds at once (per instantiation)
     if (!slots) {
@@ -524,6 +573,11 @@ static int launch_split(const mhip_conv_f32_t *p, split_args_t g) {
 }
 template <int GATHER, int NPL>
 static int launch_split_bm(const mhip_conv_f32_t *p, const split_args_t &g) {
+    if (p->out_rec) { // (two pieces only: checked by the caller)
+        if (p->out_c > 64) return launch_split<128, 2, 4, GATHER, 2, true>(p, g);
+        if (p->out_c > 32) return launch_split<64, 1, 8, GATHER, 2, true>(p, g);
+        return launch_split<32, 1, 8, GATHER, 2, true>(p, g);
+    }
     if (p->out_c > 64 && NPL == 2) return launch_split<128, 2, 4, GATHER, 2>(p, g); // (three planes: the 128-row tile spills)
     if (p->out_c > 32) return launch_split<64, 1, 8, GATHER, NPL>(p, g);
     return launch_split<32, 1, 8, GATHER, NPL>(p, g);
@@ -535,7 +589,8 @@ static int launch_split_npl(const mhip_conv_f32_t *p, const split_args_t &g) { /
 
 // -2: not a shape this kernel takes (the caller falls back to conv_f32_mfma), else the launch result
 int conv_f32_try_split(const mhip_conv_f32_t *p) {
-    if (!p->w_split) return -2;
+    if (!p->w_split || p->in_rec) return -2;
+    if (p->out_rec && (p->use_mfma != 3 || p->add || (p->out_c & 7))) return -2;
     const long hw = (long)p->out_h * p->out_w, total = hw * p->frames;
     const int kwp = split_kwp(p->kw, p->stride_w);
     const long K = (long)p->in_c * p->kh * kwp;

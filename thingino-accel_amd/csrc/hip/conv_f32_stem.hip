@@ -70,6 +70,10 @@ __device__ __forceinline__ void stem_split8(const float (&x)[8], v4i &hi, v4i &m
     }
 }
 
+// RECOUT (mhip_conv_f32_t.out_rec): the results leave in record format for the one k x k convolution that reads them (layer 3 of the
+// yolov5 twins; conv_f32_split.hip says what a record is): the MFMA operands change places, a lane ends with 4 consecutive channels of
+// one pixel, v_permlane16_swap pairs them into 16-byte halves of a record.
+template <bool RECOUT>
 __global__ __launch_bounds__(ST_NT, 2) void conv_f32_stem(const mhip_conv_f32_t p, const stem_geom_t g, const int8_t *__restrict__ wpl) {
     constexpr int MI = 2, NI = 4; // 32 channels x 64 pixels per wave
     extern __shared__ __attribute__((aligned(16))) int8_t lds[];
@@ -167,9 +171,17 @@ __global__ __launch_bounds__(ST_NT, 2) void conv_f32_stem(const mhip_conv_f32_t 
     v4f acc[MI][NI], bias4[MI];
 #pragma unroll
     for (int a = 0; a < MI; a++) {
-        const int oc = a * 16 + fr;
-        const float b = p.bias && oc < p.out_c ? p.bias[oc] : 0.f;
-        bias4[a] = (v4f){b, b, b, b};
+        if (RECOUT) {
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                const int oc = a * 16 + fc * 4 + j;
+                bias4[a][j] = p.bias && oc < p.out_c ? p.bias[oc] : 0.f;
+            }
+        } else {
+            const int oc = a * 16 + fr;
+            const float b = p.bias && oc < p.out_c ? p.bias[oc] : 0.f;
+            bias4[a] = (v4f){b, b, b, b};
+        }
 #pragma unroll
         for (int n = 0; n < NI; n++) acc[a][n] = bias4[a];
     }
@@ -188,6 +200,12 @@ __global__ __launch_bounds__(ST_NT, 2) void conv_f32_stem(const mhip_conv_f32_t 
             for (int a = 0; a < MI; a++)
 #pragma unroll
                 for (int n = 0; n < NI; n++) {
+                    if (RECOUT) { // weights are the A operand: rows = channels
+                        acc[a][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh[ks][a], xm[n], acc[a][n], 0, 0, 0);
+                        acc[a][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wm[ks][a], xh[n], acc[a][n], 0, 0, 0);
+                        acc[a][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh[ks][a], xh[n], acc[a][n], 0, 0, 0);
+                        continue;
+                    }
                     acc[a][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xm[n], wh[ks][a], acc[a][n], 0, 0, 0);
                     acc[a][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xh[n], wm[ks][a], acc[a][n], 0, 0, 0);
                     acc[a][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xh[n], wh[ks][a], acc[a][n], 0, 0, 0);
@@ -198,6 +216,29 @@ __global__ __launch_bounds__(ST_NT, 2) void conv_f32_stem(const mhip_conv_f32_t 
         unsigned f;
         int oy0, ox0;
         tile_origin(t, f, oy0, ox0);
+        if (RECOUT) { // lane = pixel fr of tile n, channels 4 fc .. + 3 of channel tile a; lane rows fc, fc ^ 1 trade pieces (every lane: no branch)
+#pragma unroll
+            for (int n = 0; n < NI; n++) {
+                const unsigned pos = (unsigned)((oy0 + 2 * wv + (n >> 1)) * g.W_out + ox0 + (n & 1) * 16 + fr);
+                char *ob = (char *)p.out + (size_t)f * p.out_stride + (size_t)pos * 32u + ((fc & 1) ? 0u : 16u);
+#pragma unroll
+                for (int a = 0; a < MI; a++) {
+                    float x[8];
+#pragma unroll
+                    for (int j = 0; j < 4; j++) x[j] = p.silu ? stem_silu(acc[a][n][j]) : acc[a][n][j];
+#pragma unroll
+                    for (int j = 4; j < 8; j++) x[j] = 0.f;
+                    v4i hi, mid;
+                    stem_split8(x, hi, mid);
+                    const auto s0 = __builtin_amdgcn_permlane16_swap((unsigned)mid[0], (unsigned)hi[0], false, false);
+                    const auto s1 = __builtin_amdgcn_permlane16_swap((unsigned)mid[1], (unsigned)hi[1], false, false);
+                    const int chunk = 2 * a + (fc >> 1);
+                    if (chunk * 8 < p.out_c) *(v4i *)(ob + (size_t)chunk * hw * 32u) = (v4i){(int)s0[0], (int)s1[0], (int)s0[1], (int)s1[1]};
+                    acc[a][n] = bias4[a];
+                }
+            }
+            return;
+        }
 #pragma unroll
         for (int n = 0; n < NI; n++) {
             const unsigned pos = (unsigned)((oy0 + 2 * wv + (n >> 1)) * g.W_out + ox0 + (n & 1) * 16 + fc * 4);
@@ -332,15 +373,17 @@ extern "C" unsigned long mhip_conv_f32_stem_launches(void) { return g_stem_launc
 
 // -2: not a shape this kernel takes, else the launch result
 int conv_f32_try_stem(const mhip_conv_f32_t *p) {
-    if (!p->w_patch || p->use_mfma != 3) return -2;
+    if (!p->w_patch || p->use_mfma != 3 || p->in_rec) return -2;
     stem_geom_t g;
     if (!stem_geom(p, &g, p->frames)) return -2;
     if (p->add && p->add_stride != p->out_stride) return -2;
+    if (p->out_rec && (p->add || (p->out_c & 7))) return -2;
     static int cus = 0;
     if (!cus) {
         hipDeviceProp_t prop;
         int dev = 0;
-        if (hipFuncSetAttribute((const void *)conv_f32_stem, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess ||
+        if (hipFuncSetAttribute((const void *)conv_f32_stem<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess ||
+            hipFuncSetAttribute((const void *)conv_f32_stem<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess ||
             hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess)
             return mhip_check(hipErrorUnknown, "conv_f32_stem attribute");
         cus = prop.multiProcessorCount;
@@ -351,7 +394,8 @@ int conv_f32_try_stem(const mhip_conv_f32_t *p) {
     if (gx > g.ntiles) gx = g.ntiles;
     g.per = (g.ntiles + gx - 1) / gx;
     gx = (g.ntiles + g.per - 1) / g.per;
-    hipLaunchKernelGGL(conv_f32_stem, dim3(gx), dim3(ST_NT), (size_t)g.lds_bytes, mhip_stream_native(), *p, g, (const int8_t *)p->w_patch);
+    if (p->out_rec) hipLaunchKernelGGL(conv_f32_stem<true>, dim3(gx), dim3(ST_NT), (size_t)g.lds_bytes, mhip_stream_native(), *p, g, (const int8_t *)p->w_patch);
+    else hipLaunchKernelGGL(conv_f32_stem<false>, dim3(gx), dim3(ST_NT), (size_t)g.lds_bytes, mhip_stream_native(), *p, g, (const int8_t *)p->w_patch);
     g_stem_launches++;
     return mhip_check(hipGetLastError(), "conv_f32_stem");
 }

@@ -185,6 +185,9 @@ __global__ __launch_bounds__(NTHREADS) void conv_i8_patch(const mhip_conv_i8_t p
     // tests and a 64-bit select, cost a wave ~1800 cycles per tile in issue alone.)  Needs 31-bit offsets (in_bytes != 0).
     const __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc((void *)p.in, 0, (int)in_bytes, 0x00020000);
     auto issue_patch = [&](unsigned t, int8_t *dst) {
+#ifdef PATCH_ABL // timing-only build (tools/stamps_build.sh patchabl 1): no patch is fetched -- what the layer costs with its input already in LDS
+        return;
+#endif
         int tx, ty;
         unsigned f;
         tile_xy(t, tx, ty, f);

@@ -419,7 +419,11 @@ __device__ __forceinline__ void conv_i8_rgb_body(
             }
             const int oy = oy0 + u0 + u;
             const int soff = (int)(obase + (unsigned)(oy * p.out_w) * (unsigned)pixs);
+#ifdef RGB_ABL // timing-only build (tools/stamps_build.sh rgbabl 1): every store dropped by the buffer unit -- what the stem costs without its output
+            const bool rok = false;
+#else
             const bool rok = chok && oy < p.out_h; // stores always issue: the same vmcnt in every wave
+#endif
             if (WOC == 2) {
                 // lane rows g, g^1 trade halves: even g ends with channels 8g..8g+15 of column 2n, odd g with channels
                 // 8(g-1)..8(g-1)+15 of column 2n+1

@@ -45,6 +45,7 @@ typedef struct {
     uint8_t *host;   /* pinned staging for graph I/O: batch * bytes */
     uint8_t *dense_dev; /* padded rows only: batch * bytes, the dense copy made on the device before a download */
     int pix_c, pix_stride; /* pix_stride != 0: [pixels][pix_c] rows kept at a pix_stride-byte pitch on the device (pad_output_rows) */
+    int rec_c, rec_hw;     /* rec_c != 0: a float tensor kept in RECORD format on the device (rec_pairs): [rec_c / 8][rec_hw] x 32 bytes */
 } mtensor_t;
 
 typedef struct {
@@ -74,6 +75,8 @@ typedef struct {
                         (mhip_conv_i8_rgb_pack), or (w2_rows) a deep 3x3 layer's as conv_i8_rows streams them (mhip_conv_i8_rows_pack) */
     int w2_rows;
     size_t w3_off;   /* conv_f32: conv_f32_patch's image (unit table, schedule, two bf16 planes in its K order), or NO_OFF */
+    int w3_stem;     /* ... that image is conv_f32_stem's */
+    int in_rec, out_rec; /* conv_f32: the input / output tensor is in record format (rec_pairs; mhip_conv_f32_t.in_rec / out_rec) */
     size_t lut2_off; /* 512-entry half-step form of the fused LUT (4-instruction requantisation), or NO_OFF */
     size_t w_blob_off[2];     /* operands that live in the blob mirror */
     double macs, bytes;       /* algorithmic work per frame */
@@ -91,6 +94,9 @@ typedef struct {
     int no_vconcat; /* virtual concat switched off (a batch too large for 32-bit buffer offsets) */
     int no_download; /* mars_hip_set_output_mode(MARS_HIP_OUTPUT_ON_DEVICE): mars_run leaves the graph outputs in HBM */
     int no_bottleneck; /* fused bottlenecks (fusion level 2) switched off: one of them cannot launch at this batch */
+    int rec_frames;    /* rec_pairs: the batch the record-format pairs were chosen for (0 = one frame); a pair whose tensors reach 4 GiB at that batch is left alone */
+    int rec_skipped;   /* ... some pair was left alone for that reason (a smaller batch may take it) */
+    size_t rec_max_frames; /* ... the largest batch every chosen pair still fits */
     mtensor_t *mt;
     mars_op_t *ops;
     int n_ops, cap_ops;
@@ -152,6 +158,7 @@ MARS_INTERNAL void fuse_silu_f32(mars_model_ext_t *m);
 MARS_INTERNAL void elide_concat(mars_model_ext_t *m);
 MARS_INTERNAL void fuse_add(mars_model_ext_t *m);
 MARS_INTERNAL void fuse_add_f32(mars_model_ext_t *m);
+MARS_INTERNAL void rec_pairs(mars_model_ext_t *m);
 MARS_INTERNAL void trim_concat(mars_model_ext_t *m);
 MARS_INTERNAL int mars_preproc_prepare(int w, int h, int tw, int th); /* mars_preproc.c: gather tables of a letterbox geometry, cached */
 MARS_INTERNAL void fuse_bottleneck(mars_model_ext_t *m);
@@ -159,6 +166,7 @@ MARS_INTERNAL void virtual_concat(mars_model_ext_t *m);
 MARS_INTERNAL void pair_convs(mars_model_ext_t *m);
 MARS_INTERNAL void fuse_pool_chains(mars_model_ext_t *m);
 MARS_INTERNAL void f32_policy(mars_model_ext_t *m);
+MARS_INTERNAL void rec_pairs(mars_model_ext_t *m);
 /* mars_run.c */
 MARS_INTERNAL void conv_i8_params(const mars_model_ext_t *m, const mars_op_t *op, mhip_conv_i8_t *p);
 

@@ -180,6 +180,7 @@ mars_error_t build_plan(mars_model_ext_t *m) {
         pad_output_rows(m);
     }
     f32_policy(m);
+    if (m->fusion >= 1) rec_pairs(m);
     return (mars_error_t)m->plan_err;
 }
 
@@ -212,7 +213,11 @@ mars_error_t alloc_batch(mars_model_ext_t *m, int n) {
     const size_t vlim = env_v ? (size_t)strtoull(env_v, NULL, 0) : (size_t)0x7fffffffu, blim = env_b ? (size_t)strtoull(env_b, NULL, 0) : 0;
     /* the two batch-dependent fall-backs are decided afresh for every batch (they used to stick once a large
      * batch had switched them on): plan again with the fusions allowed, the checks below take them back if need be */
-    if (m->no_vconcat || m->no_bottleneck) {
+    /* (record-format pairs, rec_pairs: chosen per batch too -- plan again when a chosen pair would not fit this batch, or one left
+     * alone at a larger batch may fit now) */
+    const int rec_replan = (size_t)n > m->rec_max_frames || (m->rec_skipped && n < m->rec_frames);
+    m->rec_frames = n;
+    if (m->no_vconcat || m->no_bottleneck || rec_replan) {
         m->no_vconcat = m->no_bottleneck = 0;
         mars_error_t e = build_plan(m);
         if (e == MARS_OK) e = upload_params(m);

@@ -279,6 +279,7 @@ static void plan_conv(mars_model_ext_t *m, int li) {
                 if (!n3) n3 = mhip_conv_f32_patch_pack(out_c, in_c, kh, kw, sw, pl, in_h, in_w, out_h, out_w, NULL, NULL);
             }
             if (n3) {
+                op->w3_stem = stem;
                 op->w3_off = arena_reserve(m, n3);
                 if (op->w3_off == NO_OFF) return;
                 if (!m->deferred) {
@@ -1154,6 +1155,81 @@ void fuse_pool_chains(mars_model_ext_t *m) {
  * last-bit change can flip which byte wins / whether a mantissa byte is zeroed: measured, 1 value in 16 384 left the
  * tolerance), so every convolution from which one of them can be reached keeps the reference's summation order (conv_f32_kernel, bit-identical); byte-copying
  * layers (concat, upsample) and the float element-wise layers only pass small differences on. */
+/* Record-format tensors between float convolutions (f32_mfma = 3 at load, fusion >= 1).  conv_f32_patch cuts every input value into
+ * two bf16 pieces and lays them out channels-last in LDS -- per K step ~130 vector instructions of its staging phase, which is what
+ * bounds it (profiles/r05_experiments.md).  Where the tensor a k x k convolution X reads is written by another convolution P and read
+ * by nothing else (a C3 bottleneck's 1 x 1 -> 3 x 3, the stem -> layer 3, a C3's last 1 x 1 -> the stride-2 convolution behind it), P
+ * writes those pieces itself ([c / 8][h][w] records of 32 bytes, the same bytes per element: mhip_conv_f32_t.out_rec) and X fills its
+ * patch ring by LDS-DMA (conv_f32_prec).  Same arithmetic: X multiplies exactly the pieces it would have cut itself.  The tensor's
+ * bytes are then not the reference's floats: mars_hip_read_tensor / write_tensor convert (hi + mid, the value to 2^-16).  Depends on
+ * shapes and the mode only (descriptor-only ranks decide alike). */
+void rec_pairs(mars_model_ext_t *m) {
+    const int nt = (int)m->pub.header.num_tensors;
+    for (int i = 0; i < nt; i++) m->mt[i].rec_c = m->mt[i].rec_hw = 0;
+    m->rec_skipped = 0;
+    m->rec_max_frames = (size_t)-1;
+    if (getenv("MARS_HIP_NO_REC") || mhip_conv_f32_mode(-1) != 3) return;
+    const size_t frames = m->rec_frames > 0 ? (size_t)m->rec_frames : 1, lim = 0xfffffff0u; /* 32-bit byte offsets over all frames of a tensor */
+    const int dbg = getenv("MARS_HIP_DEBUG_REC") != NULL;
+    int *readers = (int *)calloc((size_t)nt + 1, sizeof(int));
+    int *writers = (int *)calloc((size_t)nt + 1, sizeof(int));
+    if (!readers || !writers) { free(readers); free(writers); return; }
+    for (int i = 0; i < m->n_ops; i++) {
+        const mars_op_t *o = &m->ops[i];
+        for (int k = 0; k < o->n_in && k < 4; k++)
+            if (o->t_in[k] >= 0) readers[o->t_in[k]]++;
+        /* (the operand of a folded Add is one of t_in[]: fuse_add_f32) */
+        for (int k = 0; k < o->nseg && k < 4; k++)
+            if (o->seg_t[k] >= 0) readers[o->seg_t[k]]++;
+        if (o->t_out >= 0) writers[o->t_out]++;
+        for (int k = 0; k < o->chain_n && k < 3; k++)
+            if (o->chain_out[k] >= 0) writers[o->chain_out[k]]++;
+    }
+    for (int j = 0; j < m->n_ops; j++) {
+        mars_op_t *x = &m->ops[j];
+        if (x->kind != OP_CONV_F32 || x->w3_off == NO_OFF || x->w3_stem || x->n_in != (x->add_t ? 2 : 1) || x->in_rec) { if (dbg) fprintf(stderr, "rec_pairs: op %d (layer %d) stops at check 1\n", j, x->layer); continue; }
+        const int T = x->t_in[0];
+        if (T < 0 || readers[T] != 1 || writers[T] != 1 || m->mt[T].io_in || m->mt[T].io_out || m->mt[T].is_weight) { if (dbg) fprintf(stderr, "rec_pairs: op %d (layer %d) stops at check 2\n", j, x->layer); continue; }
+        if (x->add_t && x->add_t - 1 == T) { if (dbg) fprintf(stderr, "rec_pairs: op %d (layer %d) stops at check 3\n", j, x->layer); continue; }
+        int i = -1;
+        for (int k = 0; k < j; k++)
+            if (m->ops[k].t_out == T) i = k;
+        if (i < 0) { if (dbg) fprintf(stderr, "rec_pairs: op %d (layer %d) stops at check 4\n", j, x->layer); continue; }
+        mars_op_t *pr = &m->ops[i];
+        if (pr->kind != OP_CONV_F32 || pr->add_t || pr->out_rec || (pr->out_c & 7) || pr->kh > 32 || pr->kw > 32) { if (dbg) fprintf(stderr, "rec_pairs: op %d (layer %d) stops at check 5\n", j, x->layer); continue; }
+        if (pr->out_c != x->in_c || pr->out_h != x->in_h || pr->out_w != x->in_w) { if (dbg) fprintf(stderr, "rec_pairs: op %d (layer %d) stops at check 6\n", j, x->layer); continue; }
+        if (!(pr->w2_off != NO_OFF || (pr->w3_off != NO_OFF && pr->w3_stem))) { if (dbg) fprintf(stderr, "rec_pairs: op %d (layer %d) stops at check 7\n", j, x->layer); continue; } /* conv_f32_split or conv_f32_stem writes it */
+        if (m->mt[T].bytes != (size_t)x->in_c * x->in_h * x->in_w * 4) { if (dbg) fprintf(stderr, "rec_pairs: op %d (layer %d) stops at check 8\n", j, x->layer); continue; }
+        const size_t n0 = mhip_conv_f32_patch_pack2(x->out_c, x->in_c, x->kh, x->kw, x->sw, x->pl, x->in_h, x->in_w, x->out_h, x->out_w, 0, NULL, NULL);
+        const size_t n1 = mhip_conv_f32_patch_pack2(x->out_c, x->in_c, x->kh, x->kw, x->sw, x->pl, x->in_h, x->in_w, x->out_h, x->out_w, 1, NULL, NULL);
+        if (!n1 || n1 != n0) { if (dbg) fprintf(stderr, "rec_pairs: op %d (layer %d) stops at check 9\n", j, x->layer); continue; } /* (the image was reserved for the plain form: same size by construction) */
+        { /* the three tensors the two launches address with 32-bit offsets: all frames of each must stay below 4 GiB */
+            const int tt[3] = {pr->t_in[0], T, x->t_out};
+            size_t worst = 0;
+            for (int q = 0; q < 3; q++)
+                if (tt[q] >= 0) {
+                    const mtensor_t *u = &m->mt[tt[q]];
+                    const size_t st = ALIGN_UP(u->extent > u->bytes ? u->extent : u->bytes, 256);
+                    if (st > worst) worst = st;
+                }
+            if (worst && worst * frames > lim) {
+                m->rec_skipped = 1;
+                continue;
+            }
+            if (worst && lim / worst < m->rec_max_frames) m->rec_max_frames = lim / worst;
+        }
+        if (!m->deferred)
+            mhip_conv_f32_patch_pack2(x->out_c, x->in_c, x->kh, x->kw, x->sw, x->pl, x->in_h, x->in_w, x->out_h, x->out_w, 1,
+                                      (const float *)(m->arena_host + x->w_off), m->arena_host + x->w3_off);
+        x->in_rec = 1;
+        pr->out_rec = 1;
+        m->mt[T].rec_c = x->in_c;
+        m->mt[T].rec_hw = x->in_h * x->in_w;
+    }
+    free(readers);
+    free(writers);
+}
+
 void f32_policy(mars_model_ext_t *m) {
     const int nt = (int)m->pub.header.num_tensors;
     unsigned char *hot = (unsigned char *)calloc((size_t)nt + 1, 1);

@@ -124,6 +124,10 @@ static int launch_op(mars_model_ext_t *m, mars_op_t *op) {
                 const int mode = mhip_conv_f32_mode(-1);
                 p.use_mfma = mode == 3 ? 3 : mode == 4 ? 2 : (mode == 2 || (mode == 1 && !op->f32_exact));
             }
+            if (op->in_rec || op->out_rec) { /* planned under f32_mfma = 3 (rec_pairs): these launches stay there whatever the mode is now */
+                p.in_rec = op->in_rec; p.out_rec = op->out_rec;
+                p.use_mfma = 3;
+            }
             return mhip_conv_f32(&p);
         }
         case OP_RELU_BYTES:
@@ -712,6 +716,28 @@ mars_error_t mars_hip_read_tensor(mars_model_t *model, int ti, int frame, void *
         frame = 0;
     }
     if (mhip_sync()) return MARS_ERR_LAYER_FAILED;
+    if (t->rec_c) { /* record format (rec_pairs): the frame comes back as the NCHW floats hi + mid (the value to 2^-16) */
+        const size_t full = (size_t)t->rec_c * t->rec_hw * 4;
+        uint8_t *raw = (uint8_t *)malloc(full);
+        float *f = (float *)malloc(full);
+        if (!raw || !f || bytes > full || mhip_d2h_async(raw, t->dev + (size_t)frame * t->stride, full) || mhip_sync()) {
+            free(raw); free(f);
+            return MARS_ERR_LAYER_FAILED;
+        }
+        for (int c = 0; c < t->rec_c; c++)
+            for (int px = 0; px < t->rec_hw; px++) {
+                const uint8_t *r = raw + ((size_t)(c >> 3) * t->rec_hw + px) * 32 + (size_t)(c & 7) * 2;
+                uint16_t h, md;
+                memcpy(&h, r, 2); memcpy(&md, r + 16, 2);
+                const uint32_t hb = (uint32_t)h << 16, mb = (uint32_t)md << 16;
+                float hf, mf;
+                memcpy(&hf, &hb, 4); memcpy(&mf, &mb, 4);
+                f[(size_t)c * t->rec_hw + px] = hf + mf;
+            }
+        memcpy(dst, f, bytes);
+        free(raw); free(f);
+        return MARS_OK;
+    }
     if (t->pix_stride) { /* padded pixel rows: the frame is packed on the device first */
         uint8_t *dense = t->dense_dev + (size_t)frame * t->bytes;
         if (bytes > t->bytes || !t->dense_dev) return MARS_ERR_INVALID_TENSOR;
@@ -729,6 +755,31 @@ mars_error_t mars_hip_write_tensor(mars_model_t *model, int ti, int frame, const
     mars_model_ext_t *m = (mars_model_ext_t *)model;
     mtensor_t *t = &m->mt[ti];
     if (!t->dev || t->is_weight || frame < 0 || frame >= m->batch || bytes > t->stride) return MARS_ERR_INVALID_TENSOR;
+    if (t->rec_c) { /* record format: whole frames only, cut into the two bf16 pieces as the producing kernel would */
+        const size_t full = (size_t)t->rec_c * t->rec_hw * 4;
+        if (bytes != full) return MARS_ERR_INVALID_TENSOR;
+        uint8_t *raw = (uint8_t *)calloc(1, full);
+        if (!raw) return MARS_ERR_ALLOC_FAILED;
+        const float *f = (const float *)src;
+        for (int c = 0; c < t->rec_c; c++)
+            for (int px = 0; px < t->rec_hw; px++) {
+                float x, hv, r;
+                memcpy(&x, &f[(size_t)c * t->rec_hw + px], 4);
+                uint32_t b;
+                memcpy(&b, &x, 4);
+                const uint16_t h = (b & 0x7fffffffu) > 0x7f800000u ? (uint16_t)((b >> 16) | 0x40u) : (uint16_t)((b + 0x7fffu + ((b >> 16) & 1u)) >> 16);
+                const uint32_t hb = (uint32_t)h << 16;
+                memcpy(&hv, &hb, 4);
+                r = hv - hv == 0.0f ? x - hv : 0.0f;
+                memcpy(&b, &r, 4);
+                const uint16_t md = (b & 0x7fffffffu) > 0x7f800000u ? (uint16_t)((b >> 16) | 0x40u) : (uint16_t)((b + 0x7fffu + ((b >> 16) & 1u)) >> 16);
+                uint8_t *q = raw + ((size_t)(c >> 3) * t->rec_hw + px) * 32 + (size_t)(c & 7) * 2;
+                memcpy(q, &h, 2); memcpy(q + 16, &md, 2);
+            }
+        const int rc = mhip_h2d_async(t->dev + (size_t)frame * t->stride, raw, full) || mhip_sync();
+        free(raw);
+        return rc ? MARS_ERR_LAYER_FAILED : MARS_OK;
+    }
     if (t->pix_stride) { /* padded pixel rows: whole pixels only */
         const size_t rows = bytes / (size_t)t->pix_c;
         if (bytes > t->bytes || rows * (size_t)t->pix_c != bytes) return MARS_ERR_INVALID_TENSOR;

@@ -152,6 +152,12 @@ typedef struct {
                      v_mfma_f32_16x16x32_bf16 with every operand split into three bf16 pieces, six piece products per
                      product (conv_f32_split.hip: errors of the size of an f32 rounding); 3: the same with two pieces
                      and three piece products ("bf16x3": relative error per product <= 2^-16, same tolerance class) */
+    int in_rec, out_rec; /* use_mfma == 3 only: the input / the output is in RECORD format instead of NCHW floats -- [c / 8][h][w] records of
+                            32 bytes = [8 x bf16 hi | 8 x bf16 mid] of 8 consecutive channels of one pixel (hi = bf16(x), mid = bf16(x - hi):
+                            the two pieces conv_f32_patch cuts every input into anyway).  Same bytes per element; a tensor written by one
+                            convolution for ONE k x k convolution to read (the planner pairs them: mars_plan.c rec_pairs).  in_rec needs
+                            w_patch packed by mhip_conv_f32_patch_pack2(rec = 1) (conv_f32_prec); out_rec: conv_f32_split / conv_f32_stem,
+                            no fused Add, out_c a multiple of 8 */
 } mhip_conv_f32_t;
 int mhip_conv_f32(const mhip_conv_f32_t *p);
 /* Bytes of, and (out != NULL) the content of, the weight image conv_f32_split reads: `planes` (2: hi, mid; 3: hi, mid, lo) planes of bf16
@@ -165,6 +171,12 @@ unsigned long mhip_conv_f32_split_launches(void); /* launches of conv_f32_split 
  * [nsteps][4] unit offsets, [nsteps] chunk schedule, two bf16 planes [oc_pad][kp] in its K order; 0 = not such a shape */
 size_t mhip_conv_f32_patch_pack(int out_c, int in_c, int kh, int kw, int stride, int pad, int in_h, int in_w, int out_h, int out_w,
                                 const float *w, void *out);
+/* rec != 0: the image for record-format input (conv_f32_prec: DMA issue schedule, a ring of up to four slots) */
+size_t mhip_conv_f32_patch_pack2(int out_c, int in_c, int kh, int kw, int stride, int pad, int in_h, int in_w, int out_h, int out_w,
+                                 int rec, const float *w, void *out);
+int mhip_conv_f32_patch_geom2(int out_c, int in_c, int kh, int kw, int stride, int pad, int in_h, int in_w, int out_h, int out_w,
+                              int rec, int *outv, int cap);
+unsigned long mhip_conv_f32_prec_launches(void); /* launches of conv_f32_prec (record-format input) since load */
 /* the layer geometry that kernel derives, as ints (tests, tools): see conv_f32_patch.hip; returns the count, 0 = not such a shape */
 int mhip_conv_f32_patch_geom(int out_c, int in_c, int kh, int kw, int stride, int pad, int in_h, int in_w, int out_h, int out_w,
                              int *outv, int cap);

@@ -44,12 +44,25 @@ LAYERS = {  # yolov5s twin at 640 x 640: h, w, in_c, out_c, k, stride, fused Add
 }
 
 
-def build_f32(h, w, ic, oc, k, s):
-    """the float32 form of the same layer: NCHW / OIHW float32 convolution + SIGMOID + MUL (folded into the conv's epilogue)"""
+def build_f32(h, w, ic, oc, k, s, add=False, chain=False):
+    """the float32 form of the same layer: NCHW / OIHW float32 convolution + SIGMOID + MUL (folded into the conv's epilogue).  chain: a
+    1 x 1 convolution ic -> ic (+ SIGMOID + MUL) in front of it (a C3 bottleneck's pair: the planner keeps the tensor between the two in
+    record format under f32_mfma = 3; `norec=1` in a --cfg switches that off) and, with add, the shortcut Add(result, x)"""
     G = marsfile.Graph()
     rng = np.random.default_rng(1)
     F, N = marsfile.F32, marsfile.NCHW
     x = G.tensor([1, ic, h, w], dtype=F, fmt=N)
+    x_in = x
+    if chain:
+        a0 = G.tensor([1, ic, h, w], dtype=F, fmt=N)
+        g0 = G.tensor([1, ic, h, w], dtype=F, fmt=N)
+        o0 = G.tensor([1, ic, h, w], dtype=F, fmt=N)
+        w0 = G.tensor([ic, ic, 1, 1], dtype=F, fmt=marsfile.OIHW, data=((rng.random((ic, ic, 1, 1), dtype=np.float32) * 2 - 1) * (1.7 / ic ** 0.5)).astype(np.float32))
+        b0 = G.tensor([ic], dtype=F, fmt=marsfile.D1, data=((rng.random(ic, dtype=np.float32) * 2 - 1) * 0.1).astype(np.float32))
+        G.conv(x, a0, w0, b0, (1, 1), (1, 1))
+        G.layer(marsfile.SIGMOID, [a0], [g0])
+        G.layer(marsfile.MUL, [a0, g0], [o0])
+        x = o0
     oh, ow = (h + s - 1) // s, (w + s - 1) // s
     a = G.tensor([1, oc, oh, ow], dtype=F, fmt=N)
     g = G.tensor([1, oc, oh, ow], dtype=F, fmt=N)
@@ -60,7 +73,11 @@ def build_f32(h, w, ic, oc, k, s):
     G.conv(x, a, wt, b, (k, k), (s, s))
     G.layer(marsfile.SIGMOID, [a], [g])
     G.layer(marsfile.MUL, [a, g], [o])
-    return G.serialise([x], [o])
+    if chain and add and s == 1 and ic == oc:
+        o2 = G.tensor([1, oc, oh, ow], dtype=F, fmt=N)
+        G.layer(marsfile.ADD, [o, x_in], [o2])
+        o = o2
+    return G.serialise([x_in], [o])
 
 
 def build(h, w, ic, oc, k, s, add):
@@ -95,17 +112,27 @@ def parse_cfg(text):
     return out
 
 
-def run(name, cfg, configs, batch, oracle, f32=False):
+def apply_tune(tune):
+    for kk, vv in tune.items():
+        if kk == "norec":  # planner switch, read from the environment when the model is loaded
+            if vv:
+                os.environ["MARS_HIP_NO_REC"] = "1"
+            else:
+                os.environ.pop("MARS_HIP_NO_REC", None)
+        else:
+            M.set_tuning(kk, vv)
+
+
+def run(name, cfg, configs, batch, oracle, f32=False, chain=False):
     h, w, ic, oc, k, s, add = cfg
-    d = build_f32(h, w, ic, oc, k, s) if f32 else build(*cfg)
+    d = build_f32(h, w, ic, oc, k, s, add, chain) if f32 else build(*cfg)
     rng = np.random.default_rng(7)
     ref = None
     inp = None
     print("%s: %dx%d %d->%d k%d s%d add=%s batch %d" % ((name,) + tuple(cfg) + (batch,)), flush=True)
     for text in configs:
         tune = parse_cfg(text)
-        for kk, vv in tune.items():
-            M.set_tuning(kk, vv)
+        apply_tune(tune)
         m = M.Model(d, batch=batch)
         if inp is None:
             inp = (rng.random(m.input_view(0).shape[0] * (m.input_view(0).shape[1] // 4), dtype=np.float32).view(np.uint8).reshape(m.input_view(0).shape)
@@ -116,10 +143,13 @@ def run(name, cfg, configs, batch, oracle, f32=False):
         m.set_profiling(True)
         best = 1e9
         nlaunch = 0
+        per = []
         for _ in range(5):
             m.run_device()
             ops = m.ops()
-            best = min(best, sum(op["ms"] for op in ops))
+            if sum(op["ms"] for op in ops) < best:
+                best = sum(op["ms"] for op in ops)
+                per = [op["ms"] for op in ops if op["ms"] > 0]
             nlaunch = sum(1 for op in ops if op["ms"] > 0)
         m.download()
         out = m.output_view(0)
@@ -146,10 +176,10 @@ def run(name, cfg, configs, batch, oracle, f32=False):
         macs = oh * ow * oc * ic * k * k * batch
         byts = (h * w * ic + oh * ow * oc * (2 if add else 1)) * batch * (4 if f32 else 1)
         print("   %-40s %7.1f us  %5.0f TOP/s  %5.0f GB/s  %d launch(es)  %s" %
-              (text, best * 1e3, 2 * macs / best / 1e9, byts / best / 1e6, nlaunch, verdict), flush=True)
+              (text, best * 1e3, 2 * macs / best / 1e9, byts / best / 1e6, nlaunch, verdict) +
+              ("  [" + " + ".join("%.1f" % (v * 1e3) for v in per) + "]" if len(per) > 1 else ""), flush=True)
         m.close()
-        for kk in tune:
-            M.set_tuning(kk, 80 if kk == "patch_lds_kb" else 1 if kk == "f32_mfma" else 0)
+        apply_tune({kk: (80 if kk == "patch_lds_kb" else 1 if kk == "f32_mfma" else 0) for kk in tune})
 
 
 def main():
@@ -158,6 +188,7 @@ def main():
     ap.add_argument("--cfg", action="append", default=None, help="default | key=value[,key=value...]; repeatable")
     ap.add_argument("--no-oracle", action="store_true")
     ap.add_argument("--f32", action="store_true", help="the float32 (NCHW) form of the layer; pick the kernel with --cfg f32_mfma=0|2|3")
+    ap.add_argument("--chain", action="store_true", help="(--f32) a 1 x 1 convolution in_c -> in_c in front of the layer, the shortcut Add behind it where the layer has one: a C3 bottleneck")
     args = ap.parse_args()
     if os.environ.get("LIB"):
         M.LIB_PATH = os.path.abspath(os.environ["LIB"])
@@ -166,7 +197,7 @@ def main():
     for name in args.layers:
         cfg = LAYERS[name] if name in LAYERS else tuple(int(v) for v in name.split(","))
         cfg = tuple(cfg[:6]) + (bool(cfg[6]),)
-        run(name, cfg, args.cfg or ["default"], batch, not args.no_oracle, args.f32)
+        run(name, cfg, args.cfg or ["default"], batch, not args.no_oracle, args.f32, args.chain)
 
 
 if __name__ == "__main__":
