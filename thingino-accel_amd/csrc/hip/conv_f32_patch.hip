@@ -530,14 +530,17 @@ __global__ __launch_bounds__(P_NT, 2) void conv_f32_patch(const mhip_conv_f32_t 
 // conv_f32_prec: the same convolution when the INPUT ARRIVES AS RECORDS (mhip_conv_f32_t.in_rec): the producing convolution
 // (conv_f32_split / conv_f32_stem with out_rec) has already cut its results into the two bf16 pieces and written them channels-last,
 // [in_c / 8 chunks][H][W] records of 32 bytes = [8 x hi | 8 x mid] -- exactly what conv_f32_patch's staging phase builds in LDS.  The
-// planner uses the format for a tensor whose only reader is one such convolution (a C3 bottleneck's 1 x 1 -> 3 x 3, stem -> layer 3).
-// What that removes from a K step's staging phase (profiles/r05_experiments.md: the staging phase, ~75 + ~130 vector instructions
-// issued at half rate beside the SIMD mate's MFMAs, is what bounds conv_f32_patch): the patch loads into registers, the split, the
-// LDS writes -- a chunk's slot is now filled by LDS-DMA (buffer_load ... lds, 1 KB per wave instruction, zero fill outside the
-// image by the buffer's range check), and so are the weight stages (four of them: a step's planes are requested three steps ahead).
-// Nothing the compiler counts is loaded inside the K loop, so every wait is counted by hand: a wave knows how many vector-memory
-// instructions it has issued after the DMA it needs (they retire in order), kept as scalar "ages" (yw*: the pending weight stages,
-// yp*: the pending chunks, a FIFO).  Phases, barriers, MFMA order, tile walk, epilogue: conv_f32_patch's.
+// planner uses the format for a tensor whose only reader is one such convolution (a C3 bottleneck's 1 x 1 -> 3 x 3; mars_plan.c rec_pairs).
+// What that removes from a K step's staging phase (profiles/r05_experiments.md: ~75 + ~130 vector instructions issued at half rate
+// beside the SIMD mate's MFMAs bound conv_f32_patch): the patch loads into registers, the split, the LDS writes -- a chunk's slot is
+// filled by LDS-DMA (buffer_load ... lds, 1 KB per wave instruction, zero fill outside the image by the buffer's range check), issued by
+// inline assembly the compiler neither counts nor guards, into a ring of FOUR slots (a chunk is requested two chunk periods before its
+// first reader).  The waits for it are counted by hand: a wave knows how many vector-memory instructions it has issued after the DMA it
+// needs (they retire in order), kept as scalar "ages" of the pending chunks (yp*, a FIFO).  Weights: through registers, as conv_f32_patch.
+// Phases, barriers, MFMA order, tile walk: conv_f32_patch's; the epilogue is branch-free (buffer loads / stores).
+// Same arithmetic as conv_f32_patch on the same values: the two forms' outputs are bit-identical (tools/layer_time.py --chain).
+// Measured (batch 256, the 3 x 3 of a bottleneck pair, us): 160 x 160 x 32: 1044 -> 851; 80 x 80 x 64: 614 -> 537; 40 x 40 x 128: 426 -> 388;
+// 20 x 20 x 256: 429 -> 380.  Not for the patches that leave room for two slots only (the large stride-2 layers): slower there.
 // s_waitcnt vmcnt(n) for a wave-uniform run-time n, rounded DOWN to one of three immediates (any smaller count is correct too, only
 // slower): HI = everything but what one step issues at most (its chunk DMA and two weight loads) may stay in flight -- the usual case, a
 // chunk is needed steps after its DMA; 2 = the chunk was issued in this very step, only the weight loads behind it; else everything.

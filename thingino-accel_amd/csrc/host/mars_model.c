@@ -180,7 +180,7 @@ mars_error_t build_plan(mars_model_ext_t *m) {
         pad_output_rows(m);
     }
     f32_policy(m);
-    if (m->fusion >= 1) rec_pairs(m);
+    rec_pairs(m); /* (fusion >= 1 only; resets the tensors' record flags in any case) */
     return (mars_error_t)m->plan_err;
 }
 

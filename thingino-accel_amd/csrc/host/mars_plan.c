@@ -1168,9 +1168,8 @@ void rec_pairs(mars_model_ext_t *m) {
     for (int i = 0; i < nt; i++) m->mt[i].rec_c = m->mt[i].rec_hw = 0;
     m->rec_skipped = 0;
     m->rec_max_frames = (size_t)-1;
-    if (getenv("MARS_HIP_NO_REC") || mhip_conv_f32_mode(-1) != 3) return;
+    if (m->fusion < 1 || getenv("MARS_HIP_NO_REC") || mhip_conv_f32_mode(-1) != 3) return;
     const size_t frames = m->rec_frames > 0 ? (size_t)m->rec_frames : 1, lim = 0xfffffff0u; /* 32-bit byte offsets over all frames of a tensor */
-    const int dbg = getenv("MARS_HIP_DEBUG_REC") != NULL;
     int *readers = (int *)calloc((size_t)nt + 1, sizeof(int));
     int *writers = (int *)calloc((size_t)nt + 1, sizeof(int));
     if (!readers || !writers) { free(readers); free(writers); return; }
@@ -1187,22 +1186,22 @@ void rec_pairs(mars_model_ext_t *m) {
     }
     for (int j = 0; j < m->n_ops; j++) {
         mars_op_t *x = &m->ops[j];
-        if (x->kind != OP_CONV_F32 || x->w3_off == NO_OFF || x->w3_stem || x->n_in != (x->add_t ? 2 : 1) || x->in_rec) { if (dbg) fprintf(stderr, "rec_pairs: op %d (layer %d) stops at check 1\n", j, x->layer); continue; }
+        if (x->kind != OP_CONV_F32 || x->w3_off == NO_OFF || x->w3_stem || x->n_in != (x->add_t ? 2 : 1) || x->in_rec) continue;
         const int T = x->t_in[0];
-        if (T < 0 || readers[T] != 1 || writers[T] != 1 || m->mt[T].io_in || m->mt[T].io_out || m->mt[T].is_weight) { if (dbg) fprintf(stderr, "rec_pairs: op %d (layer %d) stops at check 2\n", j, x->layer); continue; }
-        if (x->add_t && x->add_t - 1 == T) { if (dbg) fprintf(stderr, "rec_pairs: op %d (layer %d) stops at check 3\n", j, x->layer); continue; }
+        if (T < 0 || readers[T] != 1 || writers[T] != 1 || m->mt[T].io_in || m->mt[T].io_out || m->mt[T].is_weight) continue;
+        if (x->add_t && x->add_t - 1 == T) continue;
         int i = -1;
         for (int k = 0; k < j; k++)
             if (m->ops[k].t_out == T) i = k;
-        if (i < 0) { if (dbg) fprintf(stderr, "rec_pairs: op %d (layer %d) stops at check 4\n", j, x->layer); continue; }
+        if (i < 0) continue;
         mars_op_t *pr = &m->ops[i];
-        if (pr->kind != OP_CONV_F32 || pr->add_t || pr->out_rec || (pr->out_c & 7) || pr->kh > 32 || pr->kw > 32) { if (dbg) fprintf(stderr, "rec_pairs: op %d (layer %d) stops at check 5\n", j, x->layer); continue; }
-        if (pr->out_c != x->in_c || pr->out_h != x->in_h || pr->out_w != x->in_w) { if (dbg) fprintf(stderr, "rec_pairs: op %d (layer %d) stops at check 6\n", j, x->layer); continue; }
-        if (!(pr->w2_off != NO_OFF || (pr->w3_off != NO_OFF && pr->w3_stem))) { if (dbg) fprintf(stderr, "rec_pairs: op %d (layer %d) stops at check 7\n", j, x->layer); continue; } /* conv_f32_split or conv_f32_stem writes it */
-        if (m->mt[T].bytes != (size_t)x->in_c * x->in_h * x->in_w * 4) { if (dbg) fprintf(stderr, "rec_pairs: op %d (layer %d) stops at check 8\n", j, x->layer); continue; }
+        if (pr->kind != OP_CONV_F32 || pr->add_t || pr->out_rec || (pr->out_c & 7) || pr->kh > 32 || pr->kw > 32) continue;
+        if (pr->out_c != x->in_c || pr->out_h != x->in_h || pr->out_w != x->in_w) continue;
+        if (!(pr->w2_off != NO_OFF || (pr->w3_off != NO_OFF && pr->w3_stem))) continue; /* conv_f32_split or conv_f32_stem writes it */
+        if (m->mt[T].bytes != (size_t)x->in_c * x->in_h * x->in_w * 4) continue;
         const size_t n0 = mhip_conv_f32_patch_pack2(x->out_c, x->in_c, x->kh, x->kw, x->sw, x->pl, x->in_h, x->in_w, x->out_h, x->out_w, 0, NULL, NULL);
         const size_t n1 = mhip_conv_f32_patch_pack2(x->out_c, x->in_c, x->kh, x->kw, x->sw, x->pl, x->in_h, x->in_w, x->out_h, x->out_w, 1, NULL, NULL);
-        if (!n1 || n1 != n0) { if (dbg) fprintf(stderr, "rec_pairs: op %d (layer %d) stops at check 9\n", j, x->layer); continue; } /* (the image was reserved for the plain form: same size by construction) */
+        if (!n1 || n1 != n0) continue; /* (the image was reserved for the plain form: same size by construction) */
         { /* the three tensors the two launches address with 32-bit offsets: all frames of each must stay below 4 GiB */
             const int tt[3] = {pr->t_in[0], T, x->t_out};
             size_t worst = 0;
