@@ -1106,6 +1106,60 @@ def test_conv_f32_record_pairs(gpu, orc, shape):
         gpu.set_tuning("dual_stream_min_batch", 64)
 
 
+@pytest.mark.parametrize("shape", [(20, 20, 64, 32, 3), (40, 40, 128, 64, 4), (24, 160, 64, 32, 2), (12, 40, 96, 80, 5), (80, 80, 128, 136, 6)],
+                         ids=lambda v: "x".join(str(q) for q in v))
+def test_conv_f32_pairs(gpu, orc, shape):
+    """C3's cv1 + cv2 in the float twins: two 1 x 1 convolutions (+ SIGMOID / MUL) over the same tensor, same shape -- under f32_mfma = 3 / 4
+    ONE launch (conv_f32_split's pair form, mars_plan.c pair_convs_f32).  Both outputs against the oracle on every frame; the counter
+    proves the pair ran; at fusion level 0, in mode 2 and with MARS_HIP_NO_PAIR_F32 two launches and the same results."""
+    h, w, ic, oc, B = shape
+    rng = np.random.default_rng(h * 100 + ic + oc)
+    G = marsfile.Graph()
+    F, N = marsfile.F32, marsfile.NCHW
+    x = G.tensor([1, ic, h, w], dtype=F, fmt=N)
+    outs = []
+    for _ in range(2):
+        a = G.tensor([1, oc, h, w], dtype=F, fmt=N)
+        wt = G.tensor([oc, ic, 1, 1], dtype=F, fmt=marsfile.OIHW, data=((rng.random((oc, ic, 1, 1), dtype=np.float32) * 2 - 1) * (1.7 / ic ** 0.5)).astype(np.float32))
+        b = G.tensor([oc], dtype=F, fmt=marsfile.D1, data=((rng.random(oc, dtype=np.float32) * 2 - 1) * 0.1).astype(np.float32))
+        G.conv(x, a, wt, b, (1, 1), (1, 1))
+        g_, o_ = G.tensor([1, oc, h, w], dtype=F, fmt=N), G.tensor([1, oc, h, w], dtype=F, fmt=N)
+        G.layer(marsfile.SIGMOID, [a], [g_])
+        G.layer(marsfile.MUL, [a, g_], [o_])
+        outs.append(o_)
+    d = G.serialise([x], outs)
+    nx = min(B, 3)
+    xs = [(rng.random(ic * h * w, dtype=np.float32) * 2 - 1).astype(np.float32) for _ in range(nx)]
+    want = []
+    for q in xs:
+        g = orc.Graph(d)
+        g.set_input(0, q.tobytes())
+        assert g.run() == 0
+        want.append([g.tensor(o).copy() for o in outs])
+        g.close()
+    count = gpu.lib().mhip_conv_f32_pair_launches
+    count.restype = C.c_ulong
+    try:
+        gpu.set_tuning("dual_stream_min_batch", 0)
+        for mode, fusion, expect in ((3, 1, 1), (4, 1, 1), (3, 0, 0), (2, 1, 0)):
+            gpu.set_tuning("f32_mfma", mode)
+            m = gpu.Model(d, batch=B, fusion=fusion)
+            for f in range(B):
+                m.input_view(0)[f] = xs[f % nx].view(np.uint8)
+            n0 = count()
+            m.run()
+            assert count() - n0 == expect, (mode, fusion, count() - n0)
+            for k in range(2):
+                got = m.output_view(k).copy()
+                for f in range(B):
+                    ok = close_f32(got[f], want[f % nx][k])
+                    assert ok.all(), "mode %d fusion %d output %d frame %d: %d of %d out of tolerance" % (mode, fusion, k, f, int((~ok).sum()), ok.size)
+            m.close()
+    finally:
+        gpu.set_tuning("f32_mfma", 1)
+        gpu.set_tuning("dual_stream_min_batch", 64)
+
+
 F32_STEM_SHAPES = [
     # h, w, in_c, out_c, k, pad-as-SAME, batch, silu        conv_f32_stem (round 5)
     (64, 64, 3, 32, 6, 9, True),     # the twins' first layer at 64 x 64: 2 x 1 tiles per frame, 9 frames

@@ -138,6 +138,13 @@ struct split_args_t {
     int kwp;     // kernel row length in the packed K space (kw, or kw + 1 for GATHER 2 with an odd kw)
     int oc_pad;  // rows of a weight plane
     sdiv_t dhw, dow, dtaps, dkwp;
+    // a PAIR of convolutions over the same input in one grid (mhip_conv_f32_pair: C3's cv1 + cv2 -- same geometry, same out_c): channel tiles
+    // blockIdx.y >= noc1 belong to the second one (its weight planes, bias and output); the two workgroups of a pixel run walk the same
+    // tiles side by side, the second one's input reads hit L2.  noc1 == 0: one convolution
+    unsigned noc1;
+    const void *w_split2;
+    const float *bias2;
+    float *out2;
 };
 
 // BM = output channels per workgroup (128 | 64 | 32); waves: WM along channels x WN along pixels, WM * WN == 8
@@ -145,7 +152,13 @@ struct split_args_t {
 // 8 consecutive channels of one pixel -- for the one k x k convolution that reads them (conv_f32_prec in conv_f32_patch.hip: its staging
 // phase is then plain LDS-DMA).  The MFMA operands change places (D = W X^T), so a lane ends with 4 consecutive CHANNELS of one pixel.
 template <int BM, int WM, int WN, int GATHER, int NPL, bool RECOUT = false>
-__global__ __launch_bounds__(S_NT, BM == 32 && NPL == 2 && !RECOUT ? 4 : 2) void conv_f32_split(const mhip_conv_f32_t p, const split_args_t g) {
+__global__ __launch_bounds__(S_NT, BM == 32 && NPL == 2 && !RECOUT ? 4 : 2) void conv_f32_split(const mhip_conv_f32_t p_, const split_args_t g) {
+    mhip_conv_f32_t p = p_;
+    unsigned by = blockIdx.y;
+    if (g.noc1 && by >= g.noc1) { // the second convolution of a pair
+        by -= g.noc1;
+        p.w_split = g.w_split2; p.bias = g.bias2; p.out = g.out2;
+    }
     constexpr int TM = BM / WM, TN = S_BN / WN; // wave tile
     constexpr int MI = TM / 16, NI = TN / 16;   // MFMA tiles per wave
     constexpr int APLANE = BM * 64, BPLANE = S_BN * 64;
@@ -163,7 +176,7 @@ __global__ __launch_bounds__(S_NT, BM == 32 && NPL == 2 && !RECOUT ? 4 : 2) void
     // + gridDim.x, ...  The K pipeline runs THROUGH the tile boundary (the last two steps of a tile fetch steps 0 and 1 of the
     // next), so a tile's stores and the next tile's first loads overlap -- layers with few K steps (the stem: 4) otherwise
     // pay two exposed memory latencies and a store drain per 256 pixels
-    const int oc0 = (int)blockIdx.y * BM;
+    const int oc0 = (int)by * BM;
     const unsigned hw = (unsigned)(p.out_h * p.out_w);
     const int K = g.K, kwp = g.kwp;
     const int taps = p.kh * kwp;
@@ -558,8 +571,9 @@ static int launch_split(const mhip_conv_f32_t *p, split_args_t g) {
             return mhip_check(hipErrorUnknown, "conv_f32_split occupancy query");
         slots = (occ > 0 ? occ : 1) * prop.multiProcessorCount;
     }
-    const unsigned noc = (unsigned)((p->out_c + BM - 1) / BM);
+    const unsigned noc1 = (unsigned)((p->out_c + BM - 1) / BM), noc = g.noc1 ? 2 * noc1 : noc1;
     if (noc > 65535u) return -2;
+    if (g.noc1) g.noc1 = noc1;
     // pixel tiles per workgroup: as even as the slots allow (every workgroup walks ceil(npt / gx) tiles or one fewer)
     unsigned gx = (unsigned)slots / noc;
     if (gx < 1) gx = 1;
@@ -588,7 +602,23 @@ static int launch_split_npl(const mhip_conv_f32_t *p, const split_args_t &g) { /
 }
 
 // -2: not a shape this kernel takes (the caller falls back to conv_f32_mfma), else the launch result
-int conv_f32_try_split(const mhip_conv_f32_t *p) {
+static int try_split(const mhip_conv_f32_t *p, const mhip_conv_f32_t *q);
+static unsigned long g_pair_launches = 0;
+extern "C" unsigned long mhip_conv_f32_pair_launches(void) { return g_pair_launches; }
+int conv_f32_try_split(const mhip_conv_f32_t *p) { return try_split(p, nullptr); }
+// two convolutions over the same input, same geometry and channel count (no residual, no record output), as ONE grid; -2 = not eligible
+extern "C" int mhip_conv_f32_pair(const mhip_conv_f32_t *a, const mhip_conv_f32_t *b) {
+    if (!a || !b || !a->w_split || !b->w_split || a->w_patch || b->w_patch || a->use_mfma < 2 || a->use_mfma != b->use_mfma || mhip_conv_f32_pw_mode(-1)) return -2;
+    if (a->in != b->in || a->in_stride != b->in_stride || a->frames != b->frames || a->in_h != b->in_h || a->in_w != b->in_w || a->in_c != b->in_c ||
+        a->out_h != b->out_h || a->out_w != b->out_w || a->out_c != b->out_c || a->kh != b->kh || a->kw != b->kw || a->stride_h != b->stride_h ||
+        a->stride_w != b->stride_w || a->pad_top != b->pad_top || a->pad_left != b->pad_left || a->silu != b->silu || a->out_stride != b->out_stride)
+        return -2;
+    if (a->add || b->add || a->in_rec || b->in_rec || a->out_rec || b->out_rec || a->out == b->out) return -2;
+    const int rc = try_split(a, b);
+    if (rc == 0) g_pair_launches++;
+    return rc;
+}
+static int try_split(const mhip_conv_f32_t *p, const mhip_conv_f32_t *q) {
     if (!p->w_split || p->in_rec) return -2;
     if (p->out_rec && (p->use_mfma != 3 || p->add || (p->out_c & 7))) return -2;
     const long hw = (long)p->out_h * p->out_w, total = hw * p->frames;
@@ -601,6 +631,8 @@ int conv_f32_try_split(const mhip_conv_f32_t *p) {
     g.total_pix = (unsigned)total; g.npt = (unsigned)((total + S_BN - 1) / S_BN); g.in_bytes = (unsigned)in_bytes;
     g.K = (int)K; g.kp = (int)((K + 63) / 64 * 64) + 64; g.nks = (g.kp - 64) / 32; g.kwp = kwp; g.oc_pad = (p->out_c + 127) / 128 * 128;
     g.dhw = make_sdiv((unsigned)hw); g.dow = make_sdiv((unsigned)p->out_w); g.dtaps = make_sdiv((unsigned)(p->kh * kwp)); g.dkwp = make_sdiv((unsigned)kwp);
+    g.noc1 = q ? 1u : 0u; // (the launcher fills in the tile count)
+    g.w_split2 = q ? q->w_split : nullptr; g.bias2 = q ? q->bias : nullptr; g.out2 = q ? q->out : nullptr;
     // 16-byte gathers: 4 pixels x 1 tap (stride 1) or 2 pixels x 2 taps (stride 2) per load; pixel groups must not cross map rows
     if (p->stride_w == 1 && p->out_w % 4 == 0 && p->pad_left <= 1 && p->kw <= 8 && p->in_w >= 4) return launch_split_npl<1>(p, g);
     if (p->stride_w == 2 && p->out_w % 2 == 0 && p->pad_left <= 1 && kwp % 2 == 0 && kwp <= 16 && p->in_w >= 4) return launch_split_npl<2>(p, g);

@@ -159,6 +159,7 @@ MARS_INTERNAL void elide_concat(mars_model_ext_t *m);
 MARS_INTERNAL void fuse_add(mars_model_ext_t *m);
 MARS_INTERNAL void fuse_add_f32(mars_model_ext_t *m);
 MARS_INTERNAL void rec_pairs(mars_model_ext_t *m);
+MARS_INTERNAL void pair_convs_f32(mars_model_ext_t *m);
 MARS_INTERNAL void trim_concat(mars_model_ext_t *m);
 MARS_INTERNAL int mars_preproc_prepare(int w, int h, int tw, int th); /* mars_preproc.c: gather tables of a letterbox geometry, cached */
 MARS_INTERNAL void fuse_bottleneck(mars_model_ext_t *m);

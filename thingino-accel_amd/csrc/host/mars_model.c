@@ -180,6 +180,7 @@ mars_error_t build_plan(mars_model_ext_t *m) {
         pad_output_rows(m);
     }
     f32_policy(m);
+    if (m->fusion >= 1) pair_convs_f32(m); /* (after f32_policy: a pair shares one kernel choice) */
     rec_pairs(m); /* (fusion >= 1 only; resets the tensors' record flags in any case) */
     return (mars_error_t)m->plan_err;
 }

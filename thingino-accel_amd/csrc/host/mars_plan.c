@@ -1115,6 +1115,44 @@ void pair_convs(mars_model_ext_t *m) {
     }
 }
 
+/* The float twins' C3: cv1 and cv2 are two 1 x 1 convolutions over the same tensor with the same shape.  As one grid (conv_f32_split's
+ * pair form, mhip_conv_f32_pair) the second one's input reads hit L2: at float32 the input of these layers is 4 bytes per element and
+ * they are bound by exactly those bytes.  Formed where both take conv_f32_split (a weight image packed under f32_mfma = 3 / 4 at load),
+ * neither has a folded Add; the second is moved up next to the first when nothing in between touches its tensors (as pair_convs). */
+static int pairable_f32(const mars_op_t *o) {
+    return o->kind == OP_CONV_F32 && !o->add_t && o->n_in == 1 && o->w2_off != NO_OFF && o->w3_off == NO_OFF && !o->pair_next && !o->in_rec && !o->out_rec &&
+           o->kh == 1 && o->kw == 1;
+}
+void pair_convs_f32(mars_model_ext_t *m) {
+    if (getenv("MARS_HIP_NO_PAIR_F32")) return;
+    for (int i = 0; i + 1 < m->n_ops; i++) {
+        mars_op_t *a = &m->ops[i];
+        if (!pairable_f32(a) || (i > 0 && m->ops[i - 1].pair_next)) continue;
+        for (int j = i + 1; j < m->n_ops && j <= i + 48; j++) {
+            mars_op_t *b = &m->ops[j];
+            if (!pairable_f32(b) || b->t_in[0] != a->t_in[0] || b->t_out == a->t_out || b->t_out < 0 || a->t_out < 0) continue;
+            if (a->in_h != b->in_h || a->in_w != b->in_w || a->in_c != b->in_c || a->out_h != b->out_h || a->out_w != b->out_w || a->out_c != b->out_c ||
+                a->sh != b->sh || a->sw != b->sw || a->pt != b->pt || a->pl != b->pl || a->silu_f32 != b->silu_f32 || a->f32_exact != b->f32_exact)
+                continue;
+            if (planned_stride(&m->mt[a->t_out]) != planned_stride(&m->mt[b->t_out])) continue;
+            int ok = b->t_in[0] != b->t_out && b->t_in[0] != a->t_out;
+            for (int q = i + 1; q < j && ok; q++) {
+                const mars_op_t *o = &m->ops[q];
+                if (op_writes(o, b->t_out) || op_writes(o, b->t_in[0])) ok = 0;
+                for (int k = 0; k < o->n_in; k++)
+                    if (o->t_in[k] == b->t_out) ok = 0;
+                if (o->pair_next) ok = 0; /* (a pair stays adjacent) */
+            }
+            if (!ok) continue;
+            mars_op_t moved = *b;
+            memmove(&m->ops[i + 2], &m->ops[i + 1], sizeof(mars_op_t) * (size_t)(j - i - 1));
+            m->ops[i + 1] = moved;
+            m->ops[i].pair_next = 1;
+            break;
+        }
+    }
+}
+
 /* SPPF: MaxPool -> MaxPool -> MaxPool, stride 1, same window, each feeding the next: one launch that keeps the
  * frame in LDS (mhip_pool_chain_i8).  Every stage's tensor is still written (the concat / convolution reads them). */
 void fuse_pool_chains(mars_model_ext_t *m) {
@@ -1196,6 +1234,7 @@ void rec_pairs(mars_model_ext_t *m) {
         if (i < 0) continue;
         mars_op_t *pr = &m->ops[i];
         if (pr->kind != OP_CONV_F32 || pr->add_t || pr->out_rec || (pr->out_c & 7) || pr->kh > 32 || pr->kw > 32) continue;
+        if (pr->pair_next || (i > 0 && m->ops[i - 1].pair_next)) continue; /* (a paired launch writes plain floats) */
         if (pr->out_c != x->in_c || pr->out_h != x->in_h || pr->out_w != x->in_w) continue;
         if (!(pr->w2_off != NO_OFF || (pr->w3_off != NO_OFF && pr->w3_stem))) continue; /* conv_f32_split or conv_f32_stem writes it */
         if (m->mt[T].bytes != (size_t)x->in_c * x->in_h * x->in_w * 4) continue;

@@ -88,6 +88,32 @@ void conv_i8_params(const mars_model_ext_t *m, const mars_op_t *op, mhip_conv_i8
     if (op->nseg > 1) p->in = p->seg_in[0];
 }
 
+static void conv_f32_params(mars_model_ext_t *m, mars_op_t *op, mhip_conv_f32_t *p) {
+    const int B = m->run_frames;
+    uint8_t *A = m->arena_dev;
+    memset(p, 0, sizeof(*p));
+    p->in = (const float *)tdev(m, op->t_in[0]); p->in_stride = tstride(m, op->t_in[0]);
+    p->out = (float *)tdev(m, op->t_out); p->out_stride = tstride(m, op->t_out);
+    p->w = (const float *)(A + op->w_off);
+    p->w_split = op->w2_off != NO_OFF ? (const void *)(A + op->w2_off) : NULL;
+    p->w_patch = op->w3_off != NO_OFF ? (const void *)(A + op->w3_off) : NULL;
+    p->bias = op->b_off != NO_OFF ? (const float *)(A + op->b_off) : NULL;
+    p->frames = B;
+    p->in_h = op->in_h; p->in_w = op->in_w; p->in_c = op->in_c;
+    p->out_h = op->out_h; p->out_w = op->out_w; p->out_c = op->out_c;
+    p->kh = op->kh; p->kw = op->kw; p->stride_h = op->sh; p->stride_w = op->sw; p->pad_top = op->pt; p->pad_left = op->pl;
+    p->silu = op->silu_f32;
+    if (op->add_t) { p->add = (const float *)tdev(m, op->add_t - 1); p->add_stride = tstride(m, op->add_t - 1); }
+    {
+        const int mode = mhip_conv_f32_mode(-1);
+        p->use_mfma = mode == 3 ? 3 : mode == 4 ? 2 : (mode == 2 || (mode == 1 && !op->f32_exact));
+    }
+    if (op->in_rec || op->out_rec) { /* planned under f32_mfma = 3 (rec_pairs): these launches stay there whatever the mode is now */
+        p->in_rec = op->in_rec; p->out_rec = op->out_rec;
+        p->use_mfma = 3;
+    }
+}
+
 static int launch_op(mars_model_ext_t *m, mars_op_t *op) {
     const int B = m->run_frames;
     uint8_t *A = m->arena_dev;
@@ -107,27 +133,7 @@ static int launch_op(mars_model_ext_t *m, mars_op_t *op) {
         }
         case OP_CONV_F32: {
             mhip_conv_f32_t p;
-            memset(&p, 0, sizeof(p));
-            p.in = (const float *)tdev(m, op->t_in[0]); p.in_stride = tstride(m, op->t_in[0]);
-            p.out = (float *)tdev(m, op->t_out); p.out_stride = tstride(m, op->t_out);
-            p.w = (const float *)(A + op->w_off);
-            p.w_split = op->w2_off != NO_OFF ? (const void *)(A + op->w2_off) : NULL;
-            p.w_patch = op->w3_off != NO_OFF ? (const void *)(A + op->w3_off) : NULL;
-            p.bias = op->b_off != NO_OFF ? (const float *)(A + op->b_off) : NULL;
-            p.frames = B;
-            p.in_h = op->in_h; p.in_w = op->in_w; p.in_c = op->in_c;
-            p.out_h = op->out_h; p.out_w = op->out_w; p.out_c = op->out_c;
-            p.kh = op->kh; p.kw = op->kw; p.stride_h = op->sh; p.stride_w = op->sw; p.pad_top = op->pt; p.pad_left = op->pl;
-            p.silu = op->silu_f32;
-            if (op->add_t) { p.add = (const float *)tdev(m, op->add_t - 1); p.add_stride = tstride(m, op->add_t - 1); }
-            {
-                const int mode = mhip_conv_f32_mode(-1);
-                p.use_mfma = mode == 3 ? 3 : mode == 4 ? 2 : (mode == 2 || (mode == 1 && !op->f32_exact));
-            }
-            if (op->in_rec || op->out_rec) { /* planned under f32_mfma = 3 (rec_pairs): these launches stay there whatever the mode is now */
-                p.in_rec = op->in_rec; p.out_rec = op->out_rec;
-                p.use_mfma = 3;
-            }
+            conv_f32_params(m, op, &p);
             return mhip_conv_f32(&p);
         }
         case OP_RELU_BYTES:
@@ -285,7 +291,17 @@ static mars_error_t enqueue_range(mars_model_ext_t *m, int sid, int wait_tail) {
             op->ev_start = prof_last;
         }
         int rc;
-        if (mate) { /* one grid for both (conv_i8_persist<PAIR>); -2 = not possible at this batch: one after the other */
+        if (mate && op->kind == OP_CONV_F32) { /* one grid for both (conv_f32_split's pair form); -2: one after the other */
+            mhip_conv_f32_t pa, pb;
+            conv_f32_params(m, op, &pa);
+            conv_f32_params(m, mate, &pb);
+            rc = mhip_conv_f32_pair(&pa, &pb);
+            if (rc == -2) {
+                rc = launch_op(m, op);
+                if (!rc) rc = launch_op(m, mate);
+            }
+            i++;
+        } else if (mate) { /* one grid for both (conv_i8_persist<PAIR>); -2 = not possible at this batch: one after the other */
             mhip_conv_i8_t pa, pb;
             conv_i8_params(m, op, &pa);
             conv_i8_params(m, mate, &pb);

@@ -160,6 +160,10 @@ typedef struct {
                             no fused Add, out_c a multiple of 8 */
 } mhip_conv_f32_t;
 int mhip_conv_f32(const mhip_conv_f32_t *p);
+/* two float convolutions over the same input in one launch (use_mfma >= 2, conv_f32_split: same geometry and channel count, no residual Add, no
+ * record operands -- C3's cv1 + cv2): the second one's input reads hit L2; -2 = not eligible as a pair (launch them separately) */
+int mhip_conv_f32_pair(const mhip_conv_f32_t *a, const mhip_conv_f32_t *b);
+unsigned long mhip_conv_f32_pair_launches(void); /* paired launches since load (diagnostic) */
 /* Bytes of, and (out != NULL) the content of, the weight image conv_f32_split reads: `planes` (2: hi, mid; 3: hi, mid, lo) planes of bf16
  * [oc_pad][k_pad] -- oc_pad = roundup128(out_c), k_pad = roundup64(K') + 64, zero filled -- with w = hi + mid + lo exactly
  * (hi = bf16(w), mid = bf16(w - hi), round to nearest; use_mfma == 3 reads the first two planes).  K' = in_c * kh * kw, or in_c * kh * (kw + 1) for stride_w == 2 with an odd kw (one zero column
