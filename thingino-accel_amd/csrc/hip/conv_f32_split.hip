@@ -155,10 +155,15 @@ template <int BM, int WM, int WN, int GATHER, int NPL, bool RECOUT = false>
 __global__ __launch_bounds__(S_NT, BM == 32 && NPL == 2 && !RECOUT ? 4 : 2) void conv_f32_split(const mhip_conv_f32_t p_, const split_args_t g) {
     mhip_conv_f32_t p = p_;
     unsigned by = blockIdx.y;
-    if (g.noc1 && by >= g.noc1) { // the second convolution of a pair
+    // fz: the pair shares ONE channel tile (BM == 2 * out_c: rows 0 .. BM / 2 - 1 are the first convolution's channels, the rest the
+    // second's) -- one workgroup reads the input tile once for both (the 160 x 160 / 80 x 80 C3s of the twins, where these layers
+    // are bound by exactly those bytes); otherwise channel tiles blockIdx.y >= noc1 belong to the second one
+    const bool fz = g.noc1 == 0xffffffffu;
+    if (!fz && g.noc1 && by >= g.noc1) {
         by -= g.noc1;
         p.w_split = g.w_split2; p.bias = g.bias2; p.out = g.out2;
     }
+    const int out_c_eff = fz ? BM : p.out_c;
     constexpr int TM = BM / WM, TN = S_BN / WN; // wave tile
     constexpr int MI = TM / 16, NI = TN / 16;   // MFMA tiles per wave
     constexpr int APLANE = BM * 64, BPLANE = S_BN * 64;
@@ -219,7 +224,8 @@ __global__ __launch_bounds__(S_NT, BM == 32 && NPL == 2 && !RECOUT ? 4 : 2) void
     setup(blockIdx.x * g.per);
     // weights: row oc0 + tid / ATPR of every plane, taps (tid % ATPR) * AE .. + AE - 1 of the step
     const int arow = tid / ATPR, akc = (tid % ATPR) * AE;
-    const int8_t *wrow = (const int8_t *)p.w_split + ((size_t)(oc0 + arow) * g.kp + akc) * 2;
+    const int8_t *wrow = fz && arow >= BM / 2 ? (const int8_t *)g.w_split2 + ((size_t)(arow - BM / 2) * g.kp + akc) * 2
+                                              : (const int8_t *)p.w_split + ((size_t)(oc0 + arow) * g.kp + akc) * 2;
     const size_t wplane = (size_t)g.oc_pad * g.kp * 2;
 
     v4i bregs[2][4]; // GATHER 1 / 2: one 16-byte load each; GATHER 0: four dword loads each
@@ -352,7 +358,8 @@ __global__ __launch_bounds__(S_NT, BM == 32 && NPL == 2 && !RECOUT ? 4 : 2) void
             }
         } else {
             const int oc = oc0 + wm * TM + a * 16 + fr;
-            const float b = p.bias && oc < p.out_c ? p.bias[oc] : 0.f;
+            const float *bsel = fz && oc >= BM / 2 ? g.bias2 - BM / 2 : p.bias; // (fz: the second convolution's channels sit BM / 2 further up)
+            const float b = bsel && oc < out_c_eff ? bsel[oc] : 0.f;
             bias4[a] = (v4f){b, b, b, b};
         }
 #pragma unroll
@@ -506,18 +513,19 @@ __global__ __launch_bounds__(S_NT, BM == 32 && NPL == 2 && !RECOUT ? 4 : 2) void
                     const unsigned f = sdiv(px, g.dhw), rem = px - f * hw;
                     float *out = (float *)((char *)p.out + (size_t)f * p.out_stride);
                     const float *addp = p.add ? (const float *)((const char *)p.add + (size_t)f * p.add_stride) : nullptr;
+                    float *out2v = fz ? (float *)((char *)g.out2 + (size_t)f * p.out_stride) - (size_t)(BM / 2) * hw : out; // channel oc of the second = plane oc - BM / 2
 #pragma unroll
                     for (int a = 0; a < MI; a++) {
                         const int oc = oc0 + wm * TM + a * 16 + fr;
                         if (SPLIT_ABL & 32) asm volatile("" ::"v"(acc[a][c]));
-                        else if (oc < p.out_c) {
+                        else if (oc < out_c_eff) {
                             v4f r = acc[a][c];
                             if (p.silu && !(SPLIT_ABL & 16)) {
 #pragma unroll
                                 for (int j = 0; j < 4; j++) r[j] = NPL == 2 ? silu_fast(r[j]) : silu_split(r[j]);
                             }
                             if (addp) r += *(const v4f *)(addp + (size_t)oc * hw + rem);
-                            *(v4f *)(out + (size_t)oc * hw + rem) = r;
+                            *(v4f *)((fz && wm * TM + a * 16 >= BM / 2 ? out2v : out) + (size_t)oc * hw + rem) = r;
                         }
                     }
                 }
@@ -528,13 +536,14 @@ __global__ __launch_bounds__(S_NT, BM == 32 && NPL == 2 && !RECOUT ? 4 : 2) void
                     const unsigned f = sdiv(px + j, g.dhw), rem = px + j - f * hw;
                     float *out = (float *)((char *)p.out + (size_t)f * p.out_stride);
                     const float *addp = p.add ? (const float *)((const char *)p.add + (size_t)f * p.add_stride) : nullptr;
+                    float *out2v = fz ? (float *)((char *)g.out2 + (size_t)f * p.out_stride) - (size_t)(BM / 2) * hw : out;
 #pragma unroll
                     for (int a = 0; a < MI; a++) {
                         const int oc = oc0 + wm * TM + a * 16 + fr;
                         if (SPLIT_ABL & 32) asm volatile("" ::"v"(acc[a][c][j]));
-                        else if (oc < p.out_c) {
+                        else if (oc < out_c_eff) {
                             const float r = p.silu && !(SPLIT_ABL & 16) ? (NPL == 2 ? silu_fast(acc[a][c][j]) : silu_split(acc[a][c][j])) : acc[a][c][j];
-                            out[(size_t)oc * hw + rem] = addp ? r + addp[(size_t)oc * hw + rem] : r;
+                            (fz && wm * TM + a * 16 >= BM / 2 ? out2v : out)[(size_t)oc * hw + rem] = addp ? r + addp[(size_t)oc * hw + rem] : r;
                         }
                     }
                 }
@@ -571,9 +580,10 @@ static int launch_split(const mhip_conv_f32_t *p, split_args_t g) {
             return mhip_check(hipErrorUnknown, "conv_f32_split occupancy query");
         slots = (occ > 0 ? occ : 1) * prop.multiProcessorCount;
     }
-    const unsigned noc1 = (unsigned)((p->out_c + BM - 1) / BM), noc = g.noc1 ? 2 * noc1 : noc1;
+    const bool fz = g.noc1 == 0xffffffffu; // the pair in one channel tile
+    const unsigned noc1 = fz ? 1u : (unsigned)((p->out_c + BM - 1) / BM), noc = g.noc1 && !fz ? 2 * noc1 : noc1;
     if (noc > 65535u) return -2;
-    if (g.noc1) g.noc1 = noc1;
+    if (g.noc1 && !fz) g.noc1 = noc1;
     // pixel tiles per workgroup: as even as the slots allow (every workgroup walks ceil(npt / gx) tiles or one fewer)
     unsigned gx = (unsigned)slots / noc;
     if (gx < 1) gx = 1;
@@ -587,6 +597,11 @@ static int launch_split(const mhip_conv_f32_t *p, split_args_t g) {
 }
 template <int GATHER, int NPL>
 static int launch_split_bm(const mhip_conv_f32_t *p, const split_args_t &g) {
+    if (g.noc1 == 0xffffffffu) { // a pair in one channel tile: BM == 2 * out_c (checked by the caller)
+        if (p->out_c == 64 && NPL == 2) return launch_split<128, 2, 4, GATHER, 2>(p, g);
+        if (p->out_c == 32) return launch_split<64, 1, 8, GATHER, NPL>(p, g);
+        return launch_split<32, 1, 8, GATHER, NPL>(p, g);
+    }
     if (p->out_rec) { // (two pieces only: checked by the caller)
         if (p->out_c > 64) return launch_split<128, 2, 4, GATHER, 2, true>(p, g);
         if (p->out_c > 32) return launch_split<64, 1, 8, GATHER, 2, true>(p, g);
@@ -631,7 +646,10 @@ static int try_split(const mhip_conv_f32_t *p, const mhip_conv_f32_t *q) {
     g.total_pix = (unsigned)total; g.npt = (unsigned)((total + S_BN - 1) / S_BN); g.in_bytes = (unsigned)in_bytes;
     g.K = (int)K; g.kp = (int)((K + 63) / 64 * 64) + 64; g.nks = (g.kp - 64) / 32; g.kwp = kwp; g.oc_pad = (p->out_c + 127) / 128 * 128;
     g.dhw = make_sdiv((unsigned)hw); g.dow = make_sdiv((unsigned)p->out_w); g.dtaps = make_sdiv((unsigned)(p->kh * kwp)); g.dkwp = make_sdiv((unsigned)kwp);
-    g.noc1 = q ? 1u : 0u; // (the launcher fills in the tile count)
+    // a pair: in ONE channel tile where both fit one (2 * out_c = 32 | 64 | 128: the wave tiles then split between the two at a multiple of
+    // 16 channels), else as two runs of channel tiles (the launcher fills in the count)
+    const bool one_tile = q && (p->out_c == 16 || p->out_c == 32 || (p->out_c == 64 && p->use_mfma == 3));
+    g.noc1 = q ? (one_tile ? 0xffffffffu : 1u) : 0u;
     g.w_split2 = q ? q->w_split : nullptr; g.bias2 = q ? q->bias : nullptr; g.out2 = q ? q->out : nullptr;
     // 16-byte gathers: 4 pixels x 1 tap (stride 1) or 2 pixels x 2 taps (stride 2) per load; pixel groups must not cross map rows
     if (p->stride_w == 1 && p->out_w % 4 == 0 && p->pad_left <= 1 && p->kw <= 8 && p->in_w >= 4) return launch_split_npl<1>(p, g);
