@@ -989,6 +989,34 @@ def test_conv_f32_patch_shapes(gpu, orc, shape):
         gpu.set_tuning("dual_stream_min_batch", 64)
 
 
+@pytest.mark.parametrize("shape", [(256, 20, 20, 5, 5), (37, 13, 12, 5, 5), (9, 7, 4, 3, 3), (16, 16, 20, 2, 7), (40, 9, 36, 8, 1), (5, 3, 8, 8, 8), (64, 40, 24, 5, 5)],
+                         ids=lambda v: "x".join(str(q) for q in v))
+def test_maxpool_rows_form(gpu, orc, shape):
+    """stride-1 MAXPOOL over [H][W][C] bytes with C a multiple of 4 but not of 16 -- what the float twins' byte-wise pools are (a 20 x 20 x 256
+    float map read as H = 256, W = 20, C = 20) -- through the separable kernel (move.hip maxpool_rows_kernel): bit-identical to the
+    oracle on every frame, windows clipped at the right and bottom edge, kernels up to 8 x 8, windows larger than the map."""
+    H, W, Cc, kh, kw = shape
+    G = marsfile.Graph()
+    a = G.tensor([1, H, W, Cc], scale=0.05)
+    o = G.tensor([1, H, W, Cc], scale=0.05)
+    G.pool(a, o, (kh, kw), (1, 1))
+    d = G.serialise([a], [o])
+    rng = np.random.default_rng(H * 100 + W + Cc)
+    B = 3
+    xs = [rng.integers(0, 256, H * W * Cc, dtype=np.uint8) for _ in range(B)]
+    m = gpu.Model(d, batch=B)
+    for f in range(B):
+        m.input_view(0)[f] = xs[f]
+    m.run()
+    got = m.output_view(0).copy()
+    m.close()
+    for f in range(B):
+        g, rc = run_oracle(orc, d, xs[f])
+        assert rc == 0
+        assert np.array_equal(got[f], g.tensor(o)), "frame %d" % f
+        g.close()
+
+
 F32_REC_CHAINS = [
     # h, w, c0, producer (out_c, k, stride), consumer (out_c, k, stride), batch, residual   conv -> k x k conv with the tensor between them in record format
     (20, 20, 64, (32, 1, 1), (16, 3, 1), 3, None),       # a C3 bottleneck's pair on a 20-wide map (whole-row tiles), 4 chunks, 4 dummy units
