@@ -571,7 +571,7 @@ def main():
         # summed durations; the matrix-roof view of the same launches is reported next to it.  f32: 4-byte activations but
         # a 32x lower matrix peak (157.3 TF, v_mfma_f32_16x16x4_f32): ridge 20 flop/B against ~65 flop/B -> the roof is MFMA.
         roof = {"bound": "mfma" if f32 else "hbm",
-                "kernel": (("conv_f32_patch / conv_f32_stem (k x k layers: input patch staged and split once) + conv_f32_split (1 x 1 layers); v_mfma_f32_16x16x32_bf16, 3 per product" if args.f32_mode == 3
+                "kernel": (("conv_f32_prec / conv_f32_patch / conv_f32_stem (k x k layers: input patch staged once -- by LDS-DMA from record-format tensors where a convolution wrote them) + conv_f32_split (1 x 1 layers, C3 pairs in one launch); v_mfma_f32_16x16x32_bf16, 3 per product" if args.f32_mode == 3
                             else "conv_f32_split (v_mfma_f32_16x16x32_bf16, 6 per product)" if args.f32_mode == 4 else "conv_f32_mfma / conv_f32_kernel") if f32 else "conv_i8_*") + " (%d launches per step)" % n_conv,
                 "achieved": achieved if f32 else hbm_gbs, "peak": peak if f32 else 8000.0, "unit": "TFLOP/s" if f32 else "GB/s",
                 "frac": (achieved / peak) if f32 else hbm_gbs / 8000.0,
