@@ -765,7 +765,8 @@ def main():
             result["roofline"]["frac_of_copy_rate"] = result["roofline"]["achieved"] / copy_gbs
             result["roofline"]["frac_wall_of_copy_rate"] = result["roofline"]["wall_achieved"] / copy_gbs
         result["roofline"]["copy_rate_how"] = ("libmars_probe.so (csrc/probe/mars_probe.hip): device-to-device copy of 1 GiB, 10 back to back, the best of "
-                                               "hipMemcpyAsync and 16-byte-per-lane kernels with 1 / 4 / 8 loads in flight per lane, plain and non-temporal; "
+                                               "hipMemcpyAsync and eleven 16-byte-per-lane kernels (1 / 2 / 4 / 8 loads in flight per lane, plain and non-temporal, 64- to 1024-thread "
+                                               "workgroups at 2 to 32 per CU: the runtime blit's launch geometries among them); "
                                                "(read + write bytes) / time, GB/s; best form here: %s" % PROBE.mars_probe_copy_form().decode())
         # against what the guide says a kernel can reach at all (MI355X_MICROARCH.md: 6.3 TB/s measured, float4 copy)
         result["roofline"]["achievable_peak"] = 6300.0
