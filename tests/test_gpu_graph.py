@@ -1121,6 +1121,12 @@ def test_conv_f32_record_pairs(gpu, orc, shape):
                     w_ = mid[f % nx].view(np.float32)
                     tol = 2.0 ** -15 if rec else 1e-4
                     assert (np.abs(t.astype(np.float64) - w_) <= np.maximum(1e-4, tol * np.abs(w_))).all(), "mode %d: tensor between the convolutions, frame %d" % (mode, f)
+                if rec and slots == 0:  # ... and written: mars_hip_write_tensor cuts the floats into the two pieces the kernels would have stored
+                    probe = (np.random.default_rng(5).random(c1 * h1 * w1, dtype=np.float32) * 4 - 2).astype(np.float32)
+                    pb = probe.view(np.uint8)
+                    assert gpu.lib().mars_hip_write_tensor(m.p, t1, 1 % B, pb.ctypes.data, pb.size) == 0
+                    back = m.read_tensor(t1, 1 % B).view(np.float32)
+                    assert (np.abs(back.astype(np.float64) - probe) <= 2.0 ** -16 * np.abs(probe)).all(), "write_tensor / read_tensor round trip of a record-format tensor"
             m.close()
             for f in range(B):
                 if mode == 0:
