@@ -201,21 +201,33 @@ def kernel_source_sha16():
 def pmc_traffic(args):
     """HBM bytes one step's conv launches move, from the committed rocprofv3 PMC passes (FETCH_SIZE doubled per
     MI355X_MICROARCH.md, WRITE_SIZE; tools/pmc_summary.py) -- counters cannot be collected from inside this
-    process, so the number is the profiled one of the same workload AND the same kernel sources (the profile records
-    their hash), or None when no matching profile exists."""
-    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "pmc_traffic.json")
+    process, so the number is the profiled one of the same workload (size, width, batch, dtype) AND the same kernel sources
+    (the profile records their hash), or None when no matching profile exists.  profiles/pmc_traffic.json is the headline's;
+    the other workloads' summaries are profiles/rNN_<name>_pmc_traffic.json (tools/profile_configs.sh): the newest match wins."""
+    pdir = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles")
+    want = {"width": args.width, "hw": args.hw, "batch": args.batch}
+    dtype = "f32" if args.dtype == "f32" else "int8"
     try:
-        with open(path) as fh:
-            d = json.load(fh)
-        if d["config"] != {"width": args.width, "hw": args.hw, "batch": args.batch}:
-            return None, "profiles/pmc_traffic.json is for another workload"
-        if d.get("kernel_source_sha16") != kernel_source_sha16():
-            return None, "profiles/pmc_traffic.json was taken with other kernel sources (%s, now %s)" % (
-                d.get("kernel_source_sha16"), kernel_source_sha16())
-        c = d["conv_i8"]
-        return c["read_bytes_per_step"] + c["write_bytes_per_step"], "profiles/pmc_traffic.json (per step, all conv_i8 launches; kernel sources %s)" % d["kernel_source_sha16"]
-    except (OSError, KeyError, ValueError):
+        names = sorted((f for f in os.listdir(pdir) if f.endswith("pmc_traffic.json")), reverse=True)
+    except OSError:
         return None, None
+    why = None
+    for name in ["pmc_traffic.json"] + [n for n in names if n != "pmc_traffic.json"]:
+        try:
+            with open(os.path.join(pdir, name)) as fh:
+                d = json.load(fh)
+            if d["config"] != want or d.get("dtype", "int8") != dtype:
+                why = why or "profiles/%s is for another workload" % name
+                continue
+            if d.get("kernel_source_sha16") != kernel_source_sha16():
+                why = "profiles/%s was taken with other kernel sources (%s, now %s)" % (name, d.get("kernel_source_sha16"), kernel_source_sha16())
+                continue
+            c = d["conv_i8"]  # (the family total: conv_i8_* or, for a float workload, conv_f32_*)
+            return c["read_bytes_per_step"] + c["write_bytes_per_step"], "profiles/%s (per step, all %s launches; kernel sources %s)" % (
+                name, d.get("family", "conv_i8"), d["kernel_source_sha16"])
+        except (OSError, KeyError, ValueError):
+            continue
+    return None, why
 
 
 def reference_detections(ref_outs, scales, thresh=0.45):
@@ -557,7 +569,7 @@ def main():
         bytes_per_img = sum(op["bytes"] for op in model.ops())
         achieved = conv_ops / (conv_ms * 1e-3) / 1e12 if conv_ms > 0 else 0.0
         conv_bytes_per_img = sum(op["bytes"] for op in model.ops() if op["kind"] == ckind)
-        traffic, traffic_src = (None, None) if f32 else pmc_traffic(args)
+        traffic, traffic_src = pmc_traffic(args)
         # f32: the ceiling of the path that runs -- v_mfma_f32_16x16x4_f32 at 157.3 TF, or (mode 3) six bf16 MFMAs per product on
         # the 2.5 PF bf16 cores = 417 TF of float32 work; int8: the dense int8 MFMA rate
         mpeak = (2.5e15 / 3.0 if args.f32_mode == 3 else 2.5e15 / 6.0 if args.f32_mode == 4 else 157.3e12) if f32 else 5e15
