@@ -21,7 +21,7 @@ L.mhip_fpatch_stamps.argtypes = [C.POINTER(C.c_ulonglong), C.c_int]
 M.set_tuning("f32_mfma", 3)
 M.set_tuning("dual_stream_min_batch", 0)
 CHAIN = "--chain" in sys.argv  # a 1 x 1 in front (layer_time.build_f32 chain): the k x k layer then reads records (conv_f32_prec) -- its stamps are
-#                                0 DMA issue, 1 fragment reads (waited for), 2 MFMAs, 3 waits + barriers, 4 rest
+#                                0 weight registers -> LDS, 1 patch DMA + next weight loads issued, 2 fragment reads (waited for), 3 MFMAs, 4 DMA waits, 5 barriers, 6 rest
 for name in [a for a in sys.argv[1:] if a in LT.LAYERS] or ["D40"]:
     h, w, ic, oc, k, s, add_ = LT.LAYERS[name]
     m = M.Model(LT.build_f32(h, w, ic, oc, k, s, add_, CHAIN), batch=int(os.environ.get("BATCH", "256")))
@@ -37,7 +37,7 @@ for name in [a for a in sys.argv[1:] if a in LT.LAYERS] or ["D40"]:
     if CHAIN:
         v = [float(out[i]) for i in range(8)]
         n = max(v[7], 1.0)
-        print("%-6s %7.1f us (both launches)  conv_f32_prec per wave and K step: weight DMA issue %5.0f  patch DMA issue %5.0f  fragment reads %5.0f  MFMAs %5.0f  DMA waits %5.0f  barriers %5.0f  rest %5.0f  = %6.0f cycles   (wave-steps %.0f)"
+        print("%-6s %7.1f us (both launches)  conv_f32_prec per wave and K step: weight LDS writes %5.0f  patch DMA + weight load issue %5.0f  fragment reads %5.0f  MFMAs %5.0f  DMA waits %5.0f  barriers %5.0f  rest %5.0f  = %6.0f cycles   (wave-steps %.0f)"
               % ((name, ms * 1e3) + tuple(x / n for x in v[:7]) + (sum(v[:7]) / n, n)))
         m.close()
         continue
