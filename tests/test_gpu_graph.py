@@ -5,6 +5,7 @@ per-layer graphs of test_oracle.py."""
 import json
 import os
 import struct
+import zlib
 
 import ctypes as C
 
@@ -1137,6 +1138,58 @@ def test_conv_f32_record_pairs(gpu, orc, shape):
     finally:
         gpu.set_tuning("f32_mfma", 1)
         gpu.set_tuning("persist_slots", 0)
+        gpu.set_tuning("dual_stream_min_batch", 64)
+
+
+@pytest.mark.parametrize("shape", [(40, 40, 128, 3, 96), (160, 160, 32, 3, 16), (20, 20, 256, 3, 160)], ids=lambda v: "x".join(str(q) for q in v))
+def test_conv_f32_record_form_is_the_register_form_bit_for_bit(gpu, shape, monkeypatch):
+    """a C3 bottleneck (1 x 1 -> 3 x 3 + shortcut Add) at a batch that gives every workgroup a run of tiles: the record form
+    (conv_f32_prec, hand-counted DMA waits) multiplies exactly the pieces the register-staged form (conv_f32_patch) cuts itself, so
+    the two must write the SAME BYTES -- and the same bytes again on every repetition (a chunk read before its DMA has landed would
+    show as a difference between runs)."""
+    h, w, c, k, B = shape
+    rng = np.random.default_rng(h + c)
+    G = marsfile.Graph()
+    F, N = marsfile.F32, marsfile.NCHW
+
+    def conv_silu(xin, kk):
+        a = G.tensor([1, c, h, w], dtype=F, fmt=N)
+        wt = G.tensor([c, c, kk, kk], dtype=F, fmt=marsfile.OIHW, data=((rng.random((c, c, kk, kk), dtype=np.float32) * 2 - 1) * (1.7 / (kk * kk * c) ** 0.5)).astype(np.float32))
+        b = G.tensor([c], dtype=F, fmt=marsfile.D1, data=((rng.random(c, dtype=np.float32) * 2 - 1) * 0.1).astype(np.float32))
+        G.conv(xin, a, wt, b, (kk, kk), (1, 1), pad=marsfile.PAD_SAME)
+        g_, o_ = G.tensor([1, c, h, w], dtype=F, fmt=N), G.tensor([1, c, h, w], dtype=F, fmt=N)
+        G.layer(marsfile.SIGMOID, [a], [g_])
+        G.layer(marsfile.MUL, [a, g_], [o_])
+        return o_
+
+    x = G.tensor([1, c, h, w], dtype=F, fmt=N)
+    t2 = conv_silu(conv_silu(x, 1), k)
+    out = G.tensor([1, c, h, w], dtype=F, fmt=N)
+    G.layer(marsfile.ADD, [t2, x], [out])
+    d = G.serialise([x], [out])
+    xs = (rng.random((B, c * h * w), dtype=np.float32) * 2 - 1).astype(np.float32)
+    prec = gpu.lib().mhip_conv_f32_prec_launches
+    prec.restype = C.c_ulong
+    try:
+        gpu.set_tuning("f32_mfma", 3)
+        gpu.set_tuning("dual_stream_min_batch", 0)
+        digests = []
+        for norec in (True, False):
+            if norec:
+                monkeypatch.setenv("MARS_HIP_NO_REC", "1")
+            else:
+                monkeypatch.delenv("MARS_HIP_NO_REC", raising=False)
+            m = gpu.Model(d, batch=B)
+            m.input_view(0)[:] = xs.view(np.uint8)
+            n0 = prec()
+            for rep in range(1 if norec else 4):
+                m.run()
+                digests.append(zlib.crc32(m.output_view(0).tobytes()))
+            assert prec() - n0 == (0 if norec else 4)
+            m.close()
+        assert len(set(digests)) == 1, digests
+    finally:
+        gpu.set_tuning("f32_mfma", 1)
         gpu.set_tuning("dual_stream_min_batch", 64)
 
 
