@@ -1087,7 +1087,7 @@ def test_conv_f32_record_pairs(gpu, orc, shape):
         g.close()
     L = gpu.lib()
     counts = {}
-    for name in ("prec", "patch", "split", "stem"):
+    for name in ("prec", "recin", "patch", "split", "stem"):
         counts[name] = getattr(L, "mhip_conv_f32_%s_launches" % name)
         counts[name].restype = C.c_ulong
     geom2 = L.mhip_conv_f32_patch_geom2
@@ -1096,7 +1096,11 @@ def test_conv_f32_record_pairs(gpu, orc, shape):
     gv = np.zeros(64, dtype=np.int32)
     pad2 = (k2 - 1) // 2 if s2 == 1 else max(0, ((h2 - 1) * s2 + k2 - h1)) // 2  # SAME, as the planner derives it (top = left)
     expect_patch = geom2(c2, c1, k2, k2, s2, pad2, h1, w1, h2, w2, 0, gv.ctypes.data, 64) != 0
-    expect_rec = geom2(c2, c1, k2, k2, s2, pad2, h1, w1, h2, w2, 1, gv.ctypes.data, 64) != 0  # (four ring slots must fit: not the large stride-2 patches)
+    form_of = L.mhip_conv_f32_patch_rec_form
+    form_of.restype = C.c_int
+    form_of.argtypes = [C.c_int] * 10
+    form = form_of(c2, c1, k2, k2, s2, pad2, h1, w1, h2, w2)  # 1: conv_f32_prec (four ring slots fit), 2: conv_f32_patch's record-input form (two slots, through registers), 0: none
+    expect_rec = form != 0
     try:
         gpu.set_tuning("dual_stream_min_batch", 0)
         for mode, slots, fusion in ((3, 0, 1), (3, 3, 1), (3, 0, 0), (4, 0, 1), (0, 0, 1)):
@@ -1111,10 +1115,10 @@ def test_conv_f32_record_pairs(gpu, orc, shape):
             m.run()
             dn = {k_: c() - n0[k_] for k_, c in counts.items()}
             rec = mode == 3 and fusion == 1 and expect_rec
-            assert dn["prec"] == (1 if rec else 0), (mode, slots, fusion, dn)
+            assert dn["prec"] == (1 if rec and form == 1 else 0) and dn["recin"] == (1 if rec and form == 2 else 0), (mode, slots, fusion, form, dn)
             if mode == 3:
                 assert dn["patch"] == (0 if rec or not expect_patch else 1), (mode, fusion, dn)
-                assert dn["split"] + dn["stem"] + dn["patch"] + dn["prec"] == 2, dn
+                assert dn["split"] + dn["stem"] + dn["patch"] + dn["prec"] + dn["recin"] == 2, dn
             got = m.output_view(0).copy()
             if fusion == 1:  # the tensor between the two (the first MUL's output): NCHW floats whatever its device format is
                 for f in (0, B - 1):

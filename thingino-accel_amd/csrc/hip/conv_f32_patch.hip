@@ -147,7 +147,10 @@ __device__ __forceinline__ void psplit(const float (&x)[N], int (&hi)[N / 2], in
 // items within the workgroup's 512 threads)
 // P_BN = pixels per tile: 256, or 512 under the 64- / 32-channel tiles (a wave then has the 48 / 24 MFMAs per step that make a
 // barrier interval worth its fixed cost; with 256 pixels those layers ran 24 / 12 per step and were bound by the step skeleton)
-template <int BM, int WM, int WN, int CPI, bool DUMMY, int P_BN>
+// RECIN > 0 (mhip_conv_f32_t.in_rec where conv_f32_prec's four ring slots do not fit: the large stride-2 patches): the input arrives in record
+// format, so a chunk's staging is a plain COPY -- RECIN 16-byte half records per thread through registers into the slot (same LDS layout,
+// same schedule, same two slots), no split: ~12 instead of ~140 vector instructions per chunk and thread.  (CPI is unused then.)
+template <int BM, int WM, int WN, int CPI, bool DUMMY, int P_BN, int RECIN = 0>
 __global__ __launch_bounds__(P_NT, 2) void conv_f32_patch(const mhip_conv_f32_t p, const fpatch_geom_t g, const int *__restrict__ tabs,
                                                           const int8_t *__restrict__ wpl) {
     constexpr int TM = BM / WM, TN = P_BN / WN;
@@ -204,14 +207,40 @@ __global__ __launch_bounds__(P_NT, 2) void conv_f32_patch(const mhip_conv_f32_t 
             const unsigned seg = pdiv(V, g.dHV), f = pdiv(seg, g.dNS), st = seg - f * (unsigned)g.nstrips;
             const int iy = (int)(V - seg * (unsigned)g.HV) - g.pad;
             const bool ok = t < g.ntiles && seg < g.nsegs && iy >= 0 && iy < g.H_in;
-            rowtab[(t & 1) * P_PRCAP + tid] = make_int2(ok ? (int)(f * (unsigned)p.in_stride + (unsigned)(iy * g.W_in) * 4u) : -1,
+            rowtab[(t & 1) * P_PRCAP + tid] = make_int2(ok ? (int)(f * (unsigned)p.in_stride + (unsigned)(iy * g.W_in) * (RECIN ? 32u : 4u)) : -1,
                                                         (int)st * g.SW * g.s - g.pad - g.dx);
+        }
+    };
+    // RECIN: item q of this thread = half record tid + 512 q of the slot (patch position / 2, hi | mid); its byte offset for the tile being
+    // fetched lives in rvo[] (recomputed when the fetch stream moves on to the next tile, as in conv_f32_prec)
+    constexpr int NRI = RECIN ? RECIN : 1;
+    v4i rreg[NRI];
+    unsigned rvo[NRI];
+    auto tile_rvo = [&](unsigned t) __attribute__((always_inline)) {
+        const int2 *rtab = rowtab + (t & 1u) * P_PRCAP;
+#pragma unroll
+        for (int q = 0; q < NRI; q++) {
+            const unsigned it = (unsigned)(tid + q * P_NT), pos = it >> 1;
+            const unsigned r = pdiv(pos, g.dPWP);
+            const int cp = (int)(pos - r * (unsigned)g.PWP);
+            const int v = g.s == 2 ? (cp < g.PWH ? 2 * cp : 2 * (cp - g.PWH) + 1) : cp;
+            const bool in = (int)r < g.PR;
+            const int2 rt = rtab[in ? r : 0u];
+            const int x = rt.y + v;
+            const bool ok = in && rt.x != -1 && x >= 0 && x < g.W_in;
+            rvo[q] = ok ? (unsigned)rt.x + (unsigned)x * 32u + (it & 1u) * 16u : 0xffffffffu;
         }
     };
     v4i breg[CPI]; // the chunk in flight: channel ich * CPI + j, 4 columns
     const int irc = ir < g.PR ? ir : 0;
     int2 rt_cur = make_int2(-1, 0), rt_nxt = make_int2(-1, 0); // this thread's row-table entry for the tile being computed / the next one
     auto fetch_patch = [&](bool next_tile, int chunk) __attribute__((always_inline)) { // chunk of the current or the next tile
+        if (RECIN) { // (the caller has moved rvo[] on to the next tile where the stream crossed over)
+            const unsigned so = (unsigned)__builtin_amdgcn_readfirstlane((int)((unsigned)chunk * 8u * plane_bytes));
+#pragma unroll
+            for (int q = 0; q < NRI; q++) rreg[q] = __builtin_bit_cast(v4i, __builtin_amdgcn_raw_buffer_load_b128(xrs, rvo[q], so, 0));
+            return;
+        }
         // no divergent branch here: a select per lane (threads without an item, rows / columns outside the image: an offset
         // the buffer unit's range check turns into zeros, no memory access), the chunk in the SCALAR offset; the row-table entry
         // comes from registers (an LDS round trip in front of every fetch was 150+ cycles of the staging phase)
@@ -230,6 +259,12 @@ __global__ __launch_bounds__(P_NT, 2) void conv_f32_patch(const mhip_conv_f32_t 
         }
     };
     auto commit_patch = [&](int slot) __attribute__((always_inline)) {
+        if (RECIN) {
+#pragma unroll
+            for (int q = 0; q < NRI; q++)
+                if ((tid + q * P_NT) * 16 < g.slotpix * 32) *(v4i *)(patch + slot * (g.slotpix * 32) + (tid + q * P_NT) * 16) = rreg[q];
+            return;
+        }
         if (FPATCH_ABL & 2) {
 #pragma unroll
             for (int j = 0; j < CPI; j++) asm volatile("" ::"v"(breg[j]));
@@ -366,10 +401,12 @@ __global__ __launch_bounds__(P_NT, 2) void conv_f32_patch(const mhip_conv_f32_t 
     auto patch_commit = [&](int sc) __attribute__((always_inline)) {
         if (sc) commit_patch((sc - 1) & (P_NB - 1));
     };
+    unsigned tcur = 0; // the tile being computed (RECIN: patch_fetch moves the offsets on from it)
     auto patch_fetch = [&](int sc) __attribute__((always_inline)) {
         if (sc) {
             const int nx = sc; // chunk after the one just committed: of this tile, or nchunk + chunk of the next
             const bool nxt = nx >= g.nchunk;
+            if (RECIN && nx == g.nchunk) tile_rvo(tcur + 1); // (the next tile's row table: written in this tile's R(0); no fetch for it before step 2)
             fetch_patch(nxt, nxt ? nx - g.nchunk : nx);
         }
     };
@@ -380,6 +417,7 @@ __global__ __launch_bounds__(P_NT, 2) void conv_f32_patch(const mhip_conv_f32_t 
     fill_rowtab(t_first);
     __syncthreads();
     rt_cur = rowtab[(t_first & 1) * P_PRCAP + irc];
+    if (RECIN) tile_rvo(t_first);
     // the state every later tile starts in: what the PREVIOUS tile's steps would have done for this tile's first chunks (the
     // schedule entries that name chunk nchunk + c), in order -- chunk 0's loads, then per entry: commit, fetch the next
     fetch_patch(false, 0);
@@ -405,6 +443,7 @@ __global__ __launch_bounds__(P_NT, 2) void conv_f32_patch(const mhip_conv_f32_t 
     st_last = __builtin_readcyclecounter();
 #endif
     for (unsigned t = t_first; t < t_end; t++) {
+        tcur = t;
 #ifdef FPATCH_STAMPS
         st_steps += (unsigned long long)nsteps;
 #endif
@@ -1103,13 +1142,26 @@ extern "C" int mhip_conv_f32_patch_geom(int out_c, int in_c, int kh, int kw, int
     return mhip_conv_f32_patch_geom2(out_c, in_c, kh, kw, stride, pad, in_h, in_w, out_h, out_w, 0, outv, cap);
 }
 
-static unsigned long g_patch_launches = 0, g_prec_launches = 0;
+// which form reads this layer's input when it arrives as records: 0 none, 1 conv_f32_prec (four ring slots, LDS-DMA; the image must be
+// packed with rec = 1), 2 conv_f32_patch<..., RECIN> (two slots, through registers; the plain image)
+extern "C" int mhip_conv_f32_patch_rec_form(int out_c, int in_c, int kh, int kw, int stride, int pad, int in_h, int in_w, int out_h, int out_w) {
+    mhip_conv_f32_t p;
+    shape_of(&p, out_c, in_c, kh, kw, stride, pad, in_h, in_w, out_h, out_w);
+    fpatch_geom_t g;
+    if (out_c <= 0) return 0;
+    if (fpatch_geom(&p, &g, 1, 1)) return 1;
+    if (!fpatch_geom(&p, &g, 1, 0)) return 0;
+    return g.bn == 256 && (g.slotpix * 2 + P_NT - 1) / P_NT <= 8 ? 2 : 0;
+}
+
+static unsigned long g_patch_launches = 0, g_prec_launches = 0, g_recin_launches = 0;
+extern "C" unsigned long mhip_conv_f32_recin_launches(void) { return g_recin_launches; }
 extern "C" unsigned long mhip_conv_f32_patch_launches(void) { return g_patch_launches; }
 extern "C" unsigned long mhip_conv_f32_prec_launches(void) { return g_prec_launches; }
 
-template <int BM, int WM, int WN, int CPI, bool DUMMY, int BN>
+template <int BM, int WM, int WN, int CPI, bool DUMMY, int BN, int RECIN = 0>
 static int launch_patch(const mhip_conv_f32_t *p, fpatch_geom_t &g) {
-    auto kern = conv_f32_patch<BM, WM, WN, CPI, DUMMY, BN>;
+    auto kern = conv_f32_patch<BM, WM, WN, CPI, DUMMY, BN, RECIN>;
     static int cus = 0;
     if (!cus) {
         hipDeviceProp_t prop;
@@ -1132,7 +1184,8 @@ static int launch_patch(const mhip_conv_f32_t *p, fpatch_geom_t &g) {
     const size_t tabb = ((size_t)g.tab_ints * 4 + 255) & ~(size_t)255;
     hipLaunchKernelGGL(kern, dim3(gx, noc), dim3(P_NT), (size_t)g.lds_bytes, mhip_stream_native(), *p, g, (const int *)p->w_patch,
                        (const int8_t *)p->w_patch + tabb);
-    g_patch_launches++;
+    if (RECIN) g_recin_launches++;
+    else g_patch_launches++;
     return mhip_check(hipGetLastError(), "conv_f32_patch");
 }
 
@@ -1166,13 +1219,14 @@ static int launch_prec(const mhip_conv_f32_t *p, fpatch_geom_t &g) {
 }
 
 // -2: not a shape this kernel takes (the caller goes on to conv_f32_split), else the launch result.  in_rec: the input is in record
-// format and the image (w_patch) was packed for that form (mhip_conv_f32_patch_pack2 with rec = 1) -- the planner's pairing
+// format -- 1: conv_f32_prec, the image (w_patch) was packed for that form (mhip_conv_f32_patch_pack2 with rec = 1); 2: conv_f32_patch's
+// record-input form, the plain image (mhip_conv_f32_patch_rec_form says which one a shape takes: the planner's pairing)
 int conv_f32_try_patch(const mhip_conv_f32_t *p) {
     if (!p->w_patch || p->use_mfma != 3 || p->out_rec) return -2;
     fpatch_geom_t g;
-    if (!fpatch_geom(p, &g, p->frames, p->in_rec != 0)) return -2;
+    if (!fpatch_geom(p, &g, p->frames, p->in_rec == 1)) return -2; // in_rec 1: the four-slot DMA form (its image); 2: record input through registers (the plain image)
     if (p->add && p->add_stride != p->out_stride) return -2;
-    if (p->in_rec) {
+    if (p->in_rec == 1) {
         const int ndw = (g.ndma + 7) / 8;
 #define FR_N(BM, WM, WN, D, BN) (ndw <= 2 ? launch_prec<BM, WM, WN, D, BN, 2>(p, g) : ndw <= 3 ? launch_prec<BM, WM, WN, D, BN, 3>(p, g) : ndw <= 4 ? launch_prec<BM, WM, WN, D, BN, 4>(p, g) : ndw <= 6 ? launch_prec<BM, WM, WN, D, BN, 6>(p, g) : launch_prec<BM, WM, WN, D, BN, 8>(p, g))
 #define FR_D(BM, WM, WN, BN) (g.ndummy ? FR_N(BM, WM, WN, true, BN) : FR_N(BM, WM, WN, false, BN))
@@ -1181,6 +1235,17 @@ int conv_f32_try_patch(const mhip_conv_f32_t *p) {
         return g.bn == 512 ? FR_D(32, 1, 8, 512) : FR_D(32, 1, 8, 256);
 #undef FR_D
 #undef FR_N
+    }
+    if (p->in_rec) { // four ring slots do not fit: record input through registers, two slots (conv_f32_patch<..., RECIN>); 256-pixel tiles only
+        const int nri = (g.slotpix * 2 + P_NT - 1) / P_NT;
+        if (g.bn != 256 || nri > 8) return -2;
+#define FQ_N(BM, WM, WN, D) (nri <= 4 ? launch_patch<BM, WM, WN, 8, D, 256, 4>(p, g) : nri <= 6 ? launch_patch<BM, WM, WN, 8, D, 256, 6>(p, g) : launch_patch<BM, WM, WN, 8, D, 256, 8>(p, g))
+#define FQ_D(BM, WM, WN) (g.ndummy ? FQ_N(BM, WM, WN, true) : FQ_N(BM, WM, WN, false))
+        if (g.BM == 128) return FQ_D(128, 2, 4);
+        if (g.BM == 64) return FQ_D(64, 1, 8);
+        return FQ_D(32, 1, 8);
+#undef FQ_D
+#undef FQ_N
     }
 #define FP_D(BM, WM, WN, CPI, BN) (g.ndummy ? launch_patch<BM, WM, WN, CPI, true, BN>(p, g) : launch_patch<BM, WM, WN, CPI, false, BN>(p, g))
 #define FP_CPI(BM, WM, WN, BN) (g.cpi == 8 ? FP_D(BM, WM, WN, 8, BN) : g.cpi == 4 ? FP_D(BM, WM, WN, 4, BN) : FP_D(BM, WM, WN, 2, BN))

@@ -1238,9 +1238,13 @@ void rec_pairs(mars_model_ext_t *m) {
         if (pr->out_c != x->in_c || pr->out_h != x->in_h || pr->out_w != x->in_w) continue;
         if (!(pr->w2_off != NO_OFF || (pr->w3_off != NO_OFF && pr->w3_stem))) continue; /* conv_f32_split or conv_f32_stem writes it */
         if (m->mt[T].bytes != (size_t)x->in_c * x->in_h * x->in_w * 4) continue;
-        const size_t n0 = mhip_conv_f32_patch_pack2(x->out_c, x->in_c, x->kh, x->kw, x->sw, x->pl, x->in_h, x->in_w, x->out_h, x->out_w, 0, NULL, NULL);
-        const size_t n1 = mhip_conv_f32_patch_pack2(x->out_c, x->in_c, x->kh, x->kw, x->sw, x->pl, x->in_h, x->in_w, x->out_h, x->out_w, 1, NULL, NULL);
-        if (!n1 || n1 != n0) continue; /* (the image was reserved for the plain form: same size by construction) */
+        const int form = mhip_conv_f32_patch_rec_form(x->out_c, x->in_c, x->kh, x->kw, x->sw, x->pl, x->in_h, x->in_w, x->out_h, x->out_w);
+        if (!form) continue;
+        if (form == 1) { /* conv_f32_prec: its image replaces the plain one in place (same size by construction) */
+            const size_t n0 = mhip_conv_f32_patch_pack2(x->out_c, x->in_c, x->kh, x->kw, x->sw, x->pl, x->in_h, x->in_w, x->out_h, x->out_w, 0, NULL, NULL);
+            const size_t n1 = mhip_conv_f32_patch_pack2(x->out_c, x->in_c, x->kh, x->kw, x->sw, x->pl, x->in_h, x->in_w, x->out_h, x->out_w, 1, NULL, NULL);
+            if (!n1 || n1 != n0) continue;
+        }
         { /* the three tensors the two launches address with 32-bit offsets: all frames of each must stay below 4 GiB */
             const int tt[3] = {pr->t_in[0], T, x->t_out};
             size_t worst = 0;
@@ -1256,10 +1260,10 @@ void rec_pairs(mars_model_ext_t *m) {
             }
             if (worst && lim / worst < m->rec_max_frames) m->rec_max_frames = lim / worst;
         }
-        if (!m->deferred)
+        if (form == 1 && !m->deferred)
             mhip_conv_f32_patch_pack2(x->out_c, x->in_c, x->kh, x->kw, x->sw, x->pl, x->in_h, x->in_w, x->out_h, x->out_w, 1,
                                       (const float *)(m->arena_host + x->w_off), m->arena_host + x->w3_off);
-        x->in_rec = 1;
+        x->in_rec = form;
         pr->out_rec = 1;
         m->mt[T].rec_c = x->in_c;
         m->mt[T].rec_hw = x->in_h * x->in_w;

@@ -152,7 +152,8 @@ typedef struct {
                      v_mfma_f32_16x16x32_bf16 with every operand split into three bf16 pieces, six piece products per
                      product (conv_f32_split.hip: errors of the size of an f32 rounding); 3: the same with two pieces
                      and three piece products ("bf16x3": relative error per product <= 2^-16, same tolerance class) */
-    int in_rec, out_rec; /* use_mfma == 3 only: the input / the output is in RECORD format instead of NCHW floats -- [c / 8][h][w] records of
+    int in_rec, out_rec; /* use_mfma == 3 only: the input (1: read by conv_f32_prec, 2: by conv_f32_patch's record-input form; mhip_conv_f32_patch_rec_form) / the
+                            output is in RECORD format instead of NCHW floats -- [c / 8][h][w] records of
                             32 bytes = [8 x bf16 hi | 8 x bf16 mid] of 8 consecutive channels of one pixel (hi = bf16(x), mid = bf16(x - hi):
                             the two pieces conv_f32_patch cuts every input into anyway).  Same bytes per element; a tensor written by one
                             convolution for ONE k x k convolution to read (the planner pairs them: mars_plan.c rec_pairs).  in_rec needs
@@ -181,6 +182,10 @@ size_t mhip_conv_f32_patch_pack2(int out_c, int in_c, int kh, int kw, int stride
 int mhip_conv_f32_patch_geom2(int out_c, int in_c, int kh, int kw, int stride, int pad, int in_h, int in_w, int out_h, int out_w,
                               int rec, int *outv, int cap);
 unsigned long mhip_conv_f32_prec_launches(void); /* launches of conv_f32_prec (record-format input) since load */
+unsigned long mhip_conv_f32_recin_launches(void); /* ... of conv_f32_patch's record-input form (two slots, through registers) */
+/* which kernel reads this layer's input when it arrives as records: 0 none, 1 conv_f32_prec (pack the image with rec = 1), 2 conv_f32_patch's
+ * record-input form (the plain image) */
+int mhip_conv_f32_patch_rec_form(int out_c, int in_c, int kh, int kw, int stride, int pad, int in_h, int in_w, int out_h, int out_w);
 /* the layer geometry that kernel derives, as ints (tests, tools): see conv_f32_patch.hip; returns the count, 0 = not such a shape */
 int mhip_conv_f32_patch_geom(int out_c, int in_c, int kh, int kw, int stride, int pad, int in_h, int in_w, int out_h, int out_w,
                              int *outv, int cap);
