@@ -328,6 +328,7 @@ __global__ __launch_bounds__(MV_THREADS) void concat_kernel(const int8_t *in, si
     const int8_t *s = in + (size_t)blockIdx.y * is + pix * in_c + c;
     int8_t *d = out + (size_t)blockIdx.y * os + pix * out_c + ch_off + c;
     if (VEC == 16) *(v4i *)d = *(const v4i *)s;
+    else if (VEC == 8) *(uint2 *)d = *(const uint2 *)s;
     else if (VEC == 4) *(int *)d = *(const int *)s;
     else d[0] = s[0];
 }
@@ -343,8 +344,12 @@ extern "C" int mhip_concat_slice(const int8_t *in, size_t in_stride, int8_t *out
     // shape[3] whatever the dtype: dwords, not single bytes, for those)
     const bool v4 = (in_c % 4 == 0) && (out_c % 4 == 0) && (ch_off % 4 == 0) &&
                     ((((uintptr_t)in | (uintptr_t)out | in_stride | out_stride) & 3) == 0);
+    const bool v8 = (in_c % 8 == 0) && (out_c % 8 == 0) && (ch_off % 8 == 0) && ((((uintptr_t)in | (uintptr_t)out | in_stride | out_stride) & 7) == 0);
     if (v16)
         hipLaunchKernelGGL((concat_kernel<16>), mv_grid(npix * (in_c / 16), frames), dim3(MV_THREADS), 0,
+                           mhip_stream_native(), in, in_stride, out, out_stride, npix, in_c, out_c, ch_off);
+    else if (v8) // (the twins' 40-byte rows)
+        hipLaunchKernelGGL((concat_kernel<8>), mv_grid(npix * (in_c / 8), frames), dim3(MV_THREADS), 0,
                            mhip_stream_native(), in, in_stride, out, out_stride, npix, in_c, out_c, ch_off);
     else if (v4)
         hipLaunchKernelGGL((concat_kernel<4>), mv_grid(npix * (in_c / 4), frames), dim3(MV_THREADS), 0,
