@@ -412,8 +412,9 @@ __global__ __launch_bounds__(P_NT, 2) void conv_f32_patch(const mhip_conv_f32_t 
     };
 
     // ---- prologue: tables, the first two chunks of the first tile, the first weight steps
-    const unsigned t_first = blockIdx.x * g.per;
-    const unsigned t_end = (blockIdx.x + 1) * g.per < g.ntiles ? (blockIdx.x + 1) * g.per : g.ntiles;
+    // this workgroup's run of tiles: an even split of the tile list over the grid's x extent
+    const unsigned t_first = (unsigned)(((unsigned long long)blockIdx.x * g.ntiles) / gridDim.x);
+    const unsigned t_end = (unsigned)(((unsigned long long)(blockIdx.x + 1) * g.ntiles) / gridDim.x);
     fill_rowtab(t_first);
     __syncthreads();
     rt_cur = rowtab[(t_first & 1) * P_PRCAP + irc];
@@ -781,8 +782,9 @@ __global__ __launch_bounds__(P_NT, 2) void conv_f32_prec(const mhip_conv_f32_t p
 
     // ---- prologue: tables, the row table and DMA offsets of the first tile, what the previous tile's steps would have issued for
     // it (the schedule entries that name a chunk of the NEXT tile), the first three weight stages; everything landed
-    const unsigned t_first = blockIdx.x * g.per;
-    const unsigned t_end = (blockIdx.x + 1) * g.per < g.ntiles ? (blockIdx.x + 1) * g.per : g.ntiles;
+    // this workgroup's run of tiles: an even split of the tile list over the grid's x extent
+    const unsigned t_first = (unsigned)(((unsigned long long)blockIdx.x * g.ntiles) / gridDim.x);
+    const unsigned t_end = (unsigned)(((unsigned long long)(blockIdx.x + 1) * g.ntiles) / gridDim.x);
     fill_rowtab(t_first);
     __syncthreads();
     const int nsteps = g.nsteps;
@@ -1159,6 +1161,19 @@ extern "C" unsigned long mhip_conv_f32_recin_launches(void) { return g_recin_lau
 extern "C" unsigned long mhip_conv_f32_patch_launches(void) { return g_patch_launches; }
 extern "C" unsigned long mhip_conv_f32_prec_launches(void) { return g_prec_launches; }
 
+// The grid is (pixel runs, channel tiles), workgroups are dealt to the 8 XCDs round-robin in dispatch order (x fastest): the channel tiles of
+// one pixel run share an XCD -- and its L2, where the second, third ... tile's input reads should hit -- only if the x extent is a multiple
+// of 8.  (It was ceil(tiles / per): 58 for the 400 tiles of a 20 x 20 map over 64 slots -- the four channel tiles of a run sat on four XCDs
+// and each fetched the input itself.  PMC, config 5 per batch: conv_f32_patch<128,...>'s four float-input launches 8.2 -> 4.6 GB read,
+// conv_f32_split<128,...> 19.8 -> 11.5 GB; the TIME of those launches did not move -- the Infinity Cache had been serving the repeats.)
+static unsigned fpatch_grid_x(unsigned gx, unsigned cap, unsigned noc) {
+    if (noc > 1 && gx >= 8) {
+        const unsigned up = (gx + 7) & ~7u;
+        gx = up <= cap ? up : (gx & ~7u);
+    }
+    return gx;
+}
+
 template <int BM, int WM, int WN, int CPI, bool DUMMY, int BN, int RECIN = 0>
 static int launch_patch(const mhip_conv_f32_t *p, fpatch_geom_t &g) {
     auto kern = conv_f32_patch<BM, WM, WN, CPI, DUMMY, BN, RECIN>;
@@ -1179,7 +1194,7 @@ static int launch_patch(const mhip_conv_f32_t *p, fpatch_geom_t &g) {
     if (gx < 1) gx = 1;
     if (gx > g.ntiles) gx = g.ntiles;
     const unsigned per = (g.ntiles + gx - 1) / gx;
-    gx = (g.ntiles + per - 1) / per;
+    gx = fpatch_grid_x((g.ntiles + per - 1) / per, (unsigned)(slots > 0 ? slots : cus) / noc, noc);
     g.per = per;
     const size_t tabb = ((size_t)g.tab_ints * 4 + 255) & ~(size_t)255;
     hipLaunchKernelGGL(kern, dim3(gx, noc), dim3(P_NT), (size_t)g.lds_bytes, mhip_stream_native(), *p, g, (const int *)p->w_patch,
@@ -1209,7 +1224,7 @@ static int launch_prec(const mhip_conv_f32_t *p, fpatch_geom_t &g) {
     if (gx < 1) gx = 1;
     if (gx > g.ntiles) gx = g.ntiles;
     const unsigned per = (g.ntiles + gx - 1) / gx;
-    gx = (g.ntiles + per - 1) / per;
+    gx = fpatch_grid_x((g.ntiles + per - 1) / per, (unsigned)(slots > 0 ? slots : cus) / noc, noc);
     g.per = per;
     const size_t tabb = ((size_t)g.tab_ints * 4 + 255) & ~(size_t)255;
     hipLaunchKernelGGL(kern, dim3(gx, noc), dim3(P_NT), (size_t)g.lds_bytes, mhip_stream_native(), *p, g, (const int *)p->w_patch,

@@ -221,7 +221,9 @@ __global__ __launch_bounds__(S_NT, BM == 32 && NPL == 2 && !RECOUT ? 4 : 2) void
                     if (kx + (i & 1) < p.kw && (unsigned)(ix0 + 2 * (i >> 1) + kx + (i & 1)) < (unsigned)p.in_w) colbits |= 1u << ((kx >> 1) * 4 + i);
         }
     };
-    setup(blockIdx.x * g.per);
+    // this workgroup's run of pixel tiles: an even split of the tile list over the grid's x extent
+    const unsigned pt_first = (unsigned)(((unsigned long long)blockIdx.x * g.npt) / gridDim.x);
+    setup(pt_first);
     // weights: row oc0 + tid / ATPR of every plane, taps (tid % ATPR) * AE .. + AE - 1 of the step
     const int arow = tid / ATPR, akc = (tid % ATPR) * AE;
     const int8_t *wrow = fz && arow >= BM / 2 ? (const int8_t *)g.w_split2 + ((size_t)(arow - BM / 2) * g.kp + akc) * 2
@@ -447,8 +449,8 @@ __global__ __launch_bounds__(S_NT, BM == 32 && NPL == 2 && !RECOUT ? 4 : 2) void
 #endif
     // a workgroup walks a RUN of consecutive tiles: the halo rows (and, under stride 2, most of a tile's rows) it shares with the
     // next tile are then in its own XCD's L2 -- strided over the grid, neighbouring tiles ran on different XCDs at the same time
-    const unsigned pt_end = (blockIdx.x + 1) * g.per < g.npt ? (blockIdx.x + 1) * g.per : g.npt;
-    for (unsigned pt = blockIdx.x * g.per; pt < pt_end; pt++) {
+    const unsigned pt_end = (unsigned)(((unsigned long long)(blockIdx.x + 1) * g.npt) / gridDim.x);
+    for (unsigned pt = pt_first; pt < pt_end; pt++) {
 #ifdef SPLIT_STAMPS
         st_steps += (unsigned long long)nks;
 #endif
@@ -590,6 +592,12 @@ static int launch_split(const mhip_conv_f32_t *p, split_args_t g) {
     if (gx > g.npt) gx = g.npt;
     const unsigned per = (g.npt + gx - 1) / gx;
     gx = (g.npt + per - 1) / per;
+    // (x extent a multiple of 8 when there are several channel tiles: the tiles of one pixel run then share an XCD and its L2 -- workgroups are
+    // dealt to the XCDs round-robin in dispatch order, x fastest; conv_f32_patch.hip fpatch_grid_x has the measurement)
+    if (noc > 1 && gx >= 8) {
+        const unsigned up = (gx + 7) & ~7u, cap = (unsigned)slots / noc;
+        gx = up <= cap ? up : (gx & ~7u);
+    }
     g.per = per;
     hipLaunchKernelGGL(kern, dim3(gx, noc), dim3(S_NT), ldsb, mhip_stream_native(), *p, g);
     g_split_launches++;
