@@ -636,16 +636,19 @@ __global__ __launch_bounds__(P_NT, 2) void conv_f32_prec(const mhip_conv_f32_t p
     // 128-channel stage is 16 KB per step and the DMA path fills LDS at ~27 B/clk/CU (probe, round 4) -- 600 cycles of it per step beside
     // the patch's, every wait for either grew long (stamps: patch issue 620, DMA waits 510, barriers 1270 cycles per step on D40)
     const int arow = tid / ATPR, akc = (tid % ATPR) * AE;
-    const int8_t *wrow = wpl + ((size_t)(oc0 + arow) * g.kp + akc) * 2;
-    const size_t wplane_b = (size_t)g.oc_pad * g.kp * 2;
+    // (buffer loads: a 32-bit per-lane offset and the (plane, step) part in the scalar offset -- a 64-bit row pointer and its per-load address
+    // arithmetic cost the registers whose spill put a reload, and with it an s_waitcnt vmcnt(0), in front of the K loop)
+    const unsigned wplane_b = (unsigned)g.oc_pad * (unsigned)g.kp * 2u;
+    const __amdgpu_buffer_rsrc_t wrs = __builtin_amdgcn_make_buffer_rsrc((void *)wpl, 0, (int)(2u * wplane_b), 0x00020000);
+    const unsigned wvoff = ((unsigned)(oc0 + arow) * (unsigned)g.kp + (unsigned)akc) * 2u;
     int aregs[2][2][AD];
     auto fetch_w = [&](int ks, int (&areg)[2][AD]) __attribute__((always_inline)) {
 #pragma unroll
         for (int pl = 0; pl < 2; pl++) {
-            const int8_t *src = wrow + pl * wplane_b + (size_t)ks * 64;
-            if (AE == 8) { const v4i t = *(const v4i *)src; areg[pl][0] = t[0]; areg[pl][1 % AD] = t[1]; areg[pl][2 % AD] = t[2]; areg[pl][3 % AD] = t[3]; }
-            else if (AE == 4) { const int2 t = *(const int2 *)src; areg[pl][0] = t.x; areg[pl][1 % AD] = t.y; }
-            else areg[pl][0] = *(const int *)src;
+            const unsigned so = (unsigned)pl * wplane_b + (unsigned)ks * 64u;
+            if (AE == 8) { const v4i t = __builtin_bit_cast(v4i, __builtin_amdgcn_raw_buffer_load_b128(wrs, wvoff, so, 0)); areg[pl][0] = t[0]; areg[pl][1 % AD] = t[1]; areg[pl][2 % AD] = t[2]; areg[pl][3 % AD] = t[3]; }
+            else if (AE == 4) { const auto t = __builtin_amdgcn_raw_buffer_load_b64(wrs, wvoff, so, 0); areg[pl][0] = (int)t[0]; areg[pl][1 % AD] = (int)t[1]; }
+            else areg[pl][0] = (int)__builtin_amdgcn_raw_buffer_load_b32(wrs, wvoff, so, 0);
         }
     };
     auto commit_w = [&](int buf, const int (&areg)[2][AD]) __attribute__((always_inline)) {
