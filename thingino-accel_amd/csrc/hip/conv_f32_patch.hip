@@ -293,16 +293,18 @@ __global__ __launch_bounds__(P_NT, 2) void conv_f32_patch(const mhip_conv_f32_t 
 
     // ---- weights: row oc0 + tid / ATPR of both planes, elements (tid % ATPR) * AE .. of the step (as conv_f32_split)
     const int arow = tid / ATPR, akc = (tid % ATPR) * AE;
-    const int8_t *wrow = wpl + ((size_t)(oc0 + arow) * g.kp + akc) * 2;
-    const size_t wplane = (size_t)g.oc_pad * g.kp * 2;
+    // (buffer loads: a 32-bit per-lane offset, the (plane, step) part in the scalar offset: no 64-bit row pointer and address arithmetic per load)
+    const unsigned wplane = (unsigned)g.oc_pad * (unsigned)g.kp * 2u;
+    const __amdgpu_buffer_rsrc_t wrs = __builtin_amdgcn_make_buffer_rsrc((void *)wpl, 0, (int)(2u * wplane), 0x00020000);
+    const unsigned wvoff = ((unsigned)(oc0 + arow) * (unsigned)g.kp + (unsigned)akc) * 2u;
     int aregs[2][2][AD];
     auto fetch_w = [&](int ks, int (&areg)[2][AD]) __attribute__((always_inline)) {
 #pragma unroll
         for (int pl = 0; pl < 2; pl++) {
-            const int8_t *src = wrow + pl * wplane + (size_t)ks * 64;
-            if (AE == 8) { const v4i t = *(const v4i *)src; areg[pl][0] = t[0]; areg[pl][1 % AD] = t[1]; areg[pl][2 % AD] = t[2]; areg[pl][3 % AD] = t[3]; }
-            else if (AE == 4) { const int2 t = *(const int2 *)src; areg[pl][0] = t.x; areg[pl][1 % AD] = t.y; }
-            else areg[pl][0] = *(const int *)src;
+            const unsigned so = (unsigned)pl * wplane + (unsigned)ks * 64u;
+            if (AE == 8) { const v4i t = __builtin_bit_cast(v4i, __builtin_amdgcn_raw_buffer_load_b128(wrs, wvoff, so, 0)); areg[pl][0] = t[0]; areg[pl][1 % AD] = t[1]; areg[pl][2 % AD] = t[2]; areg[pl][3 % AD] = t[3]; }
+            else if (AE == 4) { const auto t = __builtin_amdgcn_raw_buffer_load_b64(wrs, wvoff, so, 0); areg[pl][0] = (int)t[0]; areg[pl][1 % AD] = (int)t[1]; }
+            else areg[pl][0] = (int)__builtin_amdgcn_raw_buffer_load_b32(wrs, wvoff, so, 0);
         }
     };
     auto commit_w = [&](int buf, const int (&areg)[2][AD]) __attribute__((always_inline)) {
