@@ -95,8 +95,10 @@ def direct_conv(x, w, s, pad, out_h, out_w):
     return out
 
 
-def emulate_patch_kernel(g, tabs, wk, x, frames, t_first, t_end):
-    """the workgroup that walks tiles [t_first, t_end): returns {tile: acc[256, oc_rows]} following conv_f32_patch's control flow"""
+def emulate_patch_kernel(g, tabs, wk, x, frames, t_first, t_end, recin=False):
+    """the workgroup that walks tiles [t_first, t_end): returns {tile: acc[256, oc_rows]} following conv_f32_patch's control flow.
+    recin: the record-input form (conv_f32_patch<..., RECIN>): a thread's items are the 16-byte half records tid + 512 q of the slot
+    (position = item / 2 -> (patch row, column) as the kernel derives it), copied through registers at the same schedule"""
     s, pad, PWP, PWH, SW, HV = g["s"], g["pad"], g["PWP"], g["PWH"], g["SW"], g["HV"]
     nchunk, nsteps, slotpix = g["nchunk"], g["nsteps"], g["slotpix"]
     dutab, sched = tabs[:nsteps * 4].reshape(nsteps, 4), tabs[nsteps * 4:nsteps * 5]
@@ -128,7 +130,25 @@ def emulate_patch_kernel(g, tabs, wk, x, frames, t_first, t_end):
     nsub = 8 // cpi  # items per (row, 4-column group): each fetches cpi of the chunk's 8 channels
     assert g["nitems"] == g["PR"] * g["ngrp"] * nsub
 
+    def fetch_rec(t, chunk):
+        vals = np.zeros((slotpix, 8))
+        for pos in range(slotpix):
+            r, cp = divmod(pos, PWP)
+            if r >= g["PR"]:
+                continue
+            v = (2 * cp if cp < PWH else 2 * (cp - PWH) + 1) if s == 2 else cp
+            src, xal = tables[t & 1][r]
+            xx = xal + v
+            if src is not None and 0 <= xx < g["W_in"]:
+                vals[pos] = x[src[0], chunk * 8:chunk * 8 + 8, src[1], xx]
+        return vals
+
+    def commit_rec(slot, vals):
+        slots[slot * slotpix:(slot + 1) * slotpix] = vals
+
     def fetch(t, chunk):
+        if recin:
+            return fetch_rec(t, chunk)
         vals = np.zeros((g["nitems"], 4, cpi))
         for it in range(g["nitems"]):
             cell, ich = divmod(it, nsub)
@@ -142,6 +162,8 @@ def emulate_patch_kernel(g, tabs, wk, x, frames, t_first, t_end):
         return vals
 
     def commit(slot, vals):
+        if recin:
+            return commit_rec(slot, vals)
         for it in range(g["nitems"]):
             cell, ich = divmod(it, nsub)
             ir, igq = divmod(cell, g["ngrp"])
@@ -333,6 +355,60 @@ def test_conv_f32_patch_tables_reproduce_a_direct_convolution(shape, rec):
             got = acc[ok]
             assert not np.isnan(got).any(), "tile %d read a slot before its chunk was committed" % t
             assert np.abs(got - ref).max() <= 1e-3 * max(1.0, np.abs(ref).max()), (shape, t)
+
+
+@pytest.mark.parametrize("shape", [s_ for s_ in PATCH_SHAPES if s_[3] == 2])
+def test_conv_f32_patch_record_input_through_registers(shape):
+    """the stride-2 shapes whose patch leaves no room for conv_f32_prec's four ring slots read records through registers
+    (conv_f32_patch<..., RECIN>): the plain image and schedule, a chunk's staging a copy of half records -- emulated against a direct
+    convolution like the float form"""
+    out_c, in_c, k, s, pad, in_h, in_w, frames = shape
+    out_h, out_w = (in_h + s - 1) // s, (in_w + s - 1) // s
+    L = marsrt.lib()
+    form = L.mhip_conv_f32_patch_rec_form
+    form.restype = C.c_int
+    form.argtypes = [C.c_int] * 10
+    f = form(out_c, in_c, k, k, s, pad, in_h, in_w, out_h, out_w)
+    assert f in (1, 2)
+    if f == 1:
+        pytest.skip("four slots fit: conv_f32_prec takes this shape")
+    g = patch_geom(L, out_c, in_c, k, k, s, pad, in_h, in_w, out_h, out_w, 0)
+    assert g["bn"] == 256 and (g["slotpix"] * 2 + 511) // 512 <= 8
+    rng = np.random.default_rng(k * 100 + in_c)
+    w = (rng.random((out_c, in_c, k, k), dtype=np.float32) - np.float32(0.5)).astype(np.float32)
+    x = rng.random((frames, in_c, in_h, in_w), dtype=np.float32).astype(np.float64)
+    img = patch_pack(L, w, s, pad, in_h, in_w, out_h, out_w, 0)
+    tabb = (g["tab_ints"] * 4 + 255) & ~255
+    tabs = img[:g["tab_ints"] * 4].view(np.int32)
+    planes = img[tabb:].view(np.uint16).reshape(2, g["oc_pad"], g["kp"])
+    wk = (bf16_to_f32(planes[0]).astype(np.float64) + bf16_to_f32(planes[1]).astype(np.float64))[:out_c]
+    want = direct_conv(x, w, s, pad, out_h, out_w)
+    total = frames * out_h * out_w
+    ntiles = (total + g["bn"] - 1) // g["bn"]
+    for t0, t1 in ([(0, ntiles)] if ntiles < 3 else [(0, ntiles), (1, 3)]):
+        for t, (q, acc) in emulate_patch_kernel(g, tabs, wk, x, frames, t0, t1, recin=True).items():
+            ok = q < total
+            R, xs = q // g["SW"], q % g["SW"]
+            seg, y = R // out_h, R % out_h
+            f_, st = seg // g["nstrips"], seg % g["nstrips"]
+            ref = want[f_[ok], :, y[ok], st[ok] * g["SW"] + xs[ok]]
+            assert not np.isnan(acc[ok]).any() and np.abs(acc[ok] - ref).max() <= 1e-3 * max(1.0, np.abs(ref).max()), (shape, t)
+
+
+def test_conv_f32_record_forms_of_the_twins_layers():
+    """mhip_conv_f32_patch_rec_form: which kernel reads a layer's input when it arrives as records -- the bottlenecks' 3 x 3 (four ring
+    slots fit: conv_f32_prec, 1), the stride-2 layers behind the stem / a C3 (2: through registers), shapes the patch kernels decline (0)"""
+    L = marsrt.lib()
+    form = L.mhip_conv_f32_patch_rec_form
+    form.restype = C.c_int
+    form.argtypes = [C.c_int] * 10
+    for (oc, ic, k, s, h) in ((32, 32, 3, 1, 160), (64, 64, 3, 1, 80), (128, 128, 3, 1, 40), (256, 256, 3, 1, 20)):
+        assert form(oc, ic, k, k, s, 1, h, h, h, h) == 1, (oc, ic, h)
+    for (oc, ic, h) in ((64, 32, 320), (128, 64, 160), (256, 128, 80), (512, 256, 40)):
+        assert form(oc, ic, 3, 3, 2, 1, h, h, h // 2, h // 2) == 2, (oc, ic, h)
+    assert form(32, 24, 3, 3, 1, 1, 40, 40, 40, 40) == 0      # fewer than four chunks
+    assert form(32, 64, 1, 1, 1, 0, 40, 40, 40, 40) == 0      # 1 x 1
+    assert form(32, 3, 6, 6, 2, 2, 640, 640, 320, 320) == 0   # the stem's own shape
 
 
 def test_conv_f32_patch_declines_what_it_cannot_take():
