@@ -1145,6 +1145,58 @@ def test_conv_f32_record_pairs(gpu, orc, shape):
         gpu.set_tuning("dual_stream_min_batch", 64)
 
 
+def test_record_pairs_are_chosen_per_batch(gpu, orc, monkeypatch):
+    """rec_pairs addresses a pair's tensors with 32-bit offsets: a batch that takes all frames of one of them past the limit
+    (MARS_HIP_REC_LIMIT here, 4 GiB in production) plans WITHOUT the record format, a smaller batch afterwards WITH it again --
+    same results either way (mars_hip_set_batch re-plans: alloc_batch)."""
+    h, w, c = 20, 20, 64
+    rng = np.random.default_rng(77)
+    G = marsfile.Graph()
+    F, N = marsfile.F32, marsfile.NCHW
+
+    def conv_silu(xin, kk):
+        a = G.tensor([1, c, h, w], dtype=F, fmt=N)
+        wt = G.tensor([c, c, kk, kk], dtype=F, fmt=marsfile.OIHW, data=((rng.random((c, c, kk, kk), dtype=np.float32) * 2 - 1) * (1.7 / (kk * kk * c) ** 0.5)).astype(np.float32))
+        b = G.tensor([c], dtype=F, fmt=marsfile.D1, data=((rng.random(c, dtype=np.float32) * 2 - 1) * 0.1).astype(np.float32))
+        G.conv(xin, a, wt, b, (kk, kk), (1, 1), pad=marsfile.PAD_SAME)
+        g_, o_ = G.tensor([1, c, h, w], dtype=F, fmt=N), G.tensor([1, c, h, w], dtype=F, fmt=N)
+        G.layer(marsfile.SIGMOID, [a], [g_])
+        G.layer(marsfile.MUL, [a, g_], [o_])
+        return o_
+
+    x = G.tensor([1, c, h, w], dtype=F, fmt=N)
+    out = conv_silu(conv_silu(x, 1), 3)
+    d = G.serialise([x], [out])
+    xin = (rng.random(c * h * w, dtype=np.float32) * 2 - 1).astype(np.float32)
+    g = orc.Graph(d)
+    g.set_input(0, xin.tobytes())
+    assert g.run() == 0
+    want = g.tensor(out).copy()
+    g.close()
+    prec = gpu.lib().mhip_conv_f32_prec_launches
+    prec.restype = C.c_ulong
+    frame_bytes = c * h * w * 4  # 102400: every tensor of the pair
+    monkeypatch.setenv("MARS_HIP_REC_LIMIT", str(frame_bytes * 10))
+    try:
+        gpu.set_tuning("f32_mfma", 3)
+        gpu.set_tuning("dual_stream_min_batch", 0)
+        m = gpu.Model(d, batch=4)
+        for B, expect in ((4, 1), (16, 0), (9, 1), (11, 0), (2, 1)):
+            m.set_batch(B)
+            for f in range(B):
+                m.input_view(0)[f] = xin.view(np.uint8)
+            n0 = prec()
+            m.run()
+            assert prec() - n0 == expect, "batch %d: %d record-form launch(es)" % (B, prec() - n0)
+            got = m.output_view(0)
+            for f in (0, B - 1):
+                assert close_f32(got[f], want).all(), "batch %d frame %d" % (B, f)
+        m.close()
+    finally:
+        gpu.set_tuning("f32_mfma", 1)
+        gpu.set_tuning("dual_stream_min_batch", 64)
+
+
 @pytest.mark.parametrize("shape", [(40, 40, 128, 3, 96), (160, 160, 32, 3, 16), (20, 20, 256, 3, 160)], ids=lambda v: "x".join(str(q) for q in v))
 def test_conv_f32_record_form_is_the_register_form_bit_for_bit(gpu, shape, monkeypatch):
     """a C3 bottleneck (1 x 1 -> 3 x 3 + shortcut Add) at a batch that gives every workgroup a run of tiles: the record form

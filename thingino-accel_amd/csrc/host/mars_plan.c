@@ -1207,7 +1207,8 @@ void rec_pairs(mars_model_ext_t *m) {
     m->rec_skipped = 0;
     m->rec_max_frames = (size_t)-1;
     if (m->fusion < 1 || getenv("MARS_HIP_NO_REC") || mhip_conv_f32_mode(-1) != 3) return;
-    const size_t frames = m->rec_frames > 0 ? (size_t)m->rec_frames : 1, lim = 0xfffffff0u; /* 32-bit byte offsets over all frames of a tensor */
+    const char *lim_env = getenv("MARS_HIP_REC_LIMIT"); /* (tests lower it to see the per-batch decision with small tensors) */
+    const size_t frames = m->rec_frames > 0 ? (size_t)m->rec_frames : 1, lim = lim_env ? (size_t)strtoull(lim_env, NULL, 0) : (size_t)0xfffffff0u; /* 32-bit byte offsets over all frames of a tensor */
     int *readers = (int *)calloc((size_t)nt + 1, sizeof(int));
     int *writers = (int *)calloc((size_t)nt + 1, sizeof(int));
     if (!readers || !writers) { free(readers); free(writers); return; }
