@@ -109,28 +109,30 @@ def frames_for_rank(D, rank, world, per_gpu, nbytes, f32=False):
     return [lcg_frame(0x5EED0000 + f, nbytes) for f in D.shard_frames(per_gpu, rank, world)]
 
 
-def cpu_baseline(model_bytes, frames, out_ids, budget_s=14.0, max_frames=16):
+def cpu_baseline(model_bytes, frames, out_ids, budget_s=14.0, max_frames=16, file_model=False, on_frame=None):
     """rank 0, N=1 only: the reference's own C (or, failing that, this repo's port) on ONE host
     core over a bounded sample of the same workload: as many frames as fit in ~budget_s seconds.
     Returns (record, per-frame outputs) so the GPU results for those frames can be compared."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    # (a shipped file reads / writes past some tensors' nominal extent: the harness's wide default slack, SURVEY App. D)
+    kw = {} if file_model else dict(slack_mult=1, slack_add=4096)
     runner, kind, how = None, "port", "oracle/restate (gcc -O2)"
     try:
         import refbind
         if refbind.available():
-            runner = refbind.O2Model(model_bytes, slack_mult=1, slack_add=4096, fast=True)
+            runner = refbind.O2Model(model_bytes, fast=True, **kw)
             kind, how = "reference", "the reference's own layer functions (oracle/_ref, gcc -O3 -funroll-loops)"
     except Exception:  # noqa: BLE001
         runner = None
     if runner is None:
         import orcbind
-        runner = orcbind.Graph(model_bytes, slack_mult=1, slack_add=4096)
+        runner = orcbind.Graph(model_bytes, **kw)
     outs, spent, n = [], 0.0, 0
     while n < min(max_frames, len(frames)) and (n == 0 or spent + spent / n <= budget_s):
         if n:
             runner.close()
-            runner = (refbind.O2Model(model_bytes, slack_mult=1, slack_add=4096, fast=True) if kind == "reference"
-                      else orcbind.Graph(model_bytes, slack_mult=1, slack_add=4096))  # fresh zeroed tensors per frame
+            runner = (refbind.O2Model(model_bytes, fast=True, **kw) if kind == "reference"
+                      else orcbind.Graph(model_bytes, **kw))  # fresh zeroed tensors per frame
         runner.set_input(0, frames[n].tobytes())
         t0 = time.time()
         rc = runner.run()
@@ -138,13 +140,15 @@ def cpu_baseline(model_bytes, frames, out_ids, budget_s=14.0, max_frames=16):
         if rc != 0:
             raise RuntimeError("cpu baseline run failed: %d" % rc)
         outs.append([runner.tensor(ti) for ti in out_ids])
+        if on_frame is not None:  # --model: the caller compares every activation tensor of the frame while the run is held
+            on_frame(runner, n)
         n += 1
     runner.close()
     return dict(value=n / spent, unit="images/s", cores=1, kind=kind,
                 sample="%d frames of the same workload through %s, %.1f s of CPU time" % (n, how, spent)), outs
 
 
-def cpu_baseline_parallel(model_bytes, frames, out_ids, nthreads, ref_outs, f32=False):
+def cpu_baseline_parallel(model_bytes, frames, out_ids, nthreads, ref_outs, f32=False, file_model=False):
     """the same reference code, frames-parallel: one frame per thread, every host core this process may use (ctypes
     releases the GIL; every thread owns its model instance).  One frame per thread, so ~one single-frame time."""
     import threading
@@ -161,12 +165,13 @@ def cpu_baseline_parallel(model_bytes, frames, out_ids, nthreads, ref_outs, f32=
         use_ref = refbind.available()
     except Exception:  # noqa: BLE001
         use_ref = False
+    kw = {} if file_model else dict(slack_mult=1, slack_add=4096)
     if use_ref:
         kind = "reference"
-        mk = lambda: refbind.O2Model(model_bytes, slack_mult=1, slack_add=4096, fast=True)  # noqa: E731
+        mk = lambda: refbind.O2Model(model_bytes, fast=True, **kw)  # noqa: E731
     else:
         import orcbind
-        mk = lambda: orcbind.Graph(model_bytes, slack_mult=1, slack_add=4096)  # noqa: E731
+        mk = lambda: orcbind.Graph(model_bytes, **kw)  # noqa: E731
     runners = [mk() for _ in range(n)]
     for i, r in enumerate(runners):
         r.set_input(0, frames[i].tobytes())
@@ -185,6 +190,206 @@ def cpu_baseline_parallel(model_bytes, frames, out_ids, nthreads, ref_outs, f32=
         r.close()
     return dict(value=n / dt, unit="images/s", cores=n, host_cores=len(os.sched_getaffinity(0)), kind=kind, matches_single_core_run=bool(same),
                 sample="%d frames at once, one per thread, %.1f s wall" % (n, dt))
+
+
+def input_hw_of(t):
+    """(H, W) of a graph input by its format tag (NHWC = 7: [N, H, W, C]; anything else is read as NCHW: reference mars_runtime.c:561-562)"""
+    sh = list(t["shape"]) + [1, 1, 1, 1]
+    return (sh[1], sh[2]) if t["fmt"] == 7 else (sh[2], sh[3])
+
+
+def synth_frames(first, n, nbytes, f32):
+    """frame f = LCG(seed 0x5EED0000 + f) bytes (int8 inputs) or uniform [0, 1) floats from the same LCG (f32 inputs)"""
+    from conftest import lcg_frame
+    import cases
+    if f32:
+        return [cases.f32(0x5EED0000 + f, nbytes // 4, 0.0, 1.0).view(np.uint8) for f in range(first, first + n)]
+    return [lcg_frame(0x5EED0000 + f, nbytes) for f in range(first, first + n)]
+
+
+def reference_runner(model_bytes, file_model):
+    """the reference's own layer functions on a private arena (oracle/_ref, -O3 -funroll-loops), else this repo's restatement;
+    shipped files get the wide slack their out-of-tensor reads / writes need"""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    kw = {} if file_model else dict(slack_mult=1, slack_add=4096)
+    try:
+        import refbind
+        if refbind.available():
+            return refbind.O2Model(model_bytes, fast=True, **kw), "reference"
+    except Exception:  # noqa: BLE001
+        pass
+    import orcbind
+    return orcbind.Graph(model_bytes, **kw), "port"
+
+
+def compare_frame(model, runner, tensors, out_ids, frame, f32, every_tensor):
+    """GPU frame `frame` against the CPU run held by `runner`: graph outputs, and (every_tensor) every activation tensor the plan keeps
+    in HBM.  int8: bit for bit; f32: |a - b| <= 1e-4 * max(1, |b|).  -> (tensors compared, tensors equal, worst relative error)"""
+    def same(a, b):
+        if not f32:
+            return bool(np.array_equal(a, b)), 0.0
+        x, y = a.view(np.float32).astype(np.float64), b.view(np.float32).astype(np.float64)
+        if (np.isnan(x) != np.isnan(y)).any() or (np.isinf(x) != np.isinf(y)).any():
+            return False, float("inf")
+        bad = ~((np.isnan(x) & np.isnan(y)) | (x == y))
+        if not bad.any():
+            return True, 0.0
+        err = float((np.abs(x - y)[bad] / np.maximum(1.0, np.abs(y)[bad])).max())
+        return err <= 1e-4, err
+    n = ok = 0
+    worst = 0.0
+    for i, ti in enumerate(out_ids):
+        e, w = same(model.output_view(i)[frame], runner.tensor(ti))
+        n += 1
+        ok += int(e)
+        worst = max(worst, w)
+    if every_tensor:
+        import marsfile
+        for ti, t in enumerate(tensors):
+            if t["size"] != 0 or not marsfile.tensor_nbytes(t) or ti in out_ids:
+                continue
+            try:
+                got = model.read_tensor(ti, frame=frame)
+            except Exception:  # noqa: BLE001  (elided by a fusion pass, or written by no layer: not in HBM)
+                continue
+            e, w = same(got, runner.tensor(ti)[:len(got)])
+            n += 1
+            ok += int(e)
+            worst = max(worst, w)
+    return n, ok, worst
+
+
+def short_leg(M, name, model_bytes, batch, steps, warmup, tail, f32_mode=None, cpu_frames=1, file_model=False, what=""):
+    """One short leg of another BASELINE config under the same clock as the headline: its own model instance, frames resident in
+    HBM, `warmup` + `steps` steps between synchronisations, one further step with HIP events around the convolution launches (one
+    stream) for the roofline, then `cpu_frames` frames compared with the reference's CPU run.  -> a compact dict."""
+    import marsfile
+    hdr, tensors, _ = marsfile.parse(model_bytes)
+    tin = tensors[hdr["inputs"][0]]
+    f32 = tin["dtype"] == 0
+    nb = marsfile.tensor_nbytes(tin)
+    out_ids = list(hdr["outputs"])
+    saved_mode = M.get_tuning("f32_mfma")
+    if f32 and f32_mode is not None:
+        M.set_tuning("f32_mfma", f32_mode)
+    t_all = time.perf_counter()
+    try:
+        model = M.Model(model_bytes, batch=batch)
+        frames = synth_frames(0, batch, nb, f32)
+        iv = model.input_view(0)
+        for f in range(batch):
+            iv[f, :nb] = frames[f]
+        model.upload()
+        outputs = tuple(range(len(out_ids)))
+        tail = tail and not f32
+
+        def step():
+            model.run_device(sync=False)
+            if tail:
+                model.detect_device(outputs=outputs, thresh=0.45)
+        for _ in range(warmup):
+            step()
+        M.lib().mars_hip_sync()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            step()
+        M.lib().mars_hip_sync()
+        dt = time.perf_counter() - t0
+        model.set_profiling(2)
+        step()
+        M.lib().mars_hip_sync()
+        ops = model.ops()
+        model.set_profiling(0)
+        ckind = 1 if f32 else 0
+        conv_ms = sum(o["ms"] for o in ops if o["kind"] == ckind)
+        conv_bytes = sum(o["bytes"] for o in ops if o["kind"] == ckind) * batch
+        conv_flop = sum(2.0 * o["macs"] for o in ops if o["kind"] == ckind) * batch
+        mode = M.get_tuning("f32_mfma")
+        mpeak = (2.5e15 / 3.0 if mode == 3 else 2.5e15 / 6.0 if mode == 4 else 157.3e12) if f32 else 5e15
+        hbm_floor, mfma_floor = conv_bytes / 8e12, conv_flop / mpeak
+        bound = "hbm" if hbm_floor >= mfma_floor else "mfma"  # the roof that is nearer: whichever floor is higher
+        rec = {"workload": what, "value": batch * steps / dt, "unit": "images/s", "ms_per_step": dt / steps * 1e3, "steps": steps, "warmup": warmup,
+               "batch": batch, "dtype": ("f32 (f32_mfma mode %d)" % mode) if f32 else "int8", "tail": bool(tail),
+               "bound": bound, "frac": (max(hbm_floor, mfma_floor) / (conv_ms * 1e-3)) if conv_ms > 0 else None,
+               "frac_hbm": (hbm_floor / (conv_ms * 1e-3)) if conv_ms > 0 else None, "frac_mfma": (mfma_floor / (conv_ms * 1e-3)) if conv_ms > 0 else None,
+               "frac_wall": max(hbm_floor, mfma_floor) / (dt / steps),
+               "conv_ms_per_step": conv_ms, "conv_launches": sum(1 for o in ops if o["kind"] == ckind),
+               "conv_gmac_per_image": conv_flop / 2e9 / batch, "conv_algorithmic_mb_per_image": conv_bytes / 1e6 / batch,
+               "timing": "value: wall clock around %d steps (the library's execution mode at this batch); frac: HIP events, one stream, one further step" % steps}
+        if cpu_frames > 0:
+            model.download()
+            n = ok = 0
+            worst = 0.0
+            kind = None
+            tc = time.perf_counter()
+            picks = sorted(set([0, batch - 1][:cpu_frames])) if cpu_frames <= 2 else list(range(min(cpu_frames, batch)))
+            dets_ok = None
+            gdets = model.detect(outputs=outputs, thresh=0.45) if tail else None
+            for f in picks:
+                runner, kind = reference_runner(model_bytes, file_model)
+                runner.set_input(0, frames[f].tobytes())
+                rc = runner.run()
+                if rc != 0:
+                    raise RuntimeError("%s: cpu reference run failed: %d" % (name, rc))
+                a, b, w = compare_frame(model, runner, tensors, out_ids, f, f32, every_tensor=file_model)
+                n += a
+                ok += b
+                worst = max(worst, w)
+                if tail:
+                    want = reference_detections([runner.tensor(ti) for ti in out_ids], [float(tensors[ti]["scale"]) for ti in out_ids])
+                    dets_ok = (dets_ok is not False) and gdets[f].tobytes() == want.tobytes()
+                runner.close()
+            rec["parity"] = {"ok": bool(n > 0 and ok == n and dets_ok is not False), "frames": picks, "tensors_compared": n, "tensors_equal": ok, "cpu": kind,
+                             "rule": "|a-b| <= 1e-4*max(1,|b|)" if f32 else "bit-exact", "cpu_seconds": time.perf_counter() - tc}
+            if f32:
+                rec["parity"]["worst_relative_error"] = worst
+            if dets_ok is not None:
+                rec["parity"]["detections_bit_exact"] = bool(dets_ok)
+        model.close()
+    finally:
+        M.set_tuning("f32_mfma", saved_mode)
+    rec["leg_seconds"] = time.perf_counter() - t_all
+    return rec
+
+
+def extra_configs(M, args):
+    """BASELINE.json's other configs (and north_star's 320 x 320 frames) as short legs beside the headline, so that the driver's one
+    default run observes them: separate model instances, after the headline's timed region and every leg of it.  Sized from the
+    headline's own arguments (default: 640 x 640, batch 256), so the small test invocation runs small legs."""
+    hw, b = args.hw, args.batch
+    st, wu = max(3, min(args.steps, 12)), max(1, min(args.warmup, 3))
+    cpu = 0 if args.no_cpu_baseline else 1
+    gold = os.path.join(ROOT, "tests", "golden", "models")
+    legs = []
+    legs.append(("config3_yolov5n_int8", dict(width_x16=4, input_hw=hw), dict(batch=b, tail=True, cpu_frames=2 * cpu),
+                 "synthetic yolov5n_int8 twin (width_x16=4), %dx%d, batch %d, decode+NMS on" % (hw, hw, b)))
+    legs.append(("config3_shipped_yolov5n_int8_mars", os.path.join(gold, "yolov5n_int8.mars"), dict(batch=b, tail=False, cpu_frames=cpu),
+                 "the reference's own models/yolov5n_int8.mars (NCHW-tagged: conv2d_int8_mxu path, mxu_conv.c:630-670), 640x640, batch %d, graph only "
+                 "(its head tensors have shape [0,0,0,0]: the file's tail is all no-ops, SURVEY App. C)" % b))
+    legs.append(("config5_yolov5s_float32", dict(width_x16=args.width, input_hw=hw, float32=True), dict(batch=b, tail=False, cpu_frames=cpu, f32_mode=3),
+                 "synthetic yolov5s_float32 twin (width_x16=%d), %dx%d, batch %d, graph only, f32_mfma mode 3" % (args.width, hw, hw, b)))
+    legs.append(("yolov5s_int8_%d" % (hw // 2), dict(width_x16=args.width, input_hw=hw // 2), dict(batch=b, tail=True, cpu_frames=2 * cpu),
+                 "synthetic yolov5s_int8 twin (width_x16=%d), %dx%d, batch %d, decode+NMS on" % (args.width, hw // 2, hw // 2, b)))
+    legs.append(("yolov5n_int8_%d" % (hw // 2), dict(width_x16=4, input_hw=hw // 2), dict(batch=b, tail=True, cpu_frames=2 * cpu),
+                 "synthetic yolov5n_int8 twin (width_x16=4), %dx%d, batch %d, decode+NMS on" % (hw // 2, hw // 2, b)))
+    legs.append(("config2_tiny_160_int8_mars", os.path.join(gold, "tiny_160_int8.mars"), dict(batch=min(64, b), tail=False, cpu_frames=2 * cpu),
+                 "the reference's own models/tiny_160_int8.mars, 160x160, batch %d" % min(64, b)))
+    out = {}
+    for name, src, kw, what in legs:
+        if isinstance(src, dict) and (src["input_hw"] % 32 or src["input_hw"] < 64):
+            out[name] = {"workload": what, "skipped": "the twins need a frame size that is a multiple of 32"}
+            continue
+        try:
+            if isinstance(src, dict):
+                mb = M.synth_model(seed=1, **src)
+                out[name] = short_leg(M, name, mb, steps=st, warmup=wu, what=what, **kw)
+            else:
+                with open(src, "rb") as fh:
+                    mb = fh.read()
+                out[name] = short_leg(M, name, mb, steps=st, warmup=wu, what=what, file_model=True, **kw)
+        except Exception as e:  # noqa: BLE001  (a failing leg must not cost the headline its line)
+            out[name] = {"workload": what, "error": "%s: %s" % (type(e).__name__, e)}
+    return out
 
 
 def kernel_source_sha16():
@@ -280,7 +485,15 @@ def main():
                     help="int8 (default): the headline workload.  f32: BASELINE config 5, the yolov5s_float32 twin (NCHW / OIHW "
                          "float32) with its convolutions on the f32 matrix cores (mars_hip_set_tuning f32_mfma=2); graph only "
                          "(float heads have no int8 decode), outputs checked against the CPU reference within 1e-4*max(1,|b|)")
-    ap.add_argument("--f32-mode", type=int, default=3, help="--dtype f32: 0 exact order, 1 default policy, 2 f32 matrix cores everywhere, "
+    ap.add_argument("--model", type=str, default="",
+                    help="run this .mars file instead of a synthetic twin (any file the runtime loads, e.g. tests/golden/models/yolov5n_int8.mars: "
+                         "BASELINE config 3's literal file, NCHW-tagged -> the conv2d_int8_mxu path).  Inputs per SURVEY 8d (LCG bytes / uniform floats "
+                         "by the input's dtype), graph only (no decode + NMS), CPU leg through the reference's own layer functions with every "
+                         "activation tensor the plan keeps compared, not just the outputs")
+    ap.add_argument("--no-extra-configs", action="store_true",
+                    help="skip the short legs of the other BASELINE configs (`configs` in the line: config 3 twin and literal file, config 5, the "
+                         "320x320 workloads, config 2) that the default int8 run appends after the headline's legs")
+    ap.add_argument("--f32-mode", type=int, default=None, help="--dtype f32 (default 3) / a float --model (default 1): 0 exact order, 1 default policy, 2 f32 matrix cores everywhere, "
                                                             "3 (default) bf16 matrix cores everywhere, operands split in two (three piece products), 4 split in three (six)")
     ap.add_argument("--timed-only", action="store_true",
                     help="skip the legs after the timed region (mars_run / pipelined I/O / batch-1 latency / CPU baselines): "
@@ -303,7 +516,7 @@ def main():
     ap.add_argument("--autotune", action="store_true",
                     help="time the launch variants of every convolution once before the warmup and pin the fastest "
                          "(mars_hip_autotune; a load-time cost, outside the timed region).  Off by default: the default "
-                         "launch policy was re-derived from the tuner's choices and is within 1 % of it")
+                         "launch policy was re-derived from the tuner's choices and is within 1 %% of it")
     ap.add_argument("--no-autotune", action="store_true", help="(default; kept for older command lines)")
     ap.add_argument("--event-steps", type=int, default=1,
                     help="timed steps (the last ones) whose launches are bracketed by HIP events for the roofline; "
@@ -355,6 +568,19 @@ def main():
     import marsfile
     M.nna_init()
     f32 = args.dtype == "f32"
+    file_hdr = None
+    if args.model:  # a .mars file instead of a twin: its input's dtype / shape decide the frame bytes; graph only
+        with open(args.model, "rb") as fh:
+            model_bytes = fh.read()
+        file_hdr = marsfile.parse(model_bytes)
+        tin0 = file_hdr[1][file_hdr[0]["inputs"][0]]
+        f32 = tin0["dtype"] == 0
+        args.dtype = "f32" if f32 else "int8"
+        args.hw, args.in_w = input_hw_of(tin0)
+        args.width = 0
+        args.no_tail = True
+    if args.f32_mode is None:
+        args.f32_mode = 1 if args.model else 3
     dual_min = 64  # the library's default for "dual_stream_min_batch"
     for kv in args.tune:
         k, v = kv.split("=")
@@ -365,7 +591,8 @@ def main():
     if f32:
         args.no_tail = True
         M.set_tuning("f32_mfma", args.f32_mode)
-    model_bytes = M.synth_model(width_x16=args.width, input_hw=args.hw, seed=1, vary_scales=args.vary_scales, float32=f32)
+    if not args.model:
+        model_bytes = M.synth_model(width_x16=args.width, input_hw=args.hw, seed=1, vary_scales=args.vary_scales, float32=f32)
     hdr, tensors, _ = marsfile.parse(model_bytes)
     in_bytes = marsfile.tensor_nbytes(tensors[hdr["inputs"][0]])
     out_ids = list(hdr["outputs"])
@@ -399,7 +626,7 @@ def main():
     frames = frames_for_rank(D, rank, world, args.batch, in_bytes, f32)
     iv = model.input_view(0)
     for f in range(args.batch):
-        iv[f] = frames[f]
+        iv[f, :in_bytes] = frames[f]
     model.upload()  # inputs resident in HBM before the timed region
     outputs = tuple(range(len(out_ids)))
     if args.autotune and not args.no_autotune:
@@ -591,11 +818,16 @@ def main():
         # (5000 TOP/s / 8 TB/s = 625 op/B), so its roof is HBM: achieved = algorithmic bytes of the conv launches / their
         # summed durations; the matrix-roof view of the same launches is reported next to it.  f32: 4-byte activations but
         # a 32x lower matrix peak (157.3 TF, v_mfma_f32_16x16x4_f32): ridge 20 flop/B against ~65 flop/B -> the roof is MFMA.
-        roof = {"bound": "mfma" if f32 else "hbm",
+        # the roof that bounds the family = whichever floor is HIGHER: algorithmic bytes at 8 TB/s against 2 * MAC at the matrix peak of the
+        # path that runs (the float32 twin in mode 3 is nearer the HBM roof -- 64.7 GB / 8 TB/s = 8.1 ms against 5.0 ms of bf16x3)
+        hbm_floor_s, mfma_floor_s = conv_bytes_per_img * args.batch / 8e12, 2.0 * macs_per_img * args.batch / mpeak
+        by_hbm = hbm_floor_s >= mfma_floor_s
+        roof = {"bound": "hbm" if by_hbm else "mfma",
                 "kernel": (("conv_f32_prec / conv_f32_patch / conv_f32_stem (k x k layers: input patch staged once -- by LDS-DMA from record-format tensors where a convolution wrote them) + conv_f32_split (1 x 1 layers, C3 pairs in one launch); v_mfma_f32_16x16x32_bf16, 3 per product" if args.f32_mode == 3
                             else "conv_f32_split (v_mfma_f32_16x16x32_bf16, 6 per product)" if args.f32_mode == 4 else "conv_f32_mfma / conv_f32_kernel") if f32 else "conv_i8_*") + " (%d launches per step)" % n_conv,
-                "achieved": achieved if f32 else hbm_gbs, "peak": peak if f32 else 8000.0, "unit": "TFLOP/s" if f32 else "GB/s",
-                "frac": (achieved / peak) if f32 else hbm_gbs / 8000.0,
+                "achieved": hbm_gbs if by_hbm else achieved, "peak": 8000.0 if by_hbm else peak, "unit": "GB/s" if by_hbm else ("TFLOP/s" if f32 else "TOP/s"),
+                "frac": hbm_gbs / 8000.0 if by_hbm else (achieved / peak),
+                "floors_ms": {"hbm": hbm_floor_s * 1e3, "mfma": mfma_floor_s * 1e3},
                 "traffic": traffic, "traffic_source": traffic_src,
                 "algorithmic_bytes": conv_bytes_per_img * args.batch,
                 "intensity_ops_per_byte": 2.0 * macs_per_img / conv_bytes_per_img if conv_bytes_per_img else None,
@@ -612,13 +844,14 @@ def main():
                 "timing": "hip events, one stream, full-batch launches",
                 # the same algorithmic bytes over the step time of `value` (its execution mode: config.execution), so that
                 # kernel time <= step time holds on this line: frac_wall <= what the per-kernel view can show
-                "wall_achieved": conv_bytes_per_img * args.batch / (dt / args.steps) / 1e9 if not f32 else 2.0 * macs_per_img * args.batch / (dt / args.steps) / 1e12,
-                "frac_wall": (conv_bytes_per_img * args.batch / (dt / args.steps) / 1e9 / 8000.0) if not f32 else (2.0 * macs_per_img * args.batch / (dt / args.steps) / mpeak),
+                "wall_achieved": conv_bytes_per_img * args.batch / (dt / args.steps) / 1e9 if by_hbm else 2.0 * macs_per_img * args.batch / (dt / args.steps) / 1e12,
+                "frac_wall": (conv_bytes_per_img * args.batch / (dt / args.steps) / 1e9 / 8000.0) if by_hbm else (2.0 * macs_per_img * args.batch / (dt / args.steps) / mpeak),
                 "conv_ms_per_step": conv_ms / ev_steps,
                 "all_kernels_ms_per_step": all_ms / ev_steps,
                 "ms_per_step_by_kind": {str(k): v / ev_steps for k, v in sorted(per_kind.items())}}
         result = {
-            "metric": "images/sec %s_%s %dx%d batch%d" % ("yolov5s" if args.width == 8 else "yolov5n" if args.width == 4 else
+            "metric": ("images/sec %s %dx%d batch%d" % (os.path.basename(args.model), args.in_w, args.hw, args.batch)) if args.model else
+                      "images/sec %s_%s %dx%d batch%d" % ("yolov5s" if args.width == 8 else "yolov5n" if args.width == 4 else
                                                         "yolov5(width_x16=%d)" % args.width, "float32" if f32 else "int8",
                                                         args.hw, args.hw, args.batch),
             "value": world * args.batch * args.steps / dt,
@@ -637,7 +870,11 @@ def main():
             "dtype": ("f32 (bf16x3: operands split exactly into two bf16 pieces, three piece products, f32 accumulate)" if args.f32_mode == 3
                       else "f32 (bf16x6: three bf16 pieces, six piece products, f32 accumulate)" if args.f32_mode == 4 else "f32") if f32 else "int8",
             "data": "synthetic",
-            "config": {"workload": ("synthetic yolov5s_float32.mars twin (mars_synth_model width_x16=%d, seed 1, float32), %dx%d f32 "
+            "config": {"workload": ("file %s (sha256 %s, %d layers, input %s %s), frames per SURVEY 8d, batch %d per GPU, graph only%s" % (
+                                        os.path.basename(args.model), hashlib.sha256(model_bytes).hexdigest()[:16], hdr["layers"],
+                                        "f32" if f32 else "int8", "NHWC" if tensors[hdr["inputs"][0]]["fmt"] == 7 else "NCHW-tagged", args.batch,
+                                        ", f32_mfma mode %d" % args.f32_mode if f32 else "")) if args.model else
+                                   ("synthetic yolov5s_float32.mars twin (mars_synth_model width_x16=%d, seed 1, float32), %dx%d f32 "
                                     "NCHW frames, batch %d per GPU, graph only, f32_mfma mode %d" %
                                     (args.width, args.hw, args.hw, args.batch, args.f32_mode)) if f32 else
                                    "synthetic yolov5s_int8.mars twin (mars_synth_model width_x16=%d, seed 1), %dx%d int8 "
@@ -727,8 +964,18 @@ def main():
             result["latency_batch1"] = lat
             m1.close()
         if world == 1 and not args.no_cpu_baseline and not args.timed_only:
-            base, ref_outs = cpu_baseline(model_bytes, frames, out_ids, max_frames=1 if f32 else 16)
             model.download()
+            every = {"tensors_compared": 0, "tensors_equal": 0}
+
+            def all_tensors(runner, f):  # --model: every activation tensor the plan keeps in HBM, frame f, against the reference's
+                a, b, _ = compare_frame(model, runner, tensors, out_ids, f, f32, every_tensor=True)
+                every["tensors_compared"] += a
+                every["tensors_equal"] += b
+            base, ref_outs = cpu_baseline(model_bytes, frames, out_ids, max_frames=1 if f32 else (2 if args.model else 16), file_model=bool(args.model),
+                                          on_frame=all_tensors if args.model else None)
+            if args.model:
+                base["every_materialised_tensor"] = dict(every, rule="|a-b| <= 1e-4*max(1,|b|)" if f32 else "bit-exact",
+                                                         ok=every["tensors_compared"] > 0 and every["tensors_equal"] == every["tensors_compared"])
             if f32:  # north_star: within 1e-4 on the float32 models
                 worst = 0.0
                 heads = []  # is the comparison informative?  finite share and magnitude of every head, on both sides
@@ -774,7 +1021,7 @@ def main():
                                                 "tensors bit-identical to the reference's CPU run" % (nbox, len(ref_outs))) if (dsame and same) else "MISMATCH"
             result["cpu_baseline"] = base
             # the fair node-level figure -- frames are independent, one frame per thread on every core
-            result["cpu_baseline_all_cores"] = cpu_baseline_parallel(model_bytes, frames, out_ids, args.cpu_threads, ref_outs, f32)
+            result["cpu_baseline_all_cores"] = cpu_baseline_parallel(model_bytes, frames, out_ids, args.cpu_threads, ref_outs, f32, bool(args.model))
     if rank == 0 and world == 1 and not args.timed_only and not f32:
         # (last of all legs: after a 2 GiB allocate / copy / free the raw-heads mars_run leg ran at 9.4k instead of 15.9k img/s)
         # What a plain copy reaches on THIS box: `peak` stays the guide's 8 TB/s, but no kernel that reads and writes HBM
@@ -796,6 +1043,12 @@ def main():
         clk = (sustained or {}).get("shader_clock_mhz", {}).get("median") if sustained else None
         result["roofline"]["pipes"] = pipe_times(args, result["roofline"]["algorithmic_bytes"], copy_gbs, clk)
     model.close()
+    if rank == 0 and world == 1 and not multi and not args.timed_only and not args.no_extra_configs and not args.model and not f32 and not args.vary_scales:
+        # every BASELINE config under the same clock as the headline -- separate model instances, after the headline's
+        # timed region and all its legs (the headline's numbers are final by now)
+        t1 = time.perf_counter()
+        result["configs"] = extra_configs(M, args)
+        result["configs_seconds"] = time.perf_counter() - t1
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()

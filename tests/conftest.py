@@ -55,24 +55,29 @@ def gpu(marsrt):
     marsrt.lib().nna_deinit()
 
 
+_LCG_JUMP = None  # (mul, add): state after k + 1 steps = mul[k] * s + add[k] (mod 2^32), built once
+
+
 def lcg_frame(seed, nbytes):
     """SURVEY.md section 8d synthetic frame: x[i] = (int8)(lcg >> 24)."""
     # numpy implementation of a 32-bit LCG (Numerical Recipes constants), vectorised by jumping
+    global _LCG_JUMP
     a, c = np.uint64(1664525), np.uint64(1013904223)
     out = np.empty(nbytes, dtype=np.uint8)
     s = np.uint64(seed & 0xFFFFFFFF)
     mask = np.uint64(0xFFFFFFFF)
-    # sequential but chunked for speed
     block = 1 << 16
+    if _LCG_JUMP is None:  # powers for a block jump
+        mul = np.empty(block, dtype=np.uint64)
+        add = np.empty(block, dtype=np.uint64)
+        m, d = np.uint64(1), np.uint64(0)
+        for k in range(block):
+            m = (m * a) & mask
+            d = (d * a + c) & mask
+            mul[k], add[k] = m, d
+        _LCG_JUMP = (mul, add)
+    mul, add = _LCG_JUMP
     i = 0
-    # precompute powers for a block jump
-    mul = np.empty(block, dtype=np.uint64)
-    add = np.empty(block, dtype=np.uint64)
-    m, d = np.uint64(1), np.uint64(0)
-    for k in range(block):
-        m = (m * a) & mask
-        d = (d * a + c) & mask
-        mul[k], add[k] = m, d
     while i < nbytes:
         n = min(block, nbytes - i)
         vals = (mul[:n] * s + add[:n]) & mask

@@ -23,7 +23,7 @@ def run_bench(*extra, env=None):
 
 
 def test_bench_line_has_the_contract_fields():
-    d = run_bench()
+    d = run_bench("--hw", "192")  # (192 / 2 = 96 is still a size the twins accept: the 320-class legs run too)
     for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
               "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
         assert k in d, k
@@ -61,18 +61,48 @@ def test_bench_line_has_the_contract_fields():
     assert pp["hbm_ms_at_peak"] > 0 and pp["hbm_ms_at_achievable"] > pp["hbm_ms_at_peak"] and pp["hbm_ms_at_copy_rate"] > 0
     assert "source" in pp and "libmars_probe.so" in r["copy_rate_how"]
     assert "submitted AND drained inside the window" in d["pipelined_io"]["timing"]
+    # round 6: the other BASELINE configs as short legs of the same run -- config 3 (twin AND the reference's own
+    # NCHW-tagged file: the conv2d_int8_mxu path), config 5 (float32), the 320-class workloads, config 2 -- each with its rate, the
+    # roof that bounds it and a comparison with the reference's CPU run
+    cf = d["configs"]
+    assert set(cf) == {"config3_yolov5n_int8", "config3_shipped_yolov5n_int8_mars", "config5_yolov5s_float32", "yolov5s_int8_96", "yolov5n_int8_96",
+                       "config2_tiny_160_int8_mars"}
+    for name, leg in cf.items():
+        assert "error" not in leg, (name, leg)
+        for k in ("workload", "value", "ms_per_step", "steps", "frac", "bound", "parity"):
+            assert k in leg, (name, k)
+        assert leg["value"] > 0 and leg["ms_per_step"] > 0 and leg["bound"] in ("hbm", "mfma") and 0 < leg["frac"] <= 1.0, (name, leg)
+        assert leg["parity"]["ok"] is True and leg["parity"]["tensors_compared"] >= 1 and leg["parity"]["cpu"] in ("reference", "port"), (name, leg)
+    assert cf["config5_yolov5s_float32"]["parity"]["worst_relative_error"] <= 1e-4 and cf["config5_yolov5s_float32"]["dtype"].startswith("f32")
+    assert cf["config3_yolov5n_int8"]["parity"]["detections_bit_exact"] is True
+    # the literal file: every activation tensor the plan keeps, not just the (never written) output
+    assert cf["config3_shipped_yolov5n_int8_mars"]["parity"]["tensors_compared"] > 50
+    assert d["configs_seconds"] < 120
+
+
+def test_bench_model_flag_runs_a_shipped_file():
+    """`--model PATH`: BASELINE config 3's literal file (NCHW-tagged -> the conv2d_int8_mxu path every shipped model takes), LCG frames,
+    every activation tensor the plan keeps compared with the reference's CPU run of the same frames"""
+    d = run_bench("--model", os.path.join(ROOT, "tests", "golden", "models", "yolov5n_int8.mars"), "--sustain-s", "0")
+    assert "yolov5n_int8.mars" in d["metric"] and "640x640" in d["metric"] and d["dtype"] == "int8" and d["value"] > 0
+    assert "NCHW-tagged" in d["config"]["workload"] and "configs" not in d
+    c = d["cpu_baseline"]
+    assert c["gpu_matches_bit_exact"] is True and c["frames_compared"] >= 1 and c["kind"] in ("reference", "port")
+    assert c["every_materialised_tensor"]["ok"] is True and c["every_materialised_tensor"]["tensors_compared"] > 50
+    r = d["roofline"]
+    assert r["bound"] in ("hbm", "mfma") and 0 < r["frac"] <= 1.0
 
 
 def test_bench_sustained_leg_runs_for_the_asked_time():
-    d = run_bench("--no-cpu-baseline", "--sustain-s", "1.0")
+    d = run_bench("--no-cpu-baseline", "--no-extra-configs", "--sustain-s", "1.0")
     s = d["sustained"]
     assert 0.9 <= s["seconds"] < 5.0 and s["steps"] > 10 and s["shader_clock_mhz"]["median"] > 500
-    d = run_bench("--no-cpu-baseline", "--sustain-s", "0")
+    d = run_bench("--no-cpu-baseline", "--no-extra-configs", "--sustain-s", "0")
     assert "sustained" not in d and "sustained_images_per_s" not in d
 
 
 def test_bench_flags():
-    d = run_bench("--no-cpu-baseline", "--no-tail", "--no-autotune")
+    d = run_bench("--no-cpu-baseline", "--no-extra-configs", "--no-tail", "--no-autotune")
     assert "cpu_baseline" not in d and "tail off" in d["config"]["workload"]
     assert d["config"]["autotuned_launch_variants"] is False
 
@@ -91,7 +121,7 @@ def test_bench_multi_rank_path_with_one_rank():
 
 
 def test_bench_total_batch_flag():
-    d = run_bench("--no-cpu-baseline", "--total-batch", "6")
+    d = run_bench("--no-cpu-baseline", "--no-extra-configs", "--total-batch", "6")
     assert d["config"]["frames_per_gpu"] == 6 and d["config"]["frames_total"] == 6 and d["scaling"] == "strong"
 
 
@@ -117,7 +147,7 @@ def test_bench_starts_its_own_ranks():
 
 def test_bench_camera_leg():
     """--io camera: the reference demo's whole loop (RGB camera frames -> front-end -> graph -> decode + NMS -> detections), pipelined"""
-    d = run_bench("--no-cpu-baseline", "--io", "camera", "--sustain-s", "0")
+    d = run_bench("--no-cpu-baseline", "--no-extra-configs", "--io", "camera", "--sustain-s", "0")
     c = d["camera_io"]
     assert c["images_per_s"] > 0 and "1280x720" in c["frame"] and c["host_to_device_bytes_per_batch"] == 4 * 1280 * 720 * 3
     k = c["preproc_kernel"]

@@ -20,5 +20,5 @@ def _patched():
 
 
 bench.load_marsrt = _patched
-sys.argv = ["bench.py", "--no-cpu-baseline"] + sys.argv[2:]
+sys.argv = ["bench.py", "--no-cpu-baseline", "--no-extra-configs"] + sys.argv[2:]
 bench.main()

@@ -37,6 +37,6 @@ for N in $NAMES; do
   cp $OUT/${TAG}_${N}_pmc_traffic.json profiles/${TAG}_${N}_pmc_traffic.json  # bench.py reads it (hash-tied) for this workload's roofline.traffic
   find $OUT/${TAG}_${N}_trace -name '*kernel_stats.csv' -exec cp {} $OUT/${TAG}_${N}_kernel_stats.csv \;
   rm -rf $OUT/${TAG}_${N}_trace $OUT/${TAG}_${N}_pmc_fetch $OUT/${TAG}_${N}_pmc_write
-  python3 bench.py $ARGS --sustain-s 1 $( [ $N = f32 ] && echo "--steps 10 --warmup 3" ) > $OUT/${TAG}_${N}_bench.json 2> $OUT/${TAG}_${N}_bench.err
+  python3 bench.py $ARGS --sustain-s 1 --no-extra-configs $( [ $N = f32 ] && echo "--steps 10 --warmup 3" ) > $OUT/${TAG}_${N}_bench.json 2> $OUT/${TAG}_${N}_bench.err
   echo "$N done: $(python3 -c "import json;d=json.load(open('$OUT/${TAG}_${N}_bench.json'));print(d['value'], d['roofline']['frac'])")"
 done

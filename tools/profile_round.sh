@@ -40,9 +40,9 @@ find $OUT/${TAG}_trace -name '*kernel_trace.csv' -delete
 # un-profiled lines: per-launch table, config 3 and the 320x320 workloads WITH their CPU-baseline / bit-exact legs (shorter
 # sustained leg: these are secondary lines), the float32 workload (config 5), the default line last
 python3 bench.py --timed-only --ops $OUT/${TAG}_ops.txt > $OUT/${TAG}_bench_ops.json 2> $OUT/${TAG}_ops.err
-python3 bench.py --width 4 --sustain-s 1 > $OUT/${TAG}_bench_640_yolov5n.json 2>> $OUT/${TAG}_ops.err
-python3 bench.py --hw 320 --sustain-s 1 > $OUT/${TAG}_bench_320_yolov5s.json 2>> $OUT/${TAG}_ops.err
-python3 bench.py --hw 320 --width 4 --sustain-s 1 > $OUT/${TAG}_bench_320_yolov5n.json 2>> $OUT/${TAG}_ops.err
+python3 bench.py --width 4 --sustain-s 1 --no-extra-configs > $OUT/${TAG}_bench_640_yolov5n.json 2>> $OUT/${TAG}_ops.err
+python3 bench.py --hw 320 --sustain-s 1 --no-extra-configs > $OUT/${TAG}_bench_320_yolov5s.json 2>> $OUT/${TAG}_ops.err
+python3 bench.py --hw 320 --width 4 --sustain-s 1 --no-extra-configs > $OUT/${TAG}_bench_320_yolov5n.json 2>> $OUT/${TAG}_ops.err
 python3 bench.py --dtype f32 --steps 10 --warmup 3 --sustain-s 1 > $OUT/${TAG}_f32_bench.json 2>> $OUT/${TAG}_ops.err
 cp $OUT/${TAG}_pmc_traffic.json profiles/pmc_traffic.json  # bench.py reads it (and checks the kernel-source hash inside) for roofline.traffic
 python3 bench.py > $OUT/${TAG}_bench_default.json 2>> $OUT/${TAG}_ops.err
