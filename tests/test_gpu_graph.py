@@ -2063,3 +2063,154 @@ def test_mars_run_in_overlapped_chunks(gpu, orc):
             m.close()
     finally:
         gpu.set_tuning("run_chunk", 128)
+
+
+def _f32_conv_silu(G, rng, xin, ic, ih, iw, oc, k, st, bias=True):
+    """conv (SAME) + SIGMOID + MUL on NCHW floats; -> (output tensor, out_h, out_w)"""
+    F, N = marsfile.F32, marsfile.NCHW
+    oh, ow = (ih + st - 1) // st, (iw + st - 1) // st
+    a = G.tensor([1, oc, oh, ow], dtype=F, fmt=N)
+    amp = 1.7 / (k * k * ic) ** 0.5
+    wt = G.tensor([oc, ic, k, k], dtype=F, fmt=marsfile.OIHW, data=((rng.random((oc, ic, k, k), dtype=np.float32) * 2 - 1) * amp).astype(np.float32))
+    if bias:
+        b = G.tensor([oc], dtype=F, fmt=marsfile.D1, data=((rng.random(oc, dtype=np.float32) * 2 - 1) * 0.1).astype(np.float32))
+        G.conv(xin, a, wt, b, (k, k), (st, st), pad=marsfile.PAD_SAME)
+    else:
+        G.conv(xin, a, wt, k=(k, k), s=(st, st), pad=marsfile.PAD_SAME)
+    g_, o_ = G.tensor([1, oc, oh, ow], dtype=F, fmt=N), G.tensor([1, oc, oh, ow], dtype=F, fmt=N)
+    G.layer(marsfile.SIGMOID, [a], [g_])
+    G.layer(marsfile.MUL, [a, g_], [o_])
+    return o_, oh, ow
+
+
+@pytest.mark.parametrize("biases", [(True, False), (False, True), (False, False)], ids=["a_only", "b_only", "none"])
+@pytest.mark.parametrize("oc", [32, 64, 96])
+def test_conv_f32_pairs_without_bias(gpu, orc, biases, oc):
+    """a convolution's bias is optional, and the one-tile pair form (2 x out_c <= 128: oc 32 / 64) selects the bias row per
+    channel -- a missing second bias minus BM / 2 was a non-null pointer into page 0.  Every combination, both pair forms, against the oracle."""
+    h, w, ic, B = 20, 24, 64, 3
+    rng = np.random.default_rng(oc * 7 + biases[0] * 2 + biases[1])
+    G = marsfile.Graph()
+    x = G.tensor([1, ic, h, w], dtype=marsfile.F32, fmt=marsfile.NCHW)
+    outs = [_f32_conv_silu(G, rng, x, ic, h, w, oc, 1, 1, bias=bz)[0] for bz in biases]
+    d = G.serialise([x], outs)
+    xs = [(rng.random(ic * h * w, dtype=np.float32) * 2 - 1).astype(np.float32) for _ in range(B)]
+    count = gpu.lib().mhip_conv_f32_pair_launches
+    count.restype = C.c_ulong
+    try:
+        gpu.set_tuning("dual_stream_min_batch", 0)
+        for mode in (3, 4):
+            gpu.set_tuning("f32_mfma", mode)
+            m = gpu.Model(d, batch=B)
+            for f in range(B):
+                m.input_view(0)[f] = xs[f].view(np.uint8)
+            n0 = count()
+            m.run()
+            assert count() - n0 == 1, mode
+            for f in range(B):
+                g, rc = run_oracle(orc, d, xs[f].view(np.uint8))
+                assert rc == 0
+                for k in range(2):
+                    ok = close_f32(m.output_view(k)[f], g.tensor(outs[k]))
+                    assert ok.all(), "mode %d output %d frame %d: %d of %d out of tolerance" % (mode, k, f, int((~ok).sum()), ok.size)
+                g.close()
+            m.close()
+    finally:
+        gpu.set_tuning("f32_mfma", 1)
+        gpu.set_tuning("dual_stream_min_batch", 64)
+
+
+@pytest.mark.parametrize("prod", [(16, 5, 2), (8, 7, 2), (24, 3, 1)], ids=lambda v: "x".join(str(q) for q in v))
+def test_record_pairs_only_behind_a_producer_that_writes_records(gpu, orc, prod):
+    """rec_pairs marked a producer `out_rec` whenever it had a bf16 weight image -- but conv_f32_split declines stride-2 layers
+    with an odd kernel width and pad > 1 (5 x 5 pad 2, 7 x 7 pad 3), and nothing else writes records: the run failed with LAYER_FAILED.
+    The planner now asks mhip_conv_f32_split_takes first.  (24, 3, 1) is the control: a producer that does write records.)"""
+    ic, k, st = prod
+    h, w, B = 48, 64, 3
+    rng = np.random.default_rng(ic * 100 + k)
+    G = marsfile.Graph()
+    x = G.tensor([1, ic, h, w], dtype=marsfile.F32, fmt=marsfile.NCHW)
+    t1, h1, w1 = _f32_conv_silu(G, rng, x, ic, h, w, 32, k, st)
+    t2, h2, w2 = _f32_conv_silu(G, rng, t1, 32, h1, w1, 32, 3, 1)
+    d = G.serialise([x], [t2])
+    xs = [(rng.random(ic * h * w, dtype=np.float32) * 2 - 1).astype(np.float32) for _ in range(B)]
+    L = gpu.lib()
+    takes = L.mhip_conv_f32_split_takes
+    takes.restype = C.c_int
+    takes.argtypes = [C.c_int] * 9
+    pad = (k - 1) // 2 if st == 1 else max(0, ((h1 - 1) * st + k - h)) // 2
+    writes_records = takes(32, ic, k, k, st, st, pad, w, w1) >= 0
+    assert writes_records == (st == 1)
+    prec = L.mhip_conv_f32_prec_launches
+    prec.restype = C.c_ulong
+    recin = L.mhip_conv_f32_recin_launches
+    recin.restype = C.c_ulong
+    try:
+        gpu.set_tuning("f32_mfma", 3)
+        gpu.set_tuning("dual_stream_min_batch", 0)
+        m = gpu.Model(d, batch=B)
+        for f in range(B):
+            m.input_view(0)[f] = xs[f].view(np.uint8)
+        n0 = prec() + recin()
+        m.run()  # (MARS_ERR_LAYER_FAILED before the fix)
+        assert (prec() + recin() - n0 == 1) == writes_records
+        for f in range(B):
+            g, rc = run_oracle(orc, d, xs[f].view(np.uint8))
+            assert rc == 0
+            ok = close_f32(m.output_view(0)[f], g.tensor(t2))
+            assert ok.all(), "frame %d: %d of %d out of tolerance" % (f, int((~ok).sum()), ok.size)
+            g.close()
+        m.close()
+    finally:
+        gpu.set_tuning("f32_mfma", 1)
+        gpu.set_tuning("dual_stream_min_batch", 64)
+
+
+@pytest.mark.parametrize("how", ["process", "model"])
+def test_f32_mode_change_after_load_replans(gpu, orc, how):
+    """a float model's plan belongs to the f32_mfma mode it was built under (two bf16 planes under 3, three under 4, record
+    tensors under 3 only).  Loaded under 3 and switched to 4, conv_f32_split read a third plane that was never packed (the next op's
+    arena bytes); switched to 0, the record pairs silently stayed on the split-bf16 cores.  A change -- process-wide or per model -- now
+    plans the model again (as mars_hip_set_fusion does; inputs are filled afterwards): mode 4 inside the tolerance, mode 0 BIT-EXACT
+    (the reference's summation order), back to 3 with the record pairs again."""
+    d = gpu.synth_model(width_x16=4, input_hw=128, seed=9, float32=True)  # (the well-conditioned small float twin: cases.SYNTH v5n_128_f32)
+    hdr, tensors, _ = marsfile.parse(d)
+    n = marsfile.tensor_nbytes(tensors[hdr["inputs"][0]]) // 4
+    B = 2
+    xs = [cases.f32(0x5EED0000 + f, n, 0.0, 1.0).view(np.uint8) for f in range(B)]
+    want = []
+    for f in range(B):
+        g, rc = run_oracle(orc, d, xs[f])
+        assert rc == 0
+        want.append([g.tensor(ti).copy() for ti in hdr["outputs"]])
+        g.close()
+    L = gpu.lib()
+    for nm in ("prec", "recin", "split"):
+        getattr(L, "mhip_conv_f32_%s_launches" % nm).restype = C.c_ulong
+    prec = lambda: L.mhip_conv_f32_prec_launches() + L.mhip_conv_f32_recin_launches()  # noqa: E731  (either record reader)
+    split = L.mhip_conv_f32_split_launches
+    try:
+        gpu.set_tuning("f32_mfma", 3)
+        m = gpu.Model(d, batch=B)
+        for mode in (3, 4, 0, 3):
+            if how == "process":
+                gpu.set_tuning("f32_mfma", mode)
+            else:
+                m.set_tuning("f32_mfma", mode)
+            for f in range(B):
+                m.input_view(0)[f] = xs[f]
+            p0, s0 = prec(), split()
+            m.run()
+            assert (prec() - p0 > 0) == (mode == 3), mode       # record pairs exist under mode 3 only
+            assert (split() - s0 > 0) == (mode in (3, 4)), mode  # ... and the split-bf16 kernels under 3 / 4 only
+            for f in range(B):
+                for i in range(len(hdr["outputs"])):
+                    got = m.output_view(i)[f]
+                    if mode == 0:
+                        assert np.array_equal(got, want[f][i]), "mode 0 frame %d head %d is not bit-exact" % (f, i)
+                    else:
+                        ok = close_f32(got, want[f][i])
+                        assert ok.all(), "mode %d frame %d head %d: %d of %d out of tolerance" % (mode, f, i, int((~ok).sum()), ok.size)
+        m.close()
+    finally:
+        gpu.set_tuning("f32_mfma", 1)

@@ -360,7 +360,9 @@ __global__ __launch_bounds__(S_NT, BM == 32 && NPL == 2 && !RECOUT ? 4 : 2) void
             }
         } else {
             const int oc = oc0 + wm * TM + a * 16 + fr;
-            const float *bsel = fz && oc >= BM / 2 ? g.bias2 - BM / 2 : p.bias; // (fz: the second convolution's channels sit BM / 2 further up)
+            // (fz: the second convolution's channels sit BM / 2 further up; either convolution may have no bias -- ADVICE r5: a null bias2
+            // minus BM / 2 is not null)
+            const float *bsel = fz && oc >= BM / 2 ? (g.bias2 ? g.bias2 - BM / 2 : nullptr) : p.bias;
             const float b = bsel && oc < out_c_eff ? bsel[oc] : 0.f;
             bias4[a] = (v4f){b, b, b, b};
         }
@@ -664,6 +666,17 @@ static int try_split(const mhip_conv_f32_t *p, const mhip_conv_f32_t *q) {
     if (p->stride_w == 2 && p->out_w % 2 == 0 && p->pad_left <= 1 && kwp % 2 == 0 && kwp <= 16 && p->in_w >= 4) return launch_split_npl<2>(p, g);
     if (kwp != p->kw) return -2; // (the padded K space is GATHER 2's; nothing else reads it)
     return launch_split_npl<0>(p, g);
+}
+
+// Geometry test for the planner (rec_pairs): which gather form conv_f32_split takes for this shape -- 1 / 2 (16-byte gathers, stride 1 / 2),
+// 0 (one dword per tap) -- or -1 when try_split declines it (the same conditions, nothing batch-dependent)
+extern "C" int mhip_conv_f32_split_takes(int out_c, int in_c, int kh, int kw, int stride_h, int stride_w, int pad_left, int in_w, int out_w) {
+    if (out_c <= 0 || in_c <= 0 || kh <= 0 || kw <= 0 || stride_h <= 0 || stride_w <= 0) return -1;
+    const int kwp = split_kwp(kw, stride_w);
+    if ((long)in_c * kh * kwp > 0x7fffffffL - S_BK || kh > 32 || kwp > 32) return -1;
+    if (stride_w == 1 && out_w % 4 == 0 && pad_left <= 1 && kw <= 8 && in_w >= 4) return 1;
+    if (stride_w == 2 && out_w % 2 == 0 && pad_left <= 1 && kwp % 2 == 0 && kwp <= 16 && in_w >= 4) return 2;
+    return kwp != kw ? -1 : 0;
 }
 
 static uint16_t bf16_rn(float x) { // round to nearest even (NaN kept a NaN)

@@ -74,6 +74,7 @@ typedef struct {
     size_t w2_off;   /* a second image of the weights, or NO_OFF: the RGB stem's as conv_i8_rgb keeps them in LDS
                         (mhip_conv_i8_rgb_pack), or (w2_rows) a deep 3x3 layer's as conv_i8_rows streams them (mhip_conv_i8_rows_pack) */
     int w2_rows;
+    int w2_planes;   /* conv_f32: bf16 planes packed into the w2 image at load (2: hi, mid -- f32_mfma 3; 3: + lo -- f32_mfma 4); 0 = none */
     size_t w3_off;   /* conv_f32: conv_f32_patch's image (unit table, schedule, two bf16 planes in its K order), or NO_OFF */
     int w3_stem;     /* ... that image is conv_f32_stem's */
     int in_rec, out_rec; /* conv_f32: the input / output tensor is in record format (rec_pairs; mhip_conv_f32_t.in_rec / out_rec) */
@@ -87,7 +88,7 @@ typedef struct {
     void *ev_start; /* profiling: the event that marks this launch's start = the previous launch's ev1 (own ev0 for the first) */
 } mars_op_t;
 
-typedef struct {
+typedef struct mars_model_ext {
     mars_model_t pub; /* MUST stay first */
     int batch, fusion, profiling, deferred;
     int plan_err;   /* first allocation failure while planning (build_plan returns it; 0 = none) */
@@ -129,6 +130,8 @@ typedef struct {
     void *pipe; /* double-buffered I/O state (mars_pipe.c), NULL when closed */
     struct { char key[28]; int value, saved; } tune[MARS_MAX_MODEL_TUNE]; /* launch-policy overrides of this model */
     int n_tune, tune_depth;
+    int plan_f32_mode; /* the f32_mfma mode build_plan ran under (weight images, record pairs): replan_for_f32_mode */
+    struct mars_model_ext *live_next; /* every loaded model, newest first (mars_live_models): a process-wide mode change re-plans the float ones */
 } mars_model_ext_t;
 
 
@@ -143,6 +146,7 @@ MARS_INTERNAL int mars_verbose(void);
 #define VLOG(...) do { if (mars_verbose()) fprintf(stderr, "Mars: " __VA_ARGS__); } while (0)
 /* mars_model.c */
 MARS_INTERNAL void drop_graph(mars_model_ext_t *m);
+MARS_INTERNAL mars_model_ext_t *mars_live_models(void);
 MARS_INTERNAL mars_error_t build_plan(mars_model_ext_t *m);
 MARS_INTERNAL mars_error_t upload_params(mars_model_ext_t *m);
 MARS_INTERNAL mars_error_t alloc_batch(mars_model_ext_t *m, int n);

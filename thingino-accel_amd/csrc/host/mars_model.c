@@ -124,9 +124,15 @@ static void free_ops(mars_model_ext_t *m) {
     m->n_ops = m->cap_ops = 0;
 }
 
+/* every loaded model (single-threaded contract, like the reference's globals: SURVEY 8b "Threading") */
+static mars_model_ext_t *g_live_models = NULL;
+mars_model_ext_t *mars_live_models(void) { return g_live_models; }
+
 void mars_free(mars_model_t *model) {
     if (!model) return;
     mars_model_ext_t *m = (mars_model_ext_t *)model;
+    for (mars_model_ext_t **pp = &g_live_models; *pp; pp = &(*pp)->live_next)
+        if (*pp == m) { *pp = m->live_next; break; }
     if (m->pipe) mars_hip_pipe_close(model);
     if (mhip_ready()) mhip_sync();
     free_device_state(m);
@@ -156,6 +162,7 @@ mars_error_t build_plan(mars_model_ext_t *m) {
     if (m->arena_host) memset(m->arena_host, 0, m->arena_cap); /* re-plans must not see stale bytes */
     m->scratch_per_frame = 0;
     m->plan_err = MARS_OK;
+    m->plan_f32_mode = mhip_conv_f32_mode(-1);
     m->blob_mirror_bytes = m->pub.weights_size;
     for (uint32_t i = 0; i < nt; i++) {
         m->mt[i].extent = m->mt[i].bytes;
@@ -394,6 +401,8 @@ mars_error_t mars_hip_load_memory_ex(const void *data, size_t size, unsigned fla
     err = upload_params(m);
     if (err == MARS_OK) err = alloc_batch(m, 1);
     if (err != MARS_OK) { mars_free(&m->pub); return err; }
+    m->live_next = g_live_models;
+    g_live_models = m;
     *out_model = &m->pub;
     return MARS_OK;
 }

@@ -180,11 +180,14 @@ mars_error_t mars_hip_pipe_open(mars_model_t *model, const mars_hip_pipe_opts_t 
         }
     }
     if (err == MARS_OK && camera) { /* the front-end's gather tables: built and uploaded now, not behind the first submit */
-        mtensor_t *t0 = io_tensor(m, 0, 0);
-        const mars_tensor_t *d0 = &model->tensors[model->header.input_tensor_ids[0]].desc;
-        const int nhwc = d0->format == MARS_FORMAT_NHWC;
-        const int th = nhwc ? d0->shape[1] : d0->shape[2], tw = nhwc ? d0->shape[2] : d0->shape[3], ch = nhwc ? d0->shape[3] : d0->shape[1];
-        if (!t0 || ch != 3 || d0->dtype != MARS_DTYPE_INT8 || mars_preproc_prepare(opts->camera_w, opts->camera_h, tw, th)) err = MARS_ERR_INVALID_TENSOR;
+        mtensor_t *t0 = io_tensor(m, 0, 0); /* validates the id: the loader tolerates input ids beyond the tensor table */
+        if (!t0) err = MARS_ERR_INVALID_TENSOR;
+        else {
+            const mars_tensor_t *d0 = &model->tensors[model->header.input_tensor_ids[0]].desc;
+            const int nhwc = d0->format == MARS_FORMAT_NHWC;
+            const int th = nhwc ? d0->shape[1] : d0->shape[2], tw = nhwc ? d0->shape[2] : d0->shape[3], ch = nhwc ? d0->shape[3] : d0->shape[1];
+            if (ch != 3 || d0->dtype != MARS_DTYPE_INT8 || mars_preproc_prepare(opts->camera_w, opts->camera_h, tw, th)) err = MARS_ERR_INVALID_TENSOR;
+        }
     }
     if (err == MARS_OK && opts->detect) /* decode tables: built and uploaded once, before anything is in flight */
         err = mars_detect_prepare(m, opts->det_outputs, opts->n_det_outputs);

@@ -296,6 +296,7 @@ static void plan_conv(mars_model_ext_t *m, int li) {
                 if (n2) {
                     op->w2_off = arena_reserve(m, n2);
                     if (op->w2_off == NO_OFF) return;
+                    op->w2_planes = planes; /* what a later mode change may read (conv_f32_params) */
                     if (!m->deferred)
                         mhip_conv_f32_split_pack(out_c, in_c, kh, kw, sw, planes, (const float *)(m->arena_host + op->w_off), m->arena_host + op->w2_off);
                 }
@@ -1135,6 +1136,7 @@ void pair_convs_f32(mars_model_ext_t *m) {
                 a->sh != b->sh || a->sw != b->sw || a->pt != b->pt || a->pl != b->pl || a->silu_f32 != b->silu_f32 || a->f32_exact != b->f32_exact)
                 continue;
             if (planned_stride(&m->mt[a->t_out]) != planned_stride(&m->mt[b->t_out])) continue;
+            if (a->w2_planes != b->w2_planes) continue;
             int ok = b->t_in[0] != b->t_out && b->t_in[0] != a->t_out;
             for (int q = i + 1; q < j && ok; q++) {
                 const mars_op_t *o = &m->ops[q];
@@ -1238,6 +1240,11 @@ void rec_pairs(mars_model_ext_t *m) {
         if (pr->pair_next || (i > 0 && m->ops[i - 1].pair_next)) continue; /* (a paired launch writes plain floats) */
         if (pr->out_c != x->in_c || pr->out_h != x->in_h || pr->out_w != x->in_w) continue;
         if (!(pr->w2_off != NO_OFF || (pr->w3_off != NO_OFF && pr->w3_stem))) continue; /* conv_f32_split or conv_f32_stem writes it */
+        /* a weight image alone does not mean conv_f32_split takes the shape (stride 2 with an odd kernel width and pad > 1, maps
+         * narrower than a gather ...): it would decline at launch, and nothing else writes records -- the run would fail */
+        if (pr->w2_off != NO_OFF && mhip_conv_f32_split_takes(pr->out_c, pr->in_c, pr->kh, pr->kw, pr->sh, pr->sw, pr->pl, pr->in_w, pr->out_w) < 0) continue;
+        /* ... and the reader declines a folded Add whose operand has another frame stride than its output (conv_f32_try_patch) */
+        if (x->add_t && planned_stride(&m->mt[x->add_t - 1]) != planned_stride(&m->mt[x->t_out])) continue;
         if (m->mt[T].bytes != (size_t)x->in_c * x->in_h * x->in_w * 4) continue;
         const int form = mhip_conv_f32_patch_rec_form(x->out_c, x->in_c, x->kh, x->kw, x->sw, x->pl, x->in_h, x->in_w, x->out_h, x->out_w);
         if (!form) continue;

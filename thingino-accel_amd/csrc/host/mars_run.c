@@ -108,9 +108,18 @@ static void conv_f32_params(mars_model_ext_t *m, mars_op_t *op, mhip_conv_f32_t 
         const int mode = mhip_conv_f32_mode(-1);
         p->use_mfma = mode == 3 ? 3 : mode == 4 ? 2 : (mode == 2 || (mode == 1 && !op->f32_exact));
     }
-    if (op->in_rec || op->out_rec) { /* planned under f32_mfma = 3 (rec_pairs): these launches stay there whatever the mode is now */
+    if (op->in_rec || op->out_rec) { /* planned under f32_mfma = 3 (rec_pairs): nothing but that mode's kernels reads / writes records.  A mode change re-plans the
+                                      * model (replan_for_f32_mode); this only holds for descriptor-only ranks, which cannot */
         p->in_rec = op->in_rec; p->out_rec = op->out_rec;
         p->use_mfma = 3;
+    }
+    /* the w2 image holds the planes of the mode in force AT LOAD (two under f32_mfma = 3, three under 4).  conv_f32_split must never
+     * read a third plane that was not packed (the next op's arena bytes): without the planes the launch goes to the f32 matrix cores
+     * (conv_f32_mfma), as for a model loaded under modes 0 - 2.  Likewise conv_f32_patch / conv_f32_stem images are mode 3's. */
+    {
+        const int need = p->use_mfma == 2 ? 3 : p->use_mfma == 3 ? 2 : 0;
+        if (need > op->w2_planes) p->w_split = NULL;
+        if (p->use_mfma != 3) p->w_patch = NULL;
     }
 }
 
@@ -609,9 +618,36 @@ static int tune_raw(const char *key, int value, int *get) {
     return get ? mhip_conv_i8_tune_get(key, get) : mhip_conv_i8_tune(key, value);
 }
 
+/* the plan of a float model depends on the f32_mfma mode it was built under -- which bf16 weight images sit in the arena (two planes
+ * under 3, three under 4, conv_f32_patch / conv_f32_stem images under 3 only) and which tensors are kept in record format (rec_pairs, mode 3).
+ * When the mode in force for a model changes across the 2 | 3 | 4 boundaries it is planned again, exactly as mars_hip_set_fusion does: parameters
+ * re-packed and uploaded, tensors and I/O staging reallocated and zeroed (callers set the mode before they fill inputs).  Descriptor-only ranks
+ * (no weight blob to re-pack) keep their plan; conv_f32_params then routes every launch to a kernel whose operands exist. */
+static mars_error_t replan_for_f32_mode(mars_model_ext_t *m) {
+    if (m->deferred || !m->arena_dev) return MARS_OK;
+    int has_f32 = 0;
+    for (int i = 0; i < m->n_ops && !has_f32; i++) has_f32 = m->ops[i].kind == OP_CONV_F32;
+    if (!has_f32) return MARS_OK;
+    tune_push(m);
+    const int mode = mhip_conv_f32_mode(-1);
+    mars_error_t e = MARS_OK;
+    if (mode != m->plan_f32_mode && (mode >= 3 || m->plan_f32_mode >= 3)) {
+        mhip_sync();
+        e = build_plan(m);
+        if (e == MARS_OK) e = upload_params(m);
+        if (e == MARS_OK) e = alloc_batch(m, m->batch > 0 ? m->batch : 1);
+    }
+    tune_pop(m);
+    return e;
+}
+
 int mars_hip_set_tuning(const char *key, int value) {
     g_tune_gen++; /* captured graphs froze the launch policy they were recorded under */
-    return tune_raw(key, value, NULL);
+    int rc = tune_raw(key, value, NULL);
+    if (rc == 0 && key && !strcmp(key, "f32_mfma"))
+        for (mars_model_ext_t *m = mars_live_models(); m; m = m->live_next)
+            if (replan_for_f32_mode(m) != MARS_OK) rc = -1;
+    return rc;
 }
 
 int mars_hip_get_tuning(const char *key, int *value) { return value ? tune_raw(key, 0, value) : -1; }
@@ -633,6 +669,7 @@ int mars_hip_model_set_tuning(mars_model_t *model, const char *key, int value) {
     }
     m->tune[i].value = value;
     drop_graph(m); /* its captured graph froze the old policy */
+    if (!strcmp(key, "f32_mfma") && replan_for_f32_mode(m) != MARS_OK) return -1;
     return 0;
 }
 

@@ -171,6 +171,9 @@ unsigned long mhip_conv_f32_pair_launches(void); /* paired launches since load (
  * appended to every kernel row: taps come in pairs there). */
 size_t mhip_conv_f32_split_pack(int out_c, int in_c, int kh, int kw, int stride_w, int planes, const float *w, void *out);
 unsigned long mhip_conv_f32_split_launches(void); /* launches of conv_f32_split since load (diagnostic) */
+/* which gather form conv_f32_split takes for this shape (1 / 2: 16-byte gathers at stride 1 / 2; 0: a dword per tap), or -1: it declines the
+ * shape whatever the batch (a weight image alone does not make a layer one it runs: the planner asks before it plans record output) */
+int mhip_conv_f32_split_takes(int out_c, int in_c, int kh, int kw, int stride_h, int stride_w, int pad_left, int in_w, int out_w);
 /* conv_f32_patch (conv_f32_patch.hip: the input patch of a pixel tile staged and split once, k x k layers with >= 8 taps, stride
  * 1 / 2, in_c a multiple of 8 and >= 32, map widths multiples of 4).  Bytes of, and (w, out != NULL) the content of, its image:
  * [nsteps][4] unit offsets, [nsteps] chunk schedule, two bf16 planes [oc_pad][kp] in its K order; 0 = not such a shape */
