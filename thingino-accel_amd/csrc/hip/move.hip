@@ -9,6 +9,7 @@
 // All are HBM-bound; consecutive lanes touch consecutive channel bytes.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 
 #include "../mhip.h"
 
@@ -428,10 +429,71 @@ __global__ __launch_bounds__(MV_THREADS) void nchw_to_nhwc_kernel(const int8_t *
     *(v4i *)(out + (size_t)blockIdx.y * os + (size_t)pix * c_pad + g * 16) = v;
 }
 
+// 4 x 4 byte transpose: r[e] = 4 consecutive pixels of channel e  ->  t[p] = channels 0..3 of pixel p (v_perm_b32: 8 per block)
+__device__ __forceinline__ void tr4x4(const uint32_t (&r)[4], uint32_t (&t)[4]) {
+    const uint32_t lo_ab = __builtin_amdgcn_perm(r[1], r[0], 0x05010400u), hi_ab = __builtin_amdgcn_perm(r[1], r[0], 0x07030602u);
+    const uint32_t lo_cd = __builtin_amdgcn_perm(r[3], r[2], 0x05010400u), hi_cd = __builtin_amdgcn_perm(r[3], r[2], 0x07030602u);
+    t[0] = __builtin_amdgcn_perm(lo_cd, lo_ab, 0x05040100u);
+    t[1] = __builtin_amdgcn_perm(lo_cd, lo_ab, 0x07060302u);
+    t[2] = __builtin_amdgcn_perm(hi_cd, hi_ab, 0x05040100u);
+    t[3] = __builtin_amdgcn_perm(hi_cd, hi_ab, 0x07060302u);
+}
+
+// Round 6: the same relayout at dword granularity (hw % 4 == 0, 4-byte aligned frames: every map of the shipped files).  The byte-wise
+// kernel above read 16 single bytes per 16-byte store and wrote 16-byte pieces c_pad apart: 1.7 TB/s of its read + write bytes, and
+// 44 % of the GPU time of yolov5n_int8.mars at batch 256 (rocprofv3, profiles/r06_shipped_*).  Here a thread owns FOUR consecutive
+// pixels: per group of 16 channels it loads 16 dwords (a wave reads 256 contiguous bytes of each channel row), transposes them with
+// v_perm_b32 (4 blocks of 4 x 4 bytes) and stores 16 bytes to each of its 4 pixel rows; the groups of a pixel are walked by the SAME
+// thread back to back, so the 16-byte pieces of a c_pad-byte pixel row arrive together and merge in L2.
+__global__ __launch_bounds__(MV_THREADS) void nchw_to_nhwc4_kernel(const int8_t *in, size_t is, int8_t *out, size_t os, int c, int hw, int c_pad) {
+    const size_t q = (size_t)blockIdx.x * MV_THREADS + threadIdx.x; // 4-pixel group
+    if (q * 4 >= (size_t)hw) return;
+    const int8_t *s = in + (size_t)blockIdx.y * is + q * 4;
+    int8_t *d = out + (size_t)blockIdx.y * os + q * 4 * (size_t)c_pad;
+    for (int g = 0; g < c_pad; g += 16) {
+        uint32_t r[16];
+#pragma unroll
+        for (int e = 0; e < 16; e++) r[e] = g + e < c ? *(const uint32_t *)(s + (size_t)(g + e) * hw) : 0u;
+        uint32_t t[4][4];
+#pragma unroll
+        for (int b = 0; b < 4; b++) {
+            const uint32_t rb[4] = {r[4 * b], r[4 * b + 1], r[4 * b + 2], r[4 * b + 3]};
+            tr4x4(rb, t[b]);
+        }
+#pragma unroll
+        for (int p = 0; p < 4; p++) *(v4i *)(d + (size_t)p * c_pad + g) = (v4i){(int)t[0][p], (int)t[1][p], (int)t[2][p], (int)t[3][p]};
+    }
+}
+
+// [C <= 4][HW] -> [HW][4] (the small-channel stem's input: every pixel widened to 4 bytes): one 16-byte store per 4 pixels
+__global__ __launch_bounds__(MV_THREADS) void nchw_to_nhwc_c4_kernel(const int8_t *in, size_t is, int8_t *out, size_t os, int c, int hw) {
+    const size_t q = (size_t)blockIdx.x * MV_THREADS + threadIdx.x;
+    if (q * 4 >= (size_t)hw) return;
+    const int8_t *s = in + (size_t)blockIdx.y * is + q * 4;
+    uint32_t r[4], t[4];
+#pragma unroll
+    for (int e = 0; e < 4; e++) r[e] = e < c ? *(const uint32_t *)(s + (size_t)e * hw) : 0u;
+    tr4x4(r, t);
+    *(v4i *)(out + (size_t)blockIdx.y * os + q * 16) = (v4i){(int)t[0], (int)t[1], (int)t[2], (int)t[3]};
+}
+
+// c_pad: a multiple of 16, or 4 (c <= 4: the small-channel layout)
 extern "C" int mhip_nchw_to_nhwc_pad(const int8_t *in, size_t in_stride, int8_t *out, size_t out_stride, int frames,
                                      int c, int hw, int c_pad) {
-    if (!in || !out || frames <= 0 || c <= 0 || hw <= 0 || c_pad < c || (c_pad & 15)) return -1;
+    if (!in || !out || frames <= 0 || c <= 0 || hw <= 0 || c_pad < c || ((c_pad & 15) && c_pad != 4)) return -1;
     if ((((uintptr_t)out | out_stride) & 15) != 0) return -1;
+    const bool dwords = (hw & 3) == 0 && (((uintptr_t)in | in_stride) & 3) == 0;
+    if (c_pad == 4) {
+        if (!dwords) return -1; // (the planner only chooses the 4-byte layout for maps it can serve: mars_plan.c plan_conv)
+        hipLaunchKernelGGL(nchw_to_nhwc_c4_kernel, mv_grid((size_t)hw / 4, frames), dim3(MV_THREADS), 0, mhip_stream_native(), in, in_stride, out,
+                           out_stride, c, hw);
+        return mhip_check(hipGetLastError(), "nchw_to_nhwc_c4");
+    }
+    if (dwords && !getenv("MARS_HIP_NCHW_BYTEWISE")) {
+        hipLaunchKernelGGL(nchw_to_nhwc4_kernel, mv_grid((size_t)hw / 4, frames), dim3(MV_THREADS), 0, mhip_stream_native(), in, in_stride, out,
+                           out_stride, c, hw, c_pad);
+        return mhip_check(hipGetLastError(), "nchw_to_nhwc4");
+    }
     hipLaunchKernelGGL(nchw_to_nhwc_kernel, mv_grid((size_t)hw * (c_pad / 16), frames), dim3(MV_THREADS), 0,
                        mhip_stream_native(), in, in_stride, out, out_stride, c, hw, c_pad);
     return mhip_check(hipGetLastError(), "nchw_to_nhwc");

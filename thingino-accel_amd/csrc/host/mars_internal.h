@@ -46,6 +46,7 @@ typedef struct {
     uint8_t *dense_dev; /* padded rows only: batch * bytes, the dense copy made on the device before a download */
     int pix_c, pix_stride; /* pix_stride != 0: [pixels][pix_c] rows kept at a pix_stride-byte pitch on the device (pad_output_rows) */
     int rec_c, rec_hw;     /* rec_c != 0: a float tensor kept in RECORD format on the device (rec_pairs): [rec_c / 8][rec_hw] x 32 bytes */
+    int nhwc_c, nhwc_hw;   /* nhwc_c != 0: an NCHW-tagged int8 tensor kept as [nhwc_hw][nhwc_c] (pixels x channels) on the device (nhwc_internal) */
 } mtensor_t;
 
 typedef struct {
@@ -53,7 +54,8 @@ typedef struct {
     int t_in[4], n_in, t_out; /* tensor indices, -1 if none */
     /* geometry (conv / pool / concat / upsample share these) */
     int in_h, in_w, in_c, out_h, out_w, out_c, kh, kw, sh, sw, pt, pl;
-    int nchw, relu, is_mul, is_f32, leaky, safe;
+    int nchw, relu, is_mul, is_f32, leaky, safe; /* nchw (conv_i8): the INPUT is [C][H][W] bytes and is relaid into scratch before the launch */
+    int out_nchw;  /* conv_i8: the result is stored [O][H][W] (the reference's conv2d_int8_mxu); both set by the input's tag, cleared per side by nhwc_internal */
     int silu_f32;  /* conv_f32 with the float SIGMOID + MUL pair (ONNX SiLU) folded into its epilogue */
     int f32_exact; /* conv_f32 whose result reaches a byte-wise MAXPOOL over float bytes: keeps the reference's summation order */
     int variant; /* conv_i8 launch variant pinned by mars_hip_autotune (0 = default policy) */
@@ -157,6 +159,7 @@ MARS_INTERNAL size_t reference_buffer_size(const mars_model_ext_t *m);
 MARS_INTERNAL size_t arena_reserve(mars_model_ext_t *m, size_t bytes);
 MARS_INTERNAL void blob_read(const mars_model_ext_t *m, size_t off, size_t n, void *dst);
 MARS_INTERNAL void plan_layer(mars_model_ext_t *m, int li);
+MARS_INTERNAL void nhwc_internal(mars_model_ext_t *m);
 MARS_INTERNAL void fuse_silu(mars_model_ext_t *m);
 MARS_INTERNAL void fuse_silu_f32(mars_model_ext_t *m);
 MARS_INTERNAL void elide_concat(mars_model_ext_t *m);

@@ -65,7 +65,7 @@ static void pad_output_rows(mars_model_ext_t *m) {
     if (getenv("MARS_HIP_NO_ROWPAD")) return;
     for (int i = 0; i < m->n_ops; i++) {
         mars_op_t *o = &m->ops[i];
-        if (o->kind != OP_CONV_I8 || o->nchw || o->out_pix_stride || o->out_ch_off || o->add_t || o->t_out < 0 ||
+        if (o->kind != OP_CONV_I8 || o->out_nchw || o->out_pix_stride || o->out_ch_off || o->add_t || o->t_out < 0 ||
             (o->out_c & 15) == 0 || (o->in_c & 15) != 0)
             continue;
         mtensor_t *t = &m->mt[o->t_out];
@@ -176,6 +176,7 @@ mars_error_t build_plan(mars_model_ext_t *m) {
     if (m->fusion >= 1) {
         fuse_silu(m);
         fuse_silu_f32(m);
+        nhwc_internal(m); /* (after the SiLU fold: its intermediates are gone; before Add folding / pairing: they then see NHWC convolutions) */
         fuse_add(m);
         fuse_add_f32(m);
         if (!m->no_vconcat) virtual_concat(m);
@@ -186,6 +187,7 @@ mars_error_t build_plan(mars_model_ext_t *m) {
         if (m->fusion >= 2 && !m->no_bottleneck) fuse_bottleneck(m); /* opt-in (level 2); after pairing: a paired launch stays a pair */
         pad_output_rows(m);
     }
+    if (m->fusion < 1) nhwc_internal(m); /* (resets the tensors' flags) */
     f32_policy(m);
     if (m->fusion >= 1) pair_convs_f32(m); /* (after f32_policy: a pair shares one kernel choice) */
     rec_pairs(m); /* (fusion >= 1 only; resets the tensors' record flags in any case) */
@@ -320,7 +322,7 @@ mars_error_t alloc_batch(mars_model_ext_t *m, int n) {
         }
     }
     if (m->scratch_per_frame) {
-        m->scratch_dev = (uint8_t *)mhip_malloc(ALIGN_UP(m->scratch_per_frame, 256) * (size_t)n);
+        m->scratch_dev = (uint8_t *)mhip_malloc(ALIGN_UP(m->scratch_per_frame, 256) * (size_t)n + 256); /* (+ 256: 16-byte loads at the last pixels) */
         if (!m->scratch_dev) return MARS_ERR_ALLOC_FAILED;
     }
     m->batch = n;

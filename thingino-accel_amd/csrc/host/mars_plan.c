@@ -316,7 +316,11 @@ static void plan_conv(mars_model_ext_t *m, int li) {
 
     op->prof_kind = 0;
     op->nchw = !in_nhwc; /* the kernel is chosen by the INPUT tag (:640-662) */
+    op->out_nchw = op->nchw; /* ... and conv2d_int8_mxu writes [O][H][W] whatever the output's tag says */
     op->c_pad = op->nchw ? (int)ALIGN_UP((size_t)in_c, 16) : in_c;
+    /* NCHW stem (round 6: the shipped files' first layer is 3 planes of 640 x 640): relaid to 4 bytes per pixel, the small-channel kernels'
+     * own input layout (K = 6 rows x 32 bytes), instead of 16 (K = 6 x 96: 2.4 of yolov5n_int8.mars' 12.5 ms per batch went there) */
+    if (op->nchw && in_c <= 4 && mhip_conv_i8_small_c(4, kw, out_c) && ((size_t)in_h * in_w) % 4 == 0) op->c_pad = 4;
     int c_eff = op->c_pad; /* bytes per pixel in the packed K layout (4 in small-channel mode) */
     mhip_conv_i8_pack_geom(op->c_pad, kw, out_c, &op->row_pad, &op->oc_pad, &c_eff);
     const size_t k64 = ALIGN_UP((size_t)kh * op->row_pad, 64);
@@ -367,7 +371,7 @@ static void plan_conv(mars_model_ext_t *m, int li) {
     if (op->nchw) {
         size_t need = (size_t)in_h * in_w * op->c_pad;
         if (need > m->scratch_per_frame) m->scratch_per_frame = need;
-        op->bytes += 2.0 * need;
+        /* (op->bytes stays input + output: the relayout's traffic is this implementation's cost, not algorithmic work) */
     }
 }
 
@@ -711,7 +715,7 @@ void elide_concat(mars_model_ext_t *m) {
         if (pr->out_pix_stride || pr->add_t) continue; /* a folded Add needs its other operand laid out like the output */
         const size_t npix = (size_t)cs->out_h * cs->out_w;
         int ok = 0;
-        if (pr->kind == OP_CONV_I8 && !pr->nchw) ok = (size_t)pr->out_h * pr->out_w == npix && pr->out_c == cs->in_c;
+        if (pr->kind == OP_CONV_I8 && !pr->nchw && !pr->out_nchw) ok = (size_t)pr->out_h * pr->out_w == npix && pr->out_c == cs->in_c;
         else if (pr->kind == OP_BINARY_I8) ok = pr->n == npix * (size_t)cs->in_c;
         else if (pr->kind == OP_MAXPOOL || pr->kind == OP_UPSAMPLE) ok = (size_t)pr->out_h * pr->out_w == npix && pr->in_c == cs->in_c;
         if (!ok || cs->ch_off + cs->in_c > cs->out_c) continue;
@@ -767,6 +771,75 @@ void trim_concat(mars_model_ext_t *m) {
     }
 }
 
+/* NCHW-tagged int8 graphs (every shipped model: SURVEY a7, mxu_conv.c:630-670) on the NHWC kernels without a relayout per layer (round 6).
+ * conv2d_int8_mxu reads [C][H][W] and writes [O][H][W]; the matrix-core kernels want pixels x channels, so every such convolution used to
+ * relay its input into scratch (nchw_to_nhwc_kernel: 44 % of yolov5n_int8.mars' GPU time at batch 256) and stage its result through LDS
+ * for the planar store -- and no fusion pass took them.  But a tensor that only convolutions and ELEMENT-WISE layers (LUT maps, Mul / Add:
+ * functions of corresponding bytes, whatever the order) touch need not hold the reference's byte order at all: it is kept as
+ * [H * W][C] on the device (mtensor_t.nhwc_c), the convolution reading it skips the relayout (op->nchw = 0), the one writing it stores
+ * rows (op->out_nchw = 0), and the passes that follow (Add folding, paired launches) see plain NHWC convolutions.  Same values at the
+ * same (channel, pixel): the reference's NCHW and NHWC kernels compute the same sums (mxu_conv.c:639-667 against :722-754).  Tensors a
+ * byte-wise layer touches (MAXPOOL / CONCAT / UPSAMPLE index bytes by shape[1..3] whatever the tag: :919-1041), graph inputs and
+ * outputs keep the reference's bytes.  mars_hip_read_tensor / write_tensor convert; fusion level 0 keeps every tensor as tagged. */
+void nhwc_internal(mars_model_ext_t *m) {
+    const int nt = (int)m->pub.header.num_tensors;
+    for (int i = 0; i < nt; i++) m->mt[i].nhwc_c = m->mt[i].nhwc_hw = 0;
+    if (m->fusion < 1 || getenv("MARS_HIP_NO_NHWC_INTERNAL")) return;
+    unsigned char *el = (unsigned char *)calloc((size_t)nt + 1, 1);
+    if (!el) return;
+    for (int t = 0; t < nt; t++) { /* candidates: dense [1, C, H, W] int8 activations, C a multiple of 16 (16-byte pixel rows), not NHWC-tagged */
+        const mars_tensor_t *d = &m->pub.tensors[t].desc;
+        const mtensor_t *mt = &m->mt[t];
+        if (mt->is_weight || mt->io_in || mt->io_out || !mt->needed || d->dtype != MARS_DTYPE_INT8 || d->format == MARS_FORMAT_NHWC || d->ndims != 4 ||
+            d->shape[0] != 1 || d->shape[1] <= 0 || (d->shape[1] & 15) || d->shape[2] <= 0 || d->shape[3] <= 0)
+            continue;
+        if (mt->bytes != (size_t)d->shape[1] * d->shape[2] * d->shape[3] || mt->extent != mt->bytes) continue;
+        el[t] = 1;
+    }
+#define DIMS_ARE(t, c, h, w) (m->pub.tensors[t].desc.shape[1] == (c) && m->pub.tensors[t].desc.shape[2] == (h) && m->pub.tensors[t].desc.shape[3] == (w))
+    for (int pass = 0, changed = 1; changed && pass < nt + 2; pass++) {
+        changed = 0;
+        for (int i = 0; i < m->n_ops; i++) {
+            const mars_op_t *o = &m->ops[i];
+            int ts[8], n = 0, ok[8];
+            for (int k = 0; k < o->n_in && k < 4; k++) { ts[n] = o->t_in[k]; ok[n++] = 0; }
+            const int n_in = n;
+            if (o->t_out >= 0) { ts[n] = o->t_out; ok[n++] = 0; }
+            if (o->kind == OP_CONV_I8 && !o->nseg && !o->add_t && !o->pre && !o->out_pix_stride && !o->chain_n) {
+                /* input side: the tagged-NCHW view of a tensor of exactly these dims; output side likewise */
+                if (n_in == 1 && o->nchw && ts[0] >= 0 && el[ts[0]] && DIMS_ARE(ts[0], o->in_c, o->in_h, o->in_w) && o->c_pad == o->in_c) ok[0] = 1;
+                if (o->t_out >= 0 && o->out_nchw && el[o->t_out] && DIMS_ARE(o->t_out, o->out_c, o->out_h, o->out_w) && ts[0] != o->t_out) ok[n - 1] = 1;
+            } else if ((o->kind == OP_LUT_I8 || (o->kind == OP_BINARY_I8 && !o->out_pix_stride)) && o->t_out >= 0) {
+                /* element-wise: every operand and the result in the same order, or none of them */
+                int all = 1;
+                for (int k = 0; k < n; k++)
+                    if (ts[k] < 0 || !el[ts[k]] || o->n != m->mt[ts[k]].bytes || !DIMS_ARE(ts[k], m->pub.tensors[ts[0]].desc.shape[1], m->pub.tensors[ts[0]].desc.shape[2], m->pub.tensors[ts[0]].desc.shape[3]))
+                        all = 0;
+                for (int k = 0; k < n; k++) ok[k] = all;
+            }
+            for (int k = 0; k < n; k++)
+                if (ts[k] >= 0 && el[ts[k]] && !ok[k]) { el[ts[k]] = 0; changed = 1; }
+            for (int k = 0; k < o->chain_n && k < 3; k++)
+                if (o->chain_out[k] >= 0 && el[o->chain_out[k]]) { el[o->chain_out[k]] = 0; changed = 1; }
+            for (int k = 0; k < o->nseg && k < 4; k++)
+                if (o->seg_t[k] >= 0 && el[o->seg_t[k]]) { el[o->seg_t[k]] = 0; changed = 1; }
+        }
+    }
+#undef DIMS_ARE
+    for (int i = 0; i < m->n_ops; i++) {
+        mars_op_t *o = &m->ops[i];
+        if (o->kind != OP_CONV_I8) continue;
+        if (o->n_in >= 1 && o->t_in[0] >= 0 && el[o->t_in[0]]) o->nchw = 0;
+        if (o->t_out >= 0 && el[o->t_out]) o->out_nchw = 0;
+    }
+    for (int t = 0; t < nt; t++)
+        if (el[t]) {
+            m->mt[t].nhwc_c = m->pub.tensors[t].desc.shape[1];
+            m->mt[t].nhwc_hw = m->pub.tensors[t].desc.shape[2] * m->pub.tensors[t].desc.shape[3];
+        }
+    free(el);
+}
+
 /* Residual Add folded into the convolution that produces one of its operands (the bottleneck shortcut of C3):
  * out = Add(conv_result, x) is evaluated in the convolution's epilogue with the reference's float steps
  * (mars_runtime.c ADD branch: (a*sa + b*sb) * (1/so) + 0.5f, truncated, saturated), reading x where the output
@@ -800,7 +873,7 @@ void fuse_add(mars_model_ext_t *m) {
                 if (m->ops[k].t_out == A) i = k;
             if (i < 0) continue;
             mars_op_t *c = &m->ops[i];
-            if (c->kind != OP_CONV_I8 || c->nchw || !c->safe || c->out_pix_stride || (c->out_c & 15) || (c->in_c & 15) ||
+            if (c->kind != OP_CONV_I8 || c->out_nchw || !c->safe || c->out_pix_stride || (c->out_c & 15) || (c->in_c & 15) ||
                 c->nseg || c->add_t || c->n_in != 1)
                 continue;
             if (ad->n != (size_t)c->out_h * c->out_w * c->out_c) continue;
@@ -918,7 +991,7 @@ void fuse_bottleneck(mars_model_ext_t *m) {
         if (a->kind != OP_CONV_I8 || b->kind != OP_CONV_I8 || a->pre || b->pre) continue;
         const int T = a->t_out;
         if (T < 0 || b->t_in[0] != T || readers[T] != 1 || m->mt[T].io_in || m->mt[T].io_out || m->mt[T].is_weight) continue;
-        if (a->kh != 1 || a->kw != 1 || a->sh != 1 || a->sw != 1 || a->nchw || b->nchw || !a->safe || !b->safe || a->nseg || b->nseg ||
+        if (a->kh != 1 || a->kw != 1 || a->sh != 1 || a->sw != 1 || a->nchw || b->nchw || a->out_nchw || b->out_nchw || !a->safe || !b->safe || a->nseg || b->nseg ||
             a->add_t || a->n_in != 1 || a->out_pix_stride || a->relu || a->lut2_off == NO_OFF || b->lut2_off == NO_OFF ||
             a->in_c != a->out_c || a->out_c != b->in_c || (a->in_c != 32 && a->in_c != 64) || b->sh != 1 || b->sw != 1 ||
             a->in_h != b->in_h || a->in_w != b->in_w || a->b_off == NO_OFF || a->pair_next || b->pair_next ||
@@ -1079,7 +1152,7 @@ static int same_conv_input(const mars_op_t *a, const mars_op_t *b) {
 static int pairable(const mars_op_t *o) {
     /* measured: pairs with a plain input gain 10-20 %, pairs reading a virtual concat lose (their single launches are
      * tuned individually), so only the former are formed */
-    return o->kind == OP_CONV_I8 && !o->nchw && !o->add_t && !o->nseg && o->safe && o->lut_off != NO_OFF && !o->pair_next &&
+    return o->kind == OP_CONV_I8 && !o->nchw && !o->out_nchw && !o->add_t && !o->nseg && o->safe && o->lut_off != NO_OFF && !o->pair_next &&
            (o->in_c & 15) == 0 && o->in_c > 4 && (o->out_c & 15) == 0 && !o->out_pix_stride;
 }
 static int op_writes(const mars_op_t *o, int t) {

@@ -64,7 +64,7 @@ void conv_i8_params(const mars_model_ext_t *m, const mars_op_t *op, mhip_conv_i8
     p->in_h = op->in_h; p->in_w = op->in_w;
     p->out_h = op->out_h; p->out_w = op->out_w; p->out_c = op->store_c ? op->store_c : op->out_c;
     p->kh = op->kh; p->kw = op->kw; p->stride_h = op->sh; p->stride_w = op->sw; p->pad_top = op->pt; p->pad_left = op->pl;
-    p->row_pad = op->row_pad; p->oc_pad = op->oc_pad; p->cs = op->cs; p->relu = op->relu; p->out_nchw = op->nchw;
+    p->row_pad = op->row_pad; p->oc_pad = op->oc_pad; p->cs = op->cs; p->relu = op->relu; p->out_nchw = op->out_nchw;
     p->safe = op->safe;
     p->out_pix_stride = op->out_pix_stride; p->out_ch_off = op->out_ch_off;
     p->variant = op->variant;
@@ -791,6 +791,19 @@ mars_error_t mars_hip_read_tensor(mars_model_t *model, int ti, int frame, void *
         free(raw); free(f);
         return MARS_OK;
     }
+    if (t->nhwc_c) { /* kept as pixels x channels (nhwc_internal): the frame comes back in the reference's [C][H][W] order */
+        const size_t full = (size_t)t->nhwc_c * t->nhwc_hw;
+        uint8_t *raw = (uint8_t *)malloc(full), *pl = (uint8_t *)malloc(full);
+        if (!raw || !pl || bytes > full || mhip_d2h_async(raw, t->dev + (size_t)frame * t->stride, full) || mhip_sync()) {
+            free(raw); free(pl);
+            return MARS_ERR_LAYER_FAILED;
+        }
+        for (int px = 0; px < t->nhwc_hw; px++)
+            for (int c = 0; c < t->nhwc_c; c++) pl[(size_t)c * t->nhwc_hw + px] = raw[(size_t)px * t->nhwc_c + c];
+        memcpy(dst, pl, bytes);
+        free(raw); free(pl);
+        return MARS_OK;
+    }
     if (t->pix_stride) { /* padded pixel rows: the frame is packed on the device first */
         uint8_t *dense = t->dense_dev + (size_t)frame * t->bytes;
         if (bytes > t->bytes || !t->dense_dev) return MARS_ERR_INVALID_TENSOR;
@@ -829,6 +842,18 @@ mars_error_t mars_hip_write_tensor(mars_model_t *model, int ti, int frame, const
                 uint8_t *q = raw + ((size_t)(c >> 3) * t->rec_hw + px) * 32 + (size_t)(c & 7) * 2;
                 memcpy(q, &h, 2); memcpy(q + 16, &md, 2);
             }
+        const int rc = mhip_h2d_async(t->dev + (size_t)frame * t->stride, raw, full) || mhip_sync();
+        free(raw);
+        return rc ? MARS_ERR_LAYER_FAILED : MARS_OK;
+    }
+    if (t->nhwc_c) { /* kept as pixels x channels: whole frames only, given in the reference's [C][H][W] order */
+        const size_t full = (size_t)t->nhwc_c * t->nhwc_hw;
+        if (bytes != full) return MARS_ERR_INVALID_TENSOR;
+        uint8_t *raw = (uint8_t *)malloc(full);
+        if (!raw) return MARS_ERR_ALLOC_FAILED;
+        const uint8_t *pl = (const uint8_t *)src;
+        for (int px = 0; px < t->nhwc_hw; px++)
+            for (int c = 0; c < t->nhwc_c; c++) raw[(size_t)px * t->nhwc_c + c] = pl[(size_t)c * t->nhwc_hw + px];
         const int rc = mhip_h2d_async(t->dev + (size_t)frame * t->stride, raw, full) || mhip_sync();
         free(raw);
         return rc ? MARS_ERR_LAYER_FAILED : MARS_OK;

@@ -128,6 +128,8 @@ int mhip_conv_i8_seg_ok(const mhip_conv_i8_t *p);
 /* two convolutions over the same input in one launch (the second's input reads hit L2); -2 = not eligible as a
  * pair (launch them separately), else the launch result */
 int mhip_conv_i8_pair(const mhip_conv_i8_t *a, const mhip_conv_i8_t *b);
+/* does a layer with in_c bytes per pixel take the small-channel packing (every pixel widened to 4 bytes, 32-byte kernel rows)? */
+int mhip_conv_i8_small_c(int in_c, int kw, int out_c);
 /* packing geometry shared by host packer and kernel */
 /* c_eff: bytes per input pixel in the packed K layout (4 in small-channel mode, else in_c) */
 void mhip_conv_i8_pack_geom(int in_c, int kw, int out_c, int *row_pad, int *oc_pad, int *c_eff);
