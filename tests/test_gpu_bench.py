@@ -23,7 +23,7 @@ def run_bench(*extra, env=None):
 
 
 def test_bench_line_has_the_contract_fields():
-    d = run_bench("--hw", "192")  # (192 / 2 = 96 is still a size the twins accept: the 320-class legs run too)
+    d = run_bench("--hw", "256")  # (every map width of the float twin a multiple of 4 -- the well-conditioned case, cases.SYNTH -- and 256 / 2 = 128 still a size the twins accept)
     for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
               "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
         assert k in d, k
@@ -65,7 +65,7 @@ def test_bench_line_has_the_contract_fields():
     # NCHW-tagged file: the conv2d_int8_mxu path), config 5 (float32), the 320-class workloads, config 2 -- each with its rate, the
     # roof that bounds it and a comparison with the reference's CPU run
     cf = d["configs"]
-    assert set(cf) == {"config3_yolov5n_int8", "config3_shipped_yolov5n_int8_mars", "config5_yolov5s_float32", "yolov5s_int8_96", "yolov5n_int8_96",
+    assert set(cf) == {"config3_yolov5n_int8", "config3_shipped_yolov5n_int8_mars", "config5_yolov5s_float32", "yolov5s_int8_128", "yolov5n_int8_128",
                        "config2_tiny_160_int8_mars"}
     for name, leg in cf.items():
         assert "error" not in leg, (name, leg)

@@ -2216,7 +2216,7 @@ def test_f32_mode_change_after_load_replans(gpu, orc, how):
         gpu.set_tuning("f32_mfma", 1)
 
 
-@pytest.mark.parametrize("name", ["yolov5n_int8.mars", "yolov5nu.mars", "tiny_160_int8.mars"])
+@pytest.mark.parametrize("name", ["yolov5n_int8", "yolov5nu", "tiny_160_int8"])
 @pytest.mark.parametrize("fusion", [1, 0])
 def test_shipped_files_at_batch_8_every_tensor(gpu, orc, name, fusion):
     """VERDICT r5 item 5: the reference's own NCHW-tagged files (BASELINE config 3's literal yolov5n_int8.mars; the 320 x 320 yolov5nu;
