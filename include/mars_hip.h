@@ -176,9 +176,12 @@ typedef struct {
     int camera_w, camera_h; /* both > 0: CAMERA mode.  Graph input 0 (int8, 3 channels) is fed from uint8 RGB frames of camera_w x
                              * camera_h: mars_hip_pipe_input(model, 0) is then a pinned buffer of [batch][camera_h][camera_w][3] bytes,
                              * and a submit uploads it and runs the letterbox / px - 128 front-end (the reference's load_image(),
-                             * src/mars/mars_yolo_test.c:40-77, as mars_hip_preprocess does it) on the upload stream, into the
+                             * src/mars/mars_yolo_test.c:40-77, as mars_hip_preprocess does it) on the main stream ahead of the graph
+                             * (round 6: on the upload stream it held up the next batch's copy), into the
                              * slot's graph input -- the demo's whole loop (:132-214: load_image -> run -> parse_output -> nms),
-                             * three batches in flight.  0 / 0: the graph inputs themselves are uploaded (as before). */
+                             * three batches in flight.  0 / 0: the graph inputs themselves are uploaded (as before).
+                             * The struct has grown by these two fields (round 5): callers zero-initialise it (`= {0}` / memset) before
+                             * setting what they use, so that a build against an older header still means "no camera" (ADVICE r5). */
 } mars_hip_pipe_opts_t;
 mars_error_t mars_hip_pipe_open(mars_model_t *model, const mars_hip_pipe_opts_t *opts);
 /* pinned host buffer ([batch][frame bytes]) to fill for the NEXT submit; changes after every submit */

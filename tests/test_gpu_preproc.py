@@ -107,3 +107,37 @@ def test_camera_pipe_equals_preprocess_run_detect(gpu):
     m.pipe_close()
     m.close()
     assert got == want and sum(len(b) for w_ in want for b in w_) > 0
+
+
+@pytest.mark.parametrize("form", [0, 1, 2], ids=["strips", "tiles", "per_pixel"])
+def test_letterbox_kernel_forms_write_the_same_bytes(gpu, orc, form, monkeypatch):
+    """round 6: the strip kernel (a workgroup streams the source rows of 8 output rows; the default wherever its tables fit LDS) against
+    the 16 x 16-tile kernel and the one-thread-per-pixel kernel it replaced as the default (MARS_HIP_LETTERBOX_FORM forces them): the
+    camera geometry of bench.py (1280 x 720 -> 640 x 640, bands above and below), a growing axis (Catmull-Rom), ragged row ends
+    (w * 3 not a multiple of 16), bands left and right, one and four columns per thread, NHWC and planar output -- all against the oracle."""
+    monkeypatch.setenv("MARS_HIP_LETTERBOX_FORM", str(form))
+    rng = np.random.default_rng(606)
+    for (w, h, tw, th, nhwc) in [(1280, 720, 640, 640, 1), (1280, 720, 640, 640, 0), (97, 61, 224, 160, 1), (333, 500, 320, 320, 0),
+                                 (1919, 1080, 1024, 576, 1), (50, 41, 200, 216, 1), (640, 480, 640, 640, 1)]:
+        img = rng.integers(0, 256, (h, w, 3), dtype=np.uint8)
+        got = gpu.letterbox(img, tw, th, nhwc)
+        want = orc.letterbox(img, tw, th, nhwc)
+        assert np.array_equal(got, want), (w, h, tw, th, nhwc, form, int((got != want).sum()))
+
+
+def test_letterbox_strips_over_a_batch(gpu, orc):
+    """the strip kernel over several frames at once (mars_hip_preprocess: grid = strips x frames), into an NHWC and into an NCHW-tagged
+    graph input (planar output), frames at odd byte offsets from each other (w * h * 3 odd)"""
+    B, w, h = 5, 211, 157
+    rng = np.random.default_rng(17)
+    frames = rng.integers(0, 256, (B, h, w, 3), dtype=np.uint8)
+    for nchw in (False, True):
+        d = gpu.synth_model(width_x16=4, input_hw=128, seed=5, nchw_int8=nchw)
+        hdr, tensors, _ = marsfile.parse(d)
+        tin = hdr["inputs"][0]
+        m = gpu.Model(d, batch=B)
+        m.preprocess(frames)
+        for f in range(B):
+            x = orc.letterbox(frames[f], 128, 128, 0 if nchw else 1)
+            assert np.array_equal(m.read_tensor(tin, frame=f)[:x.size].view(np.int8), x), (nchw, f)
+        m.close()

@@ -162,13 +162,226 @@ __global__ __launch_bounds__(256) void letterbox_tiled_kernel(const mhip_letterb
     }
 }
 
+// Strip form (round 6).  The tiled form above gave a workgroup one 16 x 16 output tile: 409 600 workgroups per
+// 256-frame batch, every one reading its gather lists from global memory, looking every source byte up once PER TAP, and storing three
+// single bytes per thread -- 4.5 ms per batch = 228 GB/s of the 1 GB it moves, as long as the whole 60-layer graph.  Here a workgroup owns
+// LB_R output rows over the full width and STREAMS the source rows its vertical lists touch, in increasing order:
+//   * the horizontal gather list (start / source / weight) is staged in LDS once per workgroup;
+//   * a source row arrives by 16-byte loads (the next row's loads are in flight while this one is used) and is converted to floats
+//     ONCE per byte (the /255 table) into an LDS row -- taps then read floats, not bytes through a table;
+//   * a thread owns NC output columns (x = tid + 256 i): it evaluates the row's horizontal sums for them (h = h + v * w, increasing
+//     source order from 0: the library's order) and adds them into the accumulators of those of its LB_R output rows whose vertical list
+//     holds this source row (acc = acc + h * w, increasing source order: each output's list is walked by a pointer that only moves on).
+//     Which rows those are is the same for every thread (scalar control flow);
+//   * the strip's bytes are put together in LDS and leave as 16-byte stores of contiguous runs (NHWC rows are 3 * tw contiguous bytes).
+// The same float operations in the same order as the two kernels above, bit for bit (tests/test_gpu_preproc.py); letterbox bands
+// (strips outside the resized image) are filled without touching the source.
+#define LB_R 8
+template <int NC>
+__global__ __launch_bounds__(256) void letterbox_strip_kernel(const mhip_letterbox_t p, const int n_xtaps) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char sm[];
+    const int tid = threadIdx.x;
+    const int row_f = ((p.w * 3 + 15) & ~15);                 // floats per staged source row (the tail of the last 16-byte load lands here too)
+    float *dec = (float *)sm;                                 // [256]
+    int *xs_l = (int *)(dec + 256);                           // [nw + 1] (+ pad to a multiple of 4)
+    int2 *tap_l = (int2 *)(xs_l + ((p.nw + 1 + 3) & ~3));     // [n_xtaps] {source column * 3, weight bits}
+    float *rowf = (float *)(tap_l + ((n_xtaps + 1) & ~1));    // [2][row_f]
+    int8_t *stage = (int8_t *)rowf;                           // (after the last source row) [LB_R][tw * 3] output bytes
+    const int f = blockIdx.y, y0 = blockIdx.x * LB_R;
+    const uint8_t *src = p.rgb + (size_t)f * p.rgb_stride;
+    int8_t *dst = p.out + (size_t)f * p.out_stride;
+    const int rows = min(LB_R, p.th - y0);
+    const int row_b = p.tw * 3;
+    // the strip's rows inside the resized image: [r_lo, r_hi) of its LB_R
+    const int r_lo = max(p.py - y0, 0), r_hi = min(p.py + p.nh - y0, rows);
+    if (r_hi <= r_lo) { // a letterbox band: grey, 16 bytes per lane (NHWC and planar alike: every byte of these rows is -17)
+        const unsigned g = 0xefefefefu; // (int8) -17
+        if (p.nhwc) {
+            int8_t *o = dst + (size_t)y0 * row_b;
+            const int n = rows * row_b;
+            if ((((uintptr_t)o | (unsigned)n) & 15) == 0) {
+                for (int i = tid * 16; i < n; i += 256 * 16) *(uint4 *)(o + i) = make_uint4(g, g, g, g);
+            } else {
+                for (int i = tid; i < n; i += 256) o[i] = (int8_t)-17;
+            }
+        } else {
+            for (int c = 0; c < 3; c++) {
+                int8_t *o = dst + ((size_t)c * p.th + y0) * p.tw;
+                for (int i = tid; i < rows * p.tw; i += 256) o[i] = (int8_t)-17;
+            }
+        }
+        return;
+    }
+    dec[tid] = (float)tid / 255.0f;
+    for (int i = tid; i <= p.nw; i += 256) xs_l[i] = p.xstart[i];
+    for (int i = tid; i < n_xtaps; i += 256) tap_l[i] = make_int2(p.xsrc[i] * 3, __float_as_int(p.xw[i]));
+    // vertical lists of the strip's rows (uniform: scalar registers)
+    int jp[LB_R], je[LB_R];
+    int s0 = 0x7fffffff, s1 = -1;
+#pragma unroll
+    for (int r = 0; r < LB_R; r++) {
+        const bool in = r >= r_lo && r < r_hi;
+        const int ry = in ? y0 + r - p.py : 0;
+        jp[r] = in ? p.ystart[ry] : 0;
+        je[r] = in ? p.ystart[ry + 1] : 0;
+        if (in && je[r] > jp[r]) {
+            s0 = min(s0, p.ysrc[jp[r]]);
+            s1 = max(s1, p.ysrc[je[r] - 1]);
+        }
+    }
+    float acc[LB_R][NC][3];
+#pragma unroll
+    for (int r = 0; r < LB_R; r++)
+#pragma unroll
+        for (int i = 0; i < NC; i++) acc[r][i][0] = acc[r][i][1] = acc[r][i][2] = 0.0f;
+    // a source row = w * 3 bytes from a 1-byte-aligned address: 16-byte loads (unaligned ones are served on gfx950); a ragged last
+    // piece is put together from single bytes (one thread per row: nothing is read beyond the row)
+    const int rb = p.w * 3, nld = (rb + 15) >> 4; // 16-byte pieces per row
+    uint4 ld[2];
+    auto fetch = [&](int s) __attribute__((always_inline)) {
+#pragma unroll
+        for (int k = 0; k < 2; k++) {
+            const int i = tid + 256 * k;
+            if (i < nld) {
+                const uint8_t *g = src + (size_t)s * rb + (size_t)i * 16;
+                if (i * 16 + 16 <= rb) __builtin_memcpy(&ld[k], g, 16);
+                else {
+                    unsigned v[4] = {0u, 0u, 0u, 0u};
+                    for (int b = 0; b < rb - i * 16; b++) v[b >> 2] |= (unsigned)g[b] << (8 * (b & 3));
+                    ld[k] = make_uint4(v[0], v[1], v[2], v[3]);
+                }
+            }
+        }
+    };
+    if (s1 >= s0) fetch(s0);
+    for (int s = s0; s <= s1; s++) {
+        float *rf = rowf + ((s - s0) & 1) * row_f;
+#pragma unroll
+        for (int k = 0; k < 2; k++) { // bytes -> floats, once per byte
+            const int i = tid + 256 * k;
+            if (i < nld) {
+                const unsigned v[4] = {ld[k].x, ld[k].y, ld[k].z, ld[k].w};
+#pragma unroll
+                for (int q = 0; q < 4; q++)
+                    *(float4 *)(rf + i * 16 + q * 4) = make_float4(dec[v[q] & 255u], dec[(v[q] >> 8) & 255u], dec[(v[q] >> 16) & 255u], dec[v[q] >> 24]);
+            }
+        }
+        if (s < s1) fetch(s + 1);
+        __syncthreads(); // (also orders the tables / dec staged above before their first use)
+        // does any of the strip's rows use this source row?  (uniform)
+        bool used = false;
+#pragma unroll
+        for (int r = 0; r < LB_R; r++) used |= jp[r] < je[r] && p.ysrc[jp[r]] == s;
+        if (!used) continue;
+        float h[NC][3];
+#pragma unroll
+        for (int i = 0; i < NC; i++) {
+            const int x = tid + 256 * i;
+            h[i][0] = h[i][1] = h[i][2] = 0.0f;
+            if (x < p.nw) {
+                const int k1 = xs_l[x + 1];
+                for (int k = xs_l[x]; k < k1; k++) {
+                    const int2 t = tap_l[k];
+                    const float *q = rf + t.x;
+                    const float wk = __int_as_float(t.y);
+                    h[i][0] = h[i][0] + q[0] * wk;
+                    h[i][1] = h[i][1] + q[1] * wk;
+                    h[i][2] = h[i][2] + q[2] * wk;
+                }
+            }
+        }
+#pragma unroll
+        for (int r = 0; r < LB_R; r++) {
+            while (jp[r] < je[r] && p.ysrc[jp[r]] == s) { // (clamped edges repeat a source row: every entry is its own addition, in list order)
+                const float wj = p.yw[jp[r]];
+#pragma unroll
+                for (int i = 0; i < NC; i++) {
+                    acc[r][i][0] = acc[r][i][0] + h[i][0] * wj;
+                    acc[r][i][1] = acc[r][i][1] + h[i][1] * wj;
+                    acc[r][i][2] = acc[r][i][2] + h[i][2] * wj;
+                }
+                jp[r]++;
+            }
+        }
+    }
+    __syncthreads(); // every thread is done with the float rows: the output bytes take their place
+    // grey everywhere first (bands left / right of the image, rows of the strip outside it), then the computed pixels
+    const bool planar = !p.nhwc;
+    const int nst = rows * row_b;
+    for (int i = tid * 4; i < nst; i += 1024) *(unsigned *)(stage + i) = 0xefefefefu; // (nst % 4 == 0: row_b = 3 tw, checked by the launcher)
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < LB_R; r++) {
+        if (r < r_lo || r >= r_hi) continue;
+#pragma unroll
+        for (int i = 0; i < NC; i++) {
+            const int x = tid + 256 * i;
+            if (x >= p.nw) continue;
+#pragma unroll
+            for (int c = 0; c < 3; c++) {
+                float v = acc[r][i][c];
+                v = v < 0.0f ? 0.0f : v;
+                v = v > 1.0f ? 1.0f : v;
+                const float t = v * 255.0f;
+                const int q = (int)((double)t + 0.5);
+                const int8_t b = (int8_t)((unsigned char)q - 128);
+                if (planar) stage[(r * 3 + c) * p.tw + p.px + x] = b;
+                else stage[r * row_b + (p.px + x) * 3 + c] = b;
+            }
+        }
+    }
+    __syncthreads();
+    if (!planar) { // rows y0 .. y0 + rows - 1 are one contiguous run of the frame
+        int8_t *o = dst + (size_t)y0 * row_b;
+        if ((((uintptr_t)o | (unsigned)nst) & 15) == 0) {
+            for (int i = tid * 16; i < nst; i += 256 * 16) *(uint4 *)(o + i) = *(const uint4 *)(stage + i);
+        } else {
+            for (int i = tid; i < nst; i += 256) o[i] = stage[i];
+        }
+    } else { // [3][th][tw]: per channel, rows y0 .. are contiguous
+        for (int c = 0; c < 3; c++) {
+            int8_t *o = dst + ((size_t)c * p.th + y0) * p.tw;
+            for (int i = tid; i < rows * p.tw; i += 256) o[i] = stage[((i / p.tw) * 3 + c) * p.tw + i % p.tw];
+        }
+    }
+}
+
+static size_t strip_lds(const mhip_letterbox_t *p) {
+    const size_t row_f = ((size_t)p->w * 3 + 15) & ~(size_t)15;
+    return 1024 + (((size_t)p->nw + 1 + 3) & ~(size_t)3) * 4 + (((size_t)p->n_xtaps + 1) & ~(size_t)1) * 8 + 2 * row_f * 4;
+}
+
 extern "C" int mhip_letterbox(const mhip_letterbox_t *p) {
     if (!p || !p->rgb || !p->out || !p->xstart || !p->xsrc || !p->xw || !p->ystart || !p->ysrc || !p->yw) return -1;
     if (p->frames <= 0 || p->w <= 0 || p->h <= 0 || p->tw <= 0 || p->th <= 0 || p->nw <= 0 || p->nh <= 0 || p->px < 0 ||
         p->py < 0 || p->px + p->nw > p->tw || p->py + p->nh > p->th || p->frames > 65535)
         return -1;
+    // strip form: the gather list and two float rows fit LDS, a source row is at most 512 16-byte pieces, at most 4 columns per thread,
+    // and the strip's output bytes fit where the float rows were
+    if (p->n_xtaps > 0 && p->form != 1 && p->form != 2 && p->nw <= 1024 && (p->w * 3 + 15) / 16 <= 512 && (p->tw * 3) % 4 == 0 && strip_lds(p) <= 96 * 1024 &&
+        (size_t)LB_R * p->tw * 3 <= 2 * ((((size_t)p->w * 3 + 15) & ~(size_t)15) * 4)) {
+        const dim3 g((unsigned)((p->th + LB_R - 1) / LB_R), (unsigned)p->frames);
+        const size_t lds = strip_lds(p);
+        const int nc = (p->nw + 255) / 256;
+#define LB_LAUNCH(NC)                                                                                                                     \
+    do {                                                                                                                                  \
+        static bool attr_##NC = false;                                                                                                    \
+        if (!attr_##NC) {                                                                                                                 \
+            if (hipFuncSetAttribute((const void *)letterbox_strip_kernel<NC>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024) != hipSuccess) \
+                return mhip_check(hipErrorUnknown, "letterbox (strips) attribute");                                                       \
+            attr_##NC = true;                                                                                                             \
+        }                                                                                                                                 \
+        hipLaunchKernelGGL(letterbox_strip_kernel<NC>, g, dim3(256), lds, mhip_stream_native(), *p, p->n_xtaps);                          \
+    } while (0)
+        if (nc <= 1) LB_LAUNCH(1);
+        else if (nc == 2) LB_LAUNCH(2);
+        else if (nc == 3) LB_LAUNCH(3);
+        else LB_LAUNCH(4);
+#undef LB_LAUNCH
+        return mhip_check(hipGetLastError(), "letterbox (strips)");
+    }
     dim3 grid((unsigned)((p->tw + 15) / 16), (unsigned)((p->th + 15) / 16), (unsigned)p->frames);
-    if (p->max_cols > 0 && p->max_rows > 0) {
+    if (p->max_cols > 0 && p->max_rows > 0 && p->form != 2) {
         const size_t lds = 1024 + (size_t)p->max_rows * 48 * 4 + (size_t)p->max_rows * (((size_t)p->max_cols * 3 + 3) & ~(size_t)3);
         if (lds <= 60 * 1024) {
             hipLaunchKernelGGL(letterbox_tiled_kernel, grid, dim3(256), lds, mhip_stream_native(), *p, p->max_cols, p->max_rows);

@@ -219,14 +219,9 @@ mars_error_t mars_hip_pipe_submit(mars_model_t *model) {
     for (uint32_t i = 0; i < model->header.num_inputs && !rc; i++) {
         mtensor_t *t = io_tensor(m, 0, (int)i);
         if (!t || !t->bytes) continue;
-        if (i == 0 && camera) { /* RGB frames up, then the front-end on the same stream into this slot's graph input */
-            uint8_t *own = t->dev;
+        if (i == 0 && camera) { /* RGB frames up; the front-end runs on the MAIN stream ahead of the graph (below): on this stream it stood between
+                                 * batch k's copy and batch k + 1's, and the link idled while it ran (17.7 ms per batch = copy + kernel) */
             rc = mhip_h2d_async(sl->rgb_dev, sl->in_host[0], (size_t)pp->opts.camera_w * pp->opts.camera_h * 3 * B);
-            t->dev = sl->in_dev[0];
-            if (!rc) rc = mhip_event_record(sl->ev_pre0);
-            if (!rc && mars_hip_preprocess_device(model, 0, sl->rgb_dev, pp->opts.camera_w, pp->opts.camera_h, 0, (int)B) != MARS_OK) rc = -1;
-            if (!rc) rc = mhip_event_record(sl->ev_pre1);
-            t->dev = own;
             continue;
         }
         rc = mhip_h2d_2d_async(sl->in_dev[i], t->stride, sl->in_host[i], t->bytes, t->bytes, B);
@@ -247,6 +242,12 @@ mars_error_t mars_hip_pipe_submit(mars_model_t *model) {
     for (uint32_t i = 0; i < model->header.num_outputs; i++) {
         mtensor_t *t = io_tensor(m, 1, (int)i);
         if (t) t->dev = sl->out_dev[i];
+    }
+    if (camera) { /* letterbox / px - 128 into this slot's graph input (now the input tensor's device buffer), then the graph behind it */
+        rc = mhip_event_record(sl->ev_pre0);
+        if (!rc && mars_hip_preprocess_device(model, 0, sl->rgb_dev, pp->opts.camera_w, pp->opts.camera_h, 0, (int)B) != MARS_OK) rc = -1;
+        if (!rc) rc = mhip_event_record(sl->ev_pre1);
+        if (rc) return MARS_ERR_LAYER_FAILED;
     }
     m->tail_pending = 0; /* ordering is by the slot events here, not by the single-buffer hand-off of mars_hip_detect */
     mars_error_t e = mars_hip_run_device_async(model);

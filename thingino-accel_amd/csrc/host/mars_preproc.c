@@ -181,6 +181,7 @@ done:
 typedef struct {
     int w, h, tw, th, nw, nh, px, py;
     int max_cols, max_rows; /* largest source region of a 16 x 16 output tile (for the LDS-tiled kernel) */
+    int n_xtaps;            /* entries of the horizontal gather list (the strip kernel stages it in LDS) */
     void *dev; /* [xstart][xsrc][xw][ystart][ysrc][yw] */
     size_t off[6];
 } geom_t;
@@ -225,6 +226,7 @@ static int geometry(int w, int h, int tw, int th, geom_t **out) {
     const size_t sz[6] = {sizeof(int) * ((size_t)nw + 1), sizeof(int) * (size_t)(gx.n_entries + 1), sizeof(float) * (size_t)(gx.n_entries + 1),
                           sizeof(int) * ((size_t)nh + 1), sizeof(int) * (size_t)(gy.n_entries + 1), sizeof(float) * (size_t)(gy.n_entries + 1)};
     const void *srcs[6] = {gx.start, gx.src, gx.w, gy.start, gy.src, gy.w};
+    const int n_xtaps = gx.n_entries;
     size_t total = 0, off[6];
     for (int i = 0; i < 6; i++) {
         off[i] = total;
@@ -248,6 +250,7 @@ static int geometry(int w, int h, int tw, int th, geom_t **out) {
     g_geom.nw = nw; g_geom.nh = nh;
     g_geom.px = (tw - nw) / 2; g_geom.py = (th - nh) / 2; /* :49 */
     g_geom.max_cols = max_cols; g_geom.max_rows = max_rows;
+    g_geom.n_xtaps = n_xtaps;
     g_geom.dev = dev;
     memcpy(g_geom.off, off, sizeof(off));
     *out = &g_geom;
@@ -263,6 +266,11 @@ static int run_letterbox(const geom_t *g, const uint8_t *rgb_dev, size_t rgb_str
     p.frames = frames; p.w = g->w; p.h = g->h; p.tw = g->tw; p.th = g->th; p.nhwc = nhwc;
     p.nw = g->nw; p.nh = g->nh; p.px = g->px; p.py = g->py;
     p.max_cols = g->max_cols; p.max_rows = g->max_rows;
+    p.n_xtaps = g->n_xtaps;
+    { /* tests: MARS_HIP_LETTERBOX_FORM = 1 / 2 forces the 16 x 16-tile / the one-thread-per-pixel kernel (all three write the same bytes) */
+        const char *e = getenv("MARS_HIP_LETTERBOX_FORM");
+        p.form = e ? atoi(e) : 0;
+    }
     const char *b = (const char *)g->dev;
     p.xstart = (const int *)(b + g->off[0]); p.xsrc = (const int *)(b + g->off[1]); p.xw = (const float *)(b + g->off[2]);
     p.ystart = (const int *)(b + g->off[3]); p.ysrc = (const int *)(b + g->off[4]); p.yw = (const float *)(b + g->off[5]);

@@ -273,6 +273,8 @@ typedef struct {
     const int *xstart, *xsrc; const float *xw; /* gather lists of the horizontal / vertical pass (device) */
     const int *ystart, *ysrc; const float *yw;
     int max_cols, max_rows;                  /* largest source region (columns, rows) any 16 x 16 output tile touches; 0 = unknown */
+    int n_xtaps;                             /* entries of the horizontal gather list (xstart[nw]); 0 = unknown: the strip form is not offered */
+    int form;                                /* 0: the launcher's choice (strips where they fit, else 16 x 16 tiles, else one thread per pixel); 1 / 2: tiles / per-pixel forced (tests) */
 } mhip_letterbox_t;
 int mhip_letterbox(const mhip_letterbox_t *p);
 
