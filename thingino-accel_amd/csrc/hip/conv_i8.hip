@@ -52,6 +52,7 @@ __global__ __launch_bounds__(NW * 64) void conv_i8_mfma(const mhip_conv_i8_t p, 
                                                          const unsigned nblk, const int lg_inc, const unsigned kw_magic,
                                                          const fastdiv_t dhw, const fastdiv_t dow, const int bufmode,
                                                          const unsigned in_bytes) {
+    ANAT_BEGIN();
     const bool POW2 = lg_inc >= 0; // in_c is a power of two: K position by shifts, else carried counters
     const bool masked = p.kh * p.kw <= 32;
     constexpr int SLICE = (BPX + BN) * BK;
@@ -207,6 +208,7 @@ __global__ __launch_bounds__(NW * 64) void conv_i8_mfma(const mhip_conv_i8_t p, 
 
     const int frow = lane & 15, fchunk = lane >> 4;
     int stage = 0, nstage = STAGES - 1;
+    ANAT_NOW(1);
     for (int st = 0; st < nst; st++) {
         // stages still allowed in flight once stage st must have landed
         const int ahead = nst - 1 - st;
@@ -239,6 +241,7 @@ __global__ __launch_bounds__(NW * 64) void conv_i8_mfma(const mhip_conv_i8_t p, 
         stage = stage + 1 == STAGES ? 0 : stage + 1;
         nstage = nstage + 1 == STAGES ? 0 : nstage + 1;
     }
+    ANAT_NOW(2);
     __syncthreads(); // every wave is done reading the ring: reuse it for the output tile
     if (I8M_ABL & 1) {
         int fold = 0;
@@ -250,6 +253,7 @@ __global__ __launch_bounds__(NW * 64) void conv_i8_mfma(const mhip_conv_i8_t p, 
         return;
     }
     epilogue<BPX, BN, WPX, WOC, true>(p, acc, lds, slut, rowoff, oc0, pxw, ocw, hw);
+    ANAT_END(p);
 }
 
 // ---------------------------------------------------------------------------------
@@ -418,6 +422,7 @@ __global__ __launch_bounds__(NTHREADS) void conv_i8_persist(const mhip_conv_i8_t
     // wres (host: 2-stage ring only): the weights of this workgroup's channel tile, all K steps, are fetched ONCE
     // into LDS behind the ring and stay there while the workgroup walks its pixel tiles; the ring then carries pixel
     // tiles only -- for 1x1 layers that halves the LDS-DMA bytes per tile
+    ANAT_BEGIN();
     const int STAGE = wres ? BPX * BK : (BPX + BN) * BK;
     constexpr int NWN = BN == 128 ? 2 : 1;
     constexpr int NWM = 4 / NWN;
@@ -603,6 +608,7 @@ __global__ __launch_bounds__(NTHREADS) void conv_i8_persist(const mhip_conv_i8_t
     const uint8_t *lut128 = slut + 128;
     const bool ragged = (p.out_c % (WOC * 4)) != 0;
     int stage = 0;
+    ANAT_NOW(1);
     for (unsigned tile = t0; tile < t1; tile++) {
         v4i acc[WOC][WPX];
         for (int ks = 0; ks < nks; ks++) {
@@ -644,6 +650,9 @@ __global__ __launch_bounds__(NTHREADS) void conv_i8_persist(const mhip_conv_i8_t
             nstage = nstage + 1 == STAGES ? 0 : nstage + 1;
         }
         // epilogue: requantise, optional LUT, one buffer store per pixel subtile
+#ifdef ANATOMY
+        if (tile + 1 == t1) ANAT_NOW(2); // (the last tile's epilogue has no next tile's K steps to hide behind)
+#endif
 #pragma unroll
         for (int t = 0; t < WPX; t++) {
             const unsigned pix = tile * BPX + pxw + t * 16 + (lane & 15);
@@ -690,7 +699,9 @@ __global__ __launch_bounds__(NTHREADS) void conv_i8_persist(const mhip_conv_i8_t
 #pragma unroll
         for (int i = 0; i < STAGES - 1; i++) younger[i] += ragged ? NST * (WOC == 4 ? 5 : 4) : NST;
     }
+    ANAT_END(p);
 }
+ANAT_SETTER(mhip_anatomy_set_i8)
 // ---------------------------------------------------------------------------------
 // generic kernel: any in_c (the 3-channel stem); register-staged byte gather
 __device__ __forceinline__ bool mhip_small_c_dev(int in_c, int kw, int out_c) { return in_c <= 4 && kw <= 8 && out_c <= 64; }

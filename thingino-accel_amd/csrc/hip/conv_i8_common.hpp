@@ -18,6 +18,58 @@ extern "C" const void *mhip_zero_page(void);
 typedef int v4i __attribute__((ext_vector_type(4)));
 typedef int v2i __attribute__((ext_vector_type(2)));
 
+// ---- launch anatomy (diagnostic build only: tools/anatomy_build.sh -> lib/diag/lib_anatomy.so, read by tools/launch_anatomy.py; round 6,
+// VERDICT r5 item 4).  Thread 0 of every workgroup of the int8 convolution kernels stamps the 100 MHz constant clock (s_memrealtime: the
+// same time base on every CU and XCD) at its start, when its prologue is over (tables / LUT / resident weights / first pipeline stages
+// issued: the first counted wait of the K stream comes next), when its K stream is over (the last epilogue, or for a tile walker its last
+// tile's, comes next) and at its end, and appends {launch key = output pointer, workgroup, hardware slot, 4 stamps} to a side buffer.
+// The shipped library compiles none of it.
+#ifdef ANATOMY
+struct anat_rec_t {
+    unsigned key, wg, hwid, xcc;
+    unsigned long long t[4];
+};
+static __device__ anat_rec_t *g_anat_buf; // record 0 is the header: .key = records appended so far
+static __device__ unsigned g_anat_cap;
+#define ANAT_SETTER(NAME)                                                                                                    \
+    extern "C" int NAME(void *buf, unsigned cap) {                                                                          \
+        return hipMemcpyToSymbol(HIP_SYMBOL(g_anat_buf), &buf, sizeof buf) == hipSuccess &&                                  \
+                       hipMemcpyToSymbol(HIP_SYMBOL(g_anat_cap), &cap, sizeof cap) == hipSuccess                             \
+                   ? 0                                                                                                       \
+                   : -1;                                                                                                     \
+    }
+#define ANAT_NOW(i)                                                                                                          \
+    do {                                                                                                                     \
+        __builtin_amdgcn_sched_barrier(0);                                                                                   \
+        an_t[i] = __builtin_amdgcn_s_memrealtime();                                                                          \
+        __builtin_amdgcn_sched_barrier(0);                                                                                   \
+    } while (0)
+#define ANAT_BEGIN()                                                                                                         \
+    unsigned long long an_t[4] = {0, 0, 0, 0};                                                                               \
+    ANAT_NOW(0)
+#define ANAT_END(P)                                                                                                          \
+    do {                                                                                                                     \
+        ANAT_NOW(3);                                                                                                         \
+        if (threadIdx.x == 0 && g_anat_buf) {                                                                                \
+            const unsigned an_i = atomicAdd(&g_anat_buf[0].key, 1u) + 1u;                                                    \
+            if (an_i < g_anat_cap) {                                                                                         \
+                anat_rec_t an_r;                                                                                             \
+                an_r.key = (unsigned)((size_t)(P).out >> 4) ^ (unsigned)(P).out_ch_off;                                      \
+                an_r.wg = blockIdx.x + gridDim.x * blockIdx.y;                                                               \
+                an_r.hwid = __builtin_amdgcn_s_getreg(4 | (0 << 6) | (31 << 11));  /* HW_ID: wave, simd, cu, sh, se */      \
+                an_r.xcc = __builtin_amdgcn_s_getreg(20 | (0 << 6) | (3 << 11));   /* XCC_ID */                              \
+                for (int q = 0; q < 4; q++) an_r.t[q] = an_t[q];                                                             \
+                g_anat_buf[an_i] = an_r;                                                                                     \
+            }                                                                                                                \
+        }                                                                                                                    \
+    } while (0)
+#else
+#define ANAT_SETTER(NAME)
+#define ANAT_NOW(i) do { } while (0)
+#define ANAT_BEGIN() do { } while (0)
+#define ANAT_END(P) do { } while (0)
+#endif
+
 #define BP 128      // pixels per workgroup
 #define BK 64       // K bytes per step = one MFMA
 #define NTHREADS 256

@@ -84,6 +84,7 @@ __global__ __launch_bounds__(NTHREADS) void conv_i8_patch(const mhip_conv_i8_t p
                                                           const int8_t *__restrict__ zeros, const fastdiv_t dtx,
                                                           const fastdiv_t dty, const fastdiv_t dpwp, const unsigned out_bytes,
                                                           const int ring, const int xmap, const unsigned in_bytes) {
+    ANAT_BEGIN();
     constexpr int WPX = TH / 4;  // tile rows (16-pixel subtiles) per wave
     constexpr int WOC = BN / 16; // every wave covers all BN channels of its rows
     constexpr int NST = WPX;     // buffer stores per wave and tile
@@ -251,6 +252,7 @@ __global__ __launch_bounds__(NTHREADS) void conv_i8_patch(const mhip_conv_i8_t p
     int cur = 0;       // ring slot of the tile being computed
     int pn_last = 0;   // LDS-DMA instructions issued after this tile's residual request
     bool first = true;
+    ANAT_NOW(1);
     for (; t < ntiles; t += G) {
         STAMP(st0);
         int tx, ty;
@@ -465,6 +467,8 @@ __global__ __launch_bounds__(NTHREADS) void conv_i8_patch(const mhip_conv_i8_t p
         sum_wait += st1 - st0; sum_issue += st2 - st1; sum_k += st3 - st2; sum_epi += st4 - st3; sum_tiles += 1;
 #endif
     }
+    ANAT_NOW(2);
+    ANAT_END(p);
 #ifdef PATCH_STAMPS
     if (lane == 0) {
         atomicAdd(&patch_stamp_sums[0], sum_wait); atomicAdd(&patch_stamp_sums[1], sum_issue); atomicAdd(&patch_stamp_sums[2], sum_k);
@@ -473,6 +477,7 @@ __global__ __launch_bounds__(NTHREADS) void conv_i8_patch(const mhip_conv_i8_t p
 #endif
 }
 
+ANAT_SETTER(mhip_anatomy_set_patch)
 // ---- patch-staged kernel: geometry, eligibility, launch
 struct patch_geom_t {
     int bn, tiles_x, tiles_y, PH, PW, PWP, PWH, nblk, nks, ring;

@@ -89,6 +89,7 @@ struct rows_args_t {
 // their own precomputed address each.
 template <int PWP, bool HAS_LUT>
 __global__ __launch_bounds__(512) void conv_i8_rows(const mhip_conv_i8_t p, const rows_args_t a) {
+    ANAT_BEGIN();
     extern __shared__ __attribute__((aligned(16))) int8_t dynlds[];
     uint8_t *slut = (uint8_t *)dynlds; // LDS byte address 0 (LUT look-ups use immediate offsets)
     lds_base_must_be_zero(dynlds);
@@ -264,6 +265,7 @@ __global__ __launch_bounds__(512) void conv_i8_rows(const mhip_conv_i8_t p, cons
     unsigned long long s0 = 0, s1 = 0, s2 = 0, s3 = 0, s4 = 0, sum_wait = 0, sum_pre = 0, sum_mfma = 0, sum_steps = 0;
 #endif
 
+    ANAT_NOW(1);
     for (unsigned t = t0; t < t1; t++) {
         cur_setup(t);
         const bool last_tile = t + 1 == t1;
@@ -364,6 +366,8 @@ __global__ __launch_bounds__(512) void conv_i8_rows(const mhip_conv_i8_t p, cons
         } else if (!(ROWS_ABL & 4)) epilogue_tile(t);
     }
     if (!late) __builtin_amdgcn_s_barrier(); // pairs with the trailing waves' last one
+    ANAT_NOW(2);
+    ANAT_END(p);
 #ifdef ROWS_STAMPS
     if (lane == 0) {
         const int o = late ? 8 : 0;
@@ -372,6 +376,7 @@ __global__ __launch_bounds__(512) void conv_i8_rows(const mhip_conv_i8_t p, cons
     }
 #endif
 }
+ANAT_SETTER(mhip_anatomy_set_rows)
 
 // ---------------------------------------------------------------------------------
 // host side

@@ -17,6 +17,7 @@ __global__ __launch_bounds__(NTHREADS) void conv_i8_smallc(const mhip_conv_i8_t 
                                                            const int PW, const int PWp, const fastdiv_t dhw,
                                                            const fastdiv_t dtx, const fastdiv_t dty, const fastdiv_t dgpr,
                                                            const int tile_bytes) {
+    ANAT_BEGIN();
     constexpr int BN = WOC * 16;
     constexpr int WPX = SC_TH / 4; // tile rows (= pixel subtiles of 16) per wave
     extern __shared__ __attribute__((aligned(16))) int8_t dyn[];
@@ -160,6 +161,7 @@ __global__ __launch_bounds__(NTHREADS) void conv_i8_smallc(const mhip_conv_i8_t 
         fetch(t);
         commit(patch0);
     }
+    ANAT_NOW(1);
     for (; t < ntiles; t += gridDim.x) {
         __syncthreads(); // patch[buf] committed by everyone; previous copy-out (tile, rowoff) finished
         const int8_t *patch = patch0 + buf * patch_bytes;
@@ -221,6 +223,8 @@ __global__ __launch_bounds__(NTHREADS) void conv_i8_smallc(const mhip_conv_i8_t 
             epilogue<SC_BP, BN, WPX, WOC, true>(p, acc, tile, slut, rowoff, 0, wv * (WPX * 16), 0, hw);
         }
     }
+    ANAT_NOW(2);
+    ANAT_END(p);
 }
 
 // ---------------------------------------------------------------------------------
@@ -255,6 +259,7 @@ template <int WOC, int KS, bool LUT2>
 __device__ __forceinline__ void conv_i8_rgb_body(
     const mhip_conv_i8_t &p, const int k64, const int tiles_x, const int tiles_y, const unsigned ntiles_all, const fastdiv_t dtx,
     const fastdiv_t dty, const unsigned in_bytes, const unsigned out_bytes) {
+    ANAT_BEGIN();
     constexpr int TR = RGB_TH / 4;  // output rows per wave
     constexpr int NJ = TR + KS - 1; // row pairs of the wave's window
     extern __shared__ __attribute__((aligned(16))) int8_t dyn[];
@@ -474,6 +479,7 @@ __device__ __forceinline__ void conv_i8_rgb_body(
     __syncthreads(); // table, weights, bias in LDS
     unsigned t = blockIdx.x;
     if (t < ntiles) fetch(t, jz{}, ja{});
+    ANAT_NOW(1);
     for (; t < ntiles; t += gridDim.x) {
         int tx, ty;
         unsigned f;
@@ -492,7 +498,10 @@ __device__ __forceinline__ void conv_i8_rgb_body(
         if (tn < ntiles) fetch(tn, jz{}, ja{}); // the next tile's operands travel during the second phase's requantisation
         rows_store(2, acc, oy0, ox0, obase);
     }
+    ANAT_NOW(2);
+    ANAT_END(p);
 }
+ANAT_SETTER(mhip_anatomy_set_stem)
 
 // the hot instantiation (32 channels, fused table) fits 4 waves per SIMD without spilling; the others are left to the
 // allocator (3 waves)

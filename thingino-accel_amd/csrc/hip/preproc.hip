@@ -177,15 +177,17 @@ __global__ __launch_bounds__(256) void letterbox_tiled_kernel(const mhip_letterb
 // The same float operations in the same order as the two kernels above, bit for bit (tests/test_gpu_preproc.py); letterbox bands
 // (strips outside the resized image) are filled without touching the source.
 #define LB_R 8
+#define LB_YT 64 // entries per output row of the staged vertical lists (longer lists: the launcher takes another form)
 template <int NC>
 __global__ __launch_bounds__(256) void letterbox_strip_kernel(const mhip_letterbox_t p, const int n_xtaps) {
     extern __shared__ __attribute__((aligned(16))) unsigned char sm[];
     const int tid = threadIdx.x;
-    const int row_f = ((p.w * 3 + 15) & ~15);                 // floats per staged source row (the tail of the last 16-byte load lands here too)
+    const int row_f = ((p.w * 3 + 15) & ~15);                 // floats per staged source row (the last dword's tail lands here too)
     float *dec = (float *)sm;                                 // [256]
     int *xs_l = (int *)(dec + 256);                           // [nw + 1] (+ pad to a multiple of 4)
     int2 *tap_l = (int2 *)(xs_l + ((p.nw + 1 + 3) & ~3));     // [n_xtaps] {source column * 3, weight bits}
-    float *rowf = (float *)(tap_l + ((n_xtaps + 1) & ~1));    // [2][row_f]
+    int2 *yl = tap_l + ((n_xtaps + 1) & ~1);                  // [LB_R][LB_YT] {source row, weight bits} of the strip's rows, -1 terminated
+    float *rowf = (float *)(yl + LB_R * LB_YT);               // [2][row_f]
     int8_t *stage = (int8_t *)rowf;                           // (after the last source row) [LB_R][tw * 3] output bytes
     const int f = blockIdx.y, y0 = blockIdx.x * LB_R;
     const uint8_t *src = p.rgb + (size_t)f * p.rgb_stride;
@@ -215,18 +217,21 @@ __global__ __launch_bounds__(256) void letterbox_strip_kernel(const mhip_letterb
     dec[tid] = (float)tid / 255.0f;
     for (int i = tid; i <= p.nw; i += 256) xs_l[i] = p.xstart[i];
     for (int i = tid; i < n_xtaps; i += 256) tap_l[i] = make_int2(p.xsrc[i] * 3, __float_as_int(p.xw[i]));
-    // vertical lists of the strip's rows (uniform: scalar registers)
-    int jp[LB_R], je[LB_R];
+    // vertical lists of the strip's rows: staged in LDS once (walking them in global memory cost a dependent scalar load per output row and
+    // source row: ~2400 cycles of latency per source row), each behind a terminator no source row matches; jp[r] = the list's read pointer
+    int jp[LB_R];
     int s0 = 0x7fffffff, s1 = -1;
 #pragma unroll
     for (int r = 0; r < LB_R; r++) {
         const bool in = r >= r_lo && r < r_hi;
         const int ry = in ? y0 + r - p.py : 0;
-        jp[r] = in ? p.ystart[ry] : 0;
-        je[r] = in ? p.ystart[ry + 1] : 0;
-        if (in && je[r] > jp[r]) {
-            s0 = min(s0, p.ysrc[jp[r]]);
-            s1 = max(s1, p.ysrc[je[r] - 1]);
+        const int j0 = in ? p.ystart[ry] : 0, j1 = in ? p.ystart[ry + 1] : 0;
+        jp[r] = r * LB_YT;
+        for (int j = j0 + tid; j < j1; j += 256) yl[r * LB_YT + j - j0] = make_int2(p.ysrc[j], __float_as_int(p.yw[j]));
+        if (tid == 0) yl[r * LB_YT + j1 - j0] = make_int2(-1, 0);
+        if (j1 > j0) {
+            s0 = min(s0, p.ysrc[j0]);
+            s1 = max(s1, p.ysrc[j1 - 1]);
         }
     }
     float acc[LB_R][NC][3];
@@ -234,21 +239,23 @@ __global__ __launch_bounds__(256) void letterbox_strip_kernel(const mhip_letterb
     for (int r = 0; r < LB_R; r++)
 #pragma unroll
         for (int i = 0; i < NC; i++) acc[r][i][0] = acc[r][i][1] = acc[r][i][2] = 0.0f;
-    // a source row = w * 3 bytes from a 1-byte-aligned address: 16-byte loads (unaligned ones are served on gfx950); a ragged last
-    // piece is put together from single bytes (one thread per row: nothing is read beyond the row)
-    const int rb = p.w * 3, nld = (rb + 15) >> 4; // 16-byte pieces per row
-    uint4 ld[2];
+    // a source row = w * 3 bytes from a 1-byte-aligned address, fetched as dwords (unaligned ones are served on gfx950): dword d of the row
+    // belongs to thread d % 256, so that a wave reads 256 contiguous bytes and -- converted -- writes 64 consecutive float4s (lane-linear:
+    // no bank conflicts; 16 bytes per thread put the lanes' float4s 64 bytes apart, a 4-way conflict on every write).  A ragged last dword
+    // is put together from single bytes: nothing is read beyond the row
+    const int rb = p.w * 3, nld = (rb + 3) >> 2; // dwords per row (at most 8 per thread: the launcher checks)
+    unsigned ld[8];
     auto fetch = [&](int s) __attribute__((always_inline)) {
 #pragma unroll
-        for (int k = 0; k < 2; k++) {
+        for (int k = 0; k < 8; k++) {
             const int i = tid + 256 * k;
             if (i < nld) {
-                const uint8_t *g = src + (size_t)s * rb + (size_t)i * 16;
-                if (i * 16 + 16 <= rb) __builtin_memcpy(&ld[k], g, 16);
+                const uint8_t *g = src + (size_t)s * rb + (size_t)i * 4;
+                if (i * 4 + 4 <= rb) __builtin_memcpy(&ld[k], g, 4);
                 else {
-                    unsigned v[4] = {0u, 0u, 0u, 0u};
-                    for (int b = 0; b < rb - i * 16; b++) v[b >> 2] |= (unsigned)g[b] << (8 * (b & 3));
-                    ld[k] = make_uint4(v[0], v[1], v[2], v[3]);
+                    unsigned v = 0u;
+                    for (int b = 0; b < rb - i * 4; b++) v |= (unsigned)g[b] << (8 * b);
+                    ld[k] = v;
                 }
             }
         }
@@ -257,43 +264,60 @@ __global__ __launch_bounds__(256) void letterbox_strip_kernel(const mhip_letterb
     for (int s = s0; s <= s1; s++) {
         float *rf = rowf + ((s - s0) & 1) * row_f;
 #pragma unroll
-        for (int k = 0; k < 2; k++) { // bytes -> floats, once per byte
+        for (int k = 0; k < 8; k++) { // bytes -> floats, once per byte
             const int i = tid + 256 * k;
             if (i < nld) {
-                const unsigned v[4] = {ld[k].x, ld[k].y, ld[k].z, ld[k].w};
-#pragma unroll
-                for (int q = 0; q < 4; q++)
-                    *(float4 *)(rf + i * 16 + q * 4) = make_float4(dec[v[q] & 255u], dec[(v[q] >> 8) & 255u], dec[(v[q] >> 16) & 255u], dec[v[q] >> 24]);
+                const unsigned v = ld[k];
+                *(float4 *)(rf + i * 4) = make_float4(dec[v & 255u], dec[(v >> 8) & 255u], dec[(v >> 16) & 255u], dec[v >> 24]);
             }
         }
         if (s < s1) fetch(s + 1);
         __syncthreads(); // (also orders the tables / dec staged above before their first use)
-        // does any of the strip's rows use this source row?  (uniform)
+        // the heads of the eight vertical lists: one batch of (broadcast) LDS reads; does any of the strip's rows use this source row?
+        int2 head[LB_R];
         bool used = false;
 #pragma unroll
-        for (int r = 0; r < LB_R; r++) used |= jp[r] < je[r] && p.ysrc[jp[r]] == s;
+        for (int r = 0; r < LB_R; r++) {
+            head[r] = yl[jp[r]];
+            head[r].x = __builtin_amdgcn_readfirstlane(head[r].x);
+            head[r].y = __builtin_amdgcn_readfirstlane(head[r].y);
+            used |= head[r].x == s;
+        }
         if (!used) continue;
+        // horizontal sums of this thread's NC columns, their lists walked SIDE BY SIDE (3 * NC independent chains and NC tap / pixel reads in
+        // flight per round instead of one column after the other), the next round's taps read ahead of this round's additions
         float h[NC][3];
+        int kk[NC], kn[NC], nmax = 0;
 #pragma unroll
         for (int i = 0; i < NC; i++) {
             const int x = tid + 256 * i;
             h[i][0] = h[i][1] = h[i][2] = 0.0f;
-            if (x < p.nw) {
-                const int k1 = xs_l[x + 1];
-                for (int k = xs_l[x]; k < k1; k++) {
-                    const int2 t = tap_l[k];
-                    const float *q = rf + t.x;
-                    const float wk = __int_as_float(t.y);
-                    h[i][0] = h[i][0] + q[0] * wk;
-                    h[i][1] = h[i][1] + q[1] * wk;
-                    h[i][2] = h[i][2] + q[2] * wk;
-                }
+            kk[i] = x < p.nw ? xs_l[x] : 0;
+            kn[i] = x < p.nw ? xs_l[x + 1] - kk[i] : 0;
+            nmax = max(nmax, kn[i]);
+        }
+        for (int j = 0; j < nmax; j++) {
+            int2 t[NC];
+            float v[NC][3];
+#pragma unroll
+            for (int i = 0; i < NC; i++) {
+                t[i] = j < kn[i] ? tap_l[kk[i] + j] : make_int2(0, 0); // (past a column's list: weight +0, pixel 0 -- not added, see below)
+                const float *q = rf + t[i].x;
+                v[i][0] = q[0]; v[i][1] = q[1]; v[i][2] = q[2];
             }
+#pragma unroll
+            for (int i = 0; i < NC; i++)
+                if (j < kn[i]) { // (h + x * (+0) would turn a -0 sum into +0 and an inf pixel into NaN: entries past the list are not added)
+                    const float wk = __int_as_float(t[i].y);
+                    h[i][0] = h[i][0] + v[i][0] * wk;
+                    h[i][1] = h[i][1] + v[i][1] * wk;
+                    h[i][2] = h[i][2] + v[i][2] * wk;
+                }
         }
 #pragma unroll
         for (int r = 0; r < LB_R; r++) {
-            while (jp[r] < je[r] && p.ysrc[jp[r]] == s) { // (clamped edges repeat a source row: every entry is its own addition, in list order)
-                const float wj = p.yw[jp[r]];
+            while (head[r].x == s) { // (clamped edges repeat a source row: every entry is its own addition, in list order)
+                const float wj = __int_as_float(head[r].y);
 #pragma unroll
                 for (int i = 0; i < NC; i++) {
                     acc[r][i][0] = acc[r][i][0] + h[i][0] * wj;
@@ -301,6 +325,9 @@ __global__ __launch_bounds__(256) void letterbox_strip_kernel(const mhip_letterb
                     acc[r][i][2] = acc[r][i][2] + h[i][2] * wj;
                 }
                 jp[r]++;
+                head[r] = yl[jp[r]];
+                head[r].x = __builtin_amdgcn_readfirstlane(head[r].x);
+                head[r].y = __builtin_amdgcn_readfirstlane(head[r].y);
             }
         }
     }
@@ -348,7 +375,7 @@ __global__ __launch_bounds__(256) void letterbox_strip_kernel(const mhip_letterb
 
 static size_t strip_lds(const mhip_letterbox_t *p) {
     const size_t row_f = ((size_t)p->w * 3 + 15) & ~(size_t)15;
-    return 1024 + (((size_t)p->nw + 1 + 3) & ~(size_t)3) * 4 + (((size_t)p->n_xtaps + 1) & ~(size_t)1) * 8 + 2 * row_f * 4;
+    return 1024 + (((size_t)p->nw + 1 + 3) & ~(size_t)3) * 4 + (((size_t)p->n_xtaps + 1) & ~(size_t)1) * 8 + (size_t)LB_R * LB_YT * 8 + 2 * row_f * 4;
 }
 
 extern "C" int mhip_letterbox(const mhip_letterbox_t *p) {
@@ -358,7 +385,7 @@ extern "C" int mhip_letterbox(const mhip_letterbox_t *p) {
         return -1;
     // strip form: the gather list and two float rows fit LDS, a source row is at most 512 16-byte pieces, at most 4 columns per thread,
     // and the strip's output bytes fit where the float rows were
-    if (p->n_xtaps > 0 && p->form != 1 && p->form != 2 && p->nw <= 1024 && (p->w * 3 + 15) / 16 <= 512 && (p->tw * 3) % 4 == 0 && strip_lds(p) <= 96 * 1024 &&
+    if (p->n_xtaps > 0 && p->max_ytaps > 0 && p->max_ytaps < LB_YT && p->form != 1 && p->form != 2 && p->nw <= 1024 && (p->w * 3 + 3) / 4 <= 2048 && (p->tw * 3) % 4 == 0 && strip_lds(p) <= 96 * 1024 &&
         (size_t)LB_R * p->tw * 3 <= 2 * ((((size_t)p->w * 3 + 15) & ~(size_t)15) * 4)) {
         const dim3 g((unsigned)((p->th + LB_R - 1) / LB_R), (unsigned)p->frames);
         const size_t lds = strip_lds(p);

@@ -181,7 +181,7 @@ done:
 typedef struct {
     int w, h, tw, th, nw, nh, px, py;
     int max_cols, max_rows; /* largest source region of a 16 x 16 output tile (for the LDS-tiled kernel) */
-    int n_xtaps;            /* entries of the horizontal gather list (the strip kernel stages it in LDS) */
+    int n_xtaps, max_ytaps; /* entries of the horizontal gather list / the longest vertical list of one output row (the strip kernel stages them in LDS) */
     void *dev; /* [xstart][xsrc][xw][ystart][ysrc][yw] */
     size_t off[6];
 } geom_t;
@@ -227,6 +227,9 @@ static int geometry(int w, int h, int tw, int th, geom_t **out) {
                           sizeof(int) * ((size_t)nh + 1), sizeof(int) * (size_t)(gy.n_entries + 1), sizeof(float) * (size_t)(gy.n_entries + 1)};
     const void *srcs[6] = {gx.start, gx.src, gx.w, gy.start, gy.src, gy.w};
     const int n_xtaps = gx.n_entries;
+    int max_ytaps = 0;
+    for (int o = 0; o < nh; o++)
+        if (gy.start[o + 1] - gy.start[o] > max_ytaps) max_ytaps = gy.start[o + 1] - gy.start[o];
     size_t total = 0, off[6];
     for (int i = 0; i < 6; i++) {
         off[i] = total;
@@ -250,7 +253,7 @@ static int geometry(int w, int h, int tw, int th, geom_t **out) {
     g_geom.nw = nw; g_geom.nh = nh;
     g_geom.px = (tw - nw) / 2; g_geom.py = (th - nh) / 2; /* :49 */
     g_geom.max_cols = max_cols; g_geom.max_rows = max_rows;
-    g_geom.n_xtaps = n_xtaps;
+    g_geom.n_xtaps = n_xtaps; g_geom.max_ytaps = max_ytaps;
     g_geom.dev = dev;
     memcpy(g_geom.off, off, sizeof(off));
     *out = &g_geom;
@@ -266,7 +269,7 @@ static int run_letterbox(const geom_t *g, const uint8_t *rgb_dev, size_t rgb_str
     p.frames = frames; p.w = g->w; p.h = g->h; p.tw = g->tw; p.th = g->th; p.nhwc = nhwc;
     p.nw = g->nw; p.nh = g->nh; p.px = g->px; p.py = g->py;
     p.max_cols = g->max_cols; p.max_rows = g->max_rows;
-    p.n_xtaps = g->n_xtaps;
+    p.n_xtaps = g->n_xtaps; p.max_ytaps = g->max_ytaps;
     { /* tests: MARS_HIP_LETTERBOX_FORM = 1 / 2 forces the 16 x 16-tile / the one-thread-per-pixel kernel (all three write the same bytes) */
         const char *e = getenv("MARS_HIP_LETTERBOX_FORM");
         p.form = e ? atoi(e) : 0;

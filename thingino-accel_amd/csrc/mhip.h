@@ -274,6 +274,7 @@ typedef struct {
     const int *ystart, *ysrc; const float *yw;
     int max_cols, max_rows;                  /* largest source region (columns, rows) any 16 x 16 output tile touches; 0 = unknown */
     int n_xtaps;                             /* entries of the horizontal gather list (xstart[nw]); 0 = unknown: the strip form is not offered */
+    int max_ytaps;                           /* longest vertical gather list of one output row (the strip form stages 8 of them in LDS); 0 = unknown */
     int form;                                /* 0: the launcher's choice (strips where they fit, else 16 x 16 tiles, else one thread per pixel); 1 / 2: tiles / per-pixel forced (tests) */
 } mhip_letterbox_t;
 int mhip_letterbox(const mhip_letterbox_t *p);
