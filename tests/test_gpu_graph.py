@@ -1372,90 +1372,6 @@ def test_conv_f32_stem_shapes(gpu, orc, shape):
         gpu.set_tuning("dual_stream_min_batch", 64)
 
 
-F32_PW_SHAPES = [
-    # h, w, in_c, out_c, batch, silu, add                      conv_f32_pw (round 5): 1 x 1 layers
-    (40, 40, 256, 128, 3, True, False),    # 128-channel tile, 256-pixel tiles, 8 K steps
-    (20, 20, 512, 255, 5, False, False),   # a detection head: two channel tiles (the second 127 full), 2000 pixels = 7.8 tiles
-    (80, 80, 64, 32, 2, True, True),       # 32-channel tile on 512-pixel tiles, fused residual Add
-    (16, 20, 96, 72, 7, True, False),      # 96 channels: the 4th K step's channels are beyond the tensor (zeros)
-    (12, 12, 40, 64, 9, True, True),       # 40 channels (not a multiple of 8), 64-channel tile, 1296 pixels = 2.5 tiles of 512
-    (8, 8, 1024, 512, 2, True, False),     # deep: 32 K steps, four channel tiles
-]
-
-
-@pytest.mark.parametrize("shape", F32_PW_SHAPES, ids=lambda v: "x".join(str(q) for q in v))
-def test_conv_f32_pw_shapes(gpu, orc, shape):
-    """one float32 1 x 1 convolution (+ fused SIGMOID / MUL, + fused residual Add) through conv_f32_pw (mode 3 with the opt-in knob
-    "f32_pw" = 1 -- the kernel is correct but slower than conv_f32_split, which stays the default for 1 x 1 layers: two phases per K
-    step, input split once into an LDS slot, csrc/hip/conv_f32_pw.hip): every frame against the oracle within 1e-4 * max(1, |b|),
-    one workgroup per CU and three workgroups over all tiles (`persist_slots`: the pipeline through tile boundaries); the launch
-    counter proves the kernel ran in mode 3 and did not in modes 4 / 0."""
-    h, w, ic, oc, B, silu, add = shape
-    rng = np.random.default_rng(h * 1000 + w * 10 + ic)
-    G = marsfile.Graph()
-    F, N = marsfile.F32, marsfile.NCHW
-    x = G.tensor([1, ic, h, w], dtype=F, fmt=N)
-    a = G.tensor([1, oc, h, w], dtype=F, fmt=N)
-    amp = 1.7 / ic ** 0.5
-    wt = G.tensor([oc, ic, 1, 1], dtype=F, fmt=marsfile.OIHW, data=((rng.random((oc, ic, 1, 1), dtype=np.float32) * 2 - 1) * amp).astype(np.float32))
-    b = G.tensor([oc], dtype=F, fmt=marsfile.D1, data=((rng.random(oc, dtype=np.float32) * 2 - 1) * 0.1).astype(np.float32))
-    G.conv(x, a, wt, b, (1, 1), (1, 1), pad=marsfile.PAD_VALID)
-    out = a
-    if silu:
-        g_, o_ = G.tensor([1, oc, h, w], dtype=F, fmt=N), G.tensor([1, oc, h, w], dtype=F, fmt=N)
-        G.layer(marsfile.SIGMOID, [a], [g_])
-        G.layer(marsfile.MUL, [a, g_], [o_])
-        out = o_
-    ins = [x]
-    if add:
-        r_, s_ = G.tensor([1, oc, h, w], dtype=F, fmt=N), G.tensor([1, oc, h, w], dtype=F, fmt=N)
-        G.layer(marsfile.ADD, [out, r_], [s_])
-        ins.append(r_)
-        out = s_
-    d = G.serialise(ins, [out])
-    nx = min(B, 3)
-    xs = [(rng.random(ic * h * w, dtype=np.float32) * 2 - 1).astype(np.float32) for _ in range(nx)]
-    rs = [(rng.random(oc * h * w, dtype=np.float32) * 2 - 1).astype(np.float32) for _ in range(nx)]
-    want = []
-    for q, r in zip(xs, rs):
-        g = orc.Graph(d)
-        g.set_input(0, q.tobytes())
-        if add:
-            g.set_input(1, r.tobytes())
-        assert g.run() == 0
-        want.append(g.tensor(out).copy())
-        g.close()
-    count = gpu.lib().mhip_conv_f32_pw_launches
-    count.restype = C.c_ulong
-    try:
-        gpu.set_tuning("f32_pw", 1)
-        gpu.set_tuning("dual_stream_min_batch", 0)
-        for mode, slots in ((3, 0), (3, 3), (4, 0), (0, 0)):
-            gpu.set_tuning("f32_mfma", mode)
-            gpu.set_tuning("persist_slots", slots)
-            m = gpu.Model(d, batch=B)
-            for f in range(B):
-                m.input_view(0)[f] = xs[f % nx].view(np.uint8)
-                if add:
-                    m.input_view(1)[f] = rs[f % nx].view(np.uint8)
-            n0 = count()
-            m.run()
-            assert count() - n0 == (1 if mode == 3 else 0), "mode %d: conv_f32_pw launched %d time(s)" % (mode, count() - n0)
-            got = m.output_view(0).copy()
-            m.close()
-            for f in range(B):
-                if mode == 0:
-                    assert np.array_equal(got[f], want[f % nx]), "mode 0 frame %d" % f
-                else:
-                    ok = close_f32(got[f], want[f % nx])
-                    assert ok.all(), "mode %d slots %d frame %d: %d of %d out of tolerance" % (mode, slots, f, int((~ok).sum()), ok.size)
-    finally:
-        gpu.set_tuning("f32_pw", 0)
-        gpu.set_tuning("f32_mfma", 1)
-        gpu.set_tuning("persist_slots", 0)
-        gpu.set_tuning("dual_stream_min_batch", 64)
-
-
 def test_deferred_load_and_arena_copy(gpu):
     """what every rank but 0 does in the multi-GPU job: load DESCRIPTORS only (weights blob zeroed,
     MARS_HIP_LOAD_DEFER_WEIGHTS), receive rank 0's packed parameter arena byte for byte (here: a device-to-device

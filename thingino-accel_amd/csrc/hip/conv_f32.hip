@@ -226,13 +226,7 @@ __global__ __launch_bounds__(256) void conv_f32_mfma(const mhip_conv_f32_t p, co
 int conv_f32_try_split(const mhip_conv_f32_t *p); // conv_f32_split.hip: -2 = not a shape it takes
 int conv_f32_try_patch(const mhip_conv_f32_t *p); // conv_f32_patch.hip: -2 = not a shape it takes (or no image packed)
 int conv_f32_try_stem(const mhip_conv_f32_t *p);  // conv_f32_stem.hip: likewise
-int conv_f32_try_pw(const mhip_conv_f32_t *p);    // conv_f32_pw.hip: 1 x 1 layers, likewise (reads conv_f32_split's image)
 
-static int g_f32_pw = 0;
-extern "C" int mhip_conv_f32_pw_mode(int set) { // set >= 0: 0 / 1; returns the value in force
-    if (set >= 0) g_f32_pw = set != 0;
-    return g_f32_pw;
-}
 static int g_f32_mode = -1; // -1: environment not read yet
 extern "C" int mhip_conv_f32_mode(int set) { // set >= 0: new mode; returns the mode in force
     if (g_f32_mode < 0) {
@@ -256,11 +250,6 @@ extern "C" int mhip_conv_f32(const mhip_conv_f32_t *p) {
         if (rc != -2) return rc;
         rc = conv_f32_try_patch(p); // k x k layers, three piece products: the patch-staged form (round 5)
         if (rc != -2) return rc;
-        if (g_f32_pw && !p->in_rec && !p->out_rec) { // 1 x 1 layers in the two-phase form: built and bit-checked in round 5, SLOWER than conv_f32_split (its LDS
-                        // writes are 16-way bank conflicts by construction: profiles/r05_experiments.md), so opt-in ("f32_pw" = 1)
-            rc = conv_f32_try_pw(p);
-            if (rc != -2) return rc;
-        }
         rc = p->w_split ? conv_f32_try_split(p) : -2;
         if (rc != -2) return rc;
     }

@@ -633,7 +633,7 @@ extern "C" unsigned long mhip_conv_f32_pair_launches(void) { return g_pair_launc
 int conv_f32_try_split(const mhip_conv_f32_t *p) { return try_split(p, nullptr); }
 // two convolutions over the same input, same geometry and channel count (no residual, no record output), as ONE grid; -2 = not eligible
 extern "C" int mhip_conv_f32_pair(const mhip_conv_f32_t *a, const mhip_conv_f32_t *b) {
-    if (!a || !b || !a->w_split || !b->w_split || a->w_patch || b->w_patch || a->use_mfma < 2 || a->use_mfma != b->use_mfma || mhip_conv_f32_pw_mode(-1)) return -2;
+    if (!a || !b || !a->w_split || !b->w_split || a->w_patch || b->w_patch || a->use_mfma < 2 || a->use_mfma != b->use_mfma) return -2;
     if (a->in != b->in || a->in_stride != b->in_stride || a->frames != b->frames || a->in_h != b->in_h || a->in_w != b->in_w || a->in_c != b->in_c ||
         a->out_h != b->out_h || a->out_w != b->out_w || a->out_c != b->out_c || a->kh != b->kh || a->kw != b->kw || a->stride_h != b->stride_h ||
         a->stride_w != b->stride_w || a->pad_top != b->pad_top || a->pad_left != b->pad_left || a->silu != b->silu || a->out_stride != b->out_stride)

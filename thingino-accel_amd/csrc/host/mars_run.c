@@ -609,12 +609,6 @@ static int tune_raw(const char *key, int value, int *get) {
         mhip_conv_f32_mode(value);
         return 0;
     }
-    if (!strcmp(key, "f32_pw")) { /* 1: float 1 x 1 layers through conv_f32_pw (round 5 experiment, slower: off by default) */
-        if (get) { *get = mhip_conv_f32_pw_mode(-1); return 0; }
-        if (value < 0 || value > 1) return -1;
-        mhip_conv_f32_pw_mode(value);
-        return 0;
-    }
     return get ? mhip_conv_i8_tune_get(key, get) : mhip_conv_i8_tune(key, value);
 }
 

@@ -202,8 +202,6 @@ unsigned long mhip_conv_f32_patch_launches(void); /* launches of conv_f32_patch 
 size_t mhip_conv_f32_stem_pack(int out_c, int in_c, int kh, int kw, int stride, int pad, int in_h, int in_w, int out_h, int out_w,
                                const float *w, void *out);
 unsigned long mhip_conv_f32_stem_launches(void);
-unsigned long mhip_conv_f32_pw_launches(void); /* launches of conv_f32_pw (1 x 1 layers, use_mfma == 3) since load */
-int mhip_conv_f32_pw_mode(int set); /* 1: 1 x 1 layers take conv_f32_pw under use_mfma == 3 (opt-in: measured slower than conv_f32_split); set < 0 reads */
 /* policy knob: 0 never the matrix cores, 1 (default) wherever the host proves it safe, 2 everywhere, 3 / 4 everywhere on the
  * bf16 matrix cores with operands split in two / three (three / six piece products).  set < 0 only
  * reads; returns the mode in force (first call reads MARS_HIP_F32_MFMA) */

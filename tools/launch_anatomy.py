@@ -28,6 +28,7 @@ ap = argparse.ArgumentParser()
 ap.add_argument("--width", type=int, default=8)
 ap.add_argument("--hw", type=int, default=640)
 ap.add_argument("--batch", type=int, default=256)
+ap.add_argument("--dump", default="", help="also write the raw workgroup records (numpy .npy) here, for offline analysis")
 ap.add_argument("--lib", default=os.path.join(ROOT, "thingino-accel_amd", "lib", "diag", "lib_anatomy.so"))
 args = ap.parse_args()
 spec = importlib.util.spec_from_file_location("marsrt", os.path.join(ROOT, "thingino-accel_amd", "marsrt.py"))
@@ -78,6 +79,8 @@ assert 0 < n < CAP - 1, n
 recs = np.zeros(n + 1, dtype=REC)
 assert L.mhip_d2h_async(recs.ctypes.data, buf, (n + 1) * REC.itemsize) == 0 and L.mhip_sync() == 0
 recs = recs[1:]
+if args.dump:
+    np.save(args.dump, recs)
 for name in ("i8", "patch", "stem", "rows"):
     getattr(L, "mhip_anatomy_set_" + name)(None, 0)
 L.mhip_free(buf)
