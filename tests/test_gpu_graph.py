@@ -828,19 +828,9 @@ def test_residual_add_folded_into_conv_f32(gpu, orc, order, ic, hw):
         gpu.set_tuning("f32_mfma", 1)
 
 
-F32_SPLIT_SHAPES = [
-    # h, w, in_c, out_c, k, stride, pad, batch, silu       which path of conv_f32_split (round 4)
-    (7, 9, 3, 5, 3, 1, "same", 3, True),       # odd map width: one dword per tap (GATHER 0), a 32-channel tile 5 channels full
-    (16, 20, 8, 40, 3, 1, "same", 5, True),    # stride 1, 16-byte gathers (4 pixels x 1 tap), 64-channel tile
-    (17, 18, 4, 130, 3, 2, "same", 2, False),  # stride 2, odd output width: not a split shape -> falls back to conv_f32_mfma
-    (32, 32, 16, 128, 3, 2, "same", 4, True),  # stride 2, kernel rows padded to 4 taps, 2 pixels x 2 taps per load, 128-channel tile
-    (48, 48, 8, 16, 3, 1, "same", 64, True),   # 576 pixel tiles on 512 slots: every workgroup walks two tiles (the K pipeline
-                                               # runs through the tile boundary), the last ones one
-    (64, 64, 3, 32, 6, 2, "same", 9, True),    # the stem's geometry: 6 x 6, stride 2, 3 channels
-    (12, 12, 24, 200, 1, 1, "same", 7, False), # 1 x 1, two 128-channel tiles (the second 72 channels full), K = 24 < one step
-    (20, 24, 6, 12, 3, 1, "valid", 3, True),   # no padding: no tap ever starts left of the image
-    (9, 16, 5, 7, 5, 1, "same", 2, True),      # 5 x 5, pad 2: more than one column left of the image -> GATHER 0
-]
+import f32shapes  # noqa: E402  (the shape lists and their graphs: shared with tests/golden/make_golden.py)
+
+F32_SPLIT_SHAPES = f32shapes.SPLIT
 
 
 @pytest.mark.parametrize("shape", F32_SPLIT_SHAPES, ids=lambda v: "x".join(str(q) for q in v))
@@ -850,27 +840,10 @@ def test_conv_f32_split_shapes(gpu, orc, shape):
     counts above and below the persistent grid, and a shape the kernel declines; every frame of the batch against the
     oracle within 1e-4 * max(1, |b|), and mode 0 bit-identical (the same plan through the reference-order kernel)"""
     h, w, ic, oc, k, st, pad, B, silu = shape
-    rng = np.random.default_rng(h * 1000 + w * 10 + k)
-    G = marsfile.Graph()
-    F, N = marsfile.F32, marsfile.NCHW
-    if pad == "same":
-        oh, ow = (h + st - 1) // st, (w + st - 1) // st
-    else:
-        oh, ow = (h - k) // st + 1, (w - k) // st + 1
-    x = G.tensor([1, ic, h, w], dtype=F, fmt=N)
-    a = G.tensor([1, oc, oh, ow], dtype=F, fmt=N)
-    amp = 1.7 / (k * k * ic) ** 0.5
-    wt = G.tensor([oc, ic, k, k], dtype=F, fmt=marsfile.OIHW, data=((rng.random((oc, ic, k, k), dtype=np.float32) * 2 - 1) * amp).astype(np.float32))
-    b = G.tensor([oc], dtype=F, fmt=marsfile.D1, data=((rng.random(oc, dtype=np.float32) * 2 - 1) * 0.1).astype(np.float32))
-    G.conv(x, a, wt, b, (k, k), (st, st), pad=marsfile.PAD_SAME if pad == "same" else marsfile.PAD_VALID)
-    out = a
-    if silu:
-        g_, o_ = G.tensor([1, oc, oh, ow], dtype=F, fmt=N), G.tensor([1, oc, oh, ow], dtype=F, fmt=N)
-        G.layer(marsfile.SIGMOID, [a], [g_])
-        G.layer(marsfile.MUL, [a, g_], [o_])
-        out = o_
-    d = G.serialise([x], [out])
-    xs = [(rng.random(ic * h * w, dtype=np.float32) * 2 - 1).astype(np.float32).view(np.uint8) for _ in range(min(B, 4))]
+    case = f32shapes.split_case(shape)
+    d, out, ow = case["d"], case["out"], case["ow"]
+    xs = [q.view(np.uint8) for q in case["xs"]]
+    ref = GOLD["conv_f32_family"][f32shapes.shape_id("split", shape)]  # the REFERENCE's output for each input, by digest
     want = []
     for q in xs:
         g, rc = run_oracle(orc, d, q)
@@ -896,6 +869,7 @@ def test_conv_f32_split_shapes(gpu, orc, shape):
             for f in range(B):
                 if mode == 0:
                     assert np.array_equal(got[f], want[f % len(xs)]), "mode 0 frame %d" % f
+                    assert cases.digest(got[f]) == ref[f % len(xs)], "mode 0 frame %d: not the reference's bytes" % f
                 else:
                     ok = close_f32(got[f], want[f % len(xs)])
                     assert ok.all(), "mode %d frame %d: %d of %d out of tolerance" % (mode, f, int((~ok).sum()), ok.size)
@@ -904,17 +878,7 @@ def test_conv_f32_split_shapes(gpu, orc, shape):
         gpu.set_tuning("dual_stream_min_batch", 64)
 
 
-F32_PATCH_SHAPES = [
-    # h, w, in_c, out_c, k, stride, batch, silu, add          conv_f32_patch (round 5): which geometry
-    (20, 20, 32, 16, 3, 1, 3, True, False),    # whole-row tiles that run on into the next frame; 32-channel tile half full; 4 dummy units
-    (12, 40, 64, 72, 3, 1, 5, True, True),     # 40-wide map, 128-channel tile 72 channels full, fused residual Add
-    (24, 160, 32, 64, 3, 1, 2, False, False),  # wide map: 32-column strips (2-D tiles), 64-channel tile
-    (40, 40, 32, 130, 3, 2, 3, True, False),   # stride 2 (de-interleaved patch columns), two 128-channel tiles (the second 2 channels full)
-    (32, 160, 64, 32, 3, 2, 2, True, False),   # stride 2 onto an 80-wide map: 16-column strips, 34 patch rows
-    (16, 24, 32, 20, 5, 1, 4, False, False),   # 5 x 5, pad 2: 25 taps per chunk
-    (9, 20, 96, 128, 3, 1, 37, True, True),    # short frames: several frame boundaries per tile; 12 chunks; 27 tiles
-    (80, 80, 64, 64, 3, 1, 9, True, False),    # 225 tiles: every workgroup walks a run of tiles (the ring runs through tile boundaries)
-]
+F32_PATCH_SHAPES = f32shapes.PATCH
 
 
 @pytest.mark.parametrize("shape", F32_PATCH_SHAPES, ids=lambda v: "x".join(str(q) for q in v))
@@ -925,33 +889,11 @@ def test_conv_f32_patch_shapes(gpu, orc, shape):
     workgroup per CU (the default), and `persist_slots` = 3, so that three workgroups walk ALL tiles (runs of many tiles: the
     patch ring, the weight pipeline and the row tables carried through tile boundaries)."""
     h, w, ic, oc, k, st, B, silu, add = shape
-    rng = np.random.default_rng(h * 1000 + w * 10 + k + st)
-    G = marsfile.Graph()
-    F, N = marsfile.F32, marsfile.NCHW
-    oh, ow = (h + st - 1) // st, (w + st - 1) // st
-    x = G.tensor([1, ic, h, w], dtype=F, fmt=N)
-    a = G.tensor([1, oc, oh, ow], dtype=F, fmt=N)
-    amp = 1.7 / (k * k * ic) ** 0.5
-    wt = G.tensor([oc, ic, k, k], dtype=F, fmt=marsfile.OIHW, data=((rng.random((oc, ic, k, k), dtype=np.float32) * 2 - 1) * amp).astype(np.float32))
-    b = G.tensor([oc], dtype=F, fmt=marsfile.D1, data=((rng.random(oc, dtype=np.float32) * 2 - 1) * 0.1).astype(np.float32))
-    G.conv(x, a, wt, b, (k, k), (st, st), pad=marsfile.PAD_SAME)
-    out = a
-    if silu:
-        g_, o_ = G.tensor([1, oc, oh, ow], dtype=F, fmt=N), G.tensor([1, oc, oh, ow], dtype=F, fmt=N)
-        G.layer(marsfile.SIGMOID, [a], [g_])
-        G.layer(marsfile.MUL, [a, g_], [o_])
-        out = o_
-    ins = [x]
-    if add:  # the C3 shortcut: Add(conv-chain result, another tensor of the same shape) folded into the convolution's epilogue
-        r_ = G.tensor([1, oc, oh, ow], dtype=F, fmt=N)
-        s_ = G.tensor([1, oc, oh, ow], dtype=F, fmt=N)
-        G.layer(marsfile.ADD, [out, r_], [s_])
-        ins.append(r_)
-        out = s_
-    d = G.serialise(ins, [out])
-    nx = min(B, 4)
-    xs = [(rng.random(ic * h * w, dtype=np.float32) * 2 - 1).astype(np.float32) for _ in range(nx)]
-    rs = [(rng.random(oc * oh * ow, dtype=np.float32) * 2 - 1).astype(np.float32) for _ in range(nx)]
+    case = f32shapes.patch_case(shape)
+    d, out, xs = case["d"], case["out"], case["xs"]
+    nx = len(xs)
+    rs = case["rs"] if add else [None] * nx
+    ref = GOLD["conv_f32_family"][f32shapes.shape_id("patch", shape)]
     want = []
     for q, r in zip(xs, rs):
         g = orc.Graph(d)
@@ -981,6 +923,7 @@ def test_conv_f32_patch_shapes(gpu, orc, shape):
             for f in range(B):
                 if mode == 0:
                     assert np.array_equal(got[f], want[f % nx]), "mode 0 frame %d" % f
+                    assert cases.digest(got[f]) == ref[f % nx], "mode 0 frame %d: not the reference's bytes" % f
                 else:
                     ok = close_f32(got[f], want[f % nx])
                     assert ok.all(), "mode %d slots %d frame %d: %d of %d out of tolerance" % (mode, slots, f, int((~ok).sum()), ok.size)
@@ -1303,16 +1246,7 @@ def test_conv_f32_pairs(gpu, orc, shape):
         gpu.set_tuning("dual_stream_min_batch", 64)
 
 
-F32_STEM_SHAPES = [
-    # h, w, in_c, out_c, k, pad-as-SAME, batch, silu        conv_f32_stem (round 5)
-    (64, 64, 3, 32, 6, 9, True),     # the twins' first layer at 64 x 64: 2 x 1 tiles per frame, 9 frames
-    (128, 192, 3, 32, 6, 5, True),   # 4 x 3 tiles per frame: interior tiles and every edge
-    (32, 64, 3, 20, 6, 3, False),    # 20 of the 32 channel rows
-    (96, 64, 1, 32, 6, 4, True),     # one channel
-    (96, 64, 3, 32, 4, 2, True),     # 4 x 4 under SAME padding has pad 1: odd, declined (conv_f32_split takes it)
-    (64, 128, 4, 16, 6, 7, True),    # four channels (every slot real)
-    (32, 64, 2, 32, 8, 2, True),     # 8 x 8 would be 32 units: declined (conv_f32_split takes it)
-]
+F32_STEM_SHAPES = f32shapes.STEM
 
 
 @pytest.mark.parametrize("shape", F32_STEM_SHAPES, ids=lambda v: "x".join(str(q) for q in v))
@@ -1322,25 +1256,10 @@ def test_conv_f32_stem_shapes(gpu, orc, shape):
     one workgroup per CU and with `persist_slots` = 3 (three workgroups walk all tiles: the two patch slots alternate through long
     runs); the launch counter proves which kernel ran."""
     h, w, ic, oc, k, B, silu = shape
-    rng = np.random.default_rng(h * 1000 + w * 10 + k + ic)
-    G = marsfile.Graph()
-    F, N = marsfile.F32, marsfile.NCHW
-    oh, ow = h // 2, w // 2
-    x = G.tensor([1, ic, h, w], dtype=F, fmt=N)
-    a = G.tensor([1, oc, oh, ow], dtype=F, fmt=N)
-    amp = 1.7 / (k * k * ic) ** 0.5
-    wt = G.tensor([oc, ic, k, k], dtype=F, fmt=marsfile.OIHW, data=((rng.random((oc, ic, k, k), dtype=np.float32) * 2 - 1) * amp).astype(np.float32))
-    b = G.tensor([oc], dtype=F, fmt=marsfile.D1, data=((rng.random(oc, dtype=np.float32) * 2 - 1) * 0.1).astype(np.float32))
-    G.conv(x, a, wt, b, (k, k), (2, 2), pad=marsfile.PAD_SAME)
-    out = a
-    if silu:
-        g_, o_ = G.tensor([1, oc, oh, ow], dtype=F, fmt=N), G.tensor([1, oc, oh, ow], dtype=F, fmt=N)
-        G.layer(marsfile.SIGMOID, [a], [g_])
-        G.layer(marsfile.MUL, [a, g_], [o_])
-        out = o_
-    d = G.serialise([x], [out])
-    nx = min(B, 3)
-    xs = [(rng.random(ic * h * w, dtype=np.float32) * 2 - 1).astype(np.float32) for _ in range(nx)]
+    case = f32shapes.stem_case(shape)
+    d, out, xs = case["d"], case["out"], case["xs"]
+    nx = len(xs)
+    ref = GOLD["conv_f32_family"][f32shapes.shape_id("stem", shape)]
     want = []
     for q in xs:
         g, rc = run_oracle(orc, d, q.view(np.uint8))
@@ -1352,7 +1271,7 @@ def test_conv_f32_stem_shapes(gpu, orc, shape):
     takes = k * k // 2 <= 20 and ((k - 2) // 2) % 2 == 0  # (an even pad keeps the column pairs aligned)
     try:
         gpu.set_tuning("dual_stream_min_batch", 0)
-        for mode, slots in ((3, 0), (3, 3), (4, 0)):
+        for mode, slots in ((3, 0), (3, 3), (4, 0), (0, 0)):
             gpu.set_tuning("f32_mfma", mode)
             gpu.set_tuning("persist_slots", slots)
             m = gpu.Model(d, batch=B)
@@ -1364,6 +1283,10 @@ def test_conv_f32_stem_shapes(gpu, orc, shape):
             got = m.output_view(0).copy()
             m.close()
             for f in range(B):
+                if mode == 0:  # the reference's summation order: its bytes, by the restatement and by the reference-made digest
+                    assert np.array_equal(got[f], want[f % nx]), "mode 0 frame %d" % f
+                    assert cases.digest(got[f]) == ref[f % nx], "mode 0 frame %d: not the reference's bytes" % f
+                    continue
                 ok = close_f32(got[f], want[f % nx])
                 assert ok.all(), "mode %d slots %d frame %d: %d of %d out of tolerance" % (mode, slots, f, int((~ok).sum()), ok.size)
     finally:

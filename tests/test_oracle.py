@@ -113,6 +113,17 @@ def test_conv_i8_vs_reference(orc, ref, case, seed):
     assert np.array_equal(a, b)
 
 
+@pytest.mark.parametrize("fam", ["split", "patch", "stem"])
+def test_conv_f32_family_golden(orc, fam):
+    """the float shape lists of the GPU tests (tests/f32shapes.py: one convolution + SIGMOID / MUL (+ ADD) graphs): the restatement
+    reproduces the digests the REFERENCE left for every input frame (golden.json "conv_f32_family", made by make_golden.py)"""
+    import f32shapes
+    shapes, build = {f: (s_, b) for f, s_, b in f32shapes.FAMILIES}[fam]
+    for shape in shapes:
+        got = f32shapes.reference_digests(build(shape), orc.Graph, cases.digest)
+        assert got == GOLD["conv_f32_family"][f32shapes.shape_id(fam, shape)], shape
+
+
 @pytest.mark.parametrize("fam", sorted(cases.CONV_I8_FAMILIES))
 def test_conv_i8_family_vs_reference(orc, ref, fam):
     """... and element-wise against the live reference, at a second seed the goldens do not hold"""
