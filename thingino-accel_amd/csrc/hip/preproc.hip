@@ -187,7 +187,7 @@ __global__ __launch_bounds__(256) void letterbox_strip_kernel(const mhip_letterb
     int *xs_l = (int *)(dec + 256);                           // [nw + 1] (+ pad to a multiple of 4)
     int2 *tap_l = (int2 *)(xs_l + ((p.nw + 1 + 3) & ~3));     // [n_xtaps] {source column * 3, weight bits}
     int2 *yl = tap_l + ((n_xtaps + 1) & ~1);                  // [LB_R][LB_YT] {source row, weight bits} of the strip's rows, -1 terminated
-    float *rowf = (float *)(yl + LB_R * LB_YT);               // [2][row_f]
+    float *rowf = (float *)(yl + LB_R * LB_YT);               // [row_f]: ONE float row (two of them put the workgroup at 84 KB: one workgroup, i.e. one wave per SIMD, per CU)
     int8_t *stage = (int8_t *)rowf;                           // (after the last source row) [LB_R][tw * 3] output bytes
     const int f = blockIdx.y, y0 = blockIdx.x * LB_R;
     const uint8_t *src = p.rgb + (size_t)f * p.rgb_stride;
@@ -262,7 +262,7 @@ __global__ __launch_bounds__(256) void letterbox_strip_kernel(const mhip_letterb
     };
     if (s1 >= s0) fetch(s0);
     for (int s = s0; s <= s1; s++) {
-        float *rf = rowf + ((s - s0) & 1) * row_f;
+        float *rf = rowf;
 #pragma unroll
         for (int k = 0; k < 8; k++) { // bytes -> floats, once per byte
             const int i = tid + 256 * k;
@@ -283,7 +283,10 @@ __global__ __launch_bounds__(256) void letterbox_strip_kernel(const mhip_letterb
             head[r].y = __builtin_amdgcn_readfirstlane(head[r].y);
             used |= head[r].x == s;
         }
-        if (!used) continue;
+        if (!used) {
+            __syncthreads(); // (pairs with the barrier behind the reads below: the next row's floats overwrite this one's)
+            continue;
+        }
         // horizontal sums of this thread's NC columns, their lists walked SIDE BY SIDE (3 * NC independent chains and NC tap / pixel reads in
         // flight per round instead of one column after the other), the next round's taps read ahead of this round's additions
         float h[NC][3];
@@ -330,6 +333,7 @@ __global__ __launch_bounds__(256) void letterbox_strip_kernel(const mhip_letterb
                 head[r].y = __builtin_amdgcn_readfirstlane(head[r].y);
             }
         }
+        __syncthreads(); // every thread has read this row's floats: the next row may take their place
     }
     __syncthreads(); // every thread is done with the float rows: the output bytes take their place
     // grey everywhere first (bands left / right of the image, rows of the strip outside it), then the computed pixels
@@ -375,7 +379,7 @@ __global__ __launch_bounds__(256) void letterbox_strip_kernel(const mhip_letterb
 
 static size_t strip_lds(const mhip_letterbox_t *p) {
     const size_t row_f = ((size_t)p->w * 3 + 15) & ~(size_t)15;
-    return 1024 + (((size_t)p->nw + 1 + 3) & ~(size_t)3) * 4 + (((size_t)p->n_xtaps + 1) & ~(size_t)1) * 8 + (size_t)LB_R * LB_YT * 8 + 2 * row_f * 4;
+    return 1024 + (((size_t)p->nw + 1 + 3) & ~(size_t)3) * 4 + (((size_t)p->n_xtaps + 1) & ~(size_t)1) * 8 + (size_t)LB_R * LB_YT * 8 + row_f * 4;
 }
 
 extern "C" int mhip_letterbox(const mhip_letterbox_t *p) {
@@ -385,8 +389,8 @@ extern "C" int mhip_letterbox(const mhip_letterbox_t *p) {
         return -1;
     // strip form: the gather list and two float rows fit LDS, a source row is at most 512 16-byte pieces, at most 4 columns per thread,
     // and the strip's output bytes fit where the float rows were
-    if (p->n_xtaps > 0 && p->max_ytaps > 0 && p->max_ytaps < LB_YT && p->form != 1 && p->form != 2 && p->nw <= 1024 && (p->w * 3 + 3) / 4 <= 2048 && (p->tw * 3) % 4 == 0 && strip_lds(p) <= 96 * 1024 &&
-        (size_t)LB_R * p->tw * 3 <= 2 * ((((size_t)p->w * 3 + 15) & ~(size_t)15) * 4)) {
+    if (p->n_xtaps > 0 && p->max_ytaps > 0 && p->max_ytaps < LB_YT && p->form != 1 && p->form != 2 && p->nw <= 1024 && (p->w * 3 + 3) / 4 <= 2048 && (p->tw * 3) % 4 == 0 && strip_lds(p) <= 80 * 1024 &&
+        (size_t)LB_R * p->tw * 3 <= ((((size_t)p->w * 3 + 15) & ~(size_t)15) * 4)) {
         const dim3 g((unsigned)((p->th + LB_R - 1) / LB_R), (unsigned)p->frames);
         const size_t lds = strip_lds(p);
         const int nc = (p->nw + 255) / 256;
@@ -394,7 +398,7 @@ extern "C" int mhip_letterbox(const mhip_letterbox_t *p) {
     do {                                                                                                                                  \
         static bool attr_##NC = false;                                                                                                    \
         if (!attr_##NC) {                                                                                                                 \
-            if (hipFuncSetAttribute((const void *)letterbox_strip_kernel<NC>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024) != hipSuccess) \
+            if (hipFuncSetAttribute((const void *)letterbox_strip_kernel<NC>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024) != hipSuccess) \
                 return mhip_check(hipErrorUnknown, "letterbox (strips) attribute");                                                       \
             attr_##NC = true;                                                                                                             \
         }                                                                                                                                 \
