@@ -17,6 +17,7 @@ for N in $NAMES; do
     320s) ARGS="--hw 320"; PW=8; PH=320; FAM=conv_i8; DT=int8;;
     320n) ARGS="--hw 320 --width 4"; PW=4; PH=320; FAM=conv_i8; DT=int8;;
     f32)  ARGS="--dtype f32"; PW=8; PH=640; FAM=conv_f32; DT=f32;;
+    ship) ARGS="--model tests/golden/models/yolov5n_int8.mars"; PW=0; PH=640; FAM=conv_i8; DT=int8;;  # BASELINE config 3's literal file (NCHW-tagged: the a7 path)
     *) echo "unknown workload $N"; exit 1;;
   esac
   BENCH="bench.py $ARGS --timed-only --steps $K --warmup $W --tune dual_stream_min_batch=0"
