@@ -113,6 +113,7 @@ typedef struct mars_model_ext {
     size_t act_bytes;
     uint8_t *scratch_dev;
     size_t scratch_per_frame;
+    int scratch_t, scratch_cpad, scratch_f0, scratch_n; /* what the relayout scratch holds: tensor (-1 = nothing), channel padding, frame range (enqueue_range) */
     /* detection tail */
     void *det_dev;
     int *det_counts_dev;

@@ -133,8 +133,13 @@ static int launch_op(mars_model_ext_t *m, mars_op_t *op) {
             if (op->nchw) {
                 const size_t ss = ALIGN_UP(m->scratch_per_frame, 256);
                 int8_t *scratch = (int8_t *)m->scratch_dev + (size_t)m->frame0 * ss;
-                int rc = mhip_nchw_to_nhwc_pad(p.in, p.in_stride, scratch, ss, B, op->in_c, op->in_h * op->in_w, op->c_pad);
-                if (rc) return rc;
+                /* two convolutions in a row over the same tensor (C3's cv1 + cv2) share one relayout: the scratch still holds it when
+                 * nothing has written the tensor since (enqueue_range drops the tag at every write and at the start of a range) */
+                if (!(m->scratch_t == op->t_in[0] && m->scratch_cpad == op->c_pad && m->scratch_f0 == m->frame0 && m->scratch_n == B)) {
+                    int rc = mhip_nchw_to_nhwc_pad(p.in, p.in_stride, scratch, ss, B, op->in_c, op->in_h * op->in_w, op->c_pad);
+                    if (rc) return rc;
+                    m->scratch_t = op->t_in[0]; m->scratch_cpad = op->c_pad; m->scratch_f0 = m->frame0; m->scratch_n = B;
+                }
                 p.in = scratch; p.in_stride = ss; p.in_c = op->c_pad;
             }
             if (op->add_t && !p.add) return -1; /* planner guaranteed equal strides */
@@ -277,6 +282,7 @@ static mars_error_t run_device_async(mars_model_t *model) {
 static mars_error_t enqueue_range(mars_model_ext_t *m, int sid, int wait_tail) {
     void *prof_last = NULL;
     mhip_select_stream(sid);
+    m->scratch_t = -1;
     for (int i = 0; i < m->n_ops; i++) {
         mars_op_t *op = &m->ops[i];
         if (op->kind == OP_FAIL) {
@@ -322,6 +328,15 @@ static mars_error_t enqueue_range(mars_model_ext_t *m, int sid, int wait_tail) {
             i++; /* the mate has run */
         } else {
             rc = launch_op(m, op);
+        }
+        { /* the relayout scratch's copy of a tensor dies with any write to that tensor */
+            const mars_op_t *w2[2] = {op, mate};
+            for (int q = 0; q < 2; q++)
+                if (w2[q]) {
+                    if (w2[q]->t_out == m->scratch_t) m->scratch_t = -1;
+                    for (int k = 0; k < w2[q]->chain_n; k++)
+                        if (w2[q]->chain_out[k] == m->scratch_t) m->scratch_t = -1;
+                }
         }
         if (m->profiling) { /* level 2: one event per run of launches of the same kind (their sum lands on the last one) */
             const int nx = i + 1;
