@@ -10,6 +10,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdlib.h>
+#include <string.h>
 
 #include "../mhip.h"
 
@@ -359,6 +360,68 @@ extern "C" int mhip_concat_slice(const int8_t *in, size_t in_stride, int8_t *out
         hipLaunchKernelGGL((concat_kernel<1>), mv_grid(npix * in_c, frames), dim3(MV_THREADS), 0,
                            mhip_stream_native(), in, in_stride, out, out_stride, npix, in_c, out_c, ch_off);
     return mhip_check(hipGetLastError(), "concat");
+}
+
+// ------------------------------------------------ the reference's CONCAT on NCHW-tagged tensors, pixels x channels on both sides
+// The reference's concat copies runs of shape[3] bytes whatever the tag (mars_runtime.c:971-999).  On [1, C, H, W] tensors of equal H, W
+// (every C3 concat of the shipped NCHW-tagged files) that is, in flat byte terms,  out[f + n W] = in_n[f]  for f in [0, C_out H W), input
+// after input: input n's bytes land n map rows further down, the LAST input wins wherever two overlap, and bytes of in_n beyond its own
+// C_n H W are the zeros of its private slack -- a shift by (N - 1) rows of the last input, not a channel concatenation.  This kernel
+// produces exactly those bytes when inputs and output are held pixels x channels on the device (mars_plan.c nhwc_internal): a thread
+// owns 16 channels of one output pixel; logical element (c, h, w) is flat j = (c H + h) W + w, its writer n = min(j / W, N - 1), its
+// source flat f = j - n W -> (c', h', w') of input n at [(h' W + w') C_n + c'].  Rows h >= N - 1 (all but the first N - 1 of a map) read
+// 16 consecutive channels of ONE source pixel: a 16-byte load; the rest go byte by byte.
+struct concatq_args_t {
+    const int8_t *in[4];
+    size_t in_stride[4];
+    int in_c[4];
+    int n;
+};
+__global__ __launch_bounds__(MV_THREADS) void concat_nchwq_kernel(const concatq_args_t a, int8_t *out, size_t os, int out_c, int H, int W) {
+    const int cg = out_c / 16;
+    const size_t idx = (size_t)blockIdx.x * MV_THREADS + threadIdx.x;
+    if (idx >= (size_t)H * W * cg) return;
+    const int c0 = (int)(idx % cg) * 16;
+    const int pix = (int)(idx / cg), h = pix / W, w = pix - h * W;
+    const int last = a.n - 1;
+    int8_t *d = out + (size_t)blockIdx.y * os + (size_t)pix * out_c + c0;
+    if (h >= last) { // f = (c H + h - last) W + w: channel c, row h - last of the last input, for every c of the group
+        v4i v = {0, 0, 0, 0};
+        if (c0 < a.in_c[last]) v = *(const v4i *)(a.in[last] + (size_t)blockIdx.y * a.in_stride[last] + ((size_t)(h - last) * W + w) * a.in_c[last] + c0);
+        *(v4i *)d = v;
+        return;
+    }
+    const int HW = H * W;
+    uint32_t wd[4] = {0, 0, 0, 0};
+#pragma unroll
+    for (int e = 0; e < 16; e++) {
+        const int j = ((c0 + e) * H + h) * W + w;
+        const int n = j / W < last ? j / W : last;
+        const int f = j - n * W;
+        uint32_t b = 0;
+        if (f < a.in_c[n] * HW) {
+            const int cs = f / HW, r = f - cs * HW; // r = h' W + w'
+            b = (uint8_t)a.in[n][(size_t)blockIdx.y * a.in_stride[n] + (size_t)r * a.in_c[n] + cs];
+        }
+        wd[e >> 2] |= b << (8 * (e & 3));
+    }
+    *(v4i *)d = (v4i){(int)wd[0], (int)wd[1], (int)wd[2], (int)wd[3]};
+}
+
+extern "C" int mhip_concat_nchwq(const int8_t *const *ins, const size_t *in_strides, const int *in_c, int n, int8_t *out, size_t out_stride,
+                                 int frames, int out_c, int H, int W) {
+    if (!ins || !in_strides || !in_c || !out || n < 1 || n > 4 || frames <= 0 || out_c <= 0 || (out_c & 15) || H <= 0 || W <= 0) return -1;
+    if ((long)out_c * H * W > 0x7fffffffL || ((((uintptr_t)out | out_stride) & 15) != 0)) return -1;
+    concatq_args_t a;
+    memset(&a, 0, sizeof a);
+    a.n = n;
+    for (int k = 0; k < n; k++) {
+        if (!ins[k] || in_c[k] <= 0 || (in_c[k] & 15) || ((((uintptr_t)ins[k] | in_strides[k]) & 15) != 0)) return -1;
+        a.in[k] = ins[k]; a.in_stride[k] = in_strides[k]; a.in_c[k] = in_c[k];
+    }
+    hipLaunchKernelGGL(concat_nchwq_kernel, mv_grid((size_t)H * W * (out_c / 16), frames), dim3(MV_THREADS), 0, mhip_stream_native(), a, out, out_stride,
+                       out_c, H, W);
+    return mhip_check(hipGetLastError(), "concat (NCHW-tagged, pixels x channels)");
 }
 
 // ---------------------------------------------------------------- upsample

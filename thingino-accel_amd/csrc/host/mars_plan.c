@@ -793,14 +793,54 @@ void nhwc_internal(mars_model_ext_t *m) {
         if (mt->is_weight || mt->io_in || mt->io_out || !mt->needed || d->dtype != MARS_DTYPE_INT8 || d->format == MARS_FORMAT_NHWC || d->ndims != 4 ||
             d->shape[0] != 1 || d->shape[1] <= 0 || (d->shape[1] & 15) || d->shape[2] <= 0 || d->shape[3] <= 0)
             continue;
-        if (mt->bytes != (size_t)d->shape[1] * d->shape[2] * d->shape[3] || mt->extent != mt->bytes) continue;
+        if (mt->bytes != (size_t)d->shape[1] * d->shape[2] * d->shape[3]) continue; /* (what every op touches of it is checked per op below) */
         el[t] = 1;
+    }
+    /* CONCAT layers whose inputs and output all have the same H, W (every C3 concat of the shipped files): the reference's byte logic is
+     * then a fixed function of flat indices (move.hip: concat_nchwq_kernel), computable on pixels x channels operands -- the layer's
+     * slices become ONE launch (OP_CONCAT_Q) if its tensors all stay eligible, else they all keep the reference's bytes.  grp[i] = index of
+     * the first slice op of op i's layer when that layer qualifies, else -1 */
+    int *grp = (int *)malloc(sizeof(int) * (size_t)(m->n_ops + 1));
+    if (!grp) { free(el); return; }
+    for (int i = 0; i < m->n_ops; i++) grp[i] = -1;
+    for (int i = 0; i < m->n_ops; i++) {
+        const mars_op_t *o = &m->ops[i];
+        if (o->kind != OP_CONCAT_SLICE || grp[i] != -1 || (i > 0 && m->ops[i - 1].kind == OP_CONCAT_SLICE && m->ops[i - 1].layer == o->layer)) continue;
+        int n = 0, ok = 1;
+        while (i + n < m->n_ops && m->ops[i + n].kind == OP_CONCAT_SLICE && m->ops[i + n].layer == o->layer) n++;
+        const mars_layer_t *Ld = &m->pub.layers[o->layer].desc;
+        const mars_tensor_t *od = o->t_out >= 0 ? &m->pub.tensors[o->t_out].desc : NULL;
+        if (!od || n < 1 || n > 4 || (uint32_t)n != Ld->num_inputs || od->ndims != 4) ok = 0;
+        for (int k = 0; k < n && ok; k++) {
+            const mars_op_t *q = &m->ops[i + k];
+            const mars_tensor_t *id = q->t_in[0] >= 0 ? &m->pub.tensors[q->t_in[0]].desc : NULL;
+            /* slice k: runs of W bytes at offset k W, over C_out x H "pixels" (shape[1] x shape[2] of the output) */
+            if (!id || id->ndims != 4 || q->t_out != o->t_out || q->t_in[0] == o->t_out || q->out_pix_stride || id->shape[2] != od->shape[2] ||
+                id->shape[3] != od->shape[3] || q->in_c != od->shape[3] || q->out_c != od->shape[3] || q->ch_off != k * od->shape[3] ||
+                q->out_h != od->shape[1] || q->out_w != od->shape[2] || (long)od->shape[1] * od->shape[2] * od->shape[3] > 0x7fffffffL)
+                ok = 0;
+            for (int k2 = 0; k2 < k && ok; k2++)
+                if (m->ops[i + k2].t_in[0] == q->t_in[0]) ok = 0; /* (one tensor twice: keep it simple) */
+        }
+        if (ok)
+            for (int k = 0; k < n; k++) grp[i + k] = i;
     }
 #define DIMS_ARE(t, c, h, w) (m->pub.tensors[t].desc.shape[1] == (c) && m->pub.tensors[t].desc.shape[2] == (h) && m->pub.tensors[t].desc.shape[3] == (w))
     for (int pass = 0, changed = 1; changed && pass < nt + 2; pass++) {
         changed = 0;
         for (int i = 0; i < m->n_ops; i++) {
             const mars_op_t *o = &m->ops[i];
+            if (o->kind == OP_CONCAT_SLICE && grp[i] >= 0) { /* a qualifying CONCAT layer: all of its tensors, or none */
+                if (grp[i] != i) continue;
+                int all = el[o->t_out];
+                for (int k = i; k < m->n_ops && grp[k] == i; k++) all = all && el[m->ops[k].t_in[0]];
+                if (!all) {
+                    if (el[o->t_out]) { el[o->t_out] = 0; changed = 1; }
+                    for (int k = i; k < m->n_ops && grp[k] == i; k++)
+                        if (el[m->ops[k].t_in[0]]) { el[m->ops[k].t_in[0]] = 0; changed = 1; }
+                }
+                continue;
+            }
             int ts[8], n = 0, ok[8];
             for (int k = 0; k < o->n_in && k < 4; k++) { ts[n] = o->t_in[k]; ok[n++] = 0; }
             const int n_in = n;
@@ -828,10 +868,33 @@ void nhwc_internal(mars_model_ext_t *m) {
 #undef DIMS_ARE
     for (int i = 0; i < m->n_ops; i++) {
         mars_op_t *o = &m->ops[i];
+        if (o->kind == OP_CONCAT_SLICE && grp[i] == i && el[o->t_out]) { /* the layer's slices -> one launch on pixels x channels operands */
+            const mars_tensor_t *od = &m->pub.tensors[o->t_out].desc;
+            int n = 0;
+            double bytes = (double)m->mt[o->t_out].bytes;
+            for (int k = i; k < m->n_ops && grp[k] == i; k++, n++) {
+                o->t_in[n] = m->ops[k].t_in[0];
+                bytes += (double)m->mt[m->ops[k].t_in[0]].bytes;
+                if (k != i) m->ops[k].kind = -1;
+            }
+            o->kind = OP_CONCAT_Q;
+            o->n_in = n;
+            o->out_c = od->shape[1]; o->in_h = od->shape[2]; o->in_w = od->shape[3];
+            o->out_h = od->shape[2]; o->out_w = od->shape[3];
+            o->bytes = bytes;
+            continue;
+        }
         if (o->kind != OP_CONV_I8) continue;
         if (o->n_in >= 1 && o->t_in[0] >= 0 && el[o->t_in[0]]) o->nchw = 0;
         if (o->t_out >= 0 && el[o->t_out]) o->out_nchw = 0;
     }
+    {
+        int w = 0;
+        for (int i = 0; i < m->n_ops; i++)
+            if (m->ops[i].kind != -1) m->ops[w++] = m->ops[i];
+        m->n_ops = w;
+    }
+    free(grp);
     for (int t = 0; t < nt; t++)
         if (el[t]) {
             m->mt[t].nhwc_c = m->pub.tensors[t].desc.shape[1];

@@ -199,6 +199,17 @@ static int launch_op(mars_model_ext_t *m, mars_op_t *op) {
             return mhip_concat_slice((const int8_t *)tdev(m, op->t_in[0]), tstride(m, op->t_in[0]),
                                      (int8_t *)tdev(m, op->t_out), tstride(m, op->t_out), B, op->out_h, op->out_w,
                                      op->in_c, op->out_c, op->ch_off);
+        case OP_CONCAT_Q: {
+            const int8_t *ins[4];
+            size_t strides[4];
+            int cs[4];
+            for (int k = 0; k < op->n_in && k < 4; k++) {
+                ins[k] = (const int8_t *)tdev(m, op->t_in[k]);
+                strides[k] = tstride(m, op->t_in[k]);
+                cs[k] = m->mt[op->t_in[k]].nhwc_c;
+            }
+            return mhip_concat_nchwq(ins, strides, cs, op->n_in, (int8_t *)tdev(m, op->t_out), tstride(m, op->t_out), B, op->out_c, op->in_h, op->in_w);
+        }
         case OP_UPSAMPLE:
             return mhip_upsample_i8((const int8_t *)tdev(m, op->t_in[0]), tstride(m, op->t_in[0]),
                                     (int8_t *)tdev(m, op->t_out), tstride(m, op->t_out), B, op->in_h, op->in_w, op->in_c,

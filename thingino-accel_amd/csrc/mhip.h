@@ -238,6 +238,10 @@ int mhip_pool_chain_i8(const int8_t *in, size_t in_stride, int8_t *const *outs, 
 int mhip_unpad_rows(const void *src, void *dst, size_t rows, int width, int pitch); /* device -> device */
 int mhip_concat_slice(const int8_t *in, size_t in_stride, int8_t *out, size_t out_stride, int frames,
                       int out_h, int out_w, int in_c, int out_c, int ch_off);
+/* the reference's CONCAT on [1, C, H, W]-tagged tensors of equal H, W (runs of W bytes, input n shifted n rows down, the last input wins), with
+ * every operand held pixels x channels on the device; channel counts multiples of 16, n <= 4 (move.hip: concat_nchwq_kernel) */
+int mhip_concat_nchwq(const int8_t *const *ins, const size_t *in_strides, const int *in_c, int n, int8_t *out, size_t out_stride,
+                      int frames, int out_c, int H, int W);
 int mhip_upsample_i8(const int8_t *in, size_t in_stride, int8_t *out, size_t out_stride, int frames,
                      int in_h, int in_w, int ch, int out_h, int out_w, int scale_h, int scale_w,
                      int out_pix_stride, int out_ch_off);
