@@ -424,6 +424,93 @@ extern "C" int mhip_concat_nchwq(const int8_t *const *ins, const size_t *in_stri
     return mhip_check(hipGetLastError(), "concat (NCHW-tagged, pixels x channels)");
 }
 
+// ------------------------------- the reference's UPSAMPLE / MAXPOOL on NCHW-tagged tensors, pixels x channels on both sides (round 6)
+// Both index shape[1..3] as H, W, C whatever the tag (mars_runtime.c:919-957, 1014-1041): on a [1, C, H, W] tensor their "rows" are
+// channels, their "columns" map rows, their "channels" runs of W bytes.  As for the concat above: the result is a fixed function of flat
+// byte indices, evaluated here for operands held pixels x channels (mars_plan.c nhwc_internal).
+// upsample: quirk output (oy < qoh, ox < qow, c' < qch) at flat j = (oy qow + ox) qch + c' takes quirk input (min(oy / sh, qih - 1),
+// min(ox / sw, qiw - 1), c'); bytes of the output tensor beyond qoh qow qch are never written (zero).  A thread owns 16 channels of one
+// output pixel, byte by byte (two small tensors per graph).
+__global__ __launch_bounds__(MV_THREADS) void upsample_nchwq_kernel(const int8_t *in, size_t is, int Ci, int HWi, int8_t *out, size_t os, int Co, int Ho,
+                                                                    int Wo, int qih, int qiw, int qch, int qoh, int qow, int sh, int sw) {
+    const int cg = Co / 16;
+    const size_t idx = (size_t)blockIdx.x * MV_THREADS + threadIdx.x;
+    if (idx >= (size_t)Ho * Wo * cg) return;
+    const int c0 = (int)(idx % cg) * 16, pix = (int)(idx / cg);
+    const long written = (long)qoh * qow * qch;
+    const int8_t *s = in + (size_t)blockIdx.y * is;
+    uint32_t wd[4] = {0, 0, 0, 0};
+#pragma unroll
+    for (int e = 0; e < 16; e++) {
+        const long j = (long)(c0 + e) * Ho * Wo + pix;
+        uint32_t b = 0;
+        if (j < written) {
+            const int oy = (int)(j / ((long)qow * qch)), r = (int)(j - (long)oy * qow * qch), ox = r / qch, cq = r - ox * qch;
+            int iy = oy / sh, ix = ox / sw;
+            iy = iy > qih - 1 ? qih - 1 : iy;
+            ix = ix > qiw - 1 ? qiw - 1 : ix;
+            const long f = ((long)iy * qiw + ix) * qch + cq; // flat byte of the input = (ci Hi + hi) Wi + wi
+            const int ci = (int)(f / HWi), rr = (int)(f - (long)ci * HWi);
+            b = (uint8_t)s[(size_t)rr * Ci + ci];
+        }
+        wd[e >> 2] |= b << (8 * (e & 3));
+    }
+    *(v4i *)(out + (size_t)blockIdx.y * os + (size_t)pix * Co + c0) = (v4i){(int)wd[0], (int)wd[1], (int)wd[2], (int)wd[3]};
+}
+
+extern "C" int mhip_upsample_nchwq(const int8_t *in, size_t in_stride, int Ci, int Hi, int Wi, int8_t *out, size_t out_stride, int Co, int Ho, int Wo,
+                                   int frames, int qih, int qiw, int qch, int qoh, int qow, int sh, int sw) {
+    if (!in || !out || frames <= 0 || Ci <= 0 || Hi <= 0 || Wi <= 0 || Co <= 0 || (Co & 15) || Ho <= 0 || Wo <= 0 || qih <= 0 || qiw <= 0 || qch <= 0 ||
+        qoh <= 0 || qow <= 0 || sh <= 0 || sw <= 0)
+        return -1;
+    if ((long)qih * qiw * qch > (long)Ci * Hi * Wi || (long)qoh * qow * qch > (long)Co * Ho * Wo || (long)Co * Ho * Wo > 0x7fffffffL || (((uintptr_t)out | out_stride) & 15))
+        return -1;
+    hipLaunchKernelGGL(upsample_nchwq_kernel, mv_grid((size_t)Ho * Wo * (Co / 16), frames), dim3(MV_THREADS), 0, mhip_stream_native(), in, in_stride, Ci,
+                       Hi * Wi, out, out_stride, Co, Ho, Wo, qih, qiw, qch, qoh, qow, sh, sw);
+    return mhip_check(hipGetLastError(), "upsample (NCHW-tagged, pixels x channels)");
+}
+
+// max-pool, stride 1, output size = input size (SPPF's pools): the window runs over CHANNELS c .. c + kh - 1 and map rows h .. h + kw - 1 of
+// one column w (clipped at C and H; no padding, identity -128).  A thread owns 16 channels of one pixel: per window row it loads the
+// channels c0 .. c0 + 15 + kh - 1 (two 16-byte loads), takes the maximum over the rows per channel, then the sliding maximum over channels.
+__global__ __launch_bounds__(MV_THREADS) void maxpool_nchwq_kernel(const int8_t *in, size_t is, int8_t *out, size_t os, int C, int H, int W, int kh, int kw) {
+    const int cg = C / 16;
+    const size_t idx = (size_t)blockIdx.x * MV_THREADS + threadIdx.x;
+    if (idx >= (size_t)H * W * cg) return;
+    const int c0 = (int)(idx % cg) * 16, pix = (int)(idx / cg), h = pix / W;
+    const int8_t *s = in + (size_t)blockIdx.y * is + (size_t)pix * C + c0;
+    int col[32]; // maximum over the window's rows, channels c0 .. c0 + 31 (kh <= 17)
+#pragma unroll
+    for (int e = 0; e < 32; e++) col[e] = -128;
+    for (int dy = 0; dy < kw && h + dy < H; dy++) {
+        const int8_t *r = s + (size_t)dy * W * C;
+        const v4i a = *(const v4i *)r;
+        const v4i b = c0 + 16 < C ? *(const v4i *)(r + 16) : (v4i){(int)0x80808080, (int)0x80808080, (int)0x80808080, (int)0x80808080};
+#pragma unroll
+        for (int e = 0; e < 16; e++) {
+            const int va = (int)(int8_t)(a[e >> 2] >> (8 * (e & 3))), vb = (int)(int8_t)(b[e >> 2] >> (8 * (e & 3)));
+            col[e] = col[e] > va ? col[e] : va;
+            col[16 + e] = col[16 + e] > vb ? col[16 + e] : vb;
+        }
+    }
+    uint32_t wd[4] = {0, 0, 0, 0};
+#pragma unroll
+    for (int e = 0; e < 16; e++) {
+        int v = -128;
+        for (int dc = 0; dc < kh && c0 + e + dc < C; dc++) v = v > col[(e + dc) & 31] ? v : col[(e + dc) & 31]; // (e + dc <= 31: kh <= 17)
+        wd[e >> 2] |= (uint32_t)(uint8_t)v << (8 * (e & 3));
+    }
+    *(v4i *)(out + (size_t)blockIdx.y * os + (size_t)pix * C + c0) = (v4i){(int)wd[0], (int)wd[1], (int)wd[2], (int)wd[3]};
+}
+
+extern "C" int mhip_maxpool_nchwq(const int8_t *in, size_t in_stride, int8_t *out, size_t out_stride, int frames, int C, int H, int W, int kh, int kw) {
+    if (!in || !out || frames <= 0 || C <= 0 || (C & 15) || H <= 0 || W <= 0 || kh < 1 || kh > 17 || kw < 1) return -1;
+    if ((long)C * H * W > 0x7fffffffL || (((uintptr_t)in | (uintptr_t)out | in_stride | out_stride) & 15)) return -1;
+    hipLaunchKernelGGL(maxpool_nchwq_kernel, mv_grid((size_t)H * W * (C / 16), frames), dim3(MV_THREADS), 0, mhip_stream_native(), in, in_stride, out,
+                       out_stride, C, H, W, kh, kw);
+    return mhip_check(hipGetLastError(), "maxpool (NCHW-tagged, pixels x channels)");
+}
+
 // ---------------------------------------------------------------- upsample
 template <int VEC>
 __global__ __launch_bounds__(MV_THREADS) void upsample_kernel(const int8_t *in, size_t is, int8_t *out, size_t os,

@@ -27,6 +27,7 @@ enum {
     OP_MAXPOOL,
     OP_CONCAT_SLICE,
     OP_UPSAMPLE,
+    OP_UPSAMPLE_Q, OP_MAXPOOL_Q, /* UPSAMPLE / stride-1 MAXPOOL of an NCHW-tagged graph on tensors held pixels x channels (nhwc_internal) */
     OP_CONCAT_Q, /* a whole CONCAT layer of an NCHW-tagged graph on tensors held pixels x channels (nhwc_internal; mhip_concat_nchwq) */
     OP_FAIL, /* mars_run stops here with op->err, as the reference would at this layer */
 };

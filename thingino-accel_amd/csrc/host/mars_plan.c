@@ -841,6 +841,18 @@ void nhwc_internal(mars_model_ext_t *m) {
                 }
                 continue;
             }
+            if ((o->kind == OP_UPSAMPLE || (o->kind == OP_MAXPOOL && !o->chain_n)) && o->t_in[0] >= 0 && o->t_out >= 0 && o->t_in[0] != o->t_out &&
+                !o->out_pix_stride && !o->out_ch_off) {
+                /* the byte-wise UPSAMPLE / stride-1 MAXPOOL as fixed functions of flat indices (move.hip *_nchwq_kernel): both tensors or neither */
+                const mars_tensor_t *id = &m->pub.tensors[o->t_in[0]].desc, *od = &m->pub.tensors[o->t_out].desc;
+                int fits = id->ndims == 4 && od->ndims == 4 && o->in_h == id->shape[1] && o->in_w == id->shape[2] && o->in_c == id->shape[3] &&
+                           o->out_h == od->shape[1] && o->out_w == od->shape[2] && (long)o->out_h * o->out_w * o->in_c <= (long)od->shape[1] * od->shape[2] * od->shape[3];
+                if (o->kind == OP_MAXPOOL)
+                    fits = fits && o->sh == 1 && o->sw == 1 && o->kh >= 1 && o->kh <= 17 && o->kw >= 1 && od->shape[1] == id->shape[1] &&
+                           od->shape[2] == id->shape[2] && od->shape[3] == id->shape[3];
+                if (fits && el[o->t_in[0]] && el[o->t_out]) continue;
+                /* (else: the generic path below takes both tensors out) */
+            }
             int ts[8], n = 0, ok[8];
             for (int k = 0; k < o->n_in && k < 4; k++) { ts[n] = o->t_in[k]; ok[n++] = 0; }
             const int n_in = n;
@@ -882,6 +894,10 @@ void nhwc_internal(mars_model_ext_t *m) {
             o->out_c = od->shape[1]; o->in_h = od->shape[2]; o->in_w = od->shape[3];
             o->out_h = od->shape[2]; o->out_w = od->shape[3];
             o->bytes = bytes;
+            continue;
+        }
+        if ((o->kind == OP_UPSAMPLE || (o->kind == OP_MAXPOOL && !o->chain_n)) && o->t_in[0] >= 0 && o->t_out >= 0 && el[o->t_in[0]] && el[o->t_out]) {
+            o->kind = o->kind == OP_UPSAMPLE ? OP_UPSAMPLE_Q : OP_MAXPOOL_Q; /* (the fixpoint left both tensors eligible only where the op fits) */
             continue;
         }
         if (o->kind != OP_CONV_I8) continue;

@@ -199,6 +199,17 @@ static int launch_op(mars_model_ext_t *m, mars_op_t *op) {
             return mhip_concat_slice((const int8_t *)tdev(m, op->t_in[0]), tstride(m, op->t_in[0]),
                                      (int8_t *)tdev(m, op->t_out), tstride(m, op->t_out), B, op->out_h, op->out_w,
                                      op->in_c, op->out_c, op->ch_off);
+        case OP_UPSAMPLE_Q: {
+            const mars_tensor_t *id = &m->pub.tensors[op->t_in[0]].desc, *od = &m->pub.tensors[op->t_out].desc;
+            return mhip_upsample_nchwq((const int8_t *)tdev(m, op->t_in[0]), tstride(m, op->t_in[0]), id->shape[1], id->shape[2], id->shape[3],
+                                       (int8_t *)tdev(m, op->t_out), tstride(m, op->t_out), od->shape[1], od->shape[2], od->shape[3], B, op->in_h, op->in_w,
+                                       op->in_c, op->out_h, op->out_w, op->scale_h, op->scale_w);
+        }
+        case OP_MAXPOOL_Q: {
+            const mars_tensor_t *id = &m->pub.tensors[op->t_in[0]].desc;
+            return mhip_maxpool_nchwq((const int8_t *)tdev(m, op->t_in[0]), tstride(m, op->t_in[0]), (int8_t *)tdev(m, op->t_out), tstride(m, op->t_out), B,
+                                      id->shape[1], id->shape[2], id->shape[3], op->kh, op->kw);
+        }
         case OP_CONCAT_Q: {
             const int8_t *ins[4];
             size_t strides[4];

@@ -242,6 +242,11 @@ int mhip_concat_slice(const int8_t *in, size_t in_stride, int8_t *out, size_t ou
  * every operand held pixels x channels on the device; channel counts multiples of 16, n <= 4 (move.hip: concat_nchwq_kernel) */
 int mhip_concat_nchwq(const int8_t *const *ins, const size_t *in_strides, const int *in_c, int n, int8_t *out, size_t out_stride,
                       int frames, int out_c, int H, int W);
+/* ... and its UPSAMPLE (quirk dims qih x qiw x qch -> qoh x qow x qch, factors sh / sw) and stride-1, same-size MAXPOOL (window kh channels x kw
+ * map rows) on such tensors: Ci / Co / C multiples of 16 */
+int mhip_upsample_nchwq(const int8_t *in, size_t in_stride, int Ci, int Hi, int Wi, int8_t *out, size_t out_stride, int Co, int Ho, int Wo,
+                        int frames, int qih, int qiw, int qch, int qoh, int qow, int sh, int sw);
+int mhip_maxpool_nchwq(const int8_t *in, size_t in_stride, int8_t *out, size_t out_stride, int frames, int C, int H, int W, int kh, int kw);
 int mhip_upsample_i8(const int8_t *in, size_t in_stride, int8_t *out, size_t out_stride, int frames,
                      int in_h, int in_w, int ch, int out_h, int out_w, int scale_h, int scale_w,
                      int out_pix_stride, int out_ch_off);
