@@ -2111,3 +2111,77 @@ def _readable(gpu, m, ti):
         return True
     except gpu.MarsError:
         return False
+
+
+@pytest.mark.parametrize("cfg", [(16, 16, 12, 20, 2), (32, 16, 9, 7, 3), (16, 48, 20, 20, 2), (64, 32, 5, 6, 4)], ids=lambda v: "x".join(str(q) for q in v))
+def test_nchw_tagged_bytewise_layers_on_internal_layout(gpu, orc, cfg, monkeypatch):
+    """round 6: NCHW-tagged int8 graphs keep convolution-only tensors pixels x channels on the device (mars_plan.c nhwc_internal) -- and the
+    reference's byte-wise CONCAT (equal map sizes), stride-1 MAXPOOL and UPSAMPLE, which index shape[1..3] as H, W, C whatever the tag, are
+    evaluated ON that layout as functions of flat byte indices (move.hip *_nchwq_kernel).  A graph with all three between convolutions:
+    every activation tensor against the oracle at the default fusion level, with the pass switched off (MARS_HIP_NO_NHWC_INTERNAL: every
+    byte-wise layer on the reference's bytes) and at fusion level 0; several frames, odd map sizes, 2 - 4 concat inputs."""
+    c1, c2, h, w, nin = cfg
+    rng = np.random.default_rng(c1 * 100 + h * 10 + nin)
+    G = marsfile.Graph()
+    N = marsfile.NCHW
+
+    def conv(xin, ic, oc, ih, iw, k=1, st=1):
+        oh, ow = (ih + st - 1) // st, (iw + st - 1) // st
+        o = G.tensor([1, oc, oh, ow], fmt=N, scale=0.05)
+        wt = G.tensor([oc, ic, k, k], fmt=marsfile.OIHW, scale=0.01, data=rng.integers(-127, 128, (oc, ic, k, k), dtype=np.int8))
+        b = G.tensor([oc], dtype=marsfile.I32, fmt=marsfile.D1, data=rng.integers(-2000, 2000, oc, dtype=np.int32))
+        G.conv(xin, o, wt, b, (k, k), (st, st), pad=marsfile.PAD_SAME)
+        return o
+
+    x = G.tensor([1, 16, h, w], fmt=N, scale=0.04)
+    a = conv(x, 16, c1, h, w, 3)
+    parts = [a] + [conv(x, 16, c2, h, w) for _ in range(nin - 1)]
+    cat = G.tensor([1, c1 + c2 * (nin - 1), h, w], fmt=N, scale=0.05)
+    G.concat(parts, cat, axis=1)
+    o1 = conv(cat, c1 + c2 * (nin - 1), 32, h, w)
+    p1 = G.tensor([1, c1, h, w], fmt=N, scale=0.05)
+    G.pool(a, p1, (5, 5), (1, 1))
+    p2 = G.tensor([1, c1, h, w], fmt=N, scale=0.05)
+    G.pool(p1, p2, (5, 5), (1, 1))
+    cat2 = G.tensor([1, 3 * c1, h, w], fmt=N, scale=0.05)
+    G.concat([a, p1, p2], cat2, axis=1)
+    o2 = conv(cat2, 3 * c1, 16, h, w)
+    up = G.tensor([1, c1, 2 * h, 2 * w], fmt=N, scale=0.05)
+    G.upsample(a, up, 2, 2)
+    o3 = conv(up, c1, 16, 2 * h, 2 * w, 3, 2)
+    d = G.serialise([x], [o1, o2, o3])
+    hdr, tensors, _ = marsfile.parse(d)
+    B = 3
+    nb = 16 * h * w
+    xs = [rng.integers(0, 256, nb, dtype=np.uint8) for _ in range(B)]
+    oracles = []
+    for f in range(B):
+        g, rc = run_oracle(orc, d, xs[f])
+        assert rc == 0
+        oracles.append(g)
+    launches = {}
+    for tag, fusion, env in (("internal", 1, None), ("tagged", 1, "1"), ("unfused", 0, None)):
+        if env:
+            monkeypatch.setenv("MARS_HIP_NO_NHWC_INTERNAL", env)
+        else:
+            monkeypatch.delenv("MARS_HIP_NO_NHWC_INTERNAL", raising=False)
+        m = gpu.Model(d, batch=B, fusion=fusion)
+        for f in range(B):
+            m.input_view(0)[f] = xs[f]
+        m.run()
+        launches[tag] = len(m.ops())
+        n = 0
+        for f in range(B):
+            for ti, t in enumerate(tensors):
+                if t["size"] != 0 or not marsfile.tensor_nbytes(t):
+                    continue
+                got = m.read_tensor(ti, frame=f)
+                want = oracles[f].tensor(ti)[:len(got)]
+                assert np.array_equal(got, want), "%s frame %d tensor %d: %d of %d bytes differ" % (tag, f, ti, int((got != want).sum()), len(got))
+                n += 1
+        assert n == B * (len([t for t in tensors if t["size"] == 0 and marsfile.tensor_nbytes(t)]))
+        m.close()
+    for g in oracles:
+        g.close()
+    # on the internal layout a CONCAT layer is ONE launch (on the reference's bytes: one copy per input)
+    assert launches["internal"] == launches["tagged"] - (nin - 1) - 2, launches
