@@ -437,20 +437,20 @@ __global__ __launch_bounds__(MV_THREADS) void upsample_nchwq_kernel(const int8_t
     const size_t idx = (size_t)blockIdx.x * MV_THREADS + threadIdx.x;
     if (idx >= (size_t)Ho * Wo * cg) return;
     const int c0 = (int)(idx % cg) * 16, pix = (int)(idx / cg);
-    const long written = (long)qoh * qow * qch;
+    const unsigned written = (unsigned)qoh * qow * qch, row = (unsigned)qow * qch; // (every tensor below 2^31 bytes: the launcher checks)
     const int8_t *s = in + (size_t)blockIdx.y * is;
     uint32_t wd[4] = {0, 0, 0, 0};
 #pragma unroll
     for (int e = 0; e < 16; e++) {
-        const long j = (long)(c0 + e) * Ho * Wo + pix;
+        const unsigned j = (unsigned)(c0 + e) * (unsigned)(Ho * Wo) + (unsigned)pix;
         uint32_t b = 0;
         if (j < written) {
-            const int oy = (int)(j / ((long)qow * qch)), r = (int)(j - (long)oy * qow * qch), ox = r / qch, cq = r - ox * qch;
-            int iy = oy / sh, ix = ox / sw;
-            iy = iy > qih - 1 ? qih - 1 : iy;
-            ix = ix > qiw - 1 ? qiw - 1 : ix;
-            const long f = ((long)iy * qiw + ix) * qch + cq; // flat byte of the input = (ci Hi + hi) Wi + wi
-            const int ci = (int)(f / HWi), rr = (int)(f - (long)ci * HWi);
+            const unsigned oy = j / row, r = j - oy * row, ox = r / (unsigned)qch, cq = r - ox * (unsigned)qch;
+            unsigned iy = oy / (unsigned)sh, ix = ox / (unsigned)sw;
+            iy = iy > (unsigned)qih - 1 ? (unsigned)qih - 1 : iy;
+            ix = ix > (unsigned)qiw - 1 ? (unsigned)qiw - 1 : ix;
+            const unsigned f = (iy * (unsigned)qiw + ix) * (unsigned)qch + cq; // flat byte of the input = (ci Hi + hi) Wi + wi
+            const unsigned ci = f / (unsigned)HWi, rr = f - ci * (unsigned)HWi;
             b = (uint8_t)s[(size_t)rr * Ci + ci];
         }
         wd[e >> 2] |= b << (8 * (e & 3));
@@ -458,13 +458,32 @@ __global__ __launch_bounds__(MV_THREADS) void upsample_nchwq_kernel(const int8_t
     *(v4i *)(out + (size_t)blockIdx.y * os + (size_t)pix * Co + c0) = (v4i){(int)wd[0], (int)wd[1], (int)wd[2], (int)wd[3]};
 }
 
+// The case every shipped graph has -- [1, C, H, W] -> [1, C, 2H, 2W], factors 2 / 2: in flat terms the reference's loop writes
+// out(co, ho, wo) = in(co, ho mod H, wo mod W) for co < C / 2 (oy = 2 co + (ho >= H), ox = 2 (ho mod H) + (wo >= W), both halved again by
+// the factors) and nothing for co >= C / 2: the map tiled 2 x 2 into the first half of the channels.  One 16-byte copy per thread.
+__global__ __launch_bounds__(MV_THREADS) void upsample_nchwq_tile2_kernel(const int8_t *in, size_t is, int8_t *out, size_t os, int C, int H, int W) {
+    const int cg = C / 16, Wo = 2 * W;
+    const size_t idx = (size_t)blockIdx.x * MV_THREADS + threadIdx.x;
+    if (idx >= (size_t)4 * H * W * cg) return;
+    const int c0 = (int)(idx % cg) * 16, pix = (int)(idx / cg), ho = pix / Wo, wo = pix - ho * Wo;
+    v4i v = {0, 0, 0, 0};
+    if (c0 < C / 2) v = *(const v4i *)(in + (size_t)blockIdx.y * is + ((size_t)(ho >= H ? ho - H : ho) * W + (wo >= W ? wo - W : wo)) * C + c0);
+    *(v4i *)(out + (size_t)blockIdx.y * os + (size_t)pix * C + c0) = v;
+}
+
 extern "C" int mhip_upsample_nchwq(const int8_t *in, size_t in_stride, int Ci, int Hi, int Wi, int8_t *out, size_t out_stride, int Co, int Ho, int Wo,
                                    int frames, int qih, int qiw, int qch, int qoh, int qow, int sh, int sw) {
     if (!in || !out || frames <= 0 || Ci <= 0 || Hi <= 0 || Wi <= 0 || Co <= 0 || (Co & 15) || Ho <= 0 || Wo <= 0 || qih <= 0 || qiw <= 0 || qch <= 0 ||
         qoh <= 0 || qow <= 0 || sh <= 0 || sw <= 0)
         return -1;
-    if ((long)qih * qiw * qch > (long)Ci * Hi * Wi || (long)qoh * qow * qch > (long)Co * Ho * Wo || (long)Co * Ho * Wo > 0x7fffffffL || (((uintptr_t)out | out_stride) & 15))
+    if ((long)qih * qiw * qch > (long)Ci * Hi * Wi || (long)qoh * qow * qch > (long)Co * Ho * Wo || (long)Co * Ho * Wo > 0x7fffffffL || (long)Ci * Hi * Wi > 0x7fffffffL || (((uintptr_t)out | out_stride) & 15))
         return -1;
+    if (Co == Ci && Ho == 2 * Hi && Wo == 2 * Wi && qih == Ci && qiw == Hi && qch == Wi && qoh == Ci && qow == Ho && sh == 2 && sw == 2 && (Ci & 31) == 0 &&
+        (((uintptr_t)in | in_stride) & 15) == 0 && !getenv("MARS_HIP_UPSAMPLE_GENERIC")) {
+        hipLaunchKernelGGL(upsample_nchwq_tile2_kernel, mv_grid((size_t)Ho * Wo * (Co / 16), frames), dim3(MV_THREADS), 0, mhip_stream_native(), in, in_stride,
+                           out, out_stride, Ci, Hi, Wi);
+        return mhip_check(hipGetLastError(), "upsample (NCHW-tagged, pixels x channels, 2 x 2)");
+    }
     hipLaunchKernelGGL(upsample_nchwq_kernel, mv_grid((size_t)Ho * Wo * (Co / 16), frames), dim3(MV_THREADS), 0, mhip_stream_native(), in, in_stride, Ci,
                        Hi * Wi, out, out_stride, Co, Ho, Wo, qih, qiw, qch, qoh, qow, sh, sw);
     return mhip_check(hipGetLastError(), "upsample (NCHW-tagged, pixels x channels)");
