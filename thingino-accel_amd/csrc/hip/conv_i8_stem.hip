@@ -61,7 +61,10 @@ __global__ __launch_bounds__(NTHREADS) void conv_i8_smallc(const mhip_conv_i8_t 
     v4i pre[2];
     int shf[2]; // fast path: column shift of the loaded pixels (PRE_ZERO: nothing of this unit is inside the image)
     constexpr int PRE_ZERO = 8, PRE_DONE = -100;
-    const bool fast3 = HOT || (p.in_c == 3 && p.in_w >= 4);
+    // (round 6: 4-byte pixels -- an NCHW-tagged graph's 3-plane input relaid to [HW][4] -- take the same clamped 16-byte loads: a unit is
+    // 16 contiguous bytes there; they used to go byte by byte under bounds tests, 0.85 ms for the shipped yolov5n_int8.mars stem)
+    const int fastpb = HOT ? 3 : (p.in_w >= 4 ? (p.in_c == 3 ? 3 : (p.in_c == 4 ? 4 : 0)) : 0); // bytes per pixel of the fast form, 0 = the gather
+    const bool fast3 = fastpb != 0;
     // Workgroup ids go round-robin over the 8 XCDs (the grid is a multiple of 8, so a workgroup's XCD is blockIdx.x & 7
     // for its whole run): XCD x is given the x-th eighth of the tile list and walks it in order, so the workgroups
     // that share patch halos and 128-byte input lines run side by side under ONE L2 (measured: the kernel fetched
@@ -92,7 +95,7 @@ __global__ __launch_bounds__(NTHREADS) void conv_i8_smallc(const mhip_conv_i8_t 
                 const int iy = y0 + (urg[j] >> 8), ix = x0 + (urg[j] & 255) * 4;
                 const int iyc = iy < 0 ? 0 : (iy > p.in_h - 1 ? p.in_h - 1 : iy);
                 const int ixc = ix < 0 ? 0 : (ix > p.in_w - 4 ? p.in_w - 4 : ix);
-                __builtin_memcpy(&pre[j], src + ((long)iyc * p.in_w + ixc) * 3, 16); // unaligned dwordx4, 12 bytes used
+                __builtin_memcpy(&pre[j], src + ((long)iyc * p.in_w + ixc) * fastpb, 16); // unaligned dwordx4, 12 (16) bytes used
                 shf[j] = (iy == iyc && tid + j * NTHREADS < nunits) ? ixc - ix : PRE_ZERO;
             }
             return;
@@ -123,11 +126,13 @@ __global__ __launch_bounds__(NTHREADS) void conv_i8_smallc(const mhip_conv_i8_t 
             v4i v = pre[j];
             if (fast3) { // 4 x 3 packed bytes -> 4 pixels widened to a dword each
                 const uint32_t d0 = (uint32_t)v[0], d1 = (uint32_t)v[1], d2 = (uint32_t)v[2];
-                v4i l;
-                l[0] = (int)(d0 & 0xFFFFFFu);
-                l[1] = (int)(((d0 >> 24) | (d1 << 8)) & 0xFFFFFFu);
-                l[2] = (int)(((d1 >> 16) | (d2 << 16)) & 0xFFFFFFu);
-                l[3] = (int)(d2 >> 8);
+                v4i l = v; // (4-byte pixels: already one dword each)
+                if (HOT || fastpb == 3) {
+                    l[0] = (int)(d0 & 0xFFFFFFu);
+                    l[1] = (int)(((d0 >> 24) | (d1 << 8)) & 0xFFFFFFu);
+                    l[2] = (int)(((d1 >> 16) | (d2 << 16)) & 0xFFFFFFu);
+                    l[3] = (int)(d2 >> 8);
+                }
                 v = l;
                 if (shf[j] != 0) { // patch pixel e is loaded pixel e - shift
 #pragma unroll
