@@ -49,6 +49,7 @@ typedef struct {
     int pix_c, pix_stride; /* pix_stride != 0: [pixels][pix_c] rows kept at a pix_stride-byte pitch on the device (pad_output_rows) */
     int rec_c, rec_hw;     /* rec_c != 0: a float tensor kept in RECORD format on the device (rec_pairs): [rec_c / 8][rec_hw] x 32 bytes */
     int nhwc_c, nhwc_hw;   /* nhwc_c != 0: an NCHW-tagged int8 tensor kept as [nhwc_hw][nhwc_c] (pixels x channels) on the device (nhwc_internal) */
+    int nhwc_pitch;        /* ... bytes between its pixels (0 = nhwc_c; a write-only 255-channel head is kept at 256) */
 } mtensor_t;
 
 typedef struct {

@@ -783,7 +783,7 @@ void trim_concat(mars_model_ext_t *m) {
  * outputs keep the reference's bytes.  mars_hip_read_tensor / write_tensor convert; fusion level 0 keeps every tensor as tagged. */
 void nhwc_internal(mars_model_ext_t *m) {
     const int nt = (int)m->pub.header.num_tensors;
-    for (int i = 0; i < nt; i++) m->mt[i].nhwc_c = m->mt[i].nhwc_hw = 0;
+    for (int i = 0; i < nt; i++) m->mt[i].nhwc_c = m->mt[i].nhwc_hw = m->mt[i].nhwc_pitch = 0;
     if (m->fusion < 1 || getenv("MARS_HIP_NO_NHWC_INTERNAL")) return;
     unsigned char *el = (unsigned char *)calloc((size_t)nt + 1, 1);
     if (!el) return;
@@ -916,6 +916,43 @@ void nhwc_internal(mars_model_ext_t *m) {
             m->mt[t].nhwc_c = m->pub.tensors[t].desc.shape[1];
             m->mt[t].nhwc_hw = m->pub.tensors[t].desc.shape[2] * m->pub.tensors[t].desc.shape[3];
         }
+    /* Write-only convolution results with a ragged channel count (the 255-channel Detect convolutions of the shipped files: their readers are
+     * no-op layers): nothing in the graph reads them, so they too are kept pixels x channels, at a 16-byte-aligned pixel pitch (255 -> 256; the
+     * pad channel has zero weights, its byte is never read) -- the convolution then takes the aligned row epilogue and the tile walkers instead
+     * of the planar store through LDS.  mars_hip_read_tensor un-pads and converts. */
+    for (int i = 0; i < m->n_ops; i++) {
+        mars_op_t *o = &m->ops[i];
+        const int T = o->t_out;
+        if (o->kind != OP_CONV_I8 || !o->out_nchw || T < 0 || el[T] || (o->out_c & 15) == 0 || (o->in_c & 15) || o->out_pix_stride || o->out_ch_off ||
+            o->add_t || o->nseg || o->pre)
+            continue;
+        const mars_tensor_t *d = &m->pub.tensors[T].desc;
+        const mtensor_t *mt = &m->mt[T];
+        const int P = (o->out_c + 15) & ~15;
+        if (mt->is_weight || mt->io_in || mt->io_out || d->dtype != MARS_DTYPE_INT8 || d->format == MARS_FORMAT_NHWC || d->ndims != 4 || d->shape[0] != 1 ||
+            d->shape[1] != o->out_c || d->shape[2] != o->out_h || d->shape[3] != o->out_w || P > o->oc_pad ||
+            mt->bytes != (size_t)o->out_c * o->out_h * o->out_w || mt->extent != mt->bytes)
+            continue;
+        int touched = 0; /* any other op that reads or writes it keeps it as tagged */
+        for (int j = 0; j < m->n_ops && !touched; j++) {
+            const mars_op_t *q = &m->ops[j];
+            if (j != i && q->t_out == T) touched = 1;
+            for (int k = 0; k < q->n_in && k < 4; k++)
+                if (q->t_in[k] == T) touched = 1;
+            for (int k = 0; k < q->nseg && k < 4; k++)
+                if (q->seg_t[k] == T) touched = 1;
+            for (int k = 0; k < q->chain_n && k < 3; k++)
+                if (q->chain_out[k] == T) touched = 1;
+        }
+        if (touched) continue;
+        o->out_nchw = 0;
+        o->out_pix_stride = P;
+        o->store_c = P;
+        m->mt[T].nhwc_c = o->out_c;
+        m->mt[T].nhwc_hw = o->out_h * o->out_w;
+        m->mt[T].nhwc_pitch = P;
+        touch(m, T, (size_t)o->out_h * o->out_w * P);
+    }
     free(el);
 }
 

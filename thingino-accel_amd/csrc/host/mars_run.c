@@ -823,14 +823,14 @@ mars_error_t mars_hip_read_tensor(mars_model_t *model, int ti, int frame, void *
         return MARS_OK;
     }
     if (t->nhwc_c) { /* kept as pixels x channels (nhwc_internal): the frame comes back in the reference's [C][H][W] order */
-        const size_t full = (size_t)t->nhwc_c * t->nhwc_hw;
-        uint8_t *raw = (uint8_t *)malloc(full), *pl = (uint8_t *)malloc(full);
-        if (!raw || !pl || bytes > full || mhip_d2h_async(raw, t->dev + (size_t)frame * t->stride, full) || mhip_sync()) {
+        const size_t full = (size_t)t->nhwc_c * t->nhwc_hw, pitch = t->nhwc_pitch ? (size_t)t->nhwc_pitch : (size_t)t->nhwc_c, dev_b = pitch * t->nhwc_hw;
+        uint8_t *raw = (uint8_t *)malloc(dev_b), *pl = (uint8_t *)malloc(full);
+        if (!raw || !pl || bytes > full || dev_b > t->stride || mhip_d2h_async(raw, t->dev + (size_t)frame * t->stride, dev_b) || mhip_sync()) {
             free(raw); free(pl);
             return MARS_ERR_LAYER_FAILED;
         }
         for (int px = 0; px < t->nhwc_hw; px++)
-            for (int c = 0; c < t->nhwc_c; c++) pl[(size_t)c * t->nhwc_hw + px] = raw[(size_t)px * t->nhwc_c + c];
+            for (int c = 0; c < t->nhwc_c; c++) pl[(size_t)c * t->nhwc_hw + px] = raw[(size_t)px * pitch + c];
         memcpy(dst, pl, bytes);
         free(raw); free(pl);
         return MARS_OK;
@@ -878,14 +878,14 @@ mars_error_t mars_hip_write_tensor(mars_model_t *model, int ti, int frame, const
         return rc ? MARS_ERR_LAYER_FAILED : MARS_OK;
     }
     if (t->nhwc_c) { /* kept as pixels x channels: whole frames only, given in the reference's [C][H][W] order */
-        const size_t full = (size_t)t->nhwc_c * t->nhwc_hw;
-        if (bytes != full) return MARS_ERR_INVALID_TENSOR;
-        uint8_t *raw = (uint8_t *)malloc(full);
+        const size_t full = (size_t)t->nhwc_c * t->nhwc_hw, pitch = t->nhwc_pitch ? (size_t)t->nhwc_pitch : (size_t)t->nhwc_c, dev_b = pitch * t->nhwc_hw;
+        if (bytes != full || dev_b > t->stride) return MARS_ERR_INVALID_TENSOR;
+        uint8_t *raw = (uint8_t *)calloc(1, dev_b);
         if (!raw) return MARS_ERR_ALLOC_FAILED;
         const uint8_t *pl = (const uint8_t *)src;
         for (int px = 0; px < t->nhwc_hw; px++)
-            for (int c = 0; c < t->nhwc_c; c++) raw[(size_t)px * t->nhwc_c + c] = pl[(size_t)c * t->nhwc_hw + px];
-        const int rc = mhip_h2d_async(t->dev + (size_t)frame * t->stride, raw, full) || mhip_sync();
+            for (int c = 0; c < t->nhwc_c; c++) raw[(size_t)px * pitch + c] = pl[(size_t)c * t->nhwc_hw + px];
+        const int rc = mhip_h2d_async(t->dev + (size_t)frame * t->stride, raw, dev_b) || mhip_sync();
         free(raw);
         return rc ? MARS_ERR_LAYER_FAILED : MARS_OK;
     }
