@@ -2185,3 +2185,33 @@ def test_nchw_tagged_bytewise_layers_on_internal_layout(gpu, orc, cfg, monkeypat
         g.close()
     # on the internal layout a CONCAT layer is ONE launch (on the reference's bytes: one copy per input)
     assert launches["internal"] == launches["tagged"] - (nin - 1) - 2, launches
+
+
+def test_shipped_file_two_half_batches(gpu, orc):
+    """the NCHW-tagged path in the execution mode of the benchmark: a batch of 66 frames runs as two halves on two streams (each half
+    with its own relayout scratch range and its own share of every tensor); frames at both ends of both halves, every tensor the plan
+    keeps, against the oracle"""
+    d = model_bytes("yolov5n_int8")
+    hdr, tensors, _ = marsfile.parse(d)
+    nb = marsfile.tensor_nbytes(tensors[hdr["inputs"][0]])
+    B = 66
+    probe = (0, 32, 33, 65)
+    xs = {f: lcg_frame(0x5EED0000 + f, nb) for f in probe}
+    filler = lcg_frame(0x5EED1234, nb)
+    m = gpu.Model(d, batch=B)
+    for f in range(B):
+        m.input_view(0)[f, :nb] = xs.get(f, filler)
+    m.run()
+    for f in probe:
+        g, rc = run_oracle(orc, d, xs[f])
+        assert rc == 0
+        n = 0
+        for ti, t in enumerate(tensors):
+            if t["size"] != 0 or not marsfile.tensor_nbytes(t) or not _readable(gpu, m, ti):
+                continue
+            got = m.read_tensor(ti, frame=f)
+            assert np.array_equal(got, g.tensor(ti)[:len(got)]), "frame %d tensor %d" % (f, ti)
+            n += 1
+        assert n > 60
+        g.close()
+    m.close()
