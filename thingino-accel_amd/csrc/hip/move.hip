@@ -377,10 +377,10 @@ struct concatq_args_t {
     int in_c[4];
     int n;
 };
-__global__ __launch_bounds__(MV_THREADS) void concat_nchwq_kernel(const concatq_args_t a, int8_t *out, size_t os, int out_c, int H, int W) {
+__global__ __launch_bounds__(MV_THREADS) void concat_nchwq_kernel(const concatq_args_t a, int8_t *out, size_t os, int out_c, int H, int W, int rows) {
     const int cg = out_c / 16;
     const size_t idx = (size_t)blockIdx.x * MV_THREADS + threadIdx.x;
-    if (idx >= (size_t)H * W * cg) return;
+    if (idx >= (size_t)rows * W * cg) return; // (rows = H, or only the first rows of the map: the rest is never read -- mars_plan.c virtual_concat_q)
     const int c0 = (int)(idx % cg) * 16;
     const int pix = (int)(idx / cg), h = pix / W, w = pix - h * W;
     const int last = a.n - 1;
@@ -409,7 +409,8 @@ __global__ __launch_bounds__(MV_THREADS) void concat_nchwq_kernel(const concatq_
 }
 
 extern "C" int mhip_concat_nchwq(const int8_t *const *ins, const size_t *in_strides, const int *in_c, int n, int8_t *out, size_t out_stride,
-                                 int frames, int out_c, int H, int W) {
+                                 int frames, int out_c, int H, int W, int rows_only) {
+    const int rows = rows_only > 0 && rows_only < H ? rows_only : H;
     if (!ins || !in_strides || !in_c || !out || n < 1 || n > 4 || frames <= 0 || out_c <= 0 || (out_c & 15) || H <= 0 || W <= 0) return -1;
     if ((long)out_c * H * W > 0x7fffffffL || ((((uintptr_t)out | out_stride) & 15) != 0)) return -1;
     concatq_args_t a;
@@ -419,8 +420,8 @@ extern "C" int mhip_concat_nchwq(const int8_t *const *ins, const size_t *in_stri
         if (!ins[k] || in_c[k] <= 0 || (in_c[k] & 15) || ((((uintptr_t)ins[k] | in_strides[k]) & 15) != 0)) return -1;
         a.in[k] = ins[k]; a.in_stride[k] = in_strides[k]; a.in_c[k] = in_c[k];
     }
-    hipLaunchKernelGGL(concat_nchwq_kernel, mv_grid((size_t)H * W * (out_c / 16), frames), dim3(MV_THREADS), 0, mhip_stream_native(), a, out, out_stride,
-                       out_c, H, W);
+    hipLaunchKernelGGL(concat_nchwq_kernel, mv_grid((size_t)rows * W * (out_c / 16), frames), dim3(MV_THREADS), 0, mhip_stream_native(), a, out, out_stride,
+                       out_c, H, W, rows);
     return mhip_check(hipGetLastError(), "concat (NCHW-tagged, pixels x channels)");
 }
 

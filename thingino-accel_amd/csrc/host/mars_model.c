@@ -186,6 +186,7 @@ mars_error_t build_plan(mars_model_ext_t *m) {
         pair_convs(m);
         if (m->fusion >= 2 && !m->no_bottleneck) fuse_bottleneck(m); /* opt-in (level 2); after pairing: a paired launch stays a pair */
         pad_output_rows(m);
+        virtual_concat_q(m); /* (last: it splits a convolution in two launches over one output tensor) */
     }
     if (m->fusion < 1) nhwc_internal(m); /* (resets the tensors' flags) */
     f32_policy(m);

@@ -783,7 +783,7 @@ void trim_concat(mars_model_ext_t *m) {
  * outputs keep the reference's bytes.  mars_hip_read_tensor / write_tensor convert; fusion level 0 keeps every tensor as tagged. */
 void nhwc_internal(mars_model_ext_t *m) {
     const int nt = (int)m->pub.header.num_tensors;
-    for (int i = 0; i < nt; i++) m->mt[i].nhwc_c = m->mt[i].nhwc_hw = m->mt[i].nhwc_pitch = 0;
+    for (int i = 0; i < nt; i++) m->mt[i].nhwc_c = m->mt[i].nhwc_hw = m->mt[i].nhwc_pitch = m->mt[i].partial = 0;
     if (m->fusion < 1 || getenv("MARS_HIP_NO_NHWC_INTERNAL")) return;
     unsigned char *el = (unsigned char *)calloc((size_t)nt + 1, 1);
     if (!el) return;
@@ -954,6 +954,96 @@ void nhwc_internal(mars_model_ext_t *m) {
         touch(m, T, (size_t)o->out_h * o->out_w * P);
     }
     free(el);
+}
+
+static int op_writes(const mars_op_t *o, int t);
+
+/* The reference's CONCAT on NCHW-tagged maps of equal size is a shift of its LAST input by N - 1 map rows (move.hip: concat_nchwq_kernel):
+ *   out(c, h, w) = in_last(c, h - (N - 1), w)  for h >= N - 1 and c < C_last,   0 for c >= C_last;   the first N - 1 rows are irregular.
+ * When its only reader is a plain 1 x 1 convolution X (C3's cv3, SPPF's cv2 in the shipped files), X over rows h >= N - 1 is the SAME
+ * convolution over in_last with its K loop cut to the C_last channels that are not zero, its output N - 1 rows further down:
+ *   - the concat produces its first N - 1 rows only (rows_only; the tensor becomes `partial`),
+ *   - X is split in two launches: rows 0 .. N - 2 from those rows (all channels, the original weights), rows N - 1 .. H - 1 straight from
+ *     in_last (a second weight image: the first C_last input channels).
+ * The concat's copy of the whole map and the zero half (or three quarters) of X's K loop go.  Same bytes out: every output row is the sum
+ * the reference computes, over exactly the non-zero terms.  Runs last of the fusion passes. */
+void virtual_concat_q(mars_model_ext_t *m) {
+    if (m->fusion < 1 || getenv("MARS_HIP_NO_VCONCAT_Q")) return;
+    for (int i = 0; i < m->n_ops; i++) {
+        mars_op_t *cq = &m->ops[i];
+        if (cq->kind != OP_CONCAT_Q || cq->n_in < 2 || cq->rows_only) continue;
+        const int T = cq->t_out, N = cq->n_in, H = cq->in_h, W = cq->in_w, Cout = cq->out_c;
+        const int TL = cq->t_in[N - 1];
+        const int CL = m->mt[TL].nhwc_c;
+        if (H < N + 1 || CL <= 0 || (CL & 15) || CL >= Cout || m->mt[TL].nhwc_pitch || m->mt[T].nhwc_pitch) continue;
+        int r = -1, nr = 0;
+        for (int j = 0; j < m->n_ops; j++) {
+            const mars_op_t *o = &m->ops[j];
+            for (int k = 0; k < o->n_in && k < 4; k++)
+                if (o->t_in[k] == T) { nr++; r = j; }
+            for (int k = 0; k < o->nseg && k < 4; k++)
+                if (o->seg_t[k] == T) nr += 2;
+            if (j != i && op_writes(o, T)) nr += 2;
+        }
+        if (nr != 1 || r <= i) continue;
+        mars_op_t *cv = &m->ops[r];
+        if (cv->kind != OP_CONV_I8 || cv->kh != 1 || cv->kw != 1 || cv->sh != 1 || cv->sw != 1 || cv->pt || cv->pl || cv->nchw || cv->out_nchw ||
+            cv->nseg || cv->add_t || cv->pre || cv->pair_next || (r > 0 && m->ops[r - 1].pair_next) || cv->out_pix_stride || cv->out_ch_off ||
+            cv->n_in != 1 || cv->in_c != Cout || cv->in_h != H || cv->in_w != W || cv->out_h != H || cv->out_w != W || cv->in_byte_off ||
+            cv->out_byte_off || cv->t_out == TL || cv->t_out == T || (cv->out_c & 15) || m->mt[cv->t_out].nhwc_pitch)
+            continue;
+        int clash = 0; /* in_last must still hold at X what it held at the concat */
+        for (int j = i + 1; j < r && !clash; j++)
+            if (op_writes(&m->ops[j], TL)) clash = 1;
+        if (clash) continue;
+        /* the second weight image: input channels [0, C_last) of every output channel (1 x 1: OIHW and OHWI coincide) */
+        const mars_layer_t *L = &m->pub.layers[cv->layer].desc;
+        const int tw = find_tensor(m, L->params.conv.weight_tensor_id);
+        if (tw < 0) continue;
+        int row_pad2, oc_pad2, c_eff2;
+        mhip_conv_i8_pack_geom(CL, 1, cv->out_c, &row_pad2, &oc_pad2, &c_eff2);
+        if (oc_pad2 != cv->oc_pad || c_eff2 != CL) continue;
+        const size_t k64 = ALIGN_UP((size_t)row_pad2, 64);
+        const size_t w_off2 = arena_reserve(m, (size_t)oc_pad2 * k64);
+        if (w_off2 == NO_OFF) return;
+        if (!m->deferred) {
+            const size_t full = (size_t)cv->out_c * Cout, cut = (size_t)cv->out_c * CL;
+            int8_t *tmp = (int8_t *)malloc(full ? full : 1), *sel = (int8_t *)malloc(cut ? cut : 1);
+            if (!tmp || !sel) { free(tmp); free(sel); m->plan_err = MARS_ERR_ALLOC_FAILED; return; }
+            blob_read(m, (size_t)m->pub.tensors[tw].desc.data_offset, full, tmp);
+            for (int oc = 0; oc < cv->out_c; oc++) memcpy(sel + (size_t)oc * CL, tmp + (size_t)oc * Cout, (size_t)CL);
+            mars_pack_conv_i8(sel, cut, 1, cv->out_c, CL, 1, 1, c_eff2, row_pad2, oc_pad2, (int8_t *)m->arena_host + w_off2);
+            free(tmp); free(sel);
+        }
+        /* ops: [concat: first N - 1 rows] ... [X over those rows] [X over in_last] */
+        if (m->n_ops == m->cap_ops) {
+            const int cap = m->cap_ops * 2;
+            mars_op_t *np = (mars_op_t *)realloc(m->ops, (size_t)cap * sizeof(mars_op_t));
+            if (!np) { m->plan_err = MARS_ERR_ALLOC_FAILED; return; }
+            m->ops = np; m->cap_ops = cap;
+            cq = &m->ops[i]; cv = &m->ops[r];
+        }
+        memmove(&m->ops[r + 2], &m->ops[r + 1], sizeof(mars_op_t) * (size_t)(m->n_ops - r - 1));
+        m->n_ops++;
+        m->ops[r + 1] = m->ops[r];
+        mars_op_t *top = &m->ops[r], *mainop = &m->ops[r + 1];
+        top->in_h = top->out_h = N - 1;
+        top->macs = top->macs * (N - 1) / H;
+        top->bytes = (double)(N - 1) * W * (Cout + top->out_c);
+        top->w2_off = NO_OFF; top->w2_rows = 0;
+        mainop->t_in[0] = TL;
+        mainop->in_c = CL; mainop->c_pad = CL; mainop->row_pad = row_pad2;
+        mainop->in_h = mainop->out_h = H - (N - 1);
+        mainop->w_off = w_off2;
+        mainop->w2_off = NO_OFF; mainop->w2_rows = 0;
+        mainop->out_byte_off = (size_t)(N - 1) * W * (size_t)mainop->out_c;
+        mainop->macs = (double)(H - (N - 1)) * W * mainop->out_c * CL;
+        mainop->bytes = (double)(H - (N - 1)) * W * (CL + mainop->out_c);
+        mainop->variant = 0;
+        cq->rows_only = N - 1;
+        cq->bytes = (double)(N - 1) * W * Cout * 2.0;
+        m->mt[T].partial = 1;
+    }
 }
 
 /* Residual Add folded into the convolution that produces one of its operands (the bottleneck shortcut of C3):

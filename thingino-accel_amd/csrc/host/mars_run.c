@@ -48,6 +48,8 @@ void conv_i8_params(const mars_model_ext_t *m, const mars_op_t *op, mhip_conv_i8
     p->in = (const int8_t *)tdev(m, op->t_in[0]); p->in_stride = tstride(m, op->t_in[0]);
     p->in_c = op->in_c;
     p->out = (int8_t *)tdev(m, op->t_out); p->out_stride = tstride(m, op->t_out);
+    if (p->in) p->in += op->in_byte_off;   /* (a row range of the tensors: virtual_concat_q) */
+    if (p->out) p->out += op->out_byte_off;
     p->w = (const int8_t *)(A + op->w_off);
     p->bias = op->b_off != NO_OFF ? (const int32_t *)(A + op->b_off) : NULL;
     p->lut = op->lut_off != NO_OFF ? A + op->lut_off : NULL;
@@ -219,7 +221,8 @@ static int launch_op(mars_model_ext_t *m, mars_op_t *op) {
                 strides[k] = tstride(m, op->t_in[k]);
                 cs[k] = m->mt[op->t_in[k]].nhwc_c;
             }
-            return mhip_concat_nchwq(ins, strides, cs, op->n_in, (int8_t *)tdev(m, op->t_out), tstride(m, op->t_out), B, op->out_c, op->in_h, op->in_w);
+            return mhip_concat_nchwq(ins, strides, cs, op->n_in, (int8_t *)tdev(m, op->t_out), tstride(m, op->t_out), B, op->out_c, op->in_h, op->in_w,
+                                     op->rows_only);
         }
         case OP_UPSAMPLE:
             return mhip_upsample_i8((const int8_t *)tdev(m, op->t_in[0]), tstride(m, op->t_in[0]),
@@ -794,6 +797,7 @@ mars_error_t mars_hip_read_tensor(mars_model_t *model, int ti, int frame, void *
     mtensor_t *t = &m->mt[ti];
     if (!t->dev || frame < 0 || (!t->is_weight && frame >= m->batch)) return MARS_ERR_INVALID_TENSOR;
     if (!t->is_weight && bytes > t->stride) return MARS_ERR_INVALID_TENSOR;
+    if (t->partial) return MARS_ERR_INVALID_TENSOR; /* (like a tensor a fusion pass elided: only the rows its reader needs exist) */
     if (t->is_weight) { /* weights: one copy for every frame, bounded by the blob mirror */
         const size_t off = (size_t)m->pub.tensors[ti].desc.data_offset;
         if (off > m->blob_mirror_bytes || bytes > m->blob_mirror_bytes - off) return MARS_ERR_INVALID_TENSOR;

@@ -241,7 +241,7 @@ int mhip_concat_slice(const int8_t *in, size_t in_stride, int8_t *out, size_t ou
 /* the reference's CONCAT on [1, C, H, W]-tagged tensors of equal H, W (runs of W bytes, input n shifted n rows down, the last input wins), with
  * every operand held pixels x channels on the device; channel counts multiples of 16, n <= 4 (move.hip: concat_nchwq_kernel) */
 int mhip_concat_nchwq(const int8_t *const *ins, const size_t *in_strides, const int *in_c, int n, int8_t *out, size_t out_stride,
-                      int frames, int out_c, int H, int W);
+                      int frames, int out_c, int H, int W, int rows_only /* > 0: only the first rows_only map rows of the output */);
 /* ... and its UPSAMPLE (quirk dims qih x qiw x qch -> qoh x qow x qch, factors sh / sw) and stride-1, same-size MAXPOOL (window kh channels x kw
  * map rows) on such tensors: Ci / Co / C multiples of 16 */
 int mhip_upsample_nchwq(const int8_t *in, size_t in_stride, int Ci, int Hi, int Wi, int8_t *out, size_t out_stride, int Co, int Ho, int Wo,
