@@ -2219,3 +2219,63 @@ def test_shipped_file_two_half_batches(gpu, orc):
         assert n > 60
         g.close()
     m.close()
+
+
+def test_f32_zero_tail_k_limit(gpu, orc, monkeypatch):
+    """round 6: the reference's byte-wise CONCAT writes C H W BYTES of a float tensor that holds 4 C H W -- in the parity target's private
+    zero-initialised buffers all but the first C / 4 + 1 channels of every concat output are exact zeros (checked here on the oracle's own
+    tensors), and under the split-bf16 modes a 1 x 1 convolution reading one stops its K loop there (mars_plan.c zero_tail_f32).  The
+    float twin with and without the pass (MARS_HIP_NO_ZERO_TAIL): the same floats on every head (a skipped term is +-0 * w: only the sign
+    of a zero sum can differ), both inside 1e-4 of the oracle; the plan's multiply count drops; mode 0 keeps the full loop and stays
+    bit-identical; mars_hip_write_tensor refuses non-zero bytes where the plan relies on zeros."""
+    d = gpu.synth_model(width_x16=4, input_hw=128, seed=9, float32=True)
+    hdr, tensors, layers = marsfile.parse(d)
+    n = marsfile.tensor_nbytes(tensors[hdr["inputs"][0]]) // 4
+    B = 2
+    xs = [cases.f32(0x5EED0000 + f, n, 0.0, 1.0).view(np.uint8) for f in range(B)]
+    g, rc = run_oracle(orc, d, xs[0])
+    assert rc == 0
+    cat_ids = [l["outs"][0] for l in layers if l["type"] == marsfile.CONCAT]
+    for to in cat_ids:  # the premise, on the reference's semantics
+        a = g.tensor(to).view(np.float32).reshape(tensors[to]["shape"][1], -1)
+        live = [c for c in range(a.shape[0]) if (a[c] != 0).any()]
+        assert max(live) <= a.shape[0] // 4, (to, max(live), a.shape[0])
+    want = [g.tensor(ti).copy() for ti in hdr["outputs"]]
+    g.close()
+    res, macs = {}, {}
+    try:
+        gpu.set_tuning("f32_mfma", 3)
+        for tag, env in (("limited", None), ("full", "1")):
+            if env:
+                monkeypatch.setenv("MARS_HIP_NO_ZERO_TAIL", env)
+            else:
+                monkeypatch.delenv("MARS_HIP_NO_ZERO_TAIL", raising=False)
+            m = gpu.Model(d, batch=B)
+            for f in range(B):
+                m.input_view(0)[f] = xs[f]
+            m.run()
+            res[tag] = [m.output_view(i).copy() for i in range(len(hdr["outputs"]))]
+            macs[tag] = sum(o["macs"] for o in m.ops())
+            if tag == "limited":  # a tensor the plan relies on: zeros may be written behind its live bytes, anything else is refused
+                to = cat_ids[0]
+                nb = marsfile.tensor_nbytes(tensors[to])
+                buf = np.zeros(nb, dtype=np.uint8)
+                assert gpu.lib().mars_hip_write_tensor(m.p, to, 0, buf.ctypes.data, nb) == 0
+                buf[-1] = 1
+                assert gpu.lib().mars_hip_write_tensor(m.p, to, 0, buf.ctypes.data, nb) != 0
+            m.close()
+        assert macs["limited"] < 0.9 * macs["full"]
+        for i in range(len(hdr["outputs"])):
+            a, b = res["limited"][i].view(np.float32), res["full"][i].view(np.float32)
+            assert ((a == b) | (np.isnan(a) & np.isnan(b))).all(), "head %d: the K limit changed a value" % i
+            assert close_f32(res["limited"][i][0], want[i]).all()
+        monkeypatch.delenv("MARS_HIP_NO_ZERO_TAIL", raising=False)
+        gpu.set_tuning("f32_mfma", 0)
+        m = gpu.Model(d, batch=1)
+        m.input_view(0)[0] = xs[0]
+        m.run()
+        for i in range(len(hdr["outputs"])):
+            assert np.array_equal(m.output_view(i)[0], want[i]), "mode 0 head %d" % i
+        m.close()
+    finally:
+        gpu.set_tuning("f32_mfma", 1)

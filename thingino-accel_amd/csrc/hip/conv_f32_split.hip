@@ -638,7 +638,7 @@ extern "C" int mhip_conv_f32_pair(const mhip_conv_f32_t *a, const mhip_conv_f32_
         a->out_h != b->out_h || a->out_w != b->out_w || a->out_c != b->out_c || a->kh != b->kh || a->kw != b->kw || a->stride_h != b->stride_h ||
         a->stride_w != b->stride_w || a->pad_top != b->pad_top || a->pad_left != b->pad_left || a->silu != b->silu || a->out_stride != b->out_stride)
         return -2;
-    if (a->add || b->add || a->in_rec || b->in_rec || a->out_rec || b->out_rec || a->out == b->out) return -2;
+    if (a->add || b->add || a->in_rec || b->in_rec || a->out_rec || b->out_rec || a->out == b->out || a->k_limit != b->k_limit) return -2;
     const int rc = try_split(a, b);
     if (rc == 0) g_pair_launches++;
     return rc;
@@ -649,12 +649,15 @@ static int try_split(const mhip_conv_f32_t *p, const mhip_conv_f32_t *q) {
     const long hw = (long)p->out_h * p->out_w, total = hw * p->frames;
     const int kwp = split_kwp(p->kw, p->stride_w);
     const long K = (long)p->in_c * p->kh * kwp;
+    // k_limit: input channels from there on are exact zeros (the planner's proof): the K loop covers the others only; the weight planes keep
+    // their full row length
+    const long Kl = p->k_limit > 0 && p->k_limit < p->in_c ? (long)p->k_limit * p->kh * kwp : K;
     const size_t in_bytes = (size_t)(p->frames - 1) * p->in_stride + (size_t)p->in_c * p->in_h * p->in_w * 4;
     // 32-bit buffer offsets over the whole input (all frames); validity bit tables per kernel row / column
     if (total > 0x7fffffffL - S_BN || K > 0x7fffffffL - S_BK || in_bytes > 0xfffffff0ull || p->kh > 32 || kwp > 32) return -2;
     split_args_t g;
     g.total_pix = (unsigned)total; g.npt = (unsigned)((total + S_BN - 1) / S_BN); g.in_bytes = (unsigned)in_bytes;
-    g.K = (int)K; g.kp = (int)((K + 63) / 64 * 64) + 64; g.nks = (g.kp - 64) / 32; g.kwp = kwp; g.oc_pad = (p->out_c + 127) / 128 * 128;
+    g.K = (int)Kl; g.kp = (int)((K + 63) / 64 * 64) + 64; g.nks = (int)((Kl + 63) / 64 * 64) / 32; g.kwp = kwp; g.oc_pad = (p->out_c + 127) / 128 * 128;
     g.dhw = make_sdiv((unsigned)hw); g.dow = make_sdiv((unsigned)p->out_w); g.dtaps = make_sdiv((unsigned)(p->kh * kwp)); g.dkwp = make_sdiv((unsigned)kwp);
     // a pair: in ONE channel tile where both fit one (2 * out_c = 32 | 64 | 128: the wave tiles then split between the two at a multiple of
     // 16 channels), else as two runs of channel tiles (the launcher fills in the count)

@@ -49,6 +49,7 @@ typedef struct {
     int pix_c, pix_stride; /* pix_stride != 0: [pixels][pix_c] rows kept at a pix_stride-byte pitch on the device (pad_output_rows) */
     int rec_c, rec_hw;     /* rec_c != 0: a float tensor kept in RECORD format on the device (rec_pairs): [rec_c / 8][rec_hw] x 32 bytes */
     int nhwc_c, nhwc_hw;   /* nhwc_c != 0: an NCHW-tagged int8 tensor kept as [nhwc_hw][nhwc_c] (pixels x channels) on the device (nhwc_internal) */
+    size_t zero_from;      /* != 0: bytes from this offset on are never written by any layer (zero_tail_f32 relies on it): mars_hip_write_tensor refuses non-zero bytes there */
     int partial;           /* only part of the tensor is ever written (virtual_concat_q keeps the first rows of a concat): not readable through mars_hip_read_tensor */
     int nhwc_pitch;        /* ... bytes between its pixels (0 = nhwc_c; a write-only 255-channel head is kept at 256) */
 } mtensor_t;
@@ -60,6 +61,7 @@ typedef struct {
     int in_h, in_w, in_c, out_h, out_w, out_c, kh, kw, sh, sw, pt, pl;
     int nchw, relu, is_mul, is_f32, leaky, safe; /* nchw (conv_i8): the INPUT is [C][H][W] bytes and is relaid into scratch before the launch */
     size_t in_byte_off, out_byte_off; /* conv_i8: added to the input / output tensor's address (virtual_concat_q: a convolution over a row range of a tensor) */
+    int k_limit;   /* conv_f32 (1 x 1): input channels >= k_limit are exact zeros in every frame (zero_tail_f32): mhip_conv_f32_t.k_limit under modes 3 / 4; 0 = none */
     int rows_only; /* OP_CONCAT_Q: only the first `rows_only` map rows of the output are produced (the rest of it is never read: virtual_concat_q); 0 = all */
     int out_nchw;  /* conv_i8: the result is stored [O][H][W] (the reference's conv2d_int8_mxu); both set by the input's tag, cleared per side by nhwc_internal */
     int silu_f32;  /* conv_f32 with the float SIGMOID + MUL pair (ONNX SiLU) folded into its epilogue */
@@ -168,6 +170,7 @@ MARS_INTERNAL void blob_read(const mars_model_ext_t *m, size_t off, size_t n, vo
 MARS_INTERNAL void plan_layer(mars_model_ext_t *m, int li);
 MARS_INTERNAL void nhwc_internal(mars_model_ext_t *m);
 MARS_INTERNAL void virtual_concat_q(mars_model_ext_t *m);
+MARS_INTERNAL void zero_tail_f32(mars_model_ext_t *m);
 MARS_INTERNAL void fuse_silu(mars_model_ext_t *m);
 MARS_INTERNAL void fuse_silu_f32(mars_model_ext_t *m);
 MARS_INTERNAL void elide_concat(mars_model_ext_t *m);

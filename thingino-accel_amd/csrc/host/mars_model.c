@@ -190,6 +190,7 @@ mars_error_t build_plan(mars_model_ext_t *m) {
     }
     if (m->fusion < 1) nhwc_internal(m); /* (resets the tensors' flags) */
     f32_policy(m);
+    zero_tail_f32(m); /* (before pairing: a pair shares its input, hence its limit; resets the flags at fusion level 0) */
     if (m->fusion >= 1) pair_convs_f32(m); /* (after f32_policy: a pair shares one kernel choice) */
     rec_pairs(m); /* (fusion >= 1 only; resets the tensors' record flags in any case) */
     return (mars_error_t)m->plan_err;

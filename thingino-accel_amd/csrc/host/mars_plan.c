@@ -1559,6 +1559,62 @@ void rec_pairs(mars_model_ext_t *m) {
     free(writers);
 }
 
+/* Exact zeros the reference's byte-wise CONCAT leaves in float tensors (round 6).  The concat copies runs of shape[3] BYTES whatever the dtype
+ * (mars_runtime.c:971-999): on [1, C, H, W] float tensors it writes C H W bytes (+ the slices' offsets) of an output that holds 4 C H W -- in
+ * the private zero-initialised buffers of the parity target everything behind that is zero in every frame, i.e. all but the
+ * first C / 4 + 1 channels (measured on the twins: tests).  A 1 x 1 convolution that reads such a tensor (every C3's cv3, SPPF's cv2, the head
+ * C3s' cv1 + cv2) multiplies zeros for three quarters of its K loop.  Under the split-bf16 modes (3 / 4: results inside the tolerance, not
+ * bit-equal anyway) its K loop stops at the last channel that can be non-zero (mhip_conv_f32_t.k_limit): acc + (+-0 * w) == acc for finite w,
+ * so the sums are the same floats (up to the sign of a zero); skipped weights are checked to be finite where the blob is at hand.  Modes 0 - 2
+ * keep the full loop.  Depends on shapes only. */
+void zero_tail_f32(mars_model_ext_t *m) {
+    const int nt = (int)m->pub.header.num_tensors;
+    for (int i = 0; i < nt; i++) m->mt[i].zero_from = 0;
+    for (int i = 0; i < m->n_ops; i++) m->ops[i].k_limit = 0;
+    if (m->fusion < 1 || getenv("MARS_HIP_NO_ZERO_TAIL")) return;
+    for (int j = 0; j < m->n_ops; j++) {
+        mars_op_t *x = &m->ops[j];
+        if (x->kind != OP_CONV_F32 || x->kh != 1 || x->kw != 1 || x->sh != 1 || x->sw != 1 || x->pt || x->pl || x->in_rec || x->w2_off == NO_OFF) continue;
+        const int T = x->t_in[0];
+        if (T < 0 || m->mt[T].is_weight || m->mt[T].io_in || m->pub.tensors[T].desc.dtype != MARS_DTYPE_FLOAT32) continue;
+        if (m->mt[T].bytes != (size_t)x->in_c * x->in_h * x->in_w * 4) continue;
+        size_t written = 0; /* bytes [0, written) may be non-zero: the furthest byte any writer reaches */
+        int ok = 1, nw = 0;
+        for (int q = 0; q < m->n_ops && ok; q++) {
+            const mars_op_t *o = &m->ops[q];
+            for (int k = 0; k < o->chain_n && k < 3; k++)
+                if (o->chain_out[k] == T) ok = 0;
+            if (o->t_out != T) continue;
+            if (o->kind != OP_CONCAT_SLICE || o->out_pix_stride) { ok = 0; break; }
+            nw++;
+            const size_t npix = (size_t)o->out_h * o->out_w;
+            if (npix && o->in_c > 0) {
+                const size_t end = (npix - 1) * (size_t)o->out_c + (size_t)o->ch_off + (size_t)o->in_c;
+                if (end > written) written = end;
+            }
+        }
+        if (!ok || !nw || !written) continue;
+        const size_t plane = (size_t)x->in_h * x->in_w * 4;
+        const size_t kl = (written + plane - 1) / plane; /* channels that hold a written byte */
+        if (kl >= (size_t)x->in_c) continue;
+        if (!m->deferred) { /* 0 * w must be 0: every skipped weight finite */
+            const float *w = (const float *)(m->arena_host + x->w_off);
+            int finite = 1;
+            for (int oc = 0; oc < x->out_c && finite; oc++)
+                for (int ic = (int)kl; ic < x->in_c; ic++) {
+                    const float v = w[(size_t)oc * x->in_c + ic];
+                    if (!(v - v == 0.0f)) { finite = 0; break; }
+                }
+            if (!finite) continue;
+        }
+        x->k_limit = (int)kl;
+        if (!m->mt[T].zero_from || written > m->mt[T].zero_from) m->mt[T].zero_from = written;
+        /* the layer's algorithmic work is what is not provably zero */
+        x->macs = (double)x->out_h * x->out_w * x->out_c * (double)kl;
+        x->bytes = ((double)x->in_h * x->in_w * (double)kl + (double)x->out_h * x->out_w * x->out_c) * 4.0;
+    }
+}
+
 void f32_policy(mars_model_ext_t *m) {
     const int nt = (int)m->pub.header.num_tensors;
     unsigned char *hot = (unsigned char *)calloc((size_t)nt + 1, 1);

@@ -123,6 +123,7 @@ static void conv_f32_params(mars_model_ext_t *m, mars_op_t *op, mhip_conv_f32_t 
         if (need > op->w2_planes) p->w_split = NULL;
         if (p->use_mfma != 3) p->w_patch = NULL;
     }
+    if (p->use_mfma >= 2) p->k_limit = op->k_limit; /* (the exact-order and f32-matrix-core kernels sum every term, as the reference does) */
 }
 
 static int launch_op(mars_model_ext_t *m, mars_op_t *op) {
@@ -880,6 +881,11 @@ mars_error_t mars_hip_write_tensor(mars_model_t *model, int ti, int frame, const
         const int rc = mhip_h2d_async(t->dev + (size_t)frame * t->stride, raw, full) || mhip_sync();
         free(raw);
         return rc ? MARS_ERR_LAYER_FAILED : MARS_OK;
+    }
+    if (t->zero_from && bytes > t->zero_from) { /* a convolution skips these bytes because no layer ever writes them: they must stay zero */
+        const uint8_t *b = (const uint8_t *)src;
+        for (size_t i = t->zero_from; i < bytes; i++)
+            if (b[i]) return MARS_ERR_INVALID_TENSOR;
     }
     if (t->nhwc_c) { /* kept as pixels x channels: whole frames only, given in the reference's [C][H][W] order */
         const size_t full = (size_t)t->nhwc_c * t->nhwc_hw, pitch = t->nhwc_pitch ? (size_t)t->nhwc_pitch : (size_t)t->nhwc_c, dev_b = pitch * t->nhwc_hw;

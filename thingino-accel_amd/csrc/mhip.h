@@ -154,6 +154,9 @@ typedef struct {
                      v_mfma_f32_16x16x32_bf16 with every operand split into three bf16 pieces, six piece products per
                      product (conv_f32_split.hip: errors of the size of an f32 rounding); 3: the same with two pieces
                      and three piece products ("bf16x3": relative error per product <= 2^-16, same tolerance class) */
+    int k_limit;  /* use_mfma >= 2 (conv_f32_split): input channels >= k_limit are known to be exact zeros in every frame (the planner proves it:
+                     mars_plan.c zero_tail_f32 -- the reference's byte-wise CONCAT writes a quarter of a float tensor's bytes): the K loop stops
+                     there.  Adding +-0 to an f32 accumulator changes nothing but the sign of a zero sum.  0 = no such knowledge */
     int in_rec, out_rec; /* use_mfma == 3 only: the input (1: read by conv_f32_prec, 2: by conv_f32_patch's record-input form; mhip_conv_f32_patch_rec_form) / the
                             output is in RECORD format instead of NCHW floats -- [c / 8][h][w] records of
                             32 bytes = [8 x bf16 hi | 8 x bf16 mid] of 8 consecutive channels of one pixel (hi = bf16(x), mid = bf16(x - hi):
