@@ -875,8 +875,11 @@ def main():
                                         "f32" if f32 else "int8", "NHWC" if tensors[hdr["inputs"][0]]["fmt"] == 7 else "NCHW-tagged", args.batch,
                                         ", f32_mfma mode %d" % args.f32_mode if f32 else "")) if args.model else
                                    ("synthetic yolov5s_float32.mars twin (mars_synth_model width_x16=%d, seed 1, float32), %dx%d f32 "
-                                    "NCHW frames, batch %d per GPU, graph only, f32_mfma mode %d" %
-                                    (args.width, args.hw, args.hw, args.batch, args.f32_mode)) if f32 else
+                                    "NCHW frames, batch %d per GPU, graph only, f32_mfma mode %d%s" %
+                                    (args.width, args.hw, args.hw, args.batch, args.f32_mode,
+                                     "" if args.f32_mode < 3 or os.environ.get("MARS_HIP_NO_ZERO_TAIL") else
+                                     "; 1 x 1 convolutions that read a byte-wise CONCAT's output stop their K loop at the last channel it can have written "
+                                     "(exact zeros behind it: DESIGN.md section 5; conv_gmac_per_image counts the multiplied part; MARS_HIP_NO_ZERO_TAIL=1 runs the full loops)")) if f32 else
                                    "synthetic yolov5s_int8.mars twin (mars_synth_model width_x16=%d, seed 1), %dx%d int8 "
                                    "NHWC frames, batch %d per GPU, decode+NMS tail %s%s" %
                                    (args.width, args.hw, args.hw, args.batch, "off" if args.no_tail else "on",
