@@ -129,6 +129,11 @@ void *mars_hip_stream(void); /* hipStream_t of the library, as void* */
  * (blob mirror, packed conv weights, biases, LUTs).  Identical layout on every
  * rank that loaded the same descriptors, so rank 0 can broadcast it. */
 #define MARS_HIP_LOAD_DEFER_WEIGHTS 1u /* parse descriptors, leave the arena unfilled */
+/* The launch plan of a file as text, computed on the host only (no device needed: planner tests on the CPU, debugging): one line per launch
+ * ("op I layer L KIND in T.. out T" + its flags: relayout / planar_store / lut / add / seg / pair_next / k_limit / in_rec / out_rec / rows_only ...)
+ * and one per tensor that is not held as tagged on the device (nhwc_c / partial / zero_from / rec_c / pix_stride).  The tuning and environment in force
+ * decide as for a load.  Returns the length of the text (cut at cap, always terminated); 0 = the loader rejects the file. */
+size_t mars_hip_describe_plan(const void *data, size_t size, unsigned flags, char *out, size_t cap);
 mars_error_t mars_hip_load_memory_ex(const void *data, size_t size, unsigned flags,
                                      mars_model_t **model);
 void *mars_hip_param_arena(mars_model_t *model, size_t *bytes);

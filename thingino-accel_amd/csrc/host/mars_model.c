@@ -333,8 +333,9 @@ mars_error_t alloc_batch(mars_model_ext_t *m, int n) {
     return mhip_sync() ? MARS_ERR_ALLOC_FAILED : MARS_OK;
 }
 
-mars_error_t mars_hip_load_memory_ex(const void *data, size_t size, unsigned flags, mars_model_t **out_model) {
-    if (!data || !out_model || size < sizeof(mars_header_t)) return MARS_ERR_INVALID_FILE;
+/* the host-only part of a load: parse, validate, plan (weights packed into the host image of the parameter arena).  No device call. */
+static mars_error_t load_host(const void *data, size_t size, unsigned flags, mars_model_ext_t **out_m) {
+    if (!data || !out_m || size < sizeof(mars_header_t)) return MARS_ERR_INVALID_FILE;
     const uint8_t *p = (const uint8_t *)data;
     mars_header_t h;
     memcpy(&h, p, sizeof(h));
@@ -395,7 +396,15 @@ mars_error_t mars_hip_load_memory_ex(const void *data, size_t size, unsigned fla
     mars_error_t err = build_plan(m);
     if (err != MARS_OK) { mars_free(&m->pub); return err; }
     VLOG("%u layers -> %d launches, parameter arena %zu bytes\n", h.num_layers, m->n_ops, m->arena_size);
+    *out_m = m;
+    return MARS_OK;
+}
 
+mars_error_t mars_hip_load_memory_ex(const void *data, size_t size, unsigned flags, mars_model_t **out_model) {
+    if (!out_model) return MARS_ERR_INVALID_FILE;
+    mars_model_ext_t *m = NULL;
+    mars_error_t err = load_host(data, size, flags, &m);
+    if (err != MARS_OK) return err;
     /* everything above is host-only; from here on a GPU is required.  No CPU fallback. */
     if (!nna_is_ready() || !mhip_ready()) {
         fprintf(stderr, "Mars: no initialised MI355X device (call nna_init first); refusing to load\n");
@@ -409,6 +418,46 @@ mars_error_t mars_hip_load_memory_ex(const void *data, size_t size, unsigned fla
     g_live_models = m;
     *out_model = &m->pub;
     return MARS_OK;
+}
+
+/* The plan of a file as text, WITHOUT a device (tests of the planner on the CPU: which layers fuse, which tensors are kept pixels x channels,
+ * which K loops are cut ...): one line per launch -- "op I layer L KIND in T.. out T" + the flags that are set -- and one per tensor that is not
+ * held as tagged.  Returns the length needed (the text is cut at cap); 0 on a file the loader rejects. */
+size_t mars_hip_describe_plan(const void *data, size_t size, unsigned flags, char *out, size_t cap) {
+    static const char *const kinds[] = {"conv_i8", "conv_f32", "relu_bytes", "lut_i8", "binary_i8", "sigmoid_f32", "binary_f32", "relu_f32", "bn",
+                                        "maxpool", "concat_slice", "upsample", "upsample_q", "maxpool_q", "concat_q", "fail"};
+    mars_model_ext_t *m = NULL;
+    if (load_host(data, size, flags, &m) != MARS_OK) return 0;
+    size_t n = 0;
+    char line[512];
+#define EMIT() do { const size_t l = strlen(line); if (out && n < cap) memcpy(out + n, line, n + l <= cap ? l : cap - n); n += l; } while (0)
+    for (int i = 0; i < m->n_ops; i++) {
+        const mars_op_t *o = &m->ops[i];
+        int k = snprintf(line, sizeof line, "op %d layer %d %s in", i, o->layer, o->kind >= 0 && o->kind <= OP_FAIL ? kinds[o->kind] : "?");
+        for (int q = 0; q < o->n_in && q < 4; q++) k += snprintf(line + k, sizeof line - (size_t)k, " %d", o->t_in[q]);
+        k += snprintf(line + k, sizeof line - (size_t)k, " out %d", o->t_out);
+#define FLAG(cond, ...) if (cond) k += snprintf(line + k, sizeof line - (size_t)k, __VA_ARGS__)
+        FLAG(o->kind == OP_CONV_I8 || o->kind == OP_CONV_F32, " k%dx%d s%d c%d->%d", o->kh, o->kw, o->sw, o->in_c, o->out_c);
+        FLAG(o->nchw, " relayout"); FLAG(o->out_nchw, " planar_store"); FLAG(o->lut_off != NO_OFF, " lut"); FLAG(o->add_t, " add=%d", o->add_t - 1);
+        FLAG(o->nseg, " seg=%d", o->nseg); FLAG(o->pair_next, " pair_next"); FLAG(o->pre, " pre"); FLAG(o->silu_f32, " silu");
+        FLAG(o->k_limit, " k_limit=%d", o->k_limit); FLAG(o->in_rec, " in_rec=%d", o->in_rec); FLAG(o->out_rec, " out_rec");
+        FLAG(o->rows_only, " rows_only=%d", o->rows_only); FLAG(o->out_byte_off, " out_off=%zu", o->out_byte_off); FLAG(o->chain_n, " chain=%d", o->chain_n);
+        FLAG(o->out_pix_stride, " pix_stride=%d", o->out_pix_stride); FLAG(o->kind == OP_FAIL, " err=%d", o->err);
+#undef FLAG
+        snprintf(line + k, sizeof line - (size_t)k, "\n");
+        EMIT();
+    }
+    for (uint32_t t = 0; t < m->pub.header.num_tensors; t++) {
+        const mtensor_t *mt = &m->mt[t];
+        if (!mt->nhwc_c && !mt->partial && !mt->zero_from && !mt->rec_c && !mt->pix_stride) continue;
+        snprintf(line, sizeof line, "tensor %u nhwc_c %d pitch %d partial %d zero_from %zu rec_c %d pix_stride %d\n", t, mt->nhwc_c, mt->nhwc_pitch, mt->partial,
+                 mt->zero_from, mt->rec_c, mt->pix_stride);
+        EMIT();
+    }
+#undef EMIT
+    if (out && cap) out[n < cap ? n : cap - 1] = 0;
+    mars_free(&m->pub);
+    return n;
 }
 
 mars_error_t mars_load_memory(const void *data, size_t size, mars_model_t **model) {

@@ -915,6 +915,10 @@ void nhwc_internal(mars_model_ext_t *m) {
         if (el[t]) {
             m->mt[t].nhwc_c = m->pub.tensors[t].desc.shape[1];
             m->mt[t].nhwc_hw = m->pub.tensors[t].desc.shape[2] * m->pub.tensors[t].desc.shape[3];
+            /* every layer left on it touches exactly its nominal bytes (checked above); what the replaced concat slices would have read
+             * past them (their runs cover the OUTPUT's byte count) no longer counts -- with it a concat input had another frame stride than
+             * its producer's other operand and the residual Add in front of a C3's concat was not folded */
+            m->mt[t].extent = m->mt[t].bytes;
         }
     /* Write-only convolution results with a ragged channel count (the 255-channel Detect convolutions of the shipped files: their readers are
      * no-op layers): nothing in the graph reads them, so they too are kept pixels x channels, at a 16-byte-aligned pixel pitch (255 -> 256; the

@@ -112,7 +112,7 @@ EXPORTS = {
                    "mars_hip_run_device_async", "mars_hip_download_outputs", "mars_hip_sync",
                    "mars_hip_tensor_device", "mars_hip_tensor_row_pitch", "mars_hip_read_tensor", "mars_hip_write_tensor", "mars_hip_set_fusion",
                    "mars_hip_set_profiling", "mars_hip_num_ops", "mars_hip_op_info", "mars_hip_stream",
-                   "mars_hip_load_memory_ex", "mars_hip_param_arena", "mars_yolo_parse_output", "mars_yolo_nms",
+                   "mars_hip_load_memory_ex", "mars_hip_describe_plan", "mars_hip_param_arena", "mars_yolo_parse_output", "mars_yolo_nms",
                    "mars_hip_detect", "mars_hip_detect_device", "mars_synth_model", "mars_hip_set_tuning", "mars_hip_autotune", "mars_yolo_letterbox",
                    "mars_hip_preprocess", "mars_hip_preprocess_device", "mars_hip_tensor_frame_bytes", "mars_hip_tensor_byte_size", "mars_hip_pipe_open",
                    "mars_hip_pipe_input", "mars_hip_pipe_submit", "mars_hip_pipe_wait", "mars_hip_pipe_close", "mars_hip_pipe_camera_ms", "mars_hip_set_output_mode",
@@ -148,6 +148,8 @@ def lib():
     L.mars_load_file.argtypes = [C.c_char_p, P(P(MarsModel))]
     L.mars_load_memory.argtypes = [C.c_void_p, C.c_size_t, P(P(MarsModel))]
     L.mars_hip_load_memory_ex.argtypes = [C.c_void_p, C.c_size_t, C.c_uint, P(P(MarsModel))]
+    L.mars_hip_describe_plan.restype = C.c_size_t
+    L.mars_hip_describe_plan.argtypes = [C.c_void_p, C.c_size_t, C.c_uint, C.c_char_p, C.c_size_t]
     L.mars_free.argtypes = [P(MarsModel)]
     L.mars_free.restype = None
     L.mars_get_input.restype = P(MarsRuntimeTensor)
@@ -264,6 +266,17 @@ def synth_model(width_x16=8, depth_x3=1, input_hw=640, float32=False, nchw_int8=
     buf = (C.c_uint8 * n)()
     assert lib().mars_synth_model(C.byref(o), buf, n) == n
     return bytes(buf)
+
+
+def describe_plan(file_bytes, flags=0):
+    """the launch plan of a .mars file as a list of text lines (mars_hip_describe_plan; host only: works without a GPU)"""
+    b = bytes(file_bytes)
+    n = lib().mars_hip_describe_plan(b, len(b), flags, None, 0)
+    if n == 0:
+        raise ValueError("the loader rejects the file")
+    buf = C.create_string_buffer(n + 1)
+    lib().mars_hip_describe_plan(b, len(b), flags, buf, n + 1)
+    return buf.value.decode().splitlines()
 
 
 def compile_onnx(onnx_bytes, float32=False, nhwc=False, verbose=False):
