@@ -20,7 +20,7 @@ def build():
     convolutions take their dims by the tag, while pools / concats / upsampling index shape[1..3] as H, W, C whatever the
     tag says (the reference's behaviour), so there a pool halves "C" and "H" and a concat joins along "W" """
     G = marsfile.Graph()
-    nchw = bool(rng.integers(0, 4) == 0)
+    nchw = bool(rng.integers(0, 4) == 0) if os.environ.get("FUZZ_NCHW") is None else os.environ["FUZZ_NCHW"] == "1"
     fmt = marsfile.NCHW if nchw else marsfile.NHWC
     h, w = int(rng.integers(6, 40)), int(rng.integers(6, 40))
     c = int(rng.choice([3, 5, 8, 16, 24, 32, 40, 64]))
@@ -28,9 +28,29 @@ def build():
     x = G.tensor([1, *dims], fmt=fmt, scale=float(rng.choice([0.02, 0.04])))
     avail = [(x, *dims)]
     desc = [("nchw" if nchw else "nhwc", dims)]
+
+    def mkconv(t, tc, th, tw, k, s, oc, pad, silu, act):
+        oh, ow = (th + s - 1) // s, (tw + s - 1) // s  # the output tensor's shape; VALID still fills it (unpadded window)
+        wshape = (oc, tc, k, k) if nchw else (oc, k, k, tc)
+        wt = G.tensor(list(wshape), fmt=marsfile.OIHW if nchw else marsfile.OHWI, scale=0.003 / (k * k * tc) ** 0.5 * 8,
+                      data=rng.integers(-127, 128, wshape, dtype=np.int8))
+        b = G.tensor([oc], dtype=marsfile.I32, fmt=marsfile.D1, scale=1.0, data=rng.integers(-3000, 3000, oc, dtype=np.int32)) \
+            if rng.integers(0, 5) else marsfile.NONE
+        od = (oc, oh, ow) if nchw else (oh, ow, oc)
+        a = G.tensor([1, *od], fmt=fmt, scale=float(rng.choice([0.04, 0.06])))
+        G.conv(t, a, wt, b, (k, k), (s, s), pad=pad, act=act)
+        out = a
+        if silu:
+            sg = G.tensor([1, *od], fmt=fmt, scale=1.0 / 256)
+            o = G.tensor([1, *od], fmt=fmt, scale=float(rng.choice([0.03, 0.05])))
+            G.layer(marsfile.SIGMOID, [a], [sg])
+            G.layer(marsfile.MUL, [a, sg], [o])
+            out = o
+        return out, od
+
     for _ in range(int(rng.integers(3, 11))):
         t, d1, d2, d3 = avail[int(rng.integers(0, len(avail)))]
-        op = str(rng.choice(["conv", "conv", "conv", "pool", "act", "bin", "concat", "up"]))
+        op = str(rng.choice(["conv", "conv", "conv", "pool", "act", "bin", "concat", "up", "c3", "sppf"]))
         if op == "conv":
             tc, th, tw = (d1, d2, d3) if nchw else (d3, d1, d2)
             if th * tw > 4000 or tc > 300:
@@ -40,23 +60,8 @@ def build():
             s = int(rng.choice([1, 1, 2, 3]))
             oc = int(rng.choice([7, 16, 24, 32, 64, 81, 128]))
             pad = int(rng.choice([marsfile.PAD_SAME, marsfile.PAD_SAME, marsfile.PAD_SAME, marsfile.PAD_VALID]))
-            oh, ow = (th + s - 1) // s, (tw + s - 1) // s  # the output tensor's shape; VALID still fills it (unpadded window)
-            wshape = (oc, tc, k, k) if nchw else (oc, k, k, tc)
-            wt = G.tensor(list(wshape), fmt=marsfile.OIHW if nchw else marsfile.OHWI, scale=0.003 / (k * k * tc) ** 0.5 * 8,
-                          data=rng.integers(-127, 128, wshape, dtype=np.int8))
-            b = G.tensor([oc], dtype=marsfile.I32, fmt=marsfile.D1, scale=1.0, data=rng.integers(-3000, 3000, oc, dtype=np.int32)) \
-                if rng.integers(0, 5) else marsfile.NONE
-            od = (oc, oh, ow) if nchw else (oh, ow, oc)
-            a = G.tensor([1, *od], fmt=fmt, scale=float(rng.choice([0.04, 0.06])))
             silu = bool(rng.integers(0, 2))
-            G.conv(t, a, wt, b, (k, k), (s, s), pad=pad, act=0 if silu else int(rng.integers(0, 2)))
-            out = a
-            if silu:
-                sg = G.tensor([1, *od], fmt=fmt, scale=1.0 / 256)
-                o = G.tensor([1, *od], fmt=fmt, scale=float(rng.choice([0.03, 0.05])))
-                G.layer(marsfile.SIGMOID, [a], [sg])
-                G.layer(marsfile.MUL, [a, sg], [o])
-                out = o
+            out, od = mkconv(t, tc, th, tw, k, s, oc, pad, silu, 0 if silu else int(rng.integers(0, 2)))
             avail.append((out, *od)); desc.append(("conv", k, s, tc, oc, silu, pad))
         elif op == "pool":
             k = int(rng.choice([2, 3, 5])); s = int(rng.choice([1, 2]))
@@ -87,6 +92,44 @@ def build():
             o = G.tensor([1, d1, d2, cs], fmt=fmt, scale=G.tensors[t]["scale"])
             G.concat(parts, o)
             avail.append((o, d1, d2, cs)); desc.append(("concat", [d3] + [q[3] for q in extra]))
+        elif op in ("c3", "sppf"):
+            # the detectors' motifs, which the planner has passes for (virtual_concat / virtual_concat_q, pairs, pool chains, the byte-wise
+            # layers on the internal layout): C3 = two 1x1 convolutions of one tensor (one of them through a bottleneck with a shortcut)
+            # -> concat -> 1x1;  SPPF = 1x1 -> three chained 5x5 stride-1 pools -> concat of the four -> 1x1
+            tc, th, tw = (d1, d2, d3) if nchw else (d3, d1, d2)
+            if th * tw > 2500 or tc > 200:
+                continue
+            oc = int(rng.choice([16, 32, 64]))
+            pad = marsfile.PAD_SAME
+            silu = bool(rng.integers(0, 2))
+            if op == "c3":
+                a, od = mkconv(t, tc, th, tw, 1, 1, oc, pad, silu, 0)
+                b, _ = mkconv(t, tc, th, tw, 1, 1, oc, pad, silu, 0)
+                if rng.integers(0, 2):
+                    m1, _ = mkconv(a, oc, th, tw, 1, 1, oc, pad, silu, 0)
+                    m2, _ = mkconv(m1, oc, th, tw, 3, 1, oc, pad, silu, 0)
+                    a2 = G.tensor([1, *od], fmt=fmt, scale=float(rng.choice([0.05, 0.08])))
+                    G.layer(marsfile.ADD, [a, m2], [a2])
+                    a = a2
+                parts = [a, b]
+            else:
+                a, od = mkconv(t, tc, th, tw, 1, 1, oc, pad, silu, 0)
+                parts = [a]
+                for _i in range(3):
+                    o = G.tensor([1, *od], fmt=fmt, scale=G.tensors[parts[-1]]["scale"])
+                    G.pool(parts[-1], o, (5, 5), (1, 1))
+                    parts.append(o)
+            # (NCHW-tagged: the exporter's form, [1, sum C, H, W] along axis 1 -- which the reference's byte-wise CONCAT turns into a shift
+            #  of the last input by N - 1 map rows, reading past the inputs' ends into the arena)
+            cd = (od[0] * len(parts), od[1], od[2]) if nchw else (od[0], od[1], od[2] * len(parts))
+            cat = G.tensor([1, *cd], fmt=fmt, scale=G.tensors[parts[0]]["scale"])
+            if nchw:
+                G.concat(parts, cat, axis=1)
+            else:
+                G.concat(parts, cat)
+            cc, ch, cw = cd if nchw else (cd[2], cd[0], cd[1])
+            out, od2 = mkconv(cat, cc, ch, cw, 1, 1, int(rng.choice([16, 32, 48])), pad, silu, 0)
+            avail.append((parts[0], *od)); avail.append((out, *od2)); desc.append((op, tc, oc, silu))
         else:
             if d1 * d2 > 600:
                 continue
