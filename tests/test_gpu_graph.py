@@ -2243,6 +2243,7 @@ def test_f32_zero_tail_k_limit(gpu, orc, monkeypatch):
     want = [g.tensor(ti).copy() for ti in hdr["outputs"]]
     g.close()
     res, macs = {}, {}
+    monkeypatch.setenv("MARS_HIP_NO_VCONCAT_F32", "1")  # (the concats materialised: this test is about the zeros IN them; test_f32_virtual_concat has the other plan)
     try:
         gpu.set_tuning("f32_mfma", 3)
         for tag, env in (("limited", None), ("full", "1")):
@@ -2277,5 +2278,61 @@ def test_f32_zero_tail_k_limit(gpu, orc, monkeypatch):
         for i in range(len(hdr["outputs"])):
             assert np.array_equal(m.output_view(i)[0], want[i]), "mode 0 head %d" % i
         m.close()
+    finally:
+        gpu.set_tuning("f32_mfma", 1)
+
+
+@pytest.mark.parametrize("mode", [3, 4])
+def test_f32_virtual_concat(gpu, orc, mode, monkeypatch):
+    """round 6 (mars_plan.c virtual_concat_f32, conv_f32_vcat.hip): no float CONCAT of the twin is materialised -- its readers (C3's cv3, SPPF's
+    cv2, the head C3s' cv1 + cv2 pairs) run on a view of the concat's LAST input (W (N - 1) bytes in front of it, a quarter of the K loop) and a
+    head launch recomputes the first (N - 1) W / 4 pixels of every output plane from the other inputs' first bytes.  Against the plan with the
+    concats materialised (MARS_HIP_NO_VCONCAT_F32), three frames: the first concat's reader -- same operands in both plans -- is bit-identical
+    from pixel s on and within 1e-5 before it; every head within 1e-4 of the oracle and of the other plan; the concat tensors do not exist."""
+    d = gpu.synth_model(width_x16=4, input_hw=128, seed=9, float32=True)
+    hdr, tensors, layers = marsfile.parse(d)
+    n = marsfile.tensor_nbytes(tensors[hdr["inputs"][0]]) // 4
+    B = 3
+    xs = [cases.f32(0x5EED0000 + f, n, 0.0, 1.0).view(np.uint8) for f in range(B)]
+    cat_ids = [l["outs"][0] for l in layers if l["type"] == marsfile.CONCAT]
+    try:
+        gpu.set_tuning("f32_mfma", mode)
+        monkeypatch.delenv("MARS_HIP_NO_VCONCAT_F32", raising=False)
+        plan = gpu.describe_plan(d)
+        views = [l for l in plan if " view=-" in l]
+        heads = [l for l in plan if " conv_f32_vhead " in l]
+        assert len(views) == 17 and len(heads) == 17 and not any(" concat_slice " in l for l in plan)
+        t_first = int(views[0].split(" out ")[1].split()[0])
+        nf, run = (int(v) for v in heads[0].split(" vcat=")[1].split()[0].split("x"))
+        s_pix = nf * run
+        got = {}
+        for tag, env in (("virtual", None), ("copied", "1")):
+            if env:
+                monkeypatch.setenv("MARS_HIP_NO_VCONCAT_F32", env)
+            else:
+                monkeypatch.delenv("MARS_HIP_NO_VCONCAT_F32", raising=False)
+            m = gpu.Model(d, batch=B)
+            for f in range(B):
+                m.input_view(0)[f] = xs[f]
+            m.run()
+            got[tag] = {"heads": [m.output_view(i).copy() for i in range(len(hdr["outputs"]))],
+                        "first": [m.read_tensor(t_first, frame=f).view(np.float32).copy() for f in range(B)],
+                        "launches": len(m.ops()), "readable": [_readable(gpu, m, t) for t in cat_ids]}
+            m.close()
+        assert got["virtual"]["readable"] == [False] * len(cat_ids) and got["copied"]["readable"] == [True] * len(cat_ids)
+        # 13 concats = 29 slice launches gone, 17 head launches added
+        assert got["virtual"]["launches"] == got["copied"]["launches"] - sum(len(l["ins"]) for l in layers if l["type"] == marsfile.CONCAT) + 17
+        C = tensors[t_first]["shape"][1]
+        for f in range(B):
+            a, b = got["virtual"]["first"][f].reshape(C, -1), got["copied"]["first"][f].reshape(C, -1)
+            assert s_pix < a.shape[1] and np.array_equal(a[:, s_pix:], b[:, s_pix:]), "frame %d: the view changed a value behind the head pixels" % f
+            assert np.isfinite(a[:, :s_pix]).all() and (np.abs(a[:, :s_pix] - b[:, :s_pix]) <= 1e-5 * np.maximum(1.0, np.abs(b[:, :s_pix]))).all(), "frame %d: head pixels" % f
+        for f in range(B):
+            g, rc = run_oracle(orc, d, xs[f])
+            assert rc == 0
+            for i, ti in enumerate(hdr["outputs"]):
+                assert close_f32(got["virtual"]["heads"][i][f], g.tensor(ti)).all(), "frame %d head %d against the oracle" % (f, i)
+                assert close_f32(got["virtual"]["heads"][i][f], got["copied"]["heads"][i][f]).all(), "frame %d head %d against the other plan" % (f, i)
+            g.close()
     finally:
         gpu.set_tuning("f32_mfma", 1)

@@ -53,25 +53,44 @@ def test_descriptor_only_ranks_plan_alike(marsrt, name):
 
 def test_float_twin_zero_tail_limits(marsrt, monkeypatch):
     """zero_tail_f32: in the float twin the 17 convolutions (1 x 1) that read a CONCAT output stop their K loop at in_c / 4 + 1 channels --
-    under the split-bf16 modes only, and not with MARS_HIP_NO_ZERO_TAIL"""
+    under the split-bf16 modes only, and not with MARS_HIP_NO_ZERO_TAIL.  virtual_concat_f32 on top of it: none of the 13 concats is
+    materialised -- every such convolution reads the concat's LAST input through a view (W (N - 1) bytes early, in_c / 4 planes) and a
+    head launch recomputes the first pixels with in_c / 4 + 1 planes"""
     monkeypatch.delenv("MARS_HIP_NO_ZERO_TAIL", raising=False)
+    monkeypatch.delenv("MARS_HIP_NO_VCONCAT_F32", raising=False)
     saved = marsrt.get_tuning("f32_mfma")
     try:
         marsrt.set_tuning("f32_mfma", 3)
         d = marsrt.synth_model(width_x16=8, input_hw=640, seed=1, float32=True)
         L = marsrt.describe_plan(d)
+        k = kinds(L)
+        main = [l for l in L if " view=-" in l]
+        heads = [l for l in L if " conv_f32_vhead " in l]
+        assert len(main) == 17 and len(heads) == 17 and k["concat_slice"] == 0 and k["conv_f32_vhead"] == 17
+        for l in main:
+            in_c = int(l.split("->")[0].rsplit(" c", 1)[1])
+            assert " k1x1 " in l and int(l.split("k_limit=")[1].split()[0]) == in_c // 4, l
+        for l in heads:
+            in_c = int(l.split("->")[0].rsplit(" c", 1)[1])
+            assert int(l.split("k_limit=")[1].split()[0]) == in_c // 4 + 1 and " vcat=" in l, l
+        assert sum(l.startswith("tensor ") and " partial 1" in l for l in L) == 13
+        assert count(L, " in_rec=") >= 9 and count(L, " out_rec") >= 9 and count(L, " pair_next") >= 4  # (record pairs, C3 pairs: round 5)
+        # the concats materialised (MARS_HIP_NO_VCONCAT_F32): the zero-tail limits alone
+        monkeypatch.setenv("MARS_HIP_NO_VCONCAT_F32", "1")
+        L = marsrt.describe_plan(d)
         lim = [l for l in L if " k_limit=" in l]
-        assert len(lim) == 17
+        assert len(lim) == 17 and count(L, " view=-") == 0 and kinds(L)["concat_slice"] >= 26
         for l in lim:
             in_c = int(l.split("->")[0].rsplit(" c", 1)[1])
             assert " k1x1 " in l and int(l.split("k_limit=")[1].split()[0]) == in_c // 4 + 1, l
-        assert count(L, " in_rec=") >= 9 and count(L, " out_rec") >= 9 and count(L, " pair_next") >= 4  # (record pairs, C3 pairs: round 5)
         monkeypatch.setenv("MARS_HIP_NO_ZERO_TAIL", "1")
-        assert count(marsrt.describe_plan(d), " k_limit=") == 0
+        L = marsrt.describe_plan(d)
+        assert count(L, " k_limit=") == 0 and count(L, " view=-") == 0  # (no limit: no view either)
         monkeypatch.delenv("MARS_HIP_NO_ZERO_TAIL")
+        monkeypatch.delenv("MARS_HIP_NO_VCONCAT_F32")
         marsrt.set_tuning("f32_mfma", 1)
         L1 = marsrt.describe_plan(d)
-        assert count(L1, " k_limit=") == 0 and count(L1, " in_rec=") == 0  # (no bf16 weight images, no record tensors, full K loops)
+        assert count(L1, " k_limit=") == 0 and count(L1, " in_rec=") == 0 and count(L1, " view=-") == 0  # (no bf16 weight images, no record tensors, full K loops)
     finally:
         marsrt.set_tuning("f32_mfma", saved)
 

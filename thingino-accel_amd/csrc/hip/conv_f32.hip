@@ -246,13 +246,15 @@ extern "C" int mhip_conv_f32(const mhip_conv_f32_t *p) {
     if (p->out_c > 65535 || p->frames > 65535) return -1;
     const long hw = (long)p->out_h * p->out_w, total = hw * p->frames, K = (long)p->in_c * p->kh * p->kw;
     if (p->use_mfma >= 2) { // the bf16 matrix cores on split operands (conv_f32_split.hip): 2 = six piece products, 3 = three
-        int rc = conv_f32_try_stem(p); // the 3-channel first layer, three piece products (round 5)
+        int rc = p->k_limit_required ? -2 : conv_f32_try_stem(p); // the 3-channel first layer, three piece products (round 5)
         if (rc != -2) return rc;
-        rc = conv_f32_try_patch(p); // k x k layers, three piece products: the patch-staged form (round 5)
+        rc = p->k_limit_required ? -2 : conv_f32_try_patch(p); // k x k layers, three piece products: the patch-staged form (round 5)
         if (rc != -2) return rc;
         rc = p->w_split ? conv_f32_try_split(p) : -2;
         if (rc != -2) return rc;
     }
+    // a shifted view of another tensor (virtual_concat_f32): what lies behind k_limit planes is not zero -- only conv_f32_split stops there
+    if (p->k_limit_required) return mhip_check(hipErrorInvalidValue, "conv_f32: a K-limited input view and no kernel that honours the limit");
     // record-format tensors exist between two of the kernels above only (the planner's pairing: mars_plan.c); nothing below reads or writes them
     if (p->in_rec || p->out_rec) return mhip_check(hipErrorInvalidValue, "conv_f32: record-format operand and no kernel for it");
     if (p->use_mfma && total <= 0x7fffffffL - F_BN && K <= 0x7fffffffL - F_BK) {

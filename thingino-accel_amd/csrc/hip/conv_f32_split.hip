@@ -638,7 +638,7 @@ extern "C" int mhip_conv_f32_pair(const mhip_conv_f32_t *a, const mhip_conv_f32_
         a->out_h != b->out_h || a->out_w != b->out_w || a->out_c != b->out_c || a->kh != b->kh || a->kw != b->kw || a->stride_h != b->stride_h ||
         a->stride_w != b->stride_w || a->pad_top != b->pad_top || a->pad_left != b->pad_left || a->silu != b->silu || a->out_stride != b->out_stride)
         return -2;
-    if (a->add || b->add || a->in_rec || b->in_rec || a->out_rec || b->out_rec || a->out == b->out || a->k_limit != b->k_limit) return -2;
+    if (a->add || b->add || a->in_rec || b->in_rec || a->out_rec || b->out_rec || a->out == b->out || a->k_limit != b->k_limit || a->k_limit_required != b->k_limit_required) return -2;
     const int rc = try_split(a, b);
     if (rc == 0) g_pair_launches++;
     return rc;

@@ -29,6 +29,7 @@ enum {
     OP_UPSAMPLE,
     OP_UPSAMPLE_Q, OP_MAXPOOL_Q, /* UPSAMPLE / stride-1 MAXPOOL of an NCHW-tagged graph on tensors held pixels x channels (nhwc_internal) */
     OP_CONCAT_Q, /* a whole CONCAT layer of an NCHW-tagged graph on tensors held pixels x channels (nhwc_internal; mhip_concat_nchwq) */
+    OP_CONV_F32_VHEAD, /* the first pixels of a conv_f32 that reads a never-materialised float CONCAT (virtual_concat_f32; mhip_conv_f32_vcat_head) */
     OP_FAIL, /* mars_run stops here with op->err, as the reference would at this layer */
 };
 
@@ -62,6 +63,9 @@ typedef struct {
     int nchw, relu, is_mul, is_f32, leaky, safe; /* nchw (conv_i8): the INPUT is [C][H][W] bytes and is relaid into scratch before the launch */
     size_t in_byte_off, out_byte_off; /* conv_i8: added to the input / output tensor's address (virtual_concat_q: a convolution over a row range of a tensor) */
     int k_limit;   /* conv_f32 (1 x 1): input channels >= k_limit are exact zeros in every frame (zero_tail_f32): mhip_conv_f32_t.k_limit under modes 3 / 4; 0 = none */
+    int vc_n, vc_t[3], vc_run, vc_shift; /* conv_f32 (1 x 1) over a float CONCAT that is never materialised (virtual_concat_f32): t_in[0] is the concat's LAST input, read
+                      through a view vc_shift bytes in front of it, K loop = k_limit planes (required);  OP_CONV_F32_VHEAD: the concat's other inputs
+                      (vc_n of them, runs of vc_run floats) and k_limit = planes to sum for the first vc_n * vc_run pixels */
     int rows_only; /* OP_CONCAT_Q: only the first `rows_only` map rows of the output are produced (the rest of it is never read: virtual_concat_q); 0 = all */
     int out_nchw;  /* conv_i8: the result is stored [O][H][W] (the reference's conv2d_int8_mxu); both set by the input's tag, cleared per side by nhwc_internal */
     int silu_f32;  /* conv_f32 with the float SIGMOID + MUL pair (ONNX SiLU) folded into its epilogue */
@@ -171,6 +175,7 @@ MARS_INTERNAL void plan_layer(mars_model_ext_t *m, int li);
 MARS_INTERNAL void nhwc_internal(mars_model_ext_t *m);
 MARS_INTERNAL void virtual_concat_q(mars_model_ext_t *m);
 MARS_INTERNAL void zero_tail_f32(mars_model_ext_t *m);
+MARS_INTERNAL void virtual_concat_f32(mars_model_ext_t *m);
 MARS_INTERNAL void fuse_silu(mars_model_ext_t *m);
 MARS_INTERNAL void fuse_silu_f32(mars_model_ext_t *m);
 MARS_INTERNAL void elide_concat(mars_model_ext_t *m);

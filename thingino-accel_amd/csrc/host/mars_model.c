@@ -193,6 +193,7 @@ mars_error_t build_plan(mars_model_ext_t *m) {
     zero_tail_f32(m); /* (before pairing: a pair shares its input, hence its limit; resets the flags at fusion level 0) */
     if (m->fusion >= 1) pair_convs_f32(m); /* (after f32_policy: a pair shares one kernel choice) */
     rec_pairs(m); /* (fusion >= 1 only; resets the tensors' record flags in any case) */
+    virtual_concat_f32(m); /* (last: it replaces launches; shares rec_pairs' per-batch decision) */
     return (mars_error_t)m->plan_err;
 }
 
@@ -289,10 +290,12 @@ mars_error_t alloc_batch(mars_model_ext_t *m, int n) {
     m->act_bytes = per_frame * (size_t)n;
     /* + 256: vector loads may read up to 15 bytes past the last element they use (the stem's unaligned 16-byte loads
      * of 12-byte pixel groups); the slack keeps that inside the allocation for the last tensor too */
-    m->act_dev = (uint8_t *)mhip_malloc(m->act_bytes + 256);
+    /* 256 in front: a convolution may read a tensor through a view that starts up to 256 bytes before it (virtual_concat_f32: those
+     * results are overwritten, but the addresses must be mapped for the first tensor too) */
+    m->act_dev = (uint8_t *)mhip_malloc(m->act_bytes + 512);
     if (!m->act_dev) return MARS_ERR_ALLOC_FAILED;
-    if (mhip_memset_async(m->act_dev, 0, m->act_bytes)) return MARS_ERR_ALLOC_FAILED;
-    size_t off = 0;
+    if (mhip_memset_async(m->act_dev, 0, m->act_bytes + 256)) return MARS_ERR_ALLOC_FAILED;
+    size_t off = 256;
     for (uint32_t i = 0; i < nt; i++) {
         mtensor_t *t = &m->mt[i];
         mars_runtime_tensor_t *rt = &m->pub.tensors[i];
@@ -425,7 +428,7 @@ mars_error_t mars_hip_load_memory_ex(const void *data, size_t size, unsigned fla
  * held as tagged.  Returns the length needed (the text is cut at cap); 0 on a file the loader rejects. */
 size_t mars_hip_describe_plan(const void *data, size_t size, unsigned flags, char *out, size_t cap) {
     static const char *const kinds[] = {"conv_i8", "conv_f32", "relu_bytes", "lut_i8", "binary_i8", "sigmoid_f32", "binary_f32", "relu_f32", "bn",
-                                        "maxpool", "concat_slice", "upsample", "upsample_q", "maxpool_q", "concat_q", "fail"};
+                                        "maxpool", "concat_slice", "upsample", "upsample_q", "maxpool_q", "concat_q", "conv_f32_vhead", "fail"};
     mars_model_ext_t *m = NULL;
     if (load_host(data, size, flags, &m) != MARS_OK) return 0;
     size_t n = 0;
@@ -437,10 +440,11 @@ size_t mars_hip_describe_plan(const void *data, size_t size, unsigned flags, cha
         for (int q = 0; q < o->n_in && q < 4; q++) k += snprintf(line + k, sizeof line - (size_t)k, " %d", o->t_in[q]);
         k += snprintf(line + k, sizeof line - (size_t)k, " out %d", o->t_out);
 #define FLAG(cond, ...) if (cond) k += snprintf(line + k, sizeof line - (size_t)k, __VA_ARGS__)
-        FLAG(o->kind == OP_CONV_I8 || o->kind == OP_CONV_F32, " k%dx%d s%d c%d->%d", o->kh, o->kw, o->sw, o->in_c, o->out_c);
+        FLAG(o->kind == OP_CONV_I8 || o->kind == OP_CONV_F32 || o->kind == OP_CONV_F32_VHEAD, " k%dx%d s%d c%d->%d", o->kh, o->kw, o->sw, o->in_c, o->out_c);
         FLAG(o->nchw, " relayout"); FLAG(o->out_nchw, " planar_store"); FLAG(o->lut_off != NO_OFF, " lut"); FLAG(o->add_t, " add=%d", o->add_t - 1);
         FLAG(o->nseg, " seg=%d", o->nseg); FLAG(o->pair_next, " pair_next"); FLAG(o->pre, " pre"); FLAG(o->silu_f32, " silu");
         FLAG(o->k_limit, " k_limit=%d", o->k_limit); FLAG(o->in_rec, " in_rec=%d", o->in_rec); FLAG(o->out_rec, " out_rec");
+        FLAG(o->vc_shift, " view=-%d", o->vc_shift); FLAG(o->vc_n, " vcat=%dx%d", o->vc_n, o->vc_run);
         FLAG(o->rows_only, " rows_only=%d", o->rows_only); FLAG(o->out_byte_off, " out_off=%zu", o->out_byte_off); FLAG(o->chain_n, " chain=%d", o->chain_n);
         FLAG(o->out_pix_stride, " pix_stride=%d", o->out_pix_stride); FLAG(o->kind == OP_FAIL, " err=%d", o->err);
 #undef FLAG

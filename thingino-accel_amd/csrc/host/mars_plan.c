@@ -1619,6 +1619,152 @@ void zero_tail_f32(mars_model_ext_t *m) {
     }
 }
 
+/* A float CONCAT that no launch materialises (round 6; conv_f32_vcat.hip has the arithmetic).  On N float maps [1, C, H, W] of equal size the reference's
+ * byte-wise CONCAT (trim_concat has already cut it to what survives) leaves, per frame: the first W BYTES of every input but the last, then the first
+ * L = C_out H W bytes of the LAST input shifted by sB = (N - 1) W bytes, then zeros.  Its readers -- one 1 x 1 convolution, or a pair of them --
+ * already stop their K loop behind the written bytes (zero_tail_f32: k_limit = L / plane + 1).  For every pixel from sB / 4 on, such a convolution over
+ * the concat IS the convolution over the address (last input - sB) with L / plane input planes: it runs on that view (vc_shift, k_limit required),
+ * and a second, tiny launch (OP_CONV_F32_VHEAD) recomputes the first sB / 4 pixels of every output plane from their true operands.  The copies
+ * (two passes over a quarter of the concat tensor) and the tensor itself go.  Same tolerance class as the launch it replaces (split-bf16 modes only).
+ * Batch-dependent like rec_pairs (32-bit offsets over all frames): shares its per-batch re-planning.  Runs last. */
+void virtual_concat_f32(mars_model_ext_t *m) {
+    const int mode = mhip_conv_f32_mode(-1);
+    if (m->fusion < 1 || getenv("MARS_HIP_NO_VCONCAT_F32") || (mode != 3 && mode != 4)) return;
+    const char *lim_env = getenv("MARS_HIP_REC_LIMIT");
+    const size_t frames = m->rec_frames > 0 ? (size_t)m->rec_frames : 1, lim = lim_env ? (size_t)strtoull(lim_env, NULL, 0) : (size_t)0xfffffff0u;
+    for (int i = 0; i < m->n_ops; i++) {
+        if (m->ops[i].kind != OP_CONCAT_SLICE) continue;
+        const int T = m->ops[i].t_out, layer = m->ops[i].layer;
+        int e = i;
+        while (e + 1 < m->n_ops && m->ops[e + 1].kind == OP_CONCAT_SLICE && m->ops[e + 1].layer == layer && m->ops[e + 1].t_out == T) e++;
+        const int N = e - i + 1, first_op = i;
+        i = e; /* (whatever happens below, the scan goes on behind the group) */
+        if (N < 2 || N > 4 || T < 0 || m->mt[T].io_in || m->mt[T].io_out || m->mt[T].is_weight || m->pub.tensors[T].desc.dtype != MARS_DTYPE_FLOAT32) continue;
+        const mars_op_t *last = &m->ops[e];
+        const int Wb = last->in_c; /* bytes per run */
+        if (Wb <= 0 || (Wb & 3) || last->out_c != Wb || last->ch_off != (N - 1) * Wb || last->out_pix_stride || last->out_h <= 0 || last->out_w <= 0) continue;
+        const int TL = last->t_in[0];
+        const size_t Lb = (size_t)last->out_h * last->out_w * (size_t)Wb, sB = (size_t)(N - 1) * (size_t)Wb;
+        if (TL < 0 || TL == T || m->mt[TL].is_weight || m->mt[TL].io_in /* (a pipeline may hand the graph input over in a buffer of its own: nothing mapped in front) */ || m->mt[TL].rec_c || m->mt[TL].nhwc_c || m->mt[TL].pix_stride || m->mt[TL].bytes < Lb ||
+            m->pub.tensors[TL].desc.dtype != MARS_DTYPE_FLOAT32 || sB > 256)
+            continue;
+        int ok = 1, firsts[3] = {-1, -1, -1};
+        for (int k = 0; k < N - 1 && ok; k++) {
+            const mars_op_t *sl = &m->ops[first_op + k];
+            const int ti = sl->t_in[0];
+            if (sl->in_c != Wb || sl->out_c != Wb || sl->ch_off != k * Wb || sl->out_h != 1 || sl->out_w != 1 || sl->out_pix_stride || ti < 0 || ti == T ||
+                m->mt[ti].is_weight || m->mt[ti].rec_c || m->mt[ti].nhwc_c || m->mt[ti].bytes < (size_t)Wb)
+                ok = 0;
+            firsts[k] = ti;
+        }
+        if (!ok) continue;
+        /* who touches the concat tensor: the group writes it, one convolution (or one pair) reads it, nothing else */
+        int r1 = -1, nr = 0;
+        for (int j = 0; j < m->n_ops && ok; j++) {
+            const mars_op_t *o = &m->ops[j];
+            if (j >= first_op && j <= e) continue;
+            if (op_writes(o, T)) ok = 0;
+            for (int k = 0; k < o->nseg && k < 4; k++)
+                if (o->seg_t[k] == T) ok = 0;
+            for (int k = 0; k < o->n_in && k < 4; k++)
+                if (o->t_in[k] == T) {
+                    if (k != 0 || j <= e) ok = 0;
+                    if (r1 < 0) r1 = j;
+                    nr++;
+                }
+        }
+        if (!ok || r1 < 0 || nr > 2) continue;
+        const int paired = m->ops[r1].pair_next ? 1 : 0;
+        if (nr != 1 + paired || (r1 > 0 && m->ops[r1 - 1].pair_next) || (paired && (r1 + 1 >= m->n_ops || m->ops[r1 + 1].t_in[0] != T))) continue;
+        const int rl = r1 + paired; /* the last reader */
+        size_t km = 0, worst = 0;
+        for (int j = r1; j <= rl && ok; j++) {
+            const mars_op_t *x = &m->ops[j];
+            if (x->kind != OP_CONV_F32 || x->k_limit <= 0 || x->n_in != 1 || x->add_t || x->in_rec || x->vc_shift || x->kh != 1 || x->kw != 1 || x->sh != 1 || x->sw != 1 ||
+                x->pt || x->pl || x->w2_off == NO_OFF || x->in_h != x->out_h || x->in_w != x->out_w || x->t_out == TL || x->t_out == T || x->t_out < 0) { ok = 0; break; }
+            const size_t hw = (size_t)x->in_h * x->in_w, Pb = hw * 4;
+            if (m->mt[T].bytes != (size_t)x->in_c * Pb || Lb % Pb || sB / 4 >= hw) { ok = 0; break; }
+            km = Lb / Pb;
+            if (km < 1 || (size_t)x->k_limit != km + 1 || km + 1 > (size_t)x->in_c) { ok = 0; break; }
+            if (x->out_rec && (x->out_c & 7)) { ok = 0; break; }
+            for (int k = 0; k < N - 1; k++)
+                if (x->t_out == firsts[k]) ok = 0;
+            const size_t st = planned_stride(&m->mt[x->t_out]);
+            if (st > worst) worst = st;
+        }
+        if (!ok) continue;
+        for (int j = e + 1; j <= rl && ok; j++) { /* the operands must still hold at the readers what they held at the concat */
+            if (op_writes(&m->ops[j], TL)) ok = 0;
+            for (int k = 0; k < N - 1; k++)
+                if (op_writes(&m->ops[j], firsts[k])) ok = 0;
+        }
+        if (!ok) continue;
+        if (planned_stride(&m->mt[TL]) > worst) worst = planned_stride(&m->mt[TL]);
+        /* (the main launch's buffer range is the CONCAT tensor's size over the last input's frame stride: at most 3 strides more than frames of it) */
+        if (worst * (frames + 3) > lim) { /* conv_f32_split addresses all frames of a tensor with 32-bit offsets and nothing else honours k_limit: as rec_pairs */
+            m->rec_skipped = 1;
+            continue;
+        }
+        if (lim / worst - 3 < m->rec_max_frames) m->rec_max_frames = lim / worst - 3;
+        if (!m->deferred) { /* plane km is skipped for the pixels where the concat holds zeros: 0 * w must be 0 there (as zero_tail_f32 checks the planes behind it) */
+            for (int j = r1; j <= rl && ok; j++) {
+                const mars_op_t *x = &m->ops[j];
+                const float *w = (const float *)(m->arena_host + x->w_off);
+                for (int oc = 0; oc < x->out_c; oc++) {
+                    const float v = w[(size_t)oc * x->in_c + km];
+                    if (!(v - v == 0.0f)) { ok = 0; break; }
+                }
+            }
+            if (!ok) continue;
+        }
+        /* ops: [slices: gone] ... [readers on the view] [one head launch per reader] */
+        const int heads = 1 + paired;
+        size_t wt_off[2] = {NO_OFF, NO_OFF}; /* the head launches' weights: planes 0 .. km transposed (mhip_conv_f32_vcat_pack) */
+        for (int q = 0; q < heads; q++) {
+            const mars_op_t *x = &m->ops[r1 + q];
+            wt_off[q] = arena_reserve(m, mhip_conv_f32_vcat_pack(x->out_c, x->in_c, (int)km + 1, NULL, NULL));
+            if (wt_off[q] == NO_OFF) return;
+            if (!m->deferred)
+                mhip_conv_f32_vcat_pack(x->out_c, x->in_c, (int)km + 1, (const float *)(m->arena_host + x->w_off), (float *)(m->arena_host + wt_off[q]));
+        }
+        while (m->n_ops + heads > m->cap_ops) {
+            const int cap = m->cap_ops * 2;
+            mars_op_t *np = (mars_op_t *)realloc(m->ops, (size_t)cap * sizeof(mars_op_t));
+            if (!np) { m->plan_err = MARS_ERR_ALLOC_FAILED; return; }
+            m->ops = np; m->cap_ops = cap;
+        }
+        memmove(&m->ops[rl + 1 + heads], &m->ops[rl + 1], sizeof(mars_op_t) * (size_t)(m->n_ops - rl - 1));
+        m->n_ops += heads;
+        for (int q = 0; q < heads; q++) {
+            mars_op_t *x = &m->ops[r1 + q], *h = &m->ops[rl + 1 + q];
+            const double hw = (double)x->in_h * x->in_w;
+            x->t_in[0] = TL;
+            x->vc_shift = (int)sB;
+            x->k_limit = (int)km;
+            x->macs = hw * x->out_c * (double)km;
+            x->bytes = (hw * (double)km + hw * x->out_c) * 4.0;
+            *h = *x;
+            h->kind = OP_CONV_F32_VHEAD;
+            h->pair_next = 0; h->vc_shift = 0;
+            h->k_limit = (int)km + 1;
+            h->vc_n = N - 1; h->vc_run = Wb / 4;
+            h->n_in = N;
+            for (int k = 0; k < N - 1; k++) { h->vc_t[k] = firsts[k]; h->t_in[1 + k] = firsts[k]; }
+            h->macs = (double)(sB / 4) * x->out_c * (double)(km + 1);
+            h->bytes = ((double)(sB / 4) * (double)(km + 1) + (double)(sB / 4) * x->out_c) * 4.0;
+            h->variant = 0;
+            h->w3_off = wt_off[q]; h->w3_stem = 0;
+            h->w2_off = NO_OFF; h->w2_planes = 0;
+        }
+        memmove(&m->ops[first_op], &m->ops[e + 1], sizeof(mars_op_t) * (size_t)(m->n_ops - e - 1));
+        m->n_ops -= N;
+        m->mt[T].needed = 0;
+        m->mt[T].partial = 1;
+        m->mt[T].zero_from = 0;
+        i = first_op - 1; /* (the array moved down by N: go on at the op that now stands where the group stood) */
+    }
+}
+
 void f32_policy(mars_model_ext_t *m) {
     const int nt = (int)m->pub.header.num_tensors;
     unsigned char *hot = (unsigned char *)calloc((size_t)nt + 1, 1);

@@ -124,6 +124,12 @@ static void conv_f32_params(mars_model_ext_t *m, mars_op_t *op, mhip_conv_f32_t 
         if (p->use_mfma != 3) p->w_patch = NULL;
     }
     if (p->use_mfma >= 2) p->k_limit = op->k_limit; /* (the exact-order and f32-matrix-core kernels sum every term, as the reference does) */
+    if (op->vc_shift && op->kind == OP_CONV_F32) { /* virtual_concat_f32: the concat's last input seen vc_shift bytes early; what lies behind k_limit planes is NOT zero */
+        p->in = p->in ? (const float *)((const uint8_t *)p->in - op->vc_shift) : NULL;
+        p->k_limit = op->k_limit;
+        p->k_limit_required = 1; /* (planned under modes 3 / 4; any other kernel choice fails the launch instead of summing those planes) */
+        if (p->use_mfma < 2 || !p->w_split) p->in = NULL;
+    }
 }
 
 static int launch_op(mars_model_ext_t *m, mars_op_t *op) {
@@ -152,6 +158,20 @@ static int launch_op(mars_model_ext_t *m, mars_op_t *op) {
             mhip_conv_f32_t p;
             conv_f32_params(m, op, &p);
             return mhip_conv_f32(&p);
+        }
+        case OP_CONV_F32_VHEAD: {
+            mhip_conv_f32_t p;
+            const float *first[3] = {NULL, NULL, NULL};
+            size_t strides[3] = {0, 0, 0};
+            conv_f32_params(m, op, &p);
+            if (p.use_mfma < 2) return -1; /* (the plan is the split-bf16 modes': replan_for_f32_mode) */
+            p.k_limit = op->k_limit;
+            for (int k = 0; k < op->vc_n && k < 3; k++) {
+                first[k] = (const float *)tdev(m, op->vc_t[k]);
+                strides[k] = tstride(m, op->vc_t[k]);
+            }
+            if (op->w3_off == NO_OFF) return -1;
+            return mhip_conv_f32_vcat_head(&p, (const float *)(A + op->w3_off), first, strides, op->vc_n, op->vc_run);
         }
         case OP_RELU_BYTES:
             return mhip_relu_bytes((int8_t *)tdev(m, op->t_out), tstride(m, op->t_out), B, op->n);

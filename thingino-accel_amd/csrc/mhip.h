@@ -157,6 +157,8 @@ typedef struct {
     int k_limit;  /* use_mfma >= 2 (conv_f32_split): input channels >= k_limit are known to be exact zeros in every frame (the planner proves it:
                      mars_plan.c zero_tail_f32 -- the reference's byte-wise CONCAT writes a quarter of a float tensor's bytes): the K loop stops
                      there.  Adding +-0 to an f32 accumulator changes nothing but the sign of a zero sum.  0 = no such knowledge */
+    int k_limit_required; /* the planes from k_limit on are NOT zeros but memory the launch must not sum (`in` is a shifted view of another
+                     tensor: mars_plan.c virtual_concat_f32): only a kernel that honours k_limit may run it -- the launch fails otherwise */
     int in_rec, out_rec; /* use_mfma == 3 only: the input (1: read by conv_f32_prec, 2: by conv_f32_patch's record-input form; mhip_conv_f32_patch_rec_form) / the
                             output is in RECORD format instead of NCHW floats -- [c / 8][h][w] records of
                             32 bytes = [8 x bf16 hi | 8 x bf16 mid] of 8 consecutive channels of one pixel (hi = bf16(x), mid = bf16(x - hi):
@@ -166,6 +168,12 @@ typedef struct {
                             no fused Add, out_c a multiple of 8 */
 } mhip_conv_f32_t;
 int mhip_conv_f32(const mhip_conv_f32_t *p);
+/* the first pixels of a 1 x 1 convolution over a never-materialised byte-wise CONCAT of float maps (conv_f32_vcat.hip): p->in = the concat's LAST
+ * input, p->k_limit = planes to sum, w_t = the weights of those planes transposed to [plane][out_c] (mhip_conv_f32_vcat_pack: bytes, and with w and out
+ * the content); first[n_first] = its other inputs in order, run_floats = floats per concat run (shape[3] / 4).  Overwrites pixels
+ * [0, n_first * run_floats) of every output plane (or their records: out_rec) */
+size_t mhip_conv_f32_vcat_pack(int out_c, int in_c, int planes, const float *w, float *out);
+int mhip_conv_f32_vcat_head(const mhip_conv_f32_t *p, const float *w_t, const float *const *first, const size_t *first_strides, int n_first, int run_floats);
 /* two float convolutions over the same input in one launch (use_mfma >= 2, conv_f32_split: same geometry and channel count, no residual Add, no
  * record operands -- C3's cv1 + cv2): the second one's input reads hit L2; -2 = not eligible as a pair (launch them separately) */
 int mhip_conv_f32_pair(const mhip_conv_f32_t *a, const mhip_conv_f32_t *b);
