@@ -786,7 +786,7 @@ def main():
                   "preproc_kernel": {"ms_per_batch": pre, "algorithmic_bytes": pre_bytes,
                                      "achieved_gbs": pre_bytes / (pre * 1e-3) / 1e9 if pre else None,
                                      "frac_of_hbm_peak": pre_bytes / (pre * 1e-3) / 8e12 if pre else None,
-                                     "how": "HIP events around letterbox_tiled_kernel on the upload stream (mars_hip_pipe_camera_ms), median"}}
+                                     "how": "HIP events around the letterbox kernel (preproc.hip: letterbox_strip_kernel) on the main stream ahead of the graph (mars_hip_pipe_camera_ms), median"}}
 
     result = None
     if rank == 0 and args.ops:
@@ -879,7 +879,9 @@ def main():
                                     (args.width, args.hw, args.hw, args.batch, args.f32_mode,
                                      "" if args.f32_mode < 3 or os.environ.get("MARS_HIP_NO_ZERO_TAIL") else
                                      "; 1 x 1 convolutions that read a byte-wise CONCAT's output stop their K loop at the last channel it can have written "
-                                     "(exact zeros behind it: DESIGN.md section 5; conv_gmac_per_image counts the multiplied part; MARS_HIP_NO_ZERO_TAIL=1 runs the full loops)")) if f32 else
+                                     "(exact zeros behind it: DESIGN.md section 5; conv_gmac_per_image counts the multiplied part; MARS_HIP_NO_ZERO_TAIL=1 runs the full loops)" +
+                                     ("" if os.environ.get("MARS_HIP_NO_VCONCAT_F32") else "; those concats are not materialised: their readers run on a view of the concat's "
+                                      "last input, a head launch recomputes the first pixels (virtual_concat_f32; MARS_HIP_NO_VCONCAT_F32=1 copies them)"))) if f32 else
                                    "synthetic yolov5s_int8.mars twin (mars_synth_model width_x16=%d, seed 1), %dx%d int8 "
                                    "NHWC frames, batch %d per GPU, decode+NMS tail %s%s" %
                                    (args.width, args.hw, args.hw, args.batch, "off" if args.no_tail else "on",
