@@ -128,8 +128,12 @@ def build():
             else:
                 G.concat(parts, cat)
             cc, ch, cw = cd if nchw else (cd[2], cd[0], cd[1])
-            out, od2 = mkconv(cat, cc, ch, cw, 1, 1, int(rng.choice([16, 32, 48])), pad, silu, 0)
+            roc = int(rng.choice([16, 32, 48]))
+            out, od2 = mkconv(cat, cc, ch, cw, 1, 1, roc, pad, silu, 0)
             avail.append((parts[0], *od)); avail.append((out, *od2)); desc.append((op, tc, oc, silu))
+            if rng.integers(0, 3) == 0:  # a second reader of the same shape: the head C3s' cv1 + cv2 over a concat (one paired launch)
+                out2, _ = mkconv(cat, cc, ch, cw, 1, 1, roc, pad, silu, 0)
+                avail.append((out2, *od2))
         else:
             if d1 * d2 > 600:
                 continue

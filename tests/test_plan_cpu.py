@@ -23,17 +23,18 @@ def count(lines, what):
 
 def test_shipped_yolov5n_int8_plan(marsrt, monkeypatch):
     """BASELINE config 3's literal file (NCHW-tagged, 230 layers, 60 convolutions): with nhwc_internal only the graph input is relaid, nothing
-    is stored planar, every CONCAT / stride-1 MAXPOOL / UPSAMPLE layer runs on the internal layout, the 9 concats read by one 1 x 1
-    convolution keep their first rows only (that convolution is split in two), every residual Add is folded"""
+    is stored planar, every CONCAT / stride-1 MAXPOOL / UPSAMPLE layer runs on the internal layout, all 13 concats -- 9 read by one 1 x 1
+    convolution, 4 by a C3's cv1 + cv2 pair -- keep their first rows only (their readers are split in two, pairs stay pairs), every residual
+    Add is folded"""
     monkeypatch.delenv("MARS_HIP_NO_NHWC_INTERNAL", raising=False)
     L = marsrt.describe_plan(model_bytes("yolov5n_int8"))
     k = kinds(L)
-    assert k["conv_i8"] == 60 + 9 and k["concat_q"] == 13 and k["maxpool_q"] == 3 and k["upsample_q"] == 2
+    assert k["conv_i8"] == 60 + 9 + 8 and k["concat_q"] == 13 and k["maxpool_q"] == 3 and k["upsample_q"] == 2
     assert k["concat_slice"] == 0 and k["maxpool"] == 0 and k["upsample"] == 0 and k["binary_i8"] == 0 and k["lut_i8"] == 0 and k["fail"] == 0
     assert count(L, " relayout") == 1 and " relayout" in L[0]  # the stem: the graph input is [3][640][640] bytes
     assert count(L, " planar_store") == 0
-    assert count(L, " add=") == 7 and count(L, " pair_next") >= 4 and count(L, " rows_only=") == 9
-    assert sum(l.startswith("tensor ") and " partial 1" in l for l in L) == 9
+    assert count(L, " add=") == 7 and count(L, " pair_next") == 12 and count(L, " rows_only=") == 13  # (4 C3 pairs in the backbone + 2 x 4 split head pairs)
+    assert sum(l.startswith("tensor ") and " partial 1" in l for l in L) == 13
     assert sum(l.startswith("tensor ") and " pitch 256" in l for l in L) == 3  # the three 255-channel Detect convolutions' results
     # the same file with the pass switched off: a relayout in front of every convolution, a planar store behind it, one copy per concat input
     monkeypatch.setenv("MARS_HIP_NO_NHWC_INTERNAL", "1")

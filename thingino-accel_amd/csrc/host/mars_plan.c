@@ -980,70 +980,85 @@ void virtual_concat_q(mars_model_ext_t *m) {
         const int TL = cq->t_in[N - 1];
         const int CL = m->mt[TL].nhwc_c;
         if (H < N + 1 || CL <= 0 || (CL & 15) || CL >= Cout || m->mt[TL].nhwc_pitch || m->mt[T].nhwc_pitch) continue;
-        int r = -1, nr = 0;
+        int r = -1, nr = 0, bad = 0;
         for (int j = 0; j < m->n_ops; j++) {
             const mars_op_t *o = &m->ops[j];
             for (int k = 0; k < o->n_in && k < 4; k++)
-                if (o->t_in[k] == T) { nr++; r = j; }
+                if (o->t_in[k] == T) { nr++; if (r < 0) r = j; }
             for (int k = 0; k < o->nseg && k < 4; k++)
-                if (o->seg_t[k] == T) nr += 2;
-            if (j != i && op_writes(o, T)) nr += 2;
+                if (o->seg_t[k] == T) bad = 1;
+            if (j != i && op_writes(o, T)) bad = 1;
         }
-        if (nr != 1 || r <= i) continue;
-        mars_op_t *cv = &m->ops[r];
-        if (cv->kind != OP_CONV_I8 || cv->kh != 1 || cv->kw != 1 || cv->sh != 1 || cv->sw != 1 || cv->pt || cv->pl || cv->nchw || cv->out_nchw ||
-            cv->nseg || cv->add_t || cv->pre || cv->pair_next || (r > 0 && m->ops[r - 1].pair_next) || cv->out_pix_stride || cv->out_ch_off ||
-            cv->n_in != 1 || cv->in_c != Cout || cv->in_h != H || cv->in_w != W || cv->out_h != H || cv->out_w != W || cv->in_byte_off ||
-            cv->out_byte_off || cv->t_out == TL || cv->t_out == T || (cv->out_c & 15) || m->mt[cv->t_out].nhwc_pitch)
-            continue;
-        int clash = 0; /* in_last must still hold at X what it held at the concat */
-        for (int j = i + 1; j < r && !clash; j++)
+        if (bad || r <= i || nr < 1 || nr > 2) continue;
+        /* one reader, or the two of a paired launch (a head C3's cv1 + cv2: both are split, both halves stay pairs) */
+        const int np = m->ops[r].pair_next ? 2 : 1;
+        if (nr != np || (r > 0 && m->ops[r - 1].pair_next) || (np == 2 && (r + 1 >= m->n_ops || m->ops[r + 1].t_in[0] != T || m->ops[r + 1].pair_next))) continue;
+        int ok = 1;
+        for (int q = 0; q < np && ok; q++) {
+            const mars_op_t *cv = &m->ops[r + q];
+            if (cv->kind != OP_CONV_I8 || cv->kh != 1 || cv->kw != 1 || cv->sh != 1 || cv->sw != 1 || cv->pt || cv->pl || cv->nchw || cv->out_nchw ||
+                cv->nseg || cv->add_t || cv->pre || cv->out_pix_stride || cv->out_ch_off ||
+                cv->n_in != 1 || cv->in_c != Cout || cv->in_h != H || cv->in_w != W || cv->out_h != H || cv->out_w != W || cv->in_byte_off ||
+                cv->out_byte_off || cv->t_out == TL || cv->t_out == T || (cv->out_c & 15) || m->mt[cv->t_out].nhwc_pitch)
+                ok = 0;
+        }
+        if (!ok) continue;
+        int clash = 0; /* in_last must still hold at the readers what it held at the concat */
+        for (int j = i + 1; j < r + np && !clash; j++)
             if (op_writes(&m->ops[j], TL)) clash = 1;
         if (clash) continue;
-        /* the second weight image: input channels [0, C_last) of every output channel (1 x 1: OIHW and OHWI coincide) */
-        const mars_layer_t *L = &m->pub.layers[cv->layer].desc;
-        const int tw = find_tensor(m, L->params.conv.weight_tensor_id);
-        if (tw < 0) continue;
-        int row_pad2, oc_pad2, c_eff2;
-        mhip_conv_i8_pack_geom(CL, 1, cv->out_c, &row_pad2, &oc_pad2, &c_eff2);
-        if (oc_pad2 != cv->oc_pad || c_eff2 != CL) continue;
-        const size_t k64 = ALIGN_UP((size_t)row_pad2, 64);
-        const size_t w_off2 = arena_reserve(m, (size_t)oc_pad2 * k64);
-        if (w_off2 == NO_OFF) return;
-        if (!m->deferred) {
-            const size_t full = (size_t)cv->out_c * Cout, cut = (size_t)cv->out_c * CL;
-            int8_t *tmp = (int8_t *)malloc(full ? full : 1), *sel = (int8_t *)malloc(cut ? cut : 1);
-            if (!tmp || !sel) { free(tmp); free(sel); m->plan_err = MARS_ERR_ALLOC_FAILED; return; }
-            blob_read(m, (size_t)m->pub.tensors[tw].desc.data_offset, full, tmp);
-            for (int oc = 0; oc < cv->out_c; oc++) memcpy(sel + (size_t)oc * CL, tmp + (size_t)oc * Cout, (size_t)CL);
-            mars_pack_conv_i8(sel, cut, 1, cv->out_c, CL, 1, 1, c_eff2, row_pad2, oc_pad2, (int8_t *)m->arena_host + w_off2);
-            free(tmp); free(sel);
+        /* the second weight images: input channels [0, C_last) of every output channel (1 x 1: OIHW and OHWI coincide) */
+        size_t w_off2[2] = {NO_OFF, NO_OFF};
+        int row_pad2 = 0;
+        for (int q = 0; q < np && ok; q++) {
+            const mars_op_t *cv = &m->ops[r + q];
+            const mars_layer_t *L = &m->pub.layers[cv->layer].desc;
+            const int tw = find_tensor(m, L->params.conv.weight_tensor_id);
+            int oc_pad2, c_eff2;
+            mhip_conv_i8_pack_geom(CL, 1, cv->out_c, &row_pad2, &oc_pad2, &c_eff2);
+            if (tw < 0 || oc_pad2 != cv->oc_pad || c_eff2 != CL) { ok = 0; break; }
+            const size_t k64 = ALIGN_UP((size_t)row_pad2, 64);
+            w_off2[q] = arena_reserve(m, (size_t)oc_pad2 * k64);
+            if (w_off2[q] == NO_OFF) return;
+            cv = &m->ops[r + q];
+            if (!m->deferred) {
+                const size_t full = (size_t)cv->out_c * Cout, cut = (size_t)cv->out_c * CL;
+                int8_t *tmp = (int8_t *)malloc(full ? full : 1), *sel = (int8_t *)malloc(cut ? cut : 1);
+                if (!tmp || !sel) { free(tmp); free(sel); m->plan_err = MARS_ERR_ALLOC_FAILED; return; }
+                blob_read(m, (size_t)m->pub.tensors[tw].desc.data_offset, full, tmp);
+                for (int oc = 0; oc < cv->out_c; oc++) memcpy(sel + (size_t)oc * CL, tmp + (size_t)oc * Cout, (size_t)CL);
+                mars_pack_conv_i8(sel, cut, 1, cv->out_c, CL, 1, 1, c_eff2, row_pad2, oc_pad2, (int8_t *)m->arena_host + w_off2[q]);
+                free(tmp); free(sel);
+            }
         }
-        /* ops: [concat: first N - 1 rows] ... [X over those rows] [X over in_last] */
-        if (m->n_ops == m->cap_ops) {
+        if (!ok) continue; /* (an image reserved for the first of a pair stays unused: a few KB of the arena) */
+        /* ops: [concat: first N - 1 rows] ... [the readers over those rows] [the readers over in_last] */
+        while (m->n_ops + np > m->cap_ops) {
             const int cap = m->cap_ops * 2;
-            mars_op_t *np = (mars_op_t *)realloc(m->ops, (size_t)cap * sizeof(mars_op_t));
-            if (!np) { m->plan_err = MARS_ERR_ALLOC_FAILED; return; }
-            m->ops = np; m->cap_ops = cap;
-            cq = &m->ops[i]; cv = &m->ops[r];
+            mars_op_t *npp = (mars_op_t *)realloc(m->ops, (size_t)cap * sizeof(mars_op_t));
+            if (!npp) { m->plan_err = MARS_ERR_ALLOC_FAILED; return; }
+            m->ops = npp; m->cap_ops = cap;
         }
-        memmove(&m->ops[r + 2], &m->ops[r + 1], sizeof(mars_op_t) * (size_t)(m->n_ops - r - 1));
-        m->n_ops++;
-        m->ops[r + 1] = m->ops[r];
-        mars_op_t *top = &m->ops[r], *mainop = &m->ops[r + 1];
-        top->in_h = top->out_h = N - 1;
-        top->macs = top->macs * (N - 1) / H;
-        top->bytes = (double)(N - 1) * W * (Cout + top->out_c);
-        top->w2_off = NO_OFF; top->w2_rows = 0;
-        mainop->t_in[0] = TL;
-        mainop->in_c = CL; mainop->c_pad = CL; mainop->row_pad = row_pad2;
-        mainop->in_h = mainop->out_h = H - (N - 1);
-        mainop->w_off = w_off2;
-        mainop->w2_off = NO_OFF; mainop->w2_rows = 0;
-        mainop->out_byte_off = (size_t)(N - 1) * W * (size_t)mainop->out_c;
-        mainop->macs = (double)(H - (N - 1)) * W * mainop->out_c * CL;
-        mainop->bytes = (double)(H - (N - 1)) * W * (CL + mainop->out_c);
-        mainop->variant = 0;
+        cq = &m->ops[i];
+        memmove(&m->ops[r + 2 * np], &m->ops[r + np], sizeof(mars_op_t) * (size_t)(m->n_ops - r - np));
+        m->n_ops += np;
+        for (int q = np - 1; q >= 0; q--) m->ops[r + np + q] = m->ops[r + q]; /* (np == 2: [a b] -> [a b a b]) */
+        for (int q = 0; q < np; q++) {
+            mars_op_t *top = &m->ops[r + q], *mainop = &m->ops[r + np + q];
+            top->in_h = top->out_h = N - 1;
+            top->macs = top->macs * (N - 1) / H;
+            top->bytes = (double)(N - 1) * W * (Cout + top->out_c);
+            top->w2_off = NO_OFF; top->w2_rows = 0;
+            mainop->t_in[0] = TL;
+            mainop->in_c = CL; mainop->c_pad = CL; mainop->row_pad = row_pad2;
+            mainop->in_h = mainop->out_h = H - (N - 1);
+            mainop->w_off = w_off2[q];
+            mainop->w2_off = NO_OFF; mainop->w2_rows = 0;
+            mainop->out_byte_off = (size_t)(N - 1) * W * (size_t)mainop->out_c;
+            mainop->macs = (double)(H - (N - 1)) * W * mainop->out_c * CL;
+            mainop->bytes = (double)(H - (N - 1)) * W * (CL + mainop->out_c);
+            mainop->variant = 0;
+        }
         cq->rows_only = N - 1;
         cq->bytes = (double)(N - 1) * W * Cout * 2.0;
         m->mt[T].partial = 1;
