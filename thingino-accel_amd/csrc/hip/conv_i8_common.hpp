@@ -115,6 +115,21 @@ __device__ __forceinline__ int requant_safe(int acc, float cs, int lo, int hi) {
     asm("v_med3_i32 %0, %1, %2, %3" : "=v"(m) : "v"(r), "v"(lo), "v"(hi)); // lo <= hi is not provable for the compiler
     return m;
 }
+// The compiler does not count LDS loads issued from asm: wait for them, and thread the loaded values through the wait so that no use is
+// scheduled above it.  NV = 4 (one channel subtile: conv_i8_smallc<1>), 8 or 16 values per lane.
+template <int NV>
+__device__ __forceinline__ void wait_lds_values(int (&v)[NV]) {
+    static_assert(NV == 4 || NV == 8 || NV == 16, "values per lane");
+    if constexpr (NV == 16)
+        asm volatile("s_waitcnt lgkmcnt(0)"
+                     : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]), "+v"(v[3]), "+v"(v[4]), "+v"(v[5]), "+v"(v[6]), "+v"(v[7]), "+v"(v[8]), "+v"(v[9]),
+                       "+v"(v[10]), "+v"(v[11]), "+v"(v[12]), "+v"(v[13]), "+v"(v[14]), "+v"(v[15]));
+    else if constexpr (NV == 8)
+        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]), "+v"(v[3]), "+v"(v[4]), "+v"(v[5]), "+v"(v[6]), "+v"(v[7]));
+    else
+        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]), "+v"(v[3]));
+}
+
 __device__ __forceinline__ uint32_t pack4(int q0, int q1, int q2, int q3) { // low bytes of four ints
     const uint32_t a = __builtin_amdgcn_perm((uint32_t)q1, (uint32_t)q0, 0x0c0c0400u);
     const uint32_t b = __builtin_amdgcn_perm((uint32_t)q3, (uint32_t)q2, 0x0c0c0400u);
@@ -185,14 +200,7 @@ __device__ __forceinline__ void requant_pack_pre(const int (&a)[NV], float cs, u
                      : "=&v"(v[4 * g]), "=&v"(v[4 * g + 1]), "=&v"(v[4 * g + 2]), "=&v"(v[4 * g + 3])
                      : "v"(q[4 * g]), "v"(q[4 * g + 1]), "v"(q[4 * g + 2]), "v"(q[4 * g + 3])
                      : "memory");
-    if (NV == 16)
-        asm volatile("s_waitcnt lgkmcnt(0)"
-                     : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]), "+v"(v[3]), "+v"(v[4]), "+v"(v[5]), "+v"(v[6]), "+v"(v[7]),
-                       "+v"(v[8 % NV]), "+v"(v[9 % NV]), "+v"(v[10 % NV]), "+v"(v[11 % NV]), "+v"(v[12 % NV]), "+v"(v[13 % NV]),
-                       "+v"(v[14 % NV]), "+v"(v[15 % NV]));
-    else
-        asm volatile("s_waitcnt lgkmcnt(0)"
-                     : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]), "+v"(v[3]), "+v"(v[4]), "+v"(v[5]), "+v"(v[6]), "+v"(v[7]));
+    wait_lds_values<NV>(v);
 #pragma unroll
     for (int g = 0; g < NV / 4; g++) pk[g] = pack4(v[4 * g], v[4 * g + 1], v[4 * g + 2], v[4 * g + 3]);
 }
@@ -213,14 +221,7 @@ __device__ __forceinline__ void requant_pack(const int (&a)[NV], float cs, int l
 #pragma unroll
         for (int g = 0; g < NV / 4; g++)
             lut4_fast(q[4 * g], q[4 * g + 1], q[4 * g + 2], q[4 * g + 3], v[4 * g], v[4 * g + 1], v[4 * g + 2], v[4 * g + 3]);
-        if (NV == 16)
-            asm volatile("s_waitcnt lgkmcnt(0)"
-                         : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]), "+v"(v[3]), "+v"(v[4]), "+v"(v[5]), "+v"(v[6]), "+v"(v[7]),
-                           "+v"(v[8 % NV]), "+v"(v[9 % NV]), "+v"(v[10 % NV]), "+v"(v[11 % NV]), "+v"(v[12 % NV]), "+v"(v[13 % NV]),
-                           "+v"(v[14 % NV]), "+v"(v[15 % NV]));
-        else
-            asm volatile("s_waitcnt lgkmcnt(0)"
-                         : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]), "+v"(v[3]), "+v"(v[4]), "+v"(v[5]), "+v"(v[6]), "+v"(v[7]));
+        wait_lds_values<NV>(v);
         if (ADD) {
             const int lo8 = -128;
 #pragma unroll
@@ -238,14 +239,7 @@ __device__ __forceinline__ void requant_pack(const int (&a)[NV], float cs, int l
         for (int g = 0; g < NV / 4; g++)
             lut4_at0(q[4 * g], q[4 * g + 1], q[4 * g + 2], q[4 * g + 3], v[4 * g], v[4 * g + 1], v[4 * g + 2], v[4 * g + 3]);
         // the compiler does not count LDS loads issued from asm: wait here, and thread the values through the wait
-        if (NV == 16)
-            asm volatile("s_waitcnt lgkmcnt(0)"
-                         : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]), "+v"(v[3]), "+v"(v[4]), "+v"(v[5]), "+v"(v[6]), "+v"(v[7]),
-                           "+v"(v[8 % NV]), "+v"(v[9 % NV]), "+v"(v[10 % NV]), "+v"(v[11 % NV]), "+v"(v[12 % NV]), "+v"(v[13 % NV]),
-                           "+v"(v[14 % NV]), "+v"(v[15 % NV]));
-        else
-            asm volatile("s_waitcnt lgkmcnt(0)"
-                         : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]), "+v"(v[3]), "+v"(v[4]), "+v"(v[5]), "+v"(v[6]), "+v"(v[7]));
+        wait_lds_values<NV>(v);
         if (ADD) {
             const int lo8 = -128;
 #pragma unroll
@@ -333,7 +327,7 @@ __device__ __forceinline__ void fill_rowoff(const mhip_conv_i8_t &p, long *rowof
 // Output channels are PERMUTED inside each wave's channel range (host packer, mhip_conv_i8_oc_row): MFMA row
 // (lane>>4)*4 + r of oc-subtile s carries channel (lane>>4)*4*WOC + s*4 + r, so the WOC*4 results a lane holds
 // for one pixel are CONSECUTIVE channels.
-//  DIRECT (NHWC, 16-byte aligned rows): one 16-byte (WOC=4) / 8-byte (WOC=2) global store per pixel straight
+//  DIRECT (NHWC, 16-byte aligned rows): one 16-byte (WOC=4) / 8-byte (WOC=2) / 4-byte (WOC=1) global store per pixel straight
 //  from registers -- no LDS tile, no barrier.  Otherwise the int8 tile is staged in LDS and copied out coalesced.
 template <int BPX, int BN, int WPX, int WOC, bool HAS_LUT, bool SAFE, bool DIRECT, bool LUT0>
 __device__ __forceinline__ void epilogue_t(const mhip_conv_i8_t &p, v4i (&acc)[WOC][WPX], int8_t *tile, const uint8_t *slut,
@@ -361,7 +355,8 @@ __device__ __forceinline__ void epilogue_t(const mhip_conv_i8_t &p, v4i (&acc)[W
             if (ok) {
                 const int8_t *x = p.add + off + oc0 + chan;
                 if (WOC == 4) { const v4i t4 = *(const v4i *)x; xw[0] = t4[0]; xw[1] = t4[1]; xw[WOC > 2 ? 2 : 0] = t4[2]; xw[WOC > 3 ? 3 : 0] = t4[3]; }
-                else { const uint2 t2 = *(const uint2 *)x; xw[0] = t2.x; xw[WOC > 1 ? 1 : 0] = t2.y; }
+                else if (WOC == 2) { const uint2 t2 = *(const uint2 *)x; xw[0] = t2.x; xw[WOC > 1 ? 1 : 0] = t2.y; }
+                else xw[0] = *(const uint32_t *)x;
             }
             const add_args_t ga = {p.add_s_conv, p.add_s_other, p.add_inv};
             if (HAS_LUT && LUT0 && p.lut2) requant_pack<WOC * 4, HAS_LUT, true, LUT0, true, true>(a, p.cs, lo, lut128, pk, xw, &ga);
@@ -375,7 +370,8 @@ __device__ __forceinline__ void epilogue_t(const mhip_conv_i8_t &p, v4i (&acc)[W
             if (off >= 0 && oc0 + chan < p.out_c) {
                 int8_t *d = p.out + off + oc0 + chan;
                 if (WOC == 4) *(v4i *)d = (v4i){(int)pk[0], (int)pk[1], (int)pk[2], (int)pk[3]};
-                else *(uint2 *)d = make_uint2(pk[0], pk[WOC > 1 ? 1 : 0]);
+                else if (WOC == 2) *(uint2 *)d = make_uint2(pk[0], pk[WOC > 1 ? 1 : 0]);
+                else *(uint32_t *)d = pk[0]; // (WOC == 1: 16 channels per tile -- the small-channel stem of the shipped yolov5n files)
             }
         } else {
 #pragma unroll

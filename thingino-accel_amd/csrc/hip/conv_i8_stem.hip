@@ -36,12 +36,15 @@ __global__ __launch_bounds__(NTHREADS) void conv_i8_smallc(const mhip_conv_i8_t 
     const int hw = p.out_h * p.out_w;
     if (p.lut2) { if (tid < 128) ((uint32_t *)slut)[tid] = ((const uint32_t *)p.lut2)[tid]; }
     else if (p.lut && tid < 64) ((uint32_t *)slut)[tid] = ((const uint32_t *)p.lut)[tid];
+    // WOC == 1 (out_c <= 16 in a 32-row image): the host packed rows and bias in the two-subtile order (conv_i8_common.hpp: MFMA row 4 g + r
+    // of subtile s carries channel 8 g + 4 s + r); this form wants channel c in row c: it reads packed row 16 s + 4 g + r of channel c
+    auto packed_row = [](int c) { return WOC == 1 ? ((c >> 2) & 1) * 16 + (c >> 3) * 4 + (c & 3) : c; };
     for (int i = tid; i < BN * (k64 / 16); i += NTHREADS) {
         const int row = i / (k64 / 16), c = i - row * (k64 / 16);
-        *(v4i *)(wl + (c >> 2) * (BN * BK) + lds_off(row, c & 3)) = *(const v4i *)(p.w + (size_t)row * k64 + c * 16);
+        *(v4i *)(wl + (c >> 2) * (BN * BK) + lds_off(row, c & 3)) = *(const v4i *)(p.w + (size_t)packed_row(row) * k64 + c * 16);
     }
     for (int i = tid; i < 2 * patch_bytes / 4; i += NTHREADS) ((uint32_t *)patch0)[i] = 0;
-    if (tid < BN) ((int *)sbias)[tid] = p.bias ? p.bias[tid] : 0;
+    if (tid < BN) ((int *)sbias)[tid] = p.bias ? p.bias[packed_row(tid)] : 0;
 
     // one staging unit = 4 consecutive patch pixels of one row -> one 16-byte LDS store.
     // in_c == 3: the 12 source bytes come from ONE unaligned 16-byte global load (gfx950 serves
@@ -613,5 +616,8 @@ int conv_i8_try_smallc(const mhip_conv_i8_t *p, int k64) {
                        (direct ? 0 : (size_t)SC_BP * (oc_pad + OPAD)) + LUTB + (size_t)SC_BP * 8 + (size_t)oc_pad * 4;
     const long ntiles = (long)((p->out_w + SC_TW - 1) / SC_TW) * ((p->out_h + SC_TH - 1) / SC_TH) * p->frames;
     if ((long)PH * ((PW + 3) / 4) > 2 * NTHREADS || lds > 64 * 1024 || ntiles >= 0x0fffffffL) return -2;
+    // out_c <= 16 (the stem of the shipped yolov5n files): one channel subtile -- half the MFMAs and half the requantisation of the 32-row form
+    static const int wide16 = getenv("MARS_HIP_SMALLC_WIDE16") != nullptr; // (A / B switch)
+    if (p->out_c <= 16 && !wide16) return launch_smallc<1>(p, k64);
     return oc_pad == 32 ? launch_smallc<2>(p, k64) : launch_smallc<4>(p, k64);
 }

@@ -493,6 +493,10 @@ extern "C" int mhip_upsample_nchwq(const int8_t *in, size_t in_stride, int Ci, i
 // max-pool, stride 1, output size = input size (SPPF's pools): the window runs over CHANNELS c .. c + kh - 1 and map rows h .. h + kw - 1 of
 // one column w (clipped at C and H; no padding, identity -128).  A thread owns 16 channels of one pixel: per window row it loads the
 // channels c0 .. c0 + 15 + kh - 1 (two 16-byte loads), takes the maximum over the rows per channel, then the sliding maximum over channels.
+// KW > 0: the window's row count at compile time -- all its loads are issued before the first maximum (a row past the map is the last row again:
+// a maximum does not mind a repeated operand).  With the row loop left to run time every iteration waited for its own two loads: 39 us per
+// launch on the 20 x 20 x 128 SPPF maps of yolov5n_int8.mars at batch 256, all of it memory latency.
+template <int KW>
 __global__ __launch_bounds__(MV_THREADS) void maxpool_nchwq_kernel(const int8_t *in, size_t is, int8_t *out, size_t os, int C, int H, int W, int kh, int kw) {
     const int cg = C / 16;
     const size_t idx = (size_t)blockIdx.x * MV_THREADS + threadIdx.x;
@@ -502,22 +506,48 @@ __global__ __launch_bounds__(MV_THREADS) void maxpool_nchwq_kernel(const int8_t 
     int col[32]; // maximum over the window's rows, channels c0 .. c0 + 31 (kh <= 17)
 #pragma unroll
     for (int e = 0; e < 32; e++) col[e] = -128;
-    for (int dy = 0; dy < kw && h + dy < H; dy++) {
-        const int8_t *r = s + (size_t)dy * W * C;
-        const v4i a = *(const v4i *)r;
-        const v4i b = c0 + 16 < C ? *(const v4i *)(r + 16) : (v4i){(int)0x80808080, (int)0x80808080, (int)0x80808080, (int)0x80808080};
+    const bool two = c0 + 16 < C;
+    const v4i none = (v4i){(int)0x80808080, (int)0x80808080, (int)0x80808080, (int)0x80808080};
+    if (KW > 0) {
+        v4i a[KW > 0 ? KW : 1], b[KW > 0 ? KW : 1];
 #pragma unroll
-        for (int e = 0; e < 16; e++) {
-            const int va = (int)(int8_t)(a[e >> 2] >> (8 * (e & 3))), vb = (int)(int8_t)(b[e >> 2] >> (8 * (e & 3)));
-            col[e] = col[e] > va ? col[e] : va;
-            col[16 + e] = col[16 + e] > vb ? col[16 + e] : vb;
+        for (int dy = 0; dy < KW; dy++) {
+            const int8_t *r = s + (size_t)(h + dy < H ? dy : H - 1 - h) * W * C;
+            a[dy] = *(const v4i *)r;
+            b[dy] = two ? *(const v4i *)(r + 16) : none;
+        }
+#pragma unroll
+        for (int dy = 0; dy < KW; dy++) {
+#pragma unroll
+            for (int e = 0; e < 16; e++) {
+                const int va = (int)(int8_t)(a[dy][e >> 2] >> (8 * (e & 3))), vb = (int)(int8_t)(b[dy][e >> 2] >> (8 * (e & 3)));
+                col[e] = col[e] > va ? col[e] : va;
+                col[16 + e] = col[16 + e] > vb ? col[16 + e] : vb;
+            }
+        }
+    } else {
+        for (int dy = 0; dy < kw && h + dy < H; dy++) {
+            const int8_t *r = s + (size_t)dy * W * C;
+            const v4i a = *(const v4i *)r;
+            const v4i b = two ? *(const v4i *)(r + 16) : none;
+#pragma unroll
+            for (int e = 0; e < 16; e++) {
+                const int va = (int)(int8_t)(a[e >> 2] >> (8 * (e & 3))), vb = (int)(int8_t)(b[e >> 2] >> (8 * (e & 3)));
+                col[e] = col[e] > va ? col[e] : va;
+                col[16 + e] = col[16 + e] > vb ? col[16 + e] : vb;
+            }
         }
     }
     uint32_t wd[4] = {0, 0, 0, 0};
 #pragma unroll
     for (int e = 0; e < 16; e++) {
         int v = -128;
-        for (int dc = 0; dc < kh && c0 + e + dc < C; dc++) v = v > col[(e + dc) & 31] ? v : col[(e + dc) & 31]; // (e + dc <= 31: kh <= 17)
+        if (KW == 5 && kh == 5) { // (the shipped SPPF window: a fixed five-term maximum; columns past C hold -128 already)
+#pragma unroll
+            for (int dc = 0; dc < 5; dc++) v = v > col[e + dc] ? v : col[e + dc];
+        } else {
+            for (int dc = 0; dc < kh && c0 + e + dc < C; dc++) v = v > col[(e + dc) & 31] ? v : col[(e + dc) & 31]; // (e + dc <= 31: kh <= 17)
+        }
         wd[e >> 2] |= (uint32_t)(uint8_t)v << (8 * (e & 3));
     }
     *(v4i *)(out + (size_t)blockIdx.y * os + (size_t)pix * C + c0) = (v4i){(int)wd[0], (int)wd[1], (int)wd[2], (int)wd[3]};
@@ -526,8 +556,13 @@ __global__ __launch_bounds__(MV_THREADS) void maxpool_nchwq_kernel(const int8_t 
 extern "C" int mhip_maxpool_nchwq(const int8_t *in, size_t in_stride, int8_t *out, size_t out_stride, int frames, int C, int H, int W, int kh, int kw) {
     if (!in || !out || frames <= 0 || C <= 0 || (C & 15) || H <= 0 || W <= 0 || kh < 1 || kh > 17 || kw < 1) return -1;
     if ((long)C * H * W > 0x7fffffffL || (((uintptr_t)in | (uintptr_t)out | in_stride | out_stride) & 15)) return -1;
-    hipLaunchKernelGGL(maxpool_nchwq_kernel, mv_grid((size_t)H * W * (C / 16), frames), dim3(MV_THREADS), 0, mhip_stream_native(), in, in_stride, out,
-                       out_stride, C, H, W, kh, kw);
+    static const int generic = getenv("MARS_HIP_MAXPOOL_Q_GENERIC") != nullptr; // (A / B switch)
+    if (kw == 5 && !generic)
+        hipLaunchKernelGGL(maxpool_nchwq_kernel<5>, mv_grid((size_t)H * W * (C / 16), frames), dim3(MV_THREADS), 0, mhip_stream_native(), in, in_stride, out,
+                           out_stride, C, H, W, kh, kw);
+    else
+        hipLaunchKernelGGL(maxpool_nchwq_kernel<0>, mv_grid((size_t)H * W * (C / 16), frames), dim3(MV_THREADS), 0, mhip_stream_native(), in, in_stride, out,
+                           out_stride, C, H, W, kh, kw);
     return mhip_check(hipGetLastError(), "maxpool (NCHW-tagged, pixels x channels)");
 }
 
