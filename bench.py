@@ -290,11 +290,16 @@ def short_leg(M, name, model_bytes, batch, steps, warmup, tail, f32_mode=None, c
         for _ in range(warmup):
             step()
         M.lib().mars_hip_sync()
-        t0 = time.perf_counter()
-        for _ in range(steps):
-            step()
-        M.lib().mars_hip_sync()
-        dt = time.perf_counter() - t0
+        # three windows of `steps` steps, the MEDIAN one reported: a leg is a few tens of milliseconds long, and one stall (the previous leg's
+        # buffers still being released, a clock step) moved a single window by 10 % on some boxes.  All three are in the line.
+        windows = []
+        for _ in range(3):
+            t0 = time.perf_counter()
+            for _ in range(steps):
+                step()
+            M.lib().mars_hip_sync()
+            windows.append(time.perf_counter() - t0)
+        dt = sorted(windows)[1]
         model.set_profiling(2)
         step()
         M.lib().mars_hip_sync()
@@ -315,7 +320,8 @@ def short_leg(M, name, model_bytes, batch, steps, warmup, tail, f32_mode=None, c
                "frac_wall": max(hbm_floor, mfma_floor) / (dt / steps),
                "conv_ms_per_step": conv_ms, "conv_launches": sum(1 for o in ops if o["kind"] == ckind),
                "conv_gmac_per_image": conv_flop / 2e9 / batch, "conv_algorithmic_mb_per_image": conv_bytes / 1e6 / batch,
-               "timing": "value: wall clock around %d steps (the library's execution mode at this batch); frac: HIP events, one stream, one further step" % steps}
+               "windows_ms_per_step": [w / steps * 1e3 for w in windows],
+               "timing": "value: wall clock around %d steps, the median of three such windows (the library's execution mode at this batch); frac: HIP events, one stream, one further step" % steps}
         if cpu_frames > 0:
             model.download()
             n = ok = 0
