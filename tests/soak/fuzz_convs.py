@@ -1,6 +1,6 @@
 """Soak test (GPU box, through gpurun): random int8 convolution shapes through the C-ABI host entry point (conv2d_int8),
 default launch policy or a forced launch variant, vs the oracle.
-  python tests/soak/fuzz_convs.py SEED N [VARIANT]"""
+  python tests/soak/fuzz_convs.py SEED N [VARIANT]      (FUZZ_IC=16: that input channel count only, maps around multiples of 16)"""
 import os, sys
 import numpy as np
 sys.path.insert(0, os.path.join(os.path.dirname(__file__), ".."))
@@ -20,6 +20,10 @@ for i in range(N):
     s = int(rng.choice([1, 2, 3]))
     h, w = int(rng.integers(5, 70)), int(rng.integers(5, 70))
     if ic >= 128 and k >= 5: k = 3
+    if os.environ.get("FUZZ_IC"):  # one channel count, map sizes around multiples of 16 (the patch-staged kernel wants mostly full 16-wide tiles)
+        ic = int(os.environ["FUZZ_IC"])
+        k = int(rng.choice([2, 3, 5, 7])); s = int(rng.choice([1, 2, 2]))
+        h, w = int(rng.choice([16, 31, 32, 33, 48, 64, 80])), int(rng.choice([16, 32, 47, 48, 64, 96]))
     oh, ow = (h + s - 1) // s, (w + s - 1) // s
     ph = max((oh - 1) * s + k - h, 0) // 2; pw = max((ow - 1) * s + k - w, 0) // 2
     case = ("fz%d" % i, 1, h, w, ic, oc, k, k, s, s, ph, pw, oh, ow, 0.03, 0.003 / (k * k * ic) ** 0.5 * 8, 0.05, bool(rng.integers(0, 2)))

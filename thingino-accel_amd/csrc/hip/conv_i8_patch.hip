@@ -496,7 +496,10 @@ static size_t patch_lds_budget(int bn) {
 static bool patch_geom(const mhip_conv_i8_t *p, int th, patch_geom_t *g) {
     const bool direct = conv_i8_direct_rows(p);
     const int C = p->in_c, s = p->stride_w;
-    if (!direct || !p->safe || (C != 32 && C != 64 && C != 128) || (s != 1 && s != 2) || p->stride_h != s ||
+    // in_c == 16 (round 6: the second layer of the yolov5n models, 3 x 3 stride 2 on 320 x 320 x 16 -- one 16-byte unit per pixel, no swizzle
+    // needed: 16 consecutive pixels are 16 consecutive units); MARS_HIP_PATCH_NO_C16 sends it back to the implicit-GEMM form (A / B)
+    static const bool no_c16 = getenv("MARS_HIP_PATCH_NO_C16") != nullptr;
+    if (!direct || !p->safe || (C != 16 && C != 32 && C != 64 && C != 128) || (C == 16 && (no_c16 || p->pre_w)) || (s != 1 && s != 2) || p->stride_h != s ||
         p->kh > 7 || p->kw > 7 || p->kh * p->kw < 2 || p->row_pad != p->kw * C || persist_out_bytes(p) > 0x7fffffffL)
         return false;
     const int k64 = (p->kh * p->row_pad + BK - 1) / BK * BK;
