@@ -78,7 +78,9 @@ CONV_I8_FAMILIES = {
     "rows": (9, [(40, 40, 128, 128, 3, 3, 1), (20, 20, 256, 256, 3, 3, 1), (23, 40, 128, 256, 3, 3, 1), (9, 20, 512, 128, 3, 3, 1),
                  (7, 40, 256, 128, 3, 3, 1), (31, 20, 128, 128, 3, 3, 1)]),
     "patch": (6, [(48, 48, 64, 64, 3, 3, 1), (64, 64, 32, 64, 3, 3, 2), (47, 45, 32, 32, 3, 3, 1), (61, 63, 64, 32, 3, 3, 2),
-                  (32, 48, 32, 48, 5, 5, 1), (40, 32, 64, 16, 3, 1, 1), (64, 64, 32, 32, 1, 3, 2), (33, 31, 64, 128, 3, 3, 1)]),
+                  (32, 48, 32, 48, 5, 5, 1), (40, 32, 64, 16, 3, 1, 1), (64, 64, 32, 32, 1, 3, 2), (33, 31, 64, 128, 3, 3, 1),
+                  # 16 input channels (round 6: the yolov5n models' second layer; one 16-byte unit per pixel)
+                  (64, 64, 16, 32, 3, 3, 2), (48, 47, 16, 16, 3, 3, 1), (32, 48, 16, 64, 5, 5, 1), (63, 61, 16, 48, 3, 3, 2)]),
 }
 
 

@@ -207,7 +207,7 @@ def test_conv_i8_rows_persistent_deep(gpu, orc, slots):
 @pytest.mark.parametrize("variant,ring", [(9, 0), (10, 0), (11, 0), (10, 1), (9, 3), (11, 4), (10, 4)])
 def test_conv_i8_patch_staged(gpu, orc, variant, ring):
     """the patch-staged kernel (input patch of a tile staged once in LDS, weights resident, taps fed from LDS):
-    3x3 / 5x5 / 3x1 kernels, stride 1 and 2 (de-interleaved patch columns), in_c 32 / 64, partial tiles at the
+    3x3 / 5x5 / 3x1 kernels, stride 1 and 2 (de-interleaved patch columns), in_c 16 (round 6) / 32 / 64, partial tiles at the
     right and bottom edges, SAME padding on every side, several tiles per workgroup.  `ring` forces the depth of the patch
     ring (1 = one buffer, no prefetch; 3 / 4 = two / three patches in flight behind the one being computed, with an LDS
     budget that holds them), so that the hand-counted vector-memory waits are exercised at every depth, on interior tiles
