@@ -460,10 +460,14 @@ __global__ __launch_bounds__(NTHREADS) void conv_i8_persist(const mhip_conv_i8_t
     const int wm = wv % NWM, wn = wv / NWM;
     const int pxw = wm * (WPX * 16), ocw = wn * (WOC * 16);
 
+    // BN == 16 (round 6: out_c <= 16 -- the yolov5n models' first C3 -- ran 32-row tiles, half of every MFMA and of the requantisation for
+    // channels that do not exist): ONE channel subtile.  The host packed weight rows and bias for two subtiles (MFMA row 4 g + r of subtile
+    // s carries channel 8 g + 4 s + r: conv_i8_common.hpp); this form wants channel c in row c and reads packed row 16 s + 4 g + r for it.
+    auto packed_row16 = [](int c) { return ((c >> 2) & 1) * 16 + (c >> 3) * 4 + (c & 3); };
     v4i bias[WOC];
 #pragma unroll
     for (int s = 0; s < WOC; s++)
-        bias[s] = p.bias ? *(const v4i *)(p.bias + oc0 + ocw + s * 16 + (lane >> 4) * 4) : (v4i){0, 0, 0, 0};
+        bias[s] = p.bias ? *(const v4i *)(p.bias + (BN == 16 ? packed_row16((lane >> 4) * 4) : oc0 + ocw + s * 16 + (lane >> 4) * 4)) : (v4i){0, 0, 0, 0};
     if (HAS_LUT) {
         if (p.lut2) { if (tid < 128) ((uint32_t *)slut)[tid] = ((const uint32_t *)p.lut2)[tid]; }
         else if (tid < 64) ((uint32_t *)slut)[tid] = ((const uint32_t *)p.lut)[tid];
@@ -510,9 +514,10 @@ __global__ __launch_bounds__(NTHREADS) void conv_i8_persist(const mhip_conv_i8_t
     int wq[LW], wvoff[LW];
 #pragma unroll
     for (int j = 0; j < LW; j++) {
-        wq[j] = BN >= 64 ? wv * LW + j : (wv & 1);
-        wsrc[j] = p.w + (size_t)(oc0 + wq[j] * 16 + (lane >> 2)) * k64 + schunk * 16;
-        wvoff[j] = (oc0 + wq[j] * 16 + (lane >> 2)) * k64 + schunk * 16;
+        wq[j] = BN >= 64 ? wv * LW + j : (BN == 16 ? 0 : (wv & 1));
+        const int wrow = BN == 16 ? packed_row16(lane >> 2) : oc0 + wq[j] * 16 + (lane >> 2);
+        wsrc[j] = p.w + (size_t)wrow * k64 + schunk * 16;
+        wvoff[j] = wrow * k64 + schunk * 16;
     }
     const __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc((void *)p.in, 0, (int)in_bytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t wrs = __builtin_amdgcn_make_buffer_rsrc((void *)p.w, 0, p.oc_pad * k64, 0x00020000);
@@ -671,8 +676,10 @@ __global__ __launch_bounds__(NTHREADS) void conv_i8_persist(const mhip_conv_i8_t
             const int voff = ok ? (int)off : -1; // 0xffffffff >= num_records: dropped by the buffer unit
             if (WOC == 4)
                 __builtin_amdgcn_raw_buffer_store_b128((v4i){(int)pk[0], (int)pk[1], (int)pk[2], (int)pk[3]}, orsrc, voff, 0, 0);
-            else
+            else if (WOC == 2)
                 __builtin_amdgcn_raw_buffer_store_b64((v2i){(int)pk[0], (int)pk[WOC > 1 ? 1 : 0]}, orsrc, voff, 0, 0);
+            else
+                __builtin_amdgcn_raw_buffer_store_b32((int)pk[0], orsrc, voff, 0, 0);
             if (ragged) {
                 // out_c is not a multiple of the run (the 255-channel heads): the lane that holds the last, partial
                 // run writes it as 8 + 4 + 2 + 1 bytes; every other lane's pieces go out of range.  Always the same
@@ -943,8 +950,9 @@ static size_t wres_lds(int k64) { return LUTB + 2 * (size_t)BPX * BK + (size_t)(
 template <int BPX, int BN, int STAGES, bool HAS_LUT, bool SEG = false, bool PAIR = false>
 static int launch_persist_t(const mhip_conv_i8_t *p, long total_pix, int k64, int lg, unsigned magic,
                             const mhip_conv_i8_t *second = nullptr, int wres = 0) {
-    const unsigned noc0 = (unsigned)(p->oc_pad / BN);
-    const unsigned npt = (unsigned)((total_pix + BPX - 1) / BPX), noc = noc0 + (PAIR ? (unsigned)(second->oc_pad / BN) : 0u);
+    if (BN == 16 && (p->out_c > 16 || p->oc_pad != 32 || (PAIR && (second->out_c > 16 || second->oc_pad != 32)))) return -1; // (one tile of 16 channels out of a 32-row image)
+    const unsigned noc0 = BN == 16 ? 1u : (unsigned)(p->oc_pad / BN);
+    const unsigned npt = (unsigned)((total_pix + BPX - 1) / BPX), noc = noc0 + (PAIR ? (BN == 16 ? 1u : (unsigned)(second->oc_pad / BN)) : 0u);
     conv_out_side_t alt;
     memset(&alt, 0, sizeof(alt));
     if (PAIR) {
@@ -1189,9 +1197,18 @@ static int launch_variant_t(const mhip_conv_i8_t *p, long total_pix, int k64, co
                           : launch_persist_t<BPX, BN, 2, false>(p, total_pix, k64, lg, magic);
         return -1; // the three-stage tile walker (variants 6 / 8) is retired: round 4 pruning, never picked by the policy or the tuner
     }
-    if (v.w8) return BN == 128 ? launch_mfma<256, 128, 3, 1, 8>(p, total_pix, k64) : -1;
-    if (v.ks2) return BPX == 128 && BN >= 64 ? launch_mfma<128, (BN >= 64 ? BN : 64), 2, 2>(p, total_pix, k64) : -1;
-    return v.stages == 2 ? launch_mfma<BPX, BN, 2>(p, total_pix, k64) : launch_mfma<BPX, BN, 3>(p, total_pix, k64);
+    if constexpr (BN == 16) {
+        return -1; // (the 16-channel tile exists in the tile walker only)
+    } else {
+        if (v.w8) return BN == 128 ? launch_mfma<256, 128, 3, 1, 8>(p, total_pix, k64) : -1;
+        if (v.ks2) return BPX == 128 && BN >= 64 ? launch_mfma<128, (BN >= 64 ? BN : 64), 2, 2>(p, total_pix, k64) : -1;
+        return v.stages == 2 ? launch_mfma<BPX, BN, 2>(p, total_pix, k64) : launch_mfma<BPX, BN, 3>(p, total_pix, k64);
+    }
+}
+// out_c <= 16 in a 32-row weight image: the tile walker runs one 16-channel tile (conv_i8_persist<.., 16, ..>); MARS_HIP_NO_BN16 = the 32-row tile (A / B)
+static bool bn16_ok(const mhip_conv_i8_t *p) {
+    static const bool off = getenv("MARS_HIP_NO_BN16") != nullptr;
+    return !off && p->out_c <= 16 && p->oc_pad == 32 && p->nseg <= 1;
 }
 
 static int launch_variant(const mhip_conv_i8_t *p, long total_pix, int k64, const variant_t &v) {
@@ -1200,13 +1217,16 @@ static int launch_variant(const mhip_conv_i8_t *p, long total_pix, int k64, cons
     if (v.r128) return launch_r128(p, total_pix, v.r128);
     if (v.patch) return conv_i8_launch_patch(p, k64, v.patch);
     const int bn = p->oc_pad % 128 == 0 ? 128 : (p->oc_pad % 64 == 0 ? 64 : 32);
+    const bool b16 = v.persist && v.stages == 2 && bn16_ok(p);
     if (v.bpx == 256) {
         if (bn == 128) return launch_variant_t<256, 128>(p, total_pix, k64, v);
         if (bn == 64) return launch_variant_t<256, 64>(p, total_pix, k64, v);
+        if (b16) return launch_variant_t<256, 16>(p, total_pix, k64, v);
         return launch_variant_t<256, 32>(p, total_pix, k64, v);
     }
     if (bn == 128) return launch_variant_t<128, 128>(p, total_pix, k64, v);
     if (bn == 64) return launch_variant_t<128, 64>(p, total_pix, k64, v);
+    if (b16) return launch_variant_t<128, 16>(p, total_pix, k64, v);
     return launch_variant_t<128, 32>(p, total_pix, k64, v);
 }
 
@@ -1244,13 +1264,16 @@ extern "C" int mhip_conv_i8_pair(const mhip_conv_i8_t *a, const mhip_conv_i8_t *
     const unsigned magic = ((65536u + (unsigned)a->kw - 1u) / (unsigned)a->kw);
     const variant_t dv = default_variant(a, nks);
     const int bpx = dv.bpx ? dv.bpx : 128, wres = dv.persist && dv.wres && (tune().wres & 2);
+    const bool b16 = bn16_ok(a) && bn16_ok(b);
     if (bpx == 256) {
         if (bn == 128) return launch_pair_t<256, 128>(a, b, total_pix, k64, lg, magic, wres);
         if (bn == 64) return launch_pair_t<256, 64>(a, b, total_pix, k64, lg, magic, wres);
+        if (b16) return launch_pair_t<256, 16>(a, b, total_pix, k64, lg, magic, wres);
         return launch_pair_t<256, 32>(a, b, total_pix, k64, lg, magic, wres);
     }
     if (bn == 128) return launch_pair_t<128, 128>(a, b, total_pix, k64, lg, magic, wres);
     if (bn == 64) return launch_pair_t<128, 64>(a, b, total_pix, k64, lg, magic, wres);
+    if (b16) return launch_pair_t<128, 16>(a, b, total_pix, k64, lg, magic, wres);
     return launch_pair_t<128, 32>(a, b, total_pix, k64, lg, magic, wres);
 }
 
