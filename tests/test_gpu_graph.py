@@ -2336,3 +2336,46 @@ def test_f32_virtual_concat(gpu, orc, mode, monkeypatch):
             g.close()
     finally:
         gpu.set_tuning("f32_mfma", 1)
+
+
+@pytest.mark.parametrize("cfg", [(3, 6, 2, 16, 36, 44), (3, 3, 1, 16, 20, 20), (1, 5, 2, 32, 18, 50), (4, 3, 1, 48, 11, 16), (2, 6, 2, 7, 21, 36), (3, 8, 3, 32, 40, 90),
+                                 (3, 6, 2, 32, 130, 132), (3, 3, 2, 16, 9, 4)], ids=lambda v: "x".join(str(q) for q in v))
+def test_nchw_stem_reads_planes(gpu, orc, cfg, monkeypatch):
+    """round 6: the small-channel first layer of an NCHW-tagged graph ([C <= 4][H][W] bytes in) -- conv_i8_smallc interleaves the planes while it
+    stages its patch (mhip_conv_i8_t.in_planar) instead of a relayout launch in front.  1 - 4 planes, kernels 3 - 8, strides 1 - 3, maps whose
+    width is not a multiple of the 4-pixel staging unit, edges on every side (SAME padding), several frames: bit for bit against the oracle,
+    with the planar form and with MARS_HIP_NO_PLANAR_STEM (the relayout in front), at fusion levels 1 and 0."""
+    c, k, st, oc, h, w = cfg
+    rng = np.random.default_rng(c * 1000 + k * 100 + st * 10 + oc)
+    G = marsfile.Graph()
+    x = G.tensor([1, c, h, w], fmt=marsfile.NCHW, scale=0.02)
+    oh, ow = (h + st - 1) // st, (w + st - 1) // st
+    o = G.tensor([1, oc, oh, ow], fmt=marsfile.NCHW, scale=0.05)
+    wt = G.tensor([oc, c, k, k], fmt=marsfile.OIHW, scale=0.004, data=rng.integers(-127, 128, (oc, c, k, k), dtype=np.int8))
+    b = G.tensor([oc], dtype=marsfile.I32, fmt=marsfile.D1, data=rng.integers(-3000, 3000, oc, dtype=np.int32))
+    G.conv(x, o, wt, b, (k, k), (st, st), pad=marsfile.PAD_SAME)
+    o2 = G.tensor([1, oc, oh, ow], fmt=marsfile.NCHW, scale=0.04)
+    G.layer(marsfile.RELU, [o], [o2])
+    d = G.serialise([x], [o2])
+    hdr, tensors, _ = marsfile.parse(d)
+    B = 3
+    xs = [rng.integers(0, 256, c * h * w, dtype=np.uint8) for _ in range(B)]
+    want = []
+    for f in range(B):
+        g, rc = run_oracle(orc, d, xs[f])
+        assert rc == 0
+        want.append(g.tensor(hdr["outputs"][0]).copy())
+        g.close()
+    for env in (None, "1"):
+        if env:
+            monkeypatch.setenv("MARS_HIP_NO_PLANAR_STEM", env)
+        else:
+            monkeypatch.delenv("MARS_HIP_NO_PLANAR_STEM", raising=False)
+        for fusion in (1, 0):
+            m = gpu.Model(d, batch=B, fusion=fusion)
+            for f in range(B):
+                m.input_view(0)[f] = xs[f]
+            m.run()
+            for f in range(B):
+                assert np.array_equal(m.output_view(0)[f], want[f]), "planar=%s fusion %d frame %d" % (env is None, fusion, f)
+            m.close()

@@ -1356,6 +1356,12 @@ extern "C" int mhip_conv_i8(const mhip_conv_i8_t *p) {
     const long total_pix = (long)p->frames * p->out_h * p->out_w;
     const int k64 = (p->kh * p->row_pad + BK - 1) / BK * BK;
     if (total_pix <= 0 || total_pix > 0x7fffffffL || (total_pix + BP - 1) / BP * (oc_pad / 32) > 0x7fffffffL) return -1;
+    if (p->in_planar) { // planes [c][H][W] instead of pixels: only the patch-widening small-channel kernel reads them (it interleaves while staging)
+        if (p->in_planar > 4 || p->in_c != 4 || p->in_w < 4 || p->stride_h < 1 || p->stride_w < 1 || p->add || p->nseg > 1 ||
+            !mhip_conv_i8_small_c(p->in_c, p->kw, p->out_c))
+            return -2;
+        return conv_i8_try_smallc(p, k64); // -2: its patch / LDS budget does not take the shape
+    }
     if (mhip_conv_i8_small_c(p->in_c, p->kw, p->out_c)) {
         if (p->stride_h >= 1 && p->stride_w >= 1) {
             int rc = conv_i8_try_rgb(p, k64);

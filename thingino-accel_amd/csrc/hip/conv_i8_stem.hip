@@ -68,6 +68,10 @@ __global__ __launch_bounds__(NTHREADS) void conv_i8_smallc(const mhip_conv_i8_t 
     // 16 contiguous bytes there; they used to go byte by byte under bounds tests, 0.85 ms for the shipped yolov5n_int8.mars stem)
     const int fastpb = HOT ? 3 : (p.in_w >= 4 ? (p.in_c == 3 ? 3 : (p.in_c == 4 ? 4 : 0)) : 0); // bytes per pixel of the fast form, 0 = the gather
     const bool fast3 = fastpb != 0;
+    // planar input (in_planar planes [c][H][W]: an NCHW-tagged graph's input, host: in_c == 4, in_w >= 4): a unit is 4 consecutive pixels = ONE dword
+    // per plane, interleaved into 4-byte pixels at commit -- the fast form with three (four) loads instead of one, no relayout launch in front
+    const int planar = HOT ? 0 : p.in_planar;
+    const long plane = (long)p.in_h * p.in_w;
     // Workgroup ids go round-robin over the 8 XCDs (the grid is a multiple of 8, so a workgroup's XCD is blockIdx.x & 7
     // for its whole run): XCD x is given the x-th eighth of the tile list and walks it in order, so the workgroups
     // that share patch halos and 128-byte input lines run side by side under ONE L2 (measured: the kernel fetched
@@ -98,7 +102,16 @@ __global__ __launch_bounds__(NTHREADS) void conv_i8_smallc(const mhip_conv_i8_t 
                 const int iy = y0 + (urg[j] >> 8), ix = x0 + (urg[j] & 255) * 4;
                 const int iyc = iy < 0 ? 0 : (iy > p.in_h - 1 ? p.in_h - 1 : iy);
                 const int ixc = ix < 0 ? 0 : (ix > p.in_w - 4 ? p.in_w - 4 : ix);
-                __builtin_memcpy(&pre[j], src + ((long)iyc * p.in_w + ixc) * fastpb, 16); // unaligned dwordx4, 12 (16) bytes used
+                if (planar) {
+                    const int8_t *q = src + (long)iyc * p.in_w + ixc;
+                    int w4[4] = {0, 0, 0, 0};
+#pragma unroll
+                    for (int c = 0; c < 4; c++)
+                        if (c < planar) __builtin_memcpy(&w4[c], q + c * plane, 4); // unaligned dword (uniform branch: every lane loads)
+                    pre[j] = (v4i){w4[0], w4[1], w4[2], w4[3]};
+                } else {
+                    __builtin_memcpy(&pre[j], src + ((long)iyc * p.in_w + ixc) * fastpb, 16); // unaligned dwordx4, 12 (16) bytes used
+                }
                 shf[j] = (iy == iyc && tid + j * NTHREADS < nunits) ? ixc - ix : PRE_ZERO;
             }
             return;
@@ -130,7 +143,15 @@ __global__ __launch_bounds__(NTHREADS) void conv_i8_smallc(const mhip_conv_i8_t 
             if (fast3) { // 4 x 3 packed bytes -> 4 pixels widened to a dword each
                 const uint32_t d0 = (uint32_t)v[0], d1 = (uint32_t)v[1], d2 = (uint32_t)v[2];
                 v4i l = v; // (4-byte pixels: already one dword each)
-                if (HOT || fastpb == 3) {
+                if (planar) { // dword c = pixels 0 .. 3 of plane c  ->  dword e = channels 0 .. 3 of pixel e (a 4 x 4 byte transpose)
+                    const uint32_t a = (uint32_t)v[0], b = (uint32_t)v[1], c2 = (uint32_t)v[2], d = (uint32_t)v[3];
+                    const uint32_t ab_lo = __builtin_amdgcn_perm(b, a, 0x05010400u), ab_hi = __builtin_amdgcn_perm(b, a, 0x07030602u); // a0 b0 a1 b1 | a2 b2 a3 b3
+                    const uint32_t cd_lo = __builtin_amdgcn_perm(d, c2, 0x05010400u), cd_hi = __builtin_amdgcn_perm(d, c2, 0x07030602u);
+                    l[0] = (int)__builtin_amdgcn_perm(cd_lo, ab_lo, 0x05040100u); // a0 b0 c0 d0
+                    l[1] = (int)__builtin_amdgcn_perm(cd_lo, ab_lo, 0x07060302u);
+                    l[2] = (int)__builtin_amdgcn_perm(cd_hi, ab_hi, 0x05040100u);
+                    l[3] = (int)__builtin_amdgcn_perm(cd_hi, ab_hi, 0x07060302u);
+                } else if (HOT || fastpb == 3) {
                     l[0] = (int)(d0 & 0xFFFFFFu);
                     l[1] = (int)(((d0 >> 24) | (d1 << 8)) & 0xFFFFFFu);
                     l[2] = (int)(((d1 >> 16) | (d2 << 16)) & 0xFFFFFFu);

@@ -139,6 +139,17 @@ static int launch_op(mars_model_ext_t *m, mars_op_t *op) {
         case OP_CONV_I8: {
             mhip_conv_i8_t p;
             conv_i8_params(m, op, &p);
+            if (op->nchw && op->c_pad == 4 && op->in_c <= 4 && !op->add_t) {
+                /* the small-channel stem of an NCHW-tagged graph: conv_i8_smallc reads the planes themselves and interleaves them while it stages
+                 * its patch (round 6: no relayout launch, 0.13 ms of yolov5n_int8.mars' 2.7 ms at batch 256); -2 = it does not take the shape */
+                if (!getenv("MARS_HIP_NO_PLANAR_STEM")) { /* (A / B switch and tests; read per launch: one getenv per run) */
+                    mhip_conv_i8_t q = p;
+                    q.in_c = op->c_pad;
+                    q.in_planar = op->in_c;
+                    const int rc = mhip_conv_i8(&q);
+                    if (rc != -2) return rc;
+                }
+            }
             if (op->nchw) {
                 const size_t ss = ALIGN_UP(m->scratch_per_frame, 256);
                 int8_t *scratch = (int8_t *)m->scratch_dev + (size_t)m->frame0 * ss;

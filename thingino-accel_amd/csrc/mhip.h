@@ -82,6 +82,9 @@ typedef struct {
     float cs;                   /* (in_scale*w_scale)/out_scale, evaluated on the host in f32 */
     int relu;                   /* clamp negative results to 0 (fused ReLU, byte semantics) */
     int out_nchw;               /* store [O][H][W] instead of [H][W][O] */
+    int in_planar;              /* > 0 (small-channel stem only, in_c == 4): `in` is in_planar (<= 4) PLANES [c][in_h][in_w] per frame -- an NCHW-tagged graph's
+                                   input as the reference holds it -- which conv_i8_smallc interleaves while it stages its patch (round 6: no relayout launch);
+                                   mhip_conv_i8 returns -2 when that kernel does not take the shape (the caller relays the input and launches again) */
     int safe;                   /* host proved |acc*cs| < 2^31 and cs finite: skip the x86 overflow fix-up */
     int out_pix_stride;         /* NHWC only: bytes between consecutive output pixels (0 = out_c); with out_ch_off
                                    this writes straight into a channel slice of a wider tensor (zero-copy concat) */
