@@ -62,7 +62,7 @@ def build():
     cat = G.tensor([1, oc * nb, h, w], dtype=F, fmt=NC)
     G.concat([int(p) for p in parts], cat, axis=1)
     outs = []
-    roc = int(rng.choice([8, 16, 40, 64, 128]))
+    roc = int(rng.choice([8, 16, 40, 64, 128, 7, 255]))  # (7, 255: channel counts that are not multiples of the head kernel's 4-channel lanes)
     readers = 2 if rng.integers(0, 3) == 0 else 1
     for _ in range(readers):
         r, _, _ = conv(cat, oc * nb, h, w, 1, 1, roc, silu)
