@@ -2090,7 +2090,7 @@ def test_shipped_files_at_batch_8_every_tensor(gpu, orc, name, fusion):
             assert np.array_equal(got, want), "%s fusion %d frame %d tensor %d: %d of %d bytes differ" % (name, fusion, f, ti, int((got != want).sum()), len(got))
             compared += 1
         g.close()
-    assert compared >= (10 if name.startswith("tiny") else 150 if fusion == 0 else 60), compared
+    assert compared >= ((10 if fusion == 0 else 8) if name.startswith("tiny") else 150 if fusion == 0 else 60), compared  # (tiny: two convolution results are elided by fuse_lut at fusion 1)
     keep = [m.read_tensor(ti, frame=3) for ti in range(len(tensors)) if tensors[ti]["size"] == 0 and marsfile.tensor_nbytes(tensors[ti]) and _readable(gpu, m, ti)]
     m.close()
     m1 = gpu.Model(d, batch=1, fusion=fusion)

@@ -177,6 +177,7 @@ MARS_INTERNAL void virtual_concat_q(mars_model_ext_t *m);
 MARS_INTERNAL void zero_tail_f32(mars_model_ext_t *m);
 MARS_INTERNAL void virtual_concat_f32(mars_model_ext_t *m);
 MARS_INTERNAL void fuse_silu(mars_model_ext_t *m);
+MARS_INTERNAL void fuse_lut(mars_model_ext_t *m);
 MARS_INTERNAL void fuse_silu_f32(mars_model_ext_t *m);
 MARS_INTERNAL void elide_concat(mars_model_ext_t *m);
 MARS_INTERNAL void fuse_add(mars_model_ext_t *m);

@@ -175,6 +175,7 @@ mars_error_t build_plan(mars_model_ext_t *m) {
     if (m->plan_err != MARS_OK) return (mars_error_t)m->plan_err;
     if (m->fusion >= 1) {
         fuse_silu(m);
+        fuse_lut(m); /* (after the SiLU chains: a lone activation layer behind a convolution) */
         fuse_silu_f32(m);
         nhwc_internal(m); /* (after the SiLU fold: its intermediates are gone; before Add folding / pairing: they then see NHWC convolutions) */
         fuse_add(m);

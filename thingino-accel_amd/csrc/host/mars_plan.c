@@ -649,6 +649,58 @@ void fuse_silu(mars_model_ext_t *m) {
     free(writers);
 }
 
+/* A single int8 activation layer behind a convolution (RELU / RELU6 / LEAKY_RELU / SIGMOID as their own layers: the shipped tiny_160_int8.mars,
+ * any exporter that does not fold them): the layer is a 256-entry map of the convolution's int8 result (plan_unary builds it), which is what the
+ * convolution's fused table applies in its epilogue -- the same bytes, one launch and two passes over the tensor less.  Runs after fuse_silu (a
+ * SIGMOID that feeds a MUL belongs to that chain).  Conditions as there: the convolution's result has no other reader and is no graph tensor. */
+void fuse_lut(mars_model_ext_t *m) {
+    if (getenv("MARS_HIP_NO_FUSE_LUT")) return;
+    const int nt = (int)m->pub.header.num_tensors;
+    int *readers = (int *)calloc((size_t)nt + 1, sizeof(int));
+    int *writers = (int *)calloc((size_t)nt + 1, sizeof(int));
+    if (!readers || !writers) { free(readers); free(writers); return; }
+    for (int i = 0; i < m->n_ops; i++) {
+        for (int k = 0; k < m->ops[i].n_in; k++)
+            if (m->ops[i].t_in[k] >= 0) readers[m->ops[i].t_in[k]]++;
+        if (m->ops[i].t_out >= 0) writers[m->ops[i].t_out]++;
+    }
+    for (int i = 0; i + 1 < m->n_ops; i++) {
+        mars_op_t *c = &m->ops[i], *s = &m->ops[i + 1];
+        if (c->kind != OP_CONV_I8 || s->kind != OP_LUT_I8 || c->lut_off != NO_OFF || s->lut_off == NO_OFF) continue;
+        const int q1 = c->t_out, q2 = s->t_out;
+        if (q1 < 0 || q2 < 0 || s->t_in[0] != q1 || q1 == q2) continue;
+        int inplace = 0; /* redirecting the result onto one of the convolution's own inputs would make a parallel launch run in place */
+        for (int k = 0; k < c->n_in; k++)
+            if (c->t_in[k] == q2) inplace = 1;
+        if (inplace) continue;
+        if (readers[q1] != 1 || writers[q1] != 1 || writers[q2] != 1 || m->mt[q1].io_out || m->mt[q1].io_in || m->mt[q1].is_weight || m->mt[q2].is_weight) continue;
+        const size_t n1 = (size_t)c->out_h * c->out_w * c->out_c;
+        if (s->n != n1 || m->mt[q2].bytes < n1) continue; /* the layer must cover exactly the convolution's result */
+        if (m->pub.tensors[q1].desc.dtype != MARS_DTYPE_INT8 || m->pub.tensors[q2].desc.dtype != MARS_DTYPE_INT8) continue;
+        const int8_t *tab = (const int8_t *)(m->arena_host + s->lut_off);
+        c->lut_off = s->lut_off;
+        if (mhip_conv_i8_lut2_ok(c->cs)) { /* the half-step form, as fuse_silu builds it (the ReLU clamp folds in) */
+            int8_t tab2[512];
+            for (int k = -256; k < 256; k++) {
+                int r = k >= 0 ? (k + 1) >> 1 : -((1 - k) >> 1);
+                const int lo = c->relu ? 0 : -128;
+                r = r < lo ? lo : (r > 127 ? 127 : r);
+                tab2[k + 256] = tab[r + 128];
+            }
+            c->lut2_off = arena_reserve(m, 512);
+            if (c->lut2_off != NO_OFF) memcpy(m->arena_host + c->lut2_off, tab2, 512);
+            c = &m->ops[i]; /* (arena_reserve may move the host image, not the ops) */
+        }
+        c->t_out = q2;
+        touch(m, q2, n1);
+        m->mt[q1].needed = 0;
+        memmove(&m->ops[i + 1], &m->ops[i + 2], (size_t)(m->n_ops - i - 2) * sizeof(mars_op_t));
+        m->n_ops -= 1;
+    }
+    free(readers);
+    free(writers);
+}
+
 /* float32 form of the same chain: conv_f32 -> SIGMOID (float, :742-749) -> MUL (float, :807-816).  The epilogue evaluates
  * s = 1.0f / (1.0f + expf(-v)), out = v * s with the reference's roundings and this image's libm expf (expf_exact.h), so
  * the fused result is the same float bit for bit; the two intermediates are never written (5 of the 7 float passes over
