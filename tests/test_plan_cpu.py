@@ -106,3 +106,15 @@ def test_int8_twin_plan(marsrt):
     assert count(L, " seg=") == 17 and count(L, " lut") >= 57  # (13 concats; the four read by a C3's cv1 AND cv2 appear in both readers)
     assert count(L, " relayout") == 0 and count(L, " planar_store") == 0 and k["concat_q"] == 0
     assert sum(l.startswith("tensor ") and " pix_stride 256" in l for l in L) == 3  # the 255-channel heads at a 256-byte pitch
+
+
+def test_lone_activation_layers_fold_into_the_convolution(marsrt, monkeypatch):
+    """fuse_lut: tiny_160_int8.mars (BASELINE config 2) is conv -> RELU -> conv -> RELU -> conv; an int8 activation layer is a 256-entry map of the
+    convolution's result, which the convolution's epilogue applies itself: 3 launches instead of 5 (MARS_HIP_NO_FUSE_LUT keeps the layers)"""
+    monkeypatch.delenv("MARS_HIP_NO_FUSE_LUT", raising=False)
+    L = marsrt.describe_plan(model_bytes("tiny_160_int8"))
+    k = kinds(L)
+    assert k["conv_i8"] == 3 and k["lut_i8"] == 0 and count(L, " lut") == 2  # (the last convolution has no activation behind it)
+    monkeypatch.setenv("MARS_HIP_NO_FUSE_LUT", "1")
+    k0 = kinds(marsrt.describe_plan(model_bytes("tiny_160_int8")))
+    assert k0["conv_i8"] == 3 and k0["lut_i8"] == 2
