@@ -11,8 +11,10 @@
 #define SC_TH 16
 #define SC_TW 16
 #define SC_BP (SC_TH * SC_TW)
+// (WOC == 1, the general form: 97 VGPRs, one over the 96 of five waves per SIMD -- the hint brings it to 91 without a spill, +1.3 % on
+//  yolov5n_int8.mars; six waves (80) spill 9 registers and lose 2 %; the same hint on conv_i8_persist<128, 32> -- 83 -> 80 -- measured nothing)
 template <int WOC, bool HOT = false>
-__global__ __launch_bounds__(NTHREADS) void conv_i8_smallc(const mhip_conv_i8_t p, const int k64, const int tiles_x,
+__global__ __launch_bounds__(NTHREADS) __attribute__((amdgpu_waves_per_eu(WOC == 1 ? 5 : 1, 8))) void conv_i8_smallc(const mhip_conv_i8_t p, const int k64, const int tiles_x,
                                                            const int tiles_y, const unsigned ntiles_all, const int PH,
                                                            const int PW, const int PWp, const fastdiv_t dhw,
                                                            const fastdiv_t dtx, const fastdiv_t dty, const fastdiv_t dgpr,
